@@ -223,7 +223,7 @@ def test_train_steps_small(golden):
             # two Adam steps per net, each bounded by lr (first steps: |m/sqrt(v)| <= ~1.6)
             assert np.abs(got - ref).max() <= 2 * 2 * lr + 1e-6, k
             if k.endswith("weight"):
-                assert rel_l2(got, ref) < 2e-3, (k, rel_l2(got, ref))
+                assert rel_l2(got, ref) < 5e-3, (k, rel_l2(got, ref))
 
 
 def test_audio2mel(golden):
