@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: stage-2 GAN train-step audio samples/sec (22.05 kHz, 8192-sample window).
+
+    python bench.py --gpus 1 --steps 20 --warmup 6
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one trainer call on one batch, exactly like the reference's training_loop
+(train/train.py:80-92): calls alternate D, G, D, G ... (experiment/experiment.py:141-144).
+Workload = BASELINE.json configs[2]/[3]: B = 32 per GPU (weak scaling), 80-mel x 32-frame
+features -> 8192-sample windows, synthetic inputs already resident in HBM, seed-7 N(0, 0.02)
+weights identical on every rank, FlatAdam(1e-4, (0.5, 0.9)).  The timed region includes the
+loss .item() syncs and the G-step's D2H copy of `fake` (they are part of the reference's trainer
+contract, train.py:39-42,74).  value = world * B * 8192 * K / max-over-ranks(wall time).
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      dominant kernel (by device time in an instrumented eager D+G pass): algorithmic
+                FLOPs per launch / mean launch duration measured with HIP events on the launch
+                stream, against the fp32 MFMA/vector peak (157.3 TFLOP/s) or HBM peak (8 TB/s)
+  step_roofline sum over launches of max(bytes/8 TB/s, flops/157.3 TFLOP/s) / measured time
+  cpu_baseline  the torch-functional CPU restatement of the reference graph (oracle/torch_graph.py)
+                timed on this host's cores on a bounded sample (N=1 runs only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "music-synthesis_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK = 8.0e12        # B/s   (MI355X_MICROARCH.md: HBM3E peak)
+F32_PEAK = 157.3e12      # FLOP/s (fp32 vector == fp32-input MFMA peak)
+WINDOW = 8192
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--mels", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import featuresynth as fs
+    from featuresynth import _dist
+    from featuresynth import _workload as W
+    from featuresynth import loss as LS
+    from featuresynth._ops import lib as L
+    from featuresynth._synthetic import (module_param_shapes, synthetic_features,
+                                         synthetic_samples, synthetic_state_dict)
+    from featuresynth.train import DiscriminatorTrainer, GeneratorTrainer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
+                             "--nproc-per-node %d (one process per GPU)" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d != WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    _dist.init_from_env("nccl")
+    rank = _dist.rank()
+    L.load()
+
+    B, T = args.batch, WINDOW // 256
+    g = fs.MelGanGenerator(T, args.mels)
+    d = fs.MelGanDiscriminator()
+    gsd = synthetic_state_dict(module_param_shapes(g), seed=7)
+    dsd = synthetic_state_dict(module_param_shapes(d), seed=7)
+    g.load_state_dict({k: torch.from_numpy(v) for k, v in gsd.items()})
+    d.load_state_dict({k: torch.from_numpy(v) for k, v in dsd.items()})
+    g.to(device); d.to(device)
+    g_optim = fs.FlatAdam(g.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    d_optim = fs.FlatAdam(d.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    gt = GeneratorTrainer(g, g_optim, d, d_optim, LS.mel_gan_gen_loss)
+    dt = DiscriminatorTrainer(g, g_optim, d, d_optim, LS.mel_gan_disc_loss)
+
+    nbatches = 4   # distinct pre-staged batches, cycled
+    batches = [(torch.from_numpy(synthetic_samples(B, WINDOW, rank=rank * 16 + i)).to(device),
+                torch.from_numpy(synthetic_features(B, args.mels, T, rank=rank * 16 + i)).to(device))
+               for i in range(nbatches)]
+
+    def call(i):
+        s, f = batches[i % nbatches]
+        return dt.train(s, f) if i % 2 == 0 else gt.train(s, f)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    last = {}
+    for i in range(args.warmup):
+        last.update(call(i))
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        last.update(call(i))
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * B * WINDOW * args.steps / elapsed
+    graphs = bool(dt._runner and dt._runner.graphs and gt._runner and gt._runner.graphs)
+    log("[bench] rank %d: %d steps in %.3f s -> %.4g samples/s (hipGraph replay: %s); d_loss %.5f g_loss %.5f"
+        % (rank, args.steps, elapsed, value, graphs, last.get("d_loss", float("nan")),
+           last.get("g_loss", float("nan"))))
+
+    result = {
+        "metric": "GAN train-step audio samples/sec (22.05 kHz, 8192-sample window)",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "stage-2 GAN train step: alternating D/G trainer calls, MelGAN "
+                               "generator + 3-scale discriminator + feature-matching loss "
+                               "(BASELINE.json configs[2]%s)" % ("" if world == 1 else "/[3]"),
+                   "per_gpu_batch": B, "global_batch": world * B, "window": WINDOW,
+                   "mels": args.mels, "optimizer": "FlatAdam(1e-4,(0.5,0.9))",
+                   "parallelism": "dp%d" % world, "hipgraph": graphs},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # instrumented eager pass: HIP events around every C-ABI launch on the launch stream
+        s, f = batches[0]
+        L.profile_begin()
+        out_d = dt._fwd_bwd(s, f); d_optim.step()
+        mark = len(L.PROFILE)
+        out_g = gt._fwd_bwd(s, f); g_optim.step()
+        rec = L.profile_end()
+        del out_d, out_g
+        agg = {}
+        for name, cost, ms in rec:
+            k = cost.get("kernel") or name
+            a = agg.setdefault(k, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0})
+            a["ms"] += ms; a["n"] += 1
+            a["flops"] += cost.get("flops", 0); a["bytes"] += cost.get("bytes", 0)
+        tot_ms = sum(a["ms"] for a in agg.values())
+        top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
+        log("[bench] instrumented eager D+G pass: %.2f ms of kernels in %d launches" % (tot_ms, len(rec)))
+        for k, a in top[:12]:
+            log("    %-46s x%-4d %8.3f ms  %7.2f TFLOP/s  %7.1f GB/s" % (
+                k, a["n"], a["ms"], a["flops"] / a["ms"] / 1e9 if a["ms"] else 0,
+                a["bytes"] / a["ms"] / 1e6 if a["ms"] else 0))
+        k, a = top[0]
+        avg_s = a["ms"] / a["n"] / 1e3
+        fl, by = a["flops"] / a["n"], a["bytes"] / a["n"]
+        compute_bound = fl / F32_PEAK >= by / HBM_PEAK
+        if compute_bound:
+            roof = {"bound": "mfma", "achieved": fl / avg_s / 1e12, "peak": F32_PEAK / 1e12,
+                    "unit": "TFLOP/s"}
+        else:
+            roof = {"bound": "hbm", "achieved": by / avg_s / 1e9, "peak": HBM_PEAK / 1e9,
+                    "unit": "GB/s"}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None
+        roof.update({"kernel": k, "launches_per_DG_pair": a["n"], "avg_launch_us": avg_s * 1e6,
+                     "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
+                     "share_of_kernel_time": a["ms"] / tot_ms})
+        result["roofline"] = roof
+        launches = W.d_step_launches(B, args.mels, T) + W.g_step_launches(B, args.mels, T)
+        ideal = W.roofline_seconds(launches, HBM_PEAK, F32_PEAK)
+        pair_s = 2 * elapsed / args.steps
+        result["step_roofline"] = {
+            "ideal_ms_per_DG_pair": ideal * 1e3, "measured_ms_per_DG_pair": pair_s * 1e3,
+            "frac": ideal / pair_s, "algorithmic_gflop_per_DG_pair": W.totals(launches)["flops"] / 1e9,
+            "algorithmic_mb_per_DG_pair": W.totals(launches)["bytes"] / 1e6,
+            "kernel_ms_per_DG_pair_eager": tot_ms}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_graph as TG
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        tr = TG.Trainer(gsd, dsd)
+        s_cpu = torch.from_numpy(synthetic_samples(B, WINDOW, rank=0))
+        f_cpu = torch.from_numpy(synthetic_features(B, args.mels, T, rank=0))
+        tr.d_step(s_cpu, f_cpu)                      # warm-up (allocator, MKLDNN primitives)
+        c0 = time.perf_counter()
+        tr.d_step(s_cpu, f_cpu)
+        tr.g_step(s_cpu, f_cpu)
+        cpu_s = time.perf_counter() - c0
+        result["cpu_baseline"] = {
+            "value": 2 * B * WINDOW / cpu_s, "unit": "samples/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "1 D-step + 1 G-step at B=%d (after 1 warm-up D-step) of the torch-functional "
+                      "CPU restatement of the reference graph (oracle/torch_graph.py), %.1f s" % (B, cpu_s)}
+        log("[bench] cpu baseline: %.4g samples/s on %d threads" % (result["cpu_baseline"]["value"],
+                                                                    torch.get_num_threads()))
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,192 @@
+/*
+ * msynth.h -- C ABI of libmsynth_hip.so: the MI355X (gfx950) kernels under the
+ * featuresynth stage-2 mel->waveform GAN hot path.
+ *
+ * The reference (JohnVinyard/music-synthesis) has no native layer: its hot path
+ * is a sequence of stock PyTorch nn.Module / functional calls.  Each entry point
+ * below therefore replaces the ATen op that the cited reference line invokes;
+ * the Python side (music-synthesis_amd/featuresynth/_ops) binds them with ctypes
+ * and is the only caller.  INTEGRATION.md shows the binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - all tensors are fp32, contiguous, (B, C, L) exactly as PyTorch lays them out;
+ *   - every pointer is a DEVICE pointer owned by the caller (torch's allocator);
+ *     the library never allocates or frees device memory: scratch comes from the
+ *     caller-provided workspace (query its size with the *_workspace_bytes calls);
+ *   - all work is enqueued on the caller's hipStream_t (passed as void*); no call
+ *     synchronises the device, so every call is hipGraph-capture safe;
+ *   - return value: MS_OK (0) or a negative ms_status; nothing is thrown;
+ *   - re-entrant; no global state.
+ */
+#ifndef MSYNTH_H
+#define MSYNTH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSYNTH_VERSION 100 /* 0.1.0 */
+
+typedef void* ms_stream_t; /* hipStream_t */
+
+enum ms_status {
+    MS_OK = 0,
+    MS_ERR_INVALID_ARG = -1, /* null pointer, non-positive size, inconsistent shapes */
+    MS_ERR_UNSUPPORTED = -2, /* shape/mode outside what the kernels implement */
+    MS_ERR_WORKSPACE = -3,   /* workspace missing or too small */
+    MS_ERR_LAUNCH = -4       /* HIP launch failure (hipGetLastError) */
+};
+
+enum ms_act { MS_ACT_NONE = 0, MS_ACT_LRELU = 1, MS_ACT_TANH = 2 };
+enum ms_pad_mode { MS_PAD_ZERO = 0, MS_PAD_REFLECT = 1 };
+
+int ms_version(void);
+const char* ms_status_string(int status);
+
+/* nn.Conv1d geometry.  w is (Cout, Cin/groups, K).  Lout = (Lin + 2*pad - dil*(K-1) - 1)/stride + 1 */
+typedef struct ms_conv1d_desc {
+    int32_t B, Cin, Lin, Cout, K, stride, pad, dil, groups;
+    int32_t pad_mode; /* ms_pad_mode; REFLECT = nn.ReflectionPad1d(pad) fused in front */
+    int32_t act;      /* ms_act fused behind the conv */
+    float slope;      /* LeakyReLU negative slope */
+} ms_conv1d_desc;
+
+int ms_conv1d_out_len(const ms_conv1d_desc* d);
+
+/*
+ * y = residual + act(conv1d(x, w) + bias)
+ * Replaces nn.Conv1d (+ F.leaky_relu / nn.LeakyReLU / nn.Tanh, + the ResidualAtom skip add):
+ *   generator/full.py:23-25,43-44 ; util/modules.py:358-365,384-388 ;
+ *   discriminator/full.py:14-22,36-39.
+ * bias, residual, y_act may be NULL.  If y_act != NULL it receives act(conv+bias) WITHOUT the
+ * residual (what the backward pass needs to rebuild the LeakyReLU mask of a ResidualAtom).
+ */
+int ms_conv1d_fwd(const ms_conv1d_desc* d, const float* x, const float* w, const float* bias,
+                  const float* residual, float* y, float* y_act, void* workspace,
+                  size_t workspace_bytes, ms_stream_t stream);
+
+/*
+ * gx = gx_add + conv1d_backward_input(gy * act'(y_act), w)
+ * (autograd of the op above w.r.t. x).  y_act NULL => gy is already w.r.t. the pre-activation.
+ * gx_add NULL => no add.  pad_mode must be ZERO.
+ */
+int ms_conv1d_bwd_data(const ms_conv1d_desc* d, const float* gy, const float* y_act,
+                       const float* w, const float* gx_add, float* gx, void* workspace,
+                       size_t workspace_bytes, ms_stream_t stream);
+
+/*
+ * gw = beta*gw + conv1d_backward_weight(x, gy * act'(y_act)); gb likewise (gb may be NULL).
+ * beta is 0 (overwrite) or 1 (accumulate: the shared FullDiscriminator is applied at 3 scales,
+ * discriminator/melgan.py:16-24, so its weight grads sum over scales).
+ */
+int ms_conv1d_bwd_weight(const ms_conv1d_desc* d, const float* x, const float* gy,
+                         const float* y_act, float* gw, float* gb, float beta, void* workspace,
+                         size_t workspace_bytes, ms_stream_t stream);
+
+/* which: 0 fwd, 1 bwd_data, 2 bwd_weight */
+size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which);
+
+/* Name of the device kernel the dispatch selects for this geometry (which: 0 fwd, 1 bwd_data,
+ * 2 bwd_weight) -- lets a profiler line be matched to a layer.  Static string, never NULL. */
+const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which);
+
+/* nn.ConvTranspose1d geometry.  w is (Cin, Cout, K).  Lout = (Lin-1)*stride - 2*pad + K */
+typedef struct ms_convt1d_desc {
+    int32_t B, Cin, Lin, Cout, K, stride, pad;
+    int32_t act;
+    float slope;
+} ms_convt1d_desc;
+
+int ms_convt1d_out_len(const ms_convt1d_desc* d);
+
+/* y = act(conv_transpose1d(x, w) + bias).  Replaces generator/full.py:27-28,31-32,35-36,39-40. */
+int ms_convt1d_fwd(const ms_convt1d_desc* d, const float* x, const float* w, const float* bias,
+                   float* y, void* workspace, size_t workspace_bytes, ms_stream_t stream);
+/* gx = conv_transpose1d_backward_input(gy * act'(y_act), w) */
+int ms_convt1d_bwd_data(const ms_convt1d_desc* d, const float* gy, const float* y_act,
+                        const float* w, float* gx, void* workspace, size_t workspace_bytes,
+                        ms_stream_t stream);
+/* gw = beta*gw + backward_weight(x, gy * act'(y_act)); gb likewise */
+int ms_convt1d_bwd_weight(const ms_convt1d_desc* d, const float* x, const float* gy,
+                          const float* y_act, float* gw, float* gb, float beta, void* workspace,
+                          size_t workspace_bytes, ms_stream_t stream);
+size_t ms_convt1d_workspace_bytes(const ms_convt1d_desc* d, int which);
+const char* ms_convt1d_kernel_name(const ms_convt1d_desc* d, int which);
+
+/*
+ * F.avg_pool1d(x, kernel_size=4, stride=2, padding=2) with count_include_pad=True
+ * (discriminator/melgan.py:22).  x is (rows, Lin) with rows = B*C; Lout = (Lin + 2*2 - 4)/2 + 1.
+ */
+int ms_avg_pool1d_4_2_2_fwd(const float* x, float* y, int64_t rows, int32_t Lin, ms_stream_t stream);
+int ms_avg_pool1d_4_2_2_bwd(const float* gy, const float* gx_add, float* gx, int64_t rows,
+                            int32_t Lin, ms_stream_t stream);
+
+/* gpre = gy * act'(y_act), elementwise (stand-alone form of the fused modifier above) */
+int ms_act_bwd(const float* y_act, const float* gy, float* gpre, int64_t n, int32_t act,
+               float slope, ms_stream_t stream);
+/* out = a + b */
+int ms_add(const float* a, const float* b, float* out, int64_t n, ms_stream_t stream);
+
+/*
+ * Losses (loss/loss.py).  Every *_fwd writes ONE float to `out` (device); every *_bwd reads
+ * the upstream scalar gradient from the device pointer `gout` (so no host sync is needed) and
+ * multiplies it by the host constant `scale`.
+ *   hinge_d : mean(relu(1 - r) + relu(1 + f))          loss.py:17-18
+ *   neg_mean: mean(-f)      (hinge generator loss)     loss.py:9-10
+ *   l1_mean : mean(|r - f|) (F.l1_loss)                loss.py:62
+ *   ls_d / ls_g: least-squares variants                loss.py:5-6,13-14
+ * l1_mean_fwd needs workspace (ms_reduce_workspace_bytes(n)).
+ */
+size_t ms_reduce_workspace_bytes(int64_t n);
+int ms_hinge_d_fwd(const float* r, const float* f, int64_t n, float* out, void* workspace,
+                   size_t workspace_bytes, ms_stream_t stream);
+int ms_hinge_d_bwd(const float* r, const float* f, int64_t n, const float* gout, float scale,
+                   float* gr, float* gf, ms_stream_t stream);
+int ms_neg_mean_fwd(const float* f, int64_t n, float* out, void* workspace,
+                    size_t workspace_bytes, ms_stream_t stream);
+int ms_neg_mean_bwd(int64_t n, const float* gout, float scale, float* gf, ms_stream_t stream);
+int ms_l1_mean_fwd(const float* r, const float* f, int64_t n, float* out, void* workspace,
+                   size_t workspace_bytes, ms_stream_t stream);
+/* gf = (accumulate ? gf : 0) + sign(f - r) * scale * (*gout) / n */
+int ms_l1_mean_bwd(const float* r, const float* f, int64_t n, const float* gout, float scale,
+                   float* gf, int32_t accumulate, ms_stream_t stream);
+int ms_ls_g_fwd(const float* j, int64_t n, float* out, void* workspace, size_t workspace_bytes,
+                ms_stream_t stream);
+int ms_ls_g_bwd(const float* j, int64_t n, const float* gout, float scale, float* gj,
+                ms_stream_t stream);
+int ms_ls_d_fwd(const float* r, const float* f, int64_t n, float* out, void* workspace,
+                size_t workspace_bytes, ms_stream_t stream);
+int ms_ls_d_bwd(const float* r, const float* f, int64_t n, const float* gout, float scale,
+                float* gr, float* gf, ms_stream_t stream);
+/* out[0] = sum_i coef[i] * (*terms[i]) for n device scalars laid out contiguously in `terms` */
+int ms_weighted_sum(const float* terms, const float* coef, int32_t n, float* out,
+                    ms_stream_t stream);
+
+/*
+ * torch.optim.Adam step (no weight decay / amsgrad) over one flat fp32 bucket, as configured at
+ * experiment/experiment.py:111-117.  `step` is a DEVICE int32 counter: the call increments it and
+ * uses the new value for the bias corrections (keeps the call graph-capturable).  Gradients are
+ * multiplied by grad_scale first (1/world_size after a summing all-reduce).
+ */
+int ms_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float grad_scale, int32_t* step, ms_stream_t stream);
+
+/*
+ * Audio2Mel.forward (feature/feature.py:39-59): right-pad (n_fft-hop)/2 zeros, windowed STFT
+ * (center=False), magnitude, mel_basis @ magnitude, log10(clamp(., 1e-5)).
+ * audio (B, N); window (n_fft); mel_basis (n_mel, n_fft/2+1); out (B, n_mel, frames).
+ * n_fft must be a power of two in [64, 4096].
+ */
+int ms_audio2mel_frames(int32_t N, int32_t n_fft, int32_t hop);
+int ms_audio2mel_fwd(const float* audio, int32_t B, int32_t N, const float* window, int32_t n_fft,
+                     int32_t hop, const float* mel_basis, int32_t n_mel, float* out,
+                     ms_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSYNTH_H */

@@ -1,0 +1,202 @@
+// extern "C" entry points for the convolution family: argument validation, geometry, and the
+// dispatch between the direct (vector FMA) kernels and the f32-MFMA implicit-GEMM kernels.
+#include "ms_common.h"
+#include "conv_mfma.h"
+
+namespace {
+
+bool make_conv(const ms_conv1d_desc* d, ConvP* p) {
+    if (!d) return false;
+    if (d->B <= 0 || d->Cin <= 0 || d->Lin <= 0 || d->Cout <= 0 || d->K <= 0 || d->stride <= 0 ||
+        d->pad < 0 || d->dil <= 0 || d->groups <= 0)
+        return false;
+    if (d->Cin % d->groups || d->Cout % d->groups) return false;
+    if (d->pad_mode != MS_PAD_ZERO && d->pad_mode != MS_PAD_REFLECT) return false;
+    if (d->pad_mode == MS_PAD_REFLECT && d->pad >= d->Lin) return false;  // nn.ReflectionPad1d rule
+    if (d->act < MS_ACT_NONE || d->act > MS_ACT_TANH) return false;
+    const int eff = d->Lin + 2 * d->pad - d->dil * (d->K - 1) - 1;
+    if (eff < 0) return false;
+    p->B = d->B; p->Cin = d->Cin; p->Lin = d->Lin; p->Cout = d->Cout; p->K = d->K;
+    p->stride = d->stride; p->pad = d->pad; p->dil = d->dil; p->groups = d->groups;
+    p->Cg = d->Cin / d->groups; p->Og = d->Cout / d->groups;
+    p->Lout = eff / d->stride + 1;
+    p->pad_mode = d->pad_mode; p->act = d->act; p->slope = d->slope;
+    return true;
+}
+
+// conv whose backward-data IS the transposed conv: channels swap roles (w layout (Cin_T, Cout_T, K)
+// equals the (Cout_conv, Cin_conv, K) layout of that conv).
+bool make_convt(const ms_convt1d_desc* d, ConvP* p) {
+    if (!d) return false;
+    if (d->B <= 0 || d->Cin <= 0 || d->Lin <= 0 || d->Cout <= 0 || d->K <= 0 || d->stride <= 0 ||
+        d->pad < 0)
+        return false;
+    if (d->act < MS_ACT_NONE || d->act > MS_ACT_TANH) return false;
+    const int Lout = (d->Lin - 1) * d->stride - 2 * d->pad + d->K;
+    if (Lout <= 0) return false;
+    p->B = d->B; p->Cin = d->Cout; p->Lin = Lout; p->Cout = d->Cin; p->K = d->K;
+    p->stride = d->stride; p->pad = d->pad; p->dil = 1; p->groups = 1;
+    p->Cg = d->Cout; p->Og = d->Cin;
+    p->Lout = d->Lin;
+    p->pad_mode = MS_PAD_ZERO; p->act = d->act; p->slope = d->slope;
+    // consistency: the conv's own output length for Lin=Lout_T must give back Lin_T
+    const int chk = (Lout + 2 * d->pad - (d->K - 1) - 1) / d->stride + 1;
+    return chk == d->Lin;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ms_version(void) { return MSYNTH_VERSION; }
+
+const char* ms_status_string(int status) {
+    switch (status) {
+        case MS_OK: return "ok";
+        case MS_ERR_INVALID_ARG: return "invalid argument (null pointer, bad size or inconsistent shape)";
+        case MS_ERR_UNSUPPORTED: return "configuration not supported by the MI355X kernels";
+        case MS_ERR_WORKSPACE: return "workspace missing or too small";
+        case MS_ERR_LAUNCH: return "HIP kernel launch failed";
+        default: return "unknown status";
+    }
+}
+
+int ms_conv1d_out_len(const ms_conv1d_desc* d) {
+    ConvP p;
+    return make_conv(d, &p) ? p.Lout : MS_ERR_INVALID_ARG;
+}
+
+int ms_conv1d_fwd(const ms_conv1d_desc* d, const float* x, const float* w, const float* bias,
+                  const float* residual, float* y, float* y_act, void* workspace,
+                  size_t workspace_bytes, ms_stream_t stream) {
+    ConvP p;
+    if (!make_conv(d, &p) || !x || !w || !y) return MS_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (msm_fwd_applicable(p))
+        return msm_conv1d_fwd(p, x, nullptr, 0, w, bias, residual, y, y_act, workspace, workspace_bytes, s);
+    return msk_conv1d_fwd_direct(p, x, nullptr, 0, w, bias, residual, y, y_act, s);
+}
+
+int ms_conv1d_bwd_data(const ms_conv1d_desc* d, const float* gy, const float* y_act,
+                       const float* w, const float* gx_add, float* gx, void* workspace,
+                       size_t workspace_bytes, ms_stream_t stream) {
+    ConvP p;
+    if (!make_conv(d, &p) || !gy || !w || !gx) return MS_ERR_INVALID_ARG;
+    if (p.pad_mode != MS_PAD_ZERO) return MS_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (msm_bwd_data_applicable(p))
+        return msm_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, workspace, workspace_bytes, s);
+    return msk_conv1d_bwd_data_direct(p, gy, y_act, w, nullptr, MS_ACT_NONE, gx_add, gx, s);
+}
+
+int ms_conv1d_bwd_weight(const ms_conv1d_desc* d, const float* x, const float* gy,
+                         const float* y_act, float* gw, float* gb, float beta, void* workspace,
+                         size_t workspace_bytes, ms_stream_t stream) {
+    ConvP p;
+    if (!make_conv(d, &p) || !x || !gy || !gw) return MS_ERR_INVALID_ARG;
+    if (beta != 0.f && beta != 1.f) return MS_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (msm_bwd_weight_applicable(p))
+        return msm_conv1d_bwd_weight(p, x, nullptr, 0, gy, y_act, p.act, gw, gb, beta, workspace,
+                                     workspace_bytes, s);
+    return msk_conv1d_bwd_weight_direct(p, x, nullptr, 0, gy, y_act, p.act, gw, gb, beta, workspace,
+                                        workspace_bytes, s);
+}
+
+size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which) {
+    ConvP p;
+    if (!make_conv(d, &p)) return 0;
+    if (which == 0) return msm_fwd_applicable(p) ? msm_fwd_ws(p) : 0;
+    if (which == 1) return msm_bwd_data_applicable(p) ? msm_bwd_data_ws(p) : 0;
+    if (which == 2) return msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p);
+    return 0;
+}
+
+const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which) {
+    ConvP p;
+    if (!make_conv(d, &p)) return "";
+    if (which == 0) return msm_fwd_applicable(p) ? msm_fwd_name(p) : msk_conv1d_fwd_direct_name(p);
+    if (which == 1) return msm_bwd_data_applicable(p) ? msm_bwd_data_name(p) : msk_conv1d_bwd_data_direct_name(p);
+    if (which == 2) return msm_bwd_weight_applicable(p) ? msm_bwd_weight_name(p) : msk_conv1d_bwd_weight_direct_name(p);
+    return "";
+}
+
+const char* ms_convt1d_kernel_name(const ms_convt1d_desc* d, int which) {
+    ConvP p;
+    if (!make_convt(d, &p)) return "";
+    if (which == 0) return msm_convt_fwd_applicable(p) ? msm_convt_fwd_name(p) : msk_conv1d_bwd_data_direct_name(p);
+    if (which == 1) {
+        ConvP q = p;
+        q.act = MS_ACT_NONE;
+        return msm_fwd_applicable(q) ? msm_fwd_name(q) : msk_conv1d_fwd_direct_name(q);
+    }
+    if (which == 2) return msm_bwd_weight_applicable(p) ? msm_bwd_weight_name(p) : msk_conv1d_bwd_weight_direct_name(p);
+    return "";
+}
+
+int ms_convt1d_out_len(const ms_convt1d_desc* d) {
+    ConvP p;
+    return make_convt(d, &p) ? p.Lin : MS_ERR_INVALID_ARG;
+}
+
+// y = act(bias + conv_transpose(x, w)) == backward-data of the mirrored conv, with epilogue
+int ms_convt1d_fwd(const ms_convt1d_desc* d, const float* x, const float* w, const float* bias,
+                   float* y, void* workspace, size_t workspace_bytes, ms_stream_t stream) {
+    ConvP p;
+    if (!make_convt(d, &p) || !x || !w || !y) return MS_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (msm_convt_fwd_applicable(p))
+        return msm_convt1d_fwd(p, x, w, bias, y, workspace, workspace_bytes, s);
+    return msk_conv1d_bwd_data_direct(p, x, nullptr, w, bias, p.act, nullptr, y, s);
+}
+
+// gx = conv(gy * act'(y_act), w) with the mirrored conv geometry (no bias / activation)
+int ms_convt1d_bwd_data(const ms_convt1d_desc* d, const float* gy, const float* y_act,
+                        const float* w, float* gx, void* workspace, size_t workspace_bytes,
+                        ms_stream_t stream) {
+    ConvP p;
+    if (!make_convt(d, &p) || !gy || !w || !gx) return MS_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    ConvP q = p;
+    q.act = MS_ACT_NONE;
+    if (msm_fwd_applicable(q))
+        return msm_conv1d_fwd(q, gy, y_act, p.act, w, nullptr, nullptr, gx, nullptr, workspace,
+                              workspace_bytes, s);
+    return msk_conv1d_fwd_direct(q, gy, y_act, p.act, w, nullptr, nullptr, gx, nullptr, s);
+}
+
+// gw[ci_T, co_T, k] = sum x[b,ci_T,i] * gp[b,co_T,i*stride - pad + k]: the mirrored conv's weight
+// grad with its "input" = gp (activation modifier on that side) and its "output grad" = x.
+int ms_convt1d_bwd_weight(const ms_convt1d_desc* d, const float* x, const float* gy,
+                          const float* y_act, float* gw, float* gb, float beta, void* workspace,
+                          size_t workspace_bytes, ms_stream_t stream) {
+    ConvP p;
+    if (!make_convt(d, &p) || !x || !gy || !gw) return MS_ERR_INVALID_ARG;
+    if (beta != 0.f && beta != 1.f) return MS_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (msm_bwd_weight_applicable(p))
+        rc = msm_conv1d_bwd_weight(p, gy, y_act, p.act, x, nullptr, 0, gw, nullptr, beta, workspace,
+                                   workspace_bytes, s);
+    else
+        rc = msk_conv1d_bwd_weight_direct(p, gy, y_act, p.act, x, nullptr, 0, gw, nullptr, beta,
+                                          workspace, workspace_bytes, s);
+    if (rc != MS_OK) return rc;
+    if (gb) return msk_channel_sum(gy, y_act, p.act, p.slope, p.B, p.Cin, p.Lin, gb, beta, s);
+    return MS_OK;
+}
+
+size_t ms_convt1d_workspace_bytes(const ms_convt1d_desc* d, int which) {
+    ConvP p;
+    if (!make_convt(d, &p)) return 0;
+    if (which == 0) return msm_convt_fwd_applicable(p) ? msm_convt_fwd_ws(p) : 0;
+    if (which == 1) {
+        ConvP q = p;
+        q.act = MS_ACT_NONE;
+        return msm_fwd_applicable(q) ? msm_fwd_ws(q) : 0;
+    }
+    if (which == 2) return msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,29 @@
+// f32-MFMA implicit-GEMM convolution kernels (conv_mfma.hip): applicability predicates,
+// workspace queries and launchers used by api.hip.
+#pragma once
+#include "ms_common.h"
+
+bool msm_fwd_applicable(const ConvP& p);
+bool msm_bwd_data_applicable(const ConvP& p);
+bool msm_bwd_weight_applicable(const ConvP& p);
+bool msm_convt_fwd_applicable(const ConvP& p);  // p = mirrored conv of the transposed conv
+size_t msm_fwd_ws(const ConvP& p);
+size_t msm_bwd_data_ws(const ConvP& p);
+size_t msm_bwd_weight_ws(const ConvP& p);
+size_t msm_convt_fwd_ws(const ConvP& p);
+
+const char* msm_fwd_name(const ConvP& p);
+const char* msm_bwd_data_name(const ConvP& p);
+const char* msm_bwd_weight_name(const ConvP& p);
+const char* msm_convt_fwd_name(const ConvP& p);
+
+int msm_conv1d_fwd(const ConvP& p, const float* x, const float* x_act, int x_act_kind,
+                   const float* w, const float* bias, const float* residual, float* y,
+                   float* y_act, void* ws, size_t ws_bytes, hipStream_t s);
+int msm_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, const float* w,
+                        const float* gx_add, float* gx, void* ws, size_t ws_bytes, hipStream_t s);
+int msm_conv1d_bwd_weight(const ConvP& p, const float* x, const float* x_act, int x_act_kind,
+                          const float* gy, const float* y_act, int y_act_kind, float* gw,
+                          float* gb, float beta, void* ws, size_t ws_bytes, hipStream_t s);
+int msm_convt1d_fwd(const ConvP& p, const float* x, const float* w, const float* bias, float* y,
+                    void* ws, size_t ws_bytes, hipStream_t s);

@@ -1,0 +1,351 @@
+// HBM-bound elementwise / reduction kernels: avg-pool, activation backward, the GAN losses
+// (wavefront-shuffle reductions), fused Adam.  All streaming, coalesced along contiguous
+// audio frames, grid-strided over <= 2048 workgroups.
+#include "ms_common.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 2048;
+
+inline int grid_for(int64_t n, int per_thread = 4) {
+    int64_t b = (n + 256LL * per_thread - 1) / (256LL * per_thread);
+    if (b < 1) b = 1;
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    return (int)b;
+}
+
+// ---- avg_pool1d(k=4, s=2, p=2), zeros counted in the divisor
+__global__ __launch_bounds__(256) void k_pool_fwd(const float* __restrict__ x,
+                                                 float* __restrict__ y, int64_t rows, int Lin,
+                                                 int Lout) {
+    const int64_t total = rows * Lout;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / Lout;
+        const int o = (int)(i - r * Lout);
+        const float* xr = x + r * Lin;
+        const int s = o * 2 - 2;
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = s + j;
+            if (q >= 0 && q < Lin) a += xr[q];
+        }
+        y[i] = a * 0.25f;
+    }
+}
+
+// gx[i] = gx_add[i] + 0.25 * sum of gy[o] over windows o that cover i (o*2-2 <= i <= o*2+1)
+__global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ gy,
+                                                 const float* __restrict__ gx_add,
+                                                 float* __restrict__ gx, int64_t rows, int Lin,
+                                                 int Lout) {
+    const int64_t total = rows * Lin;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / Lin;
+        const int p = (int)(i - r * Lin);
+        const float* gr = gy + r * Lout;
+        // o in [ceil((p-1)/2), floor((p+2)/2)]
+        const int o_lo = p >> 1;  // ceil((p-1)/2) == p/2 for p >= 0 (p=0 -> 0)
+        const int o_hi = (p + 2) >> 1;
+        float a = 0.f;
+        for (int o = o_lo; o <= o_hi; ++o)
+            if (o < Lout) a += gr[o];
+        a *= 0.25f;
+        if (gx_add) a += gx_add[i];
+        gx[i] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ ya,
+                                                const float* __restrict__ gy,
+                                                float* __restrict__ out, int64_t n, int act,
+                                                float slope) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = ms_act_grad(gy[i], ya[i], act, slope);
+}
+
+__global__ __launch_bounds__(256) void k_add(const float* __restrict__ a,
+                                            const float* __restrict__ b, float* __restrict__ out,
+                                            int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = a[i] + b[i];
+}
+
+// ---- reductions: per-element term selected by MODE, two deterministic stages
+enum { R_HINGE_D = 0, R_NEG = 1, R_L1 = 2, R_LS_G = 3, R_LS_D = 4 };
+
+template <int MODE>
+__device__ __forceinline__ float term(const float* __restrict__ a, const float* __restrict__ b,
+                                      int64_t i) {
+    if (MODE == R_HINGE_D) return fmaxf(1.f - a[i], 0.f) + fmaxf(1.f + b[i], 0.f);
+    if (MODE == R_NEG) return -a[i];
+    if (MODE == R_L1) return fabsf(a[i] - b[i]);
+    if (MODE == R_LS_G) { const float d = a[i] - 1.f; return 0.5f * d * d; }
+    { const float d = a[i] - 1.f; return 0.5f * (d * d + b[i] * b[i]); }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_reduce_stage1(const float* __restrict__ a,
+                                                      const float* __restrict__ b, int64_t n,
+                                                      float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        s += term<MODE>(a, b, i);
+    const float tot = ms_block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_reduce_stage2(const float* __restrict__ partial, int np,
+                                                      float inv_n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < np; i += 256) s += partial[i];
+    const float tot = ms_block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = tot * inv_n;
+}
+
+template <int MODE>
+int reduce_mean(const float* a, const float* b, int64_t n, float* out, void* ws, size_t ws_bytes,
+                hipStream_t s) {
+    if (!a || !out || n <= 0) return MS_ERR_INVALID_ARG;
+    const int nb = grid_for(n, 8);
+    if (!ws || ws_bytes < (size_t)nb * sizeof(float)) return MS_ERR_WORKSPACE;
+    float* partial = (float*)ws;
+    hipLaunchKernelGGL((k_reduce_stage1<MODE>), dim3(nb), dim3(256), 0, s, a, b, n, partial);
+    MS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_reduce_stage2, dim3(1), dim3(256), 0, s, partial, nb, 1.0f / (float)n, out);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+__global__ __launch_bounds__(256) void k_hinge_d_bwd(const float* __restrict__ r,
+                                                    const float* __restrict__ f, int64_t n,
+                                                    const float* __restrict__ gout, float scale,
+                                                    float* __restrict__ gr,
+                                                    float* __restrict__ gf) {
+    const float g = gout[0] * scale / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (gr) gr[i] = (1.f - r[i] > 0.f) ? -g : 0.f;
+        if (gf) gf[i] = (1.f + f[i] > 0.f) ? g : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_scaled(int64_t n, const float* __restrict__ gout,
+                                                    float scale, float* __restrict__ out) {
+    const float g = gout[0] * scale / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = g;
+}
+
+__global__ __launch_bounds__(256) void k_l1_bwd(const float* __restrict__ r,
+                                               const float* __restrict__ f, int64_t n,
+                                               const float* __restrict__ gout, float scale,
+                                               float* __restrict__ gf, int accumulate) {
+    const float g = gout[0] * scale / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = f[i] - r[i];
+        float v = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+        if (accumulate) v += gf[i];
+        gf[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ls_bwd(const float* __restrict__ r,
+                                               const float* __restrict__ f, int64_t n,
+                                               const float* __restrict__ gout, float scale,
+                                               float* __restrict__ gr, float* __restrict__ gf) {
+    const float g = gout[0] * scale / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (gr) gr[i] = g * (r[i] - 1.f);
+        if (gf) gf[i] = g * f[i];
+    }
+}
+
+__global__ void k_weighted_sum(const float* __restrict__ terms, const float* __restrict__ coef,
+                               int n, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += coef[i] * terms[i];
+        out[0] = s;
+    }
+}
+
+// ---- Adam
+__global__ void k_adam_tick(int32_t* step) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1;
+}
+
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g,
+                                             float* __restrict__ m, float* __restrict__ v,
+                                             int64_t n, float lr, float b1, float b2, float eps,
+                                             float gscale, const int32_t* __restrict__ step) {
+    // bias corrections in double, once per thread (torch computes them on the host in double)
+    const double t = (double)step[0];
+    const double bc1 = 1.0 - pow((double)b1, t);
+    const double bc2 = 1.0 - pow((double)b2, t);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    const float omb1 = 1.f - b1, omb2 = 1.f - b2;
+    const int64_t n4 = n >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+        float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gi = ga[j] * gscale;
+            ma[j] = b1 * ma[j] + omb1 * gi;
+            va[j] = b2 * va[j] + omb2 * gi * gi;
+            const float denom = sqrtf(va[j]) * inv_bc2_sqrt + eps;
+            pa[j] = pa[j] - step_size * (ma[j] / denom);
+        }
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    // tail (n not a multiple of 4)
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + omb1 * gi;
+        const float vi = b2 * v[i] + omb2 * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ms_avg_pool1d_4_2_2_fwd(const float* x, float* y, int64_t rows, int32_t Lin, ms_stream_t stream) {
+    if (!x || !y || rows <= 0 || Lin <= 0) return MS_ERR_INVALID_ARG;
+    const int Lout = (Lin + 4 - 4) / 2 + 1;
+    hipLaunchKernelGGL(k_pool_fwd, dim3(grid_for(rows * Lout)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, rows, Lin, Lout);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_avg_pool1d_4_2_2_bwd(const float* gy, const float* gx_add, float* gx, int64_t rows,
+                            int32_t Lin, ms_stream_t stream) {
+    if (!gy || !gx || rows <= 0 || Lin <= 0) return MS_ERR_INVALID_ARG;
+    const int Lout = (Lin + 4 - 4) / 2 + 1;
+    hipLaunchKernelGGL(k_pool_bwd, dim3(grid_for(rows * Lin)), dim3(256), 0, (hipStream_t)stream,
+                       gy, gx_add, gx, rows, Lin, Lout);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_act_bwd(const float* y_act, const float* gy, float* gpre, int64_t n, int32_t act,
+               float slope, ms_stream_t stream) {
+    if (!y_act || !gy || !gpre || n <= 0) return MS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_act_bwd, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y_act, gy,
+                       gpre, n, act, slope);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_add(const float* a, const float* b, float* out, int64_t n, ms_stream_t stream) {
+    if (!a || !b || !out || n <= 0) return MS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_add, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+size_t ms_reduce_workspace_bytes(int64_t n) { return (size_t)grid_for(n, 8) * sizeof(float); }
+
+int ms_hinge_d_fwd(const float* r, const float* f, int64_t n, float* out, void* ws, size_t wsb,
+                   ms_stream_t stream) {
+    if (!f) return MS_ERR_INVALID_ARG;
+    return reduce_mean<R_HINGE_D>(r, f, n, out, ws, wsb, (hipStream_t)stream);
+}
+
+int ms_hinge_d_bwd(const float* r, const float* f, int64_t n, const float* gout, float scale,
+                   float* gr, float* gf, ms_stream_t stream) {
+    if (!r || !f || !gout || n <= 0) return MS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_hinge_d_bwd, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, r, f, n,
+                       gout, scale, gr, gf);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_neg_mean_fwd(const float* f, int64_t n, float* out, void* ws, size_t wsb, ms_stream_t stream) {
+    return reduce_mean<R_NEG>(f, nullptr, n, out, ws, wsb, (hipStream_t)stream);
+}
+
+int ms_neg_mean_bwd(int64_t n, const float* gout, float scale, float* gf, ms_stream_t stream) {
+    if (!gout || !gf || n <= 0) return MS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_fill_scaled, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, gout,
+                       -scale, gf);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_l1_mean_fwd(const float* r, const float* f, int64_t n, float* out, void* ws, size_t wsb,
+                   ms_stream_t stream) {
+    if (!f) return MS_ERR_INVALID_ARG;
+    return reduce_mean<R_L1>(r, f, n, out, ws, wsb, (hipStream_t)stream);
+}
+
+int ms_l1_mean_bwd(const float* r, const float* f, int64_t n, const float* gout, float scale,
+                   float* gf, int32_t accumulate, ms_stream_t stream) {
+    if (!r || !f || !gout || !gf || n <= 0) return MS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_l1_bwd, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, r, f, n, gout,
+                       scale, gf, accumulate);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_ls_g_fwd(const float* j, int64_t n, float* out, void* ws, size_t wsb, ms_stream_t stream) {
+    return reduce_mean<R_LS_G>(j, nullptr, n, out, ws, wsb, (hipStream_t)stream);
+}
+
+int ms_ls_g_bwd(const float* j, int64_t n, const float* gout, float scale, float* gj,
+                ms_stream_t stream) {
+    if (!j || !gout || !gj || n <= 0) return MS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_ls_bwd, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, j, j, n, gout,
+                       scale, gj, (float*)nullptr);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_ls_d_fwd(const float* r, const float* f, int64_t n, float* out, void* ws, size_t wsb,
+                ms_stream_t stream) {
+    if (!f) return MS_ERR_INVALID_ARG;
+    return reduce_mean<R_LS_D>(r, f, n, out, ws, wsb, (hipStream_t)stream);
+}
+
+int ms_ls_d_bwd(const float* r, const float* f, int64_t n, const float* gout, float scale,
+                float* gr, float* gf, ms_stream_t stream) {
+    if (!r || !f || !gout || n <= 0) return MS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_ls_bwd, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, r, f, n, gout,
+                       scale, gr, gf);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_weighted_sum(const float* terms, const float* coef, int32_t n, float* out, ms_stream_t stream) {
+    if (!terms || !coef || !out || n <= 0) return MS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_weighted_sum, dim3(1), dim3(64), 0, (hipStream_t)stream, terms, coef, n, out);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float grad_scale, int32_t* step, ms_stream_t stream) {
+    if (!p || !g || !m || !v || !step || n <= 0) return MS_ERR_INVALID_ARG;
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return MS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(64), 0, (hipStream_t)stream, step);
+    MS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_adam, dim3(grid_for(n, 16)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       lr, beta1, beta2, eps, grad_scale, step);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// Shared device/host helpers for libmsynth_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "msynth.h"
+
+#define MS_WAVE 64
+
+#define MS_CHECK_LAUNCH()                                   \
+    do {                                                    \
+        if (hipGetLastError() != hipSuccess) return MS_ERR_LAUNCH; \
+    } while (0)
+
+struct ConvP {  // kernel-side copy of ms_conv1d_desc (+ derived sizes)
+    int B, Cin, Lin, Cout, Lout, K, stride, pad, dil, groups, Cg, Og, pad_mode, act;
+    float slope;
+};
+
+static inline int ms_ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int ms_floor_div(int a, int b) {  // b > 0
+    int q = a / b;
+    if ((a % b) && (a < 0)) --q;
+    return q;
+}
+
+__device__ __forceinline__ float ms_apply_act(float v, int act, float slope) {
+    if (act == MS_ACT_LRELU) return v > 0.f ? v : v * slope;
+    if (act == MS_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+// d act(pre)/d pre expressed through the saved post-activation value ya
+__device__ __forceinline__ float ms_act_grad(float g, float ya, int act, float slope) {
+    if (act == MS_ACT_LRELU) return ya > 0.f ? g : g * slope;
+    if (act == MS_ACT_TANH) return g * (1.f - ya * ya);
+    return g;
+}
+
+// position in the unpadded row for padded coordinate t; -1 = zero padding
+__device__ __forceinline__ int ms_src_index(int t, int L, int pad_mode) {
+    if (t >= 0 && t < L) return t;
+    if (pad_mode == MS_PAD_REFLECT) {
+        if (t < 0) t = -t;
+        if (t >= L) t = 2 * (L - 1) - t;
+        return (t >= 0 && t < L) ? t : -1;
+    }
+    return -1;
+}
+
+__device__ __forceinline__ float ms_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum; result valid in thread 0.  `red` is >= (blockDim.x/64) floats of LDS.
+__device__ __forceinline__ float ms_block_sum(float v, float* red) {
+    v = ms_wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) r += red[i];
+    }
+    return r;
+}
+
+// internal launchers (defined in the .hip files, called from ms_api.hip)
+int msk_conv1d_fwd_direct(const ConvP& p, const float* x, const float* x_act, int x_act_kind,
+                          const float* w, const float* bias, const float* residual, float* y,
+                          float* y_act, hipStream_t s);
+int msk_conv1d_bwd_data_direct(const ConvP& p, const float* gy, const float* y_act, const float* w,
+                               const float* bias, int out_act, const float* gx_add, float* gx,
+                               hipStream_t s);
+size_t msk_conv1d_bwd_weight_ws(const ConvP& p);
+int msk_conv1d_bwd_weight_direct(const ConvP& p, const float* x, const float* x_act,
+                                 int x_act_kind, const float* gy, const float* y_act,
+                                 int y_act_kind, float* gw, float* gb, float beta, void* ws,
+                                 size_t ws_bytes, hipStream_t s);
+const char* msk_conv1d_fwd_direct_name(const ConvP& p);
+const char* msk_conv1d_bwd_data_direct_name(const ConvP& p);
+const char* msk_conv1d_bwd_weight_direct_name(const ConvP& p);
+int msk_channel_sum(const float* g, const float* y_act, int act, float slope, int B, int C, int L,
+                    float* out, float beta, hipStream_t s);

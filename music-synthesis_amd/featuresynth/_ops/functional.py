@@ -1,0 +1,305 @@
+"""torch.autograd.Function wrappers over the C-ABI kernels.
+
+Coarse-grained on purpose: one Function per network (generator, multi-scale discriminator) and
+one per composite loss, so that autograd only stitches G -> D -> loss together and every
+arithmetic pass (including gradient accumulation across the three discriminator scales and the
+skip / feature-matching gradient adds) runs in the hand-written HIP kernels.  Fine-grained
+Functions (conv, transposed conv, residual atom, pool, scalar losses) back the individual
+nn.Modules so each of them also works on its own.
+"""
+import torch
+from torch.autograd import Function
+
+from . import graph as G
+from . import lib as L
+from . import prims as P
+
+
+def _c(g):
+    return None if g is None else (g if g.is_contiguous() else g.contiguous())
+
+
+def _sink_for(params, needs):
+    """GradSink for `params`.  A parameter bound to a FlatAdam bucket (optim.py) carries
+    `_ms_slot`, its view of the flat gradient bucket: the weight-grad kernels accumulate straight
+    into it (torch semantics: .grad accumulates until zero_grad) and the gradient is not handed
+    to autograd, so no AccumulateGrad add kernels run."""
+    dests, acc, direct = [], [], []
+    for p, need in zip(params, needs):
+        slot = getattr(p, "_ms_slot", None) if need else None
+        dests.append(slot)
+        acc.append(slot is not None)
+        direct.append(slot is not None)
+    return G.GradSink(len(dests), dests, acc), direct
+
+
+def _grads_out(sink, direct, needs):
+    return tuple(None if (d or not n) else t for t, d, n in zip(sink.t, direct, needs))
+
+
+class Conv1dFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, dil, groups, pad_mode, act):
+        d, lo = P.conv_desc(x.shape, w.shape, stride, pad, dil, groups, pad_mode, act)
+        y, _ = P.conv1d_fwd(x, w, b, d, lo)
+        ctx.d = d
+        ctx.save_for_backward(x, w, y)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        gy = _c(gy)
+        d = ctx.d
+        ya = y if d.act != L.ACT_NONE else None
+        gx = gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = P.conv1d_bwd_weight(x, gy, ya, d, w.shape, want_bias=ctx.has_bias)
+        if ctx.needs_input_grad[0]:
+            gx = P.conv1d_bwd_data(gy, ya, w, d)
+        return gx, gw, (gb if ctx.has_bias else None), None, None, None, None, None, None
+
+
+class ConvTranspose1dFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, act):
+        d, lo = P.convt_desc(x.shape, w.shape, stride, pad, act)
+        y = P.convt1d_fwd(x, w, b, d, lo)
+        ctx.d = d
+        ctx.save_for_backward(x, w, y)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        gy = _c(gy)
+        d = ctx.d
+        ya = y if d.act != L.ACT_NONE else None
+        gx = gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = P.convt1d_bwd_weight(x, gy, ya, d, w.shape)
+        if ctx.needs_input_grad[0]:
+            gx = P.convt1d_bwd_data(gy, ya, w, d)
+        return gx, gw, (gb if ctx.has_bias else None), None, None, None
+
+
+class ResidualAtomFn(Function):
+    """x + lrelu(conv_k3(lrelu(conv_k3_dilated(x))))   (util/modules.py:384-388)"""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, dil):
+        out, rec = G.atom_forward(x, w0, b0, w1, b1, dil, save=True)
+        ctx.rec = rec
+        ctx.w = (w0, w1)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        sink = G.GradSink(4)
+        need_w = any(ctx.needs_input_grad[1:5])
+        gx = G.atom_backward(ctx.rec, ctx.w[0], ctx.w[1], g, sink, 0, need_wgrad=need_w,
+                             need_gx=ctx.needs_input_grad[0])
+        return (gx,) + tuple(sink.t) + (None,)
+
+
+class AvgPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return P.avg_pool_fwd(x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return P.avg_pool_bwd(_c(gy), ctx.shape)
+
+
+class GeneratorFn(Function):
+    """Whole MelGanGenerator (generator/full.py:47-50) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        save = any(ctx.needs_input_grad[1:])
+        y, tape = G.gen_forward(x, params, save)
+        ctx.tape = tape
+        ctx.params = params
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if ctx.tape is None:
+            return (None,) * (1 + len(ctx.params))
+        needs = ctx.needs_input_grad[1:]
+        sink, direct = _sink_for(ctx.params, needs)
+        G.gen_backward(ctx.tape, ctx.params, _c(gy), sink)
+        ctx.tape = None
+        return (None,) + _grads_out(sink, direct, needs)
+
+
+class MelGanDiscFn(Function):
+    """MelGanDiscriminator (discriminator/melgan.py:13-27): returns 3x6 features then 3 judgements."""
+
+    @staticmethod
+    def forward(ctx, x, scales, *params):
+        feats, judges, tctx = G.melgan_forward(x, params, scales)
+        ctx.tctx = tctx
+        ctx.params = params
+        ctx.nscale = scales + 1
+        ctx.set_materialize_grads(False)
+        flat = [f for group in feats for f in group] + list(judges)
+        return tuple(flat)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        n = ctx.nscale
+        gouts = [_c(g) for g in gouts]
+        g_feats = [gouts[6 * s:6 * s + 6] for s in range(n)]
+        g_judges = gouts[6 * n:6 * n + n]
+        need_gx = ctx.needs_input_grad[0]
+        need_w = any(ctx.needs_input_grad[2:])
+        needs = ctx.needs_input_grad[2:]
+        sink, direct = _sink_for(ctx.params, needs)
+        gx, _ = G.melgan_backward(ctx.tctx, ctx.params, g_feats, g_judges, sink, need_gx=need_gx,
+                                  need_wgrad=need_w)
+        ctx.tctx = None
+        return (gx, None) + _grads_out(sink, direct, needs)
+
+
+# ----------------------------------------------------------------------- losses
+
+class HingeDFn(Function):
+    @staticmethod
+    def forward(ctx, r, f):
+        ctx.save_for_backward(r, f)
+        return P.hinge_d_fwd(r, f)
+
+    @staticmethod
+    def backward(ctx, g):
+        r, f = ctx.saved_tensors
+        gr, gf = P.hinge_d_bwd(r, f, _c(g), 1.0, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gr, gf
+
+
+class NegMeanFn(Function):
+    @staticmethod
+    def forward(ctx, f):
+        ctx.save_for_backward(f)
+        return P.neg_mean_fwd(f)
+
+    @staticmethod
+    def backward(ctx, g):
+        (f,) = ctx.saved_tensors
+        return P.neg_mean_bwd(f, _c(g))
+
+
+class L1MeanFn(Function):
+    """F.l1_loss(r, f)."""
+
+    @staticmethod
+    def forward(ctx, r, f):
+        ctx.save_for_backward(r, f)
+        return P.l1_mean_fwd(r, f)
+
+    @staticmethod
+    def backward(ctx, g):
+        r, f = ctx.saved_tensors
+        g = _c(g)
+        gr = P.l1_mean_bwd(f, r, g) if ctx.needs_input_grad[0] else None
+        gf = P.l1_mean_bwd(r, f, g) if ctx.needs_input_grad[1] else None
+        return gr, gf
+
+
+class LsGFn(Function):
+    @staticmethod
+    def forward(ctx, j):
+        ctx.save_for_backward(j)
+        return P.ls_g_fwd(j)
+
+    @staticmethod
+    def backward(ctx, g):
+        (j,) = ctx.saved_tensors
+        return P.ls_g_bwd(j, _c(g))
+
+
+class LsDFn(Function):
+    @staticmethod
+    def forward(ctx, r, f):
+        ctx.save_for_backward(r, f)
+        return P.ls_d_fwd(r, f)
+
+    @staticmethod
+    def backward(ctx, g):
+        r, f = ctx.saved_tensors
+        return P.ls_d_bwd(r, f, _c(g))
+
+
+_COEF_CACHE = {}
+
+
+def _coef(values, device):
+    key = (tuple(values), device)
+    t = _COEF_CACHE.get(key)
+    if t is None:
+        t = torch.tensor(values, dtype=torch.float32, device=device)
+        _COEF_CACHE[key] = t
+    return t
+
+
+class MelGanDiscLossFn(Function):
+    """sum_s hinge_discriminator_loss(r_s, f_s)   (loss/loss.py:21-25 with :17-18)"""
+
+    @staticmethod
+    def forward(ctx, n, *js):
+        rs, fs = js[:n], js[n:]
+        terms = torch.empty((n,), dtype=torch.float32, device=rs[0].device)
+        for s in range(n):
+            P.hinge_d_fwd(rs[s], fs[s], terms[s])
+        ctx.n = n
+        ctx.js = js
+        return P.weighted_sum(terms, _coef([1.0] * n, terms.device))
+
+    @staticmethod
+    def backward(ctx, g):
+        n, js = ctx.n, ctx.js
+        g = _c(g)
+        grs, gfs = [], []
+        for s in range(n):
+            gr, gf = P.hinge_d_bwd(js[s], js[n + s], g, 1.0, ctx.needs_input_grad[1 + s],
+                                   ctx.needs_input_grad[1 + n + s])
+            grs.append(gr); gfs.append(gf)
+        return (None,) + tuple(grs) + tuple(gfs)
+
+
+class MelGanGenLossFn(Function):
+    """sum_s mean(-f_j) + weight * sum_{s,l} (1/S)(1/L) l1(r_f, f_f)   (loss/loss.py:28-78)
+
+    inputs: S, Lyr, weight, then S*Lyr real features, S*Lyr fake features, S fake judgements."""
+
+    @staticmethod
+    def forward(ctx, S, Lyr, weight, *ts):
+        nf = S * Lyr
+        rf, ff, fj = ts[:nf], ts[nf:2 * nf], ts[2 * nf:2 * nf + S]
+        dev = fj[0].device
+        terms = torch.empty((S + nf,), dtype=torch.float32, device=dev)
+        for s in range(S):
+            P.neg_mean_fwd(fj[s], terms[s])
+        for i in range(nf):
+            P.l1_mean_fwd(rf[i], ff[i], terms[S + i])
+        fscale = float(weight) * (1.0 / S) * (1.0 / Lyr)
+        ctx.cfg = (S, nf, fscale)
+        ctx.ts = ts
+        return P.weighted_sum(terms, _coef([1.0] * S + [fscale] * nf, dev))
+
+    @staticmethod
+    def backward(ctx, g):
+        S, nf, fscale = ctx.cfg
+        ts = ctx.ts
+        g = _c(g)
+        rf, ff, fj = ts[:nf], ts[nf:2 * nf], ts[2 * nf:2 * nf + S]
+        need = ctx.needs_input_grad[3:]
+        g_rf = [P.l1_mean_bwd(ff[i], rf[i], g, fscale) if need[i] else None for i in range(nf)]
+        g_ff = [P.l1_mean_bwd(rf[i], ff[i], g, fscale) if need[nf + i] else None for i in range(nf)]
+        g_fj = [P.neg_mean_bwd(fj[s], g) if need[2 * nf + s] else None for s in range(S)]
+        return (None, None, None) + tuple(g_rf) + tuple(g_ff) + tuple(g_fj)

@@ -1,0 +1,210 @@
+"""Whole-network forward / backward schedules over the C-ABI kernels (no autograd).
+
+The layer geometry mirrors the reference exactly:
+  generator      /root/reference/featuresynth/generator/full.py:22-45
+  residual atom  /root/reference/featuresynth/util/modules.py:350-405 (dilations 1,3,9 hard-coded :397-399)
+  discriminator  /root/reference/featuresynth/discriminator/full.py:13-22, melgan.py:13-27
+Parameters travel as flat lists in state_dict order.  Every backward fuses the activation
+derivative into the kernels' operand loaders (y_act), the skip/feature-gradient adds into the
+backward-data epilogues (gx_add) and the cross-scale weight-grad sums into the weight-grad
+epilogue (accumulate), so no stand-alone elementwise pass remains.
+"""
+from . import lib as L
+from . import prims as P
+
+G_UPSAMPLE = ((8, 4), (8, 4), (2, 1), (2, 1))     # (stride, padding) of the 4 ConvTranspose1d
+DILATIONS = (1, 3, 9)
+G_NPARAMS = 2 + 4 * (2 + 12) + 2
+# (stride, padding, groups) of FullDiscriminator.main, then judge
+D_LAYERS = ((1, 7, 1), (4, 20, 4), (4, 20, 16), (4, 20, 64), (4, 20, 256), (1, 2, 1))
+D_NPARAMS = 14
+
+
+class GradSink:
+    """Destination slots for parameter gradients (state_dict order).  A slot may be preset to a
+    view of an optimizer's flat gradient bucket; `acc[i]` says whether the next write must add
+    to what is there (a second pass over shared weights) or overwrite it."""
+
+    def __init__(self, n, dests=None, acc=None):
+        self.t = list(dests) if dests is not None else [None] * n
+        self.acc = list(acc) if acc is not None else [False] * n
+
+    def pair(self, i):
+        return self.t[i], self.t[i + 1], (self.acc[i] and self.t[i] is not None)
+
+    def put(self, i, gw, gb):
+        self.t[i], self.t[i + 1] = gw, gb
+        self.acc[i] = self.acc[i + 1] = True
+
+
+def atom_forward(h, w0, b0, w1, b1, dil, save):
+    d0, lo = P.conv_desc(h.shape, w0.shape, pad=dil, dil=dil, act=L.ACT_LRELU)
+    t, _ = P.conv1d_fwd(h, w0, b0, d0, lo)
+    d1, lo = P.conv_desc(t.shape, w1.shape, pad=1, act=L.ACT_LRELU)
+    out, u = P.conv1d_fwd(t, w1, b1, d1, lo, residual=h, want_y_act=save)
+    return out, (d0, d1, h, t, u)
+
+
+def atom_backward(rec, w0, w1, g, sink, i, need_wgrad=True, need_gx=True):
+    """g = d loss / d atom output; parameter grads go to sink slots i..i+3 (w0, b0, w1, b1)."""
+    d0, d1, h, t, u = rec
+    if need_wgrad:
+        gw, gb, acc = sink.pair(i + 2)
+        sink.put(i + 2, *P.conv1d_bwd_weight(t, g, u, d1, w1.shape, gw, gb, acc))
+    gt = P.conv1d_bwd_data(g, u, w1, d1)
+    if need_wgrad:
+        gw, gb, acc = sink.pair(i)
+        sink.put(i, *P.conv1d_bwd_weight(h, gt, t, d0, w0.shape, gw, gb, acc))
+    if not need_gx:
+        return None
+    return P.conv1d_bwd_data(gt, t, w0, d0, gx_add=g)   # skip connection: + g
+
+
+def gen_forward(x, params, save):
+    if len(params) != G_NPARAMS:
+        raise RuntimeError("generator expects %d parameter tensors, got %d" % (G_NPARAMS, len(params)))
+    L.require(x, "generator input")
+    if x.dim() != 3 or x.shape[1] != params[0].shape[1]:
+        raise RuntimeError("generator input must be (B, %d, T), got %s" %
+                           (params[0].shape[1], tuple(x.shape)))
+    i = 0
+    tape = []
+    w, b = params[i], params[i + 1]; i += 2
+    d, lo = P.conv_desc(x.shape, w.shape, pad=3, pad_mode=L.PAD_REFLECT, act=L.ACT_LRELU)
+    h, _ = P.conv1d_fwd(x, w, b, d, lo)
+    tape.append(("conv0", d, x, h))
+    for stride, pad in G_UPSAMPLE:
+        w, b = params[i], params[i + 1]; i += 2
+        dt, lo = P.convt_desc(h.shape, w.shape, stride, pad, act=L.ACT_LRELU)
+        hin = h
+        h = P.convt1d_fwd(hin, w, b, dt, lo)
+        tape.append(("convT", dt, hin, h))
+        for dil in DILATIONS:
+            h, rec = atom_forward(h, params[i], params[i + 1], params[i + 2], params[i + 3], dil, save)
+            i += 4
+            tape.append(("atom", rec))
+    w, b = params[i], params[i + 1]
+    d, lo = P.conv_desc(h.shape, w.shape, pad=3, act=L.ACT_TANH)
+    y, _ = P.conv1d_fwd(h, w, b, d, lo)
+    tape.append(("last", d, h, y))
+    return y, (tape if save else None)
+
+
+def gen_backward(tape, params, gy, sink=None):
+    """Fills (and returns) a GradSink with the parameter grads in state_dict order."""
+    L.require(gy, "generator grad_output")
+    sink = sink if sink is not None else GradSink(G_NPARAMS)
+    i = G_NPARAMS
+    g = gy
+    for rec in reversed(tape):
+        kind = rec[0]
+        if kind == "last":
+            _, d, h, y = rec
+            i -= 2
+            gw, gb, acc = sink.pair(i)
+            sink.put(i, *P.conv1d_bwd_weight(h, g, y, d, params[i].shape, gw, gb, acc))
+            g = P.conv1d_bwd_data(g, y, params[i], d)
+        elif kind == "atom":
+            i -= 4
+            g = atom_backward(rec[1], params[i], params[i + 2], g, sink, i)
+        elif kind == "convT":
+            _, dt, hin, h = rec
+            i -= 2
+            gw, gb, acc = sink.pair(i)
+            sink.put(i, *P.convt1d_bwd_weight(hin, g, h, dt, params[i].shape, gw, gb, acc))
+            g = P.convt1d_bwd_data(g, h, params[i], dt)
+        else:  # conv0: no gradient flows to the mel features
+            _, d, x, h = rec
+            i -= 2
+            gw, gb, acc = sink.pair(i)
+            sink.put(i, *P.conv1d_bwd_weight(x, g, h, d, params[i].shape, gw, gb, acc))
+    assert i == 0
+    return sink
+
+
+def disc_forward(x, params):
+    """One FullDiscriminator pass -> (features[6], judgement, tape)."""
+    if len(params) != D_NPARAMS:
+        raise RuntimeError("discriminator expects %d parameter tensors, got %d" % (D_NPARAMS, len(params)))
+    L.require(x, "discriminator input")
+    if x.dim() != 3 or x.shape[1] != 1:
+        raise RuntimeError("discriminator input must be (B, 1, L), got %s" % (tuple(x.shape),))
+    feats, tape = [], []
+    h = x
+    for li, (stride, pad, groups) in enumerate(D_LAYERS):
+        w, b = params[2 * li], params[2 * li + 1]
+        d, lo = P.conv_desc(h.shape, w.shape, stride=stride, pad=pad, groups=groups, act=L.ACT_LRELU)
+        hin = h
+        h, _ = P.conv1d_fwd(hin, w, b, d, lo)
+        tape.append((d, hin, h))
+        feats.append(h)
+    w, b = params[12], params[13]
+    dj, lo = P.conv_desc(h.shape, w.shape, pad=1)
+    j, _ = P.conv1d_fwd(h, w, b, dj, lo)
+    tape.append((dj, h, j))
+    return feats, j, tape
+
+
+def disc_backward(tape, params, g_feats, g_judge, sink, need_gx=True, need_wgrad=True):
+    """g_feats: list of 6 (entries may be None) or None; g_judge may be None (treated as zero).
+    Parameter grads go to `sink` (GradSink of 14); returns d loss / d x (or None)."""
+    dj, h5, _ = tape[6]
+
+    def own(li):  # the loss's own gradient on feature li (feature-matching term), if any
+        return g_feats[li] if (g_feats is not None and li >= 0) else None
+
+    # g = total gradient w.r.t. feature 5 (judge path + its own loss term)
+    if g_judge is not None:
+        if need_wgrad:
+            gw, gb, acc = sink.pair(12)
+            sink.put(12, *P.conv1d_bwd_weight(h5, g_judge, None, dj, params[12].shape, gw, gb, acc))
+        g = P.conv1d_bwd_data(g_judge, None, params[12], dj, gx_add=own(5))
+    else:
+        g = own(5)
+    for li in range(5, -1, -1):
+        d, hin, h = tape[li]
+        prev = own(li - 1) if li > 0 else None
+        if g is None:           # nothing flows through this layer
+            g = prev
+            continue
+        if need_wgrad:
+            gw, gb, acc = sink.pair(2 * li)
+            sink.put(2 * li, *P.conv1d_bwd_weight(hin, g, h, d, params[2 * li].shape, gw, gb, acc))
+        if li > 0:
+            g = P.conv1d_bwd_data(g, h, params[2 * li], d, gx_add=prev)
+        elif need_gx:
+            g = P.conv1d_bwd_data(g, h, params[0], d)
+        else:
+            g = None
+    return g
+
+
+def melgan_forward(x, params, scales=2):
+    """MelGanDiscriminator: the shared discriminator on x, pool(x), pool(pool(x))."""
+    feats, judges, tapes, xs = [], [], [], []
+    h = x
+    for s in range(scales + 1):
+        if s > 0:
+            h = P.avg_pool_fwd(h)
+        xs.append(h)
+        f, j, tape = disc_forward(h, params)
+        feats.append(f); judges.append(j); tapes.append(tape)
+    return feats, judges, (tapes, xs)
+
+
+def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, need_wgrad=True):
+    tapes, xs = ctx
+    sink = sink if sink is not None else GradSink(D_NPARAMS)
+    gx_next = None
+    for s in range(len(tapes) - 1, -1, -1):
+        gf = None if g_feats is None else g_feats[s]
+        gj = None if g_judges is None else g_judges[s]
+        has_any = gj is not None or (gf is not None and any(t is not None for t in gf))
+        gx = None
+        if has_any:
+            gx = disc_backward(tapes[s], params, gf, gj, sink, need_gx=need_gx or s > 0,
+                               need_wgrad=need_wgrad)
+        if gx_next is not None and (need_gx or s > 0):
+            gx = P.avg_pool_bwd(gx_next, xs[s].shape, gx_add=gx)
+        gx_next = gx
+    return gx_next, sink

@@ -1,0 +1,157 @@
+"""ctypes binding of libmsynth_hip.so (the C ABI declared in include/msynth.h).
+
+There is no CPU fallback: if the shared library is missing, or an op is handed a
+tensor that is not a contiguous fp32 HIP-device tensor, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "_lib", "libmsynth_hip.so")
+
+ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
+PAD_ZERO, PAD_REFLECT = 0, 1
+
+_c_int = ctypes.c_int32
+_c_i64 = ctypes.c_int64
+_c_f = ctypes.c_float
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, _c_int) for n in ("B", "Cin", "Lin", "Cout", "K", "stride", "pad", "dil",
+                                      "groups", "pad_mode", "act")] + [("slope", _c_f)]
+
+
+class ConvTDesc(ctypes.Structure):
+    _fields_ = [(n, _c_int) for n in ("B", "Cin", "Lin", "Cout", "K", "stride", "pad", "act")] + \
+               [("slope", _c_f)]
+
+
+# name -> (restype, argtypes); every symbol include/msynth.h declares
+SIGNATURES = {
+    "ms_version": (_c_int, []),
+    "ms_status_string": (ctypes.c_char_p, [_c_int]),
+    "ms_conv1d_out_len": (_c_int, [ctypes.POINTER(ConvDesc)]),
+    "ms_conv1d_fwd": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ms_conv1d_bwd_data": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ms_conv1d_bwd_weight": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _c_f, _vp, _sz, _vp]),
+    "ms_conv1d_workspace_bytes": (_sz, [ctypes.POINTER(ConvDesc), _c_int]),
+    "ms_conv1d_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvDesc), _c_int]),
+    "ms_convt1d_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvTDesc), _c_int]),
+    "ms_convt1d_out_len": (_c_int, [ctypes.POINTER(ConvTDesc)]),
+    "ms_convt1d_fwd": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ms_convt1d_bwd_data": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ms_convt1d_bwd_weight": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp, _vp, _vp, _c_f, _vp, _sz, _vp]),
+    "ms_convt1d_workspace_bytes": (_sz, [ctypes.POINTER(ConvTDesc), _c_int]),
+    "ms_avg_pool1d_4_2_2_fwd": (_c_int, [_vp, _vp, _c_i64, _c_int, _vp]),
+    "ms_avg_pool1d_4_2_2_bwd": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _vp]),
+    "ms_act_bwd": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _c_f, _vp]),
+    "ms_add": (_c_int, [_vp, _vp, _vp, _c_i64, _vp]),
+    "ms_reduce_workspace_bytes": (_sz, [_c_i64]),
+    "ms_hinge_d_fwd": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _sz, _vp]),
+    "ms_hinge_d_bwd": (_c_int, [_vp, _vp, _c_i64, _vp, _c_f, _vp, _vp, _vp]),
+    "ms_neg_mean_fwd": (_c_int, [_vp, _c_i64, _vp, _vp, _sz, _vp]),
+    "ms_neg_mean_bwd": (_c_int, [_c_i64, _vp, _c_f, _vp, _vp]),
+    "ms_l1_mean_fwd": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _sz, _vp]),
+    "ms_l1_mean_bwd": (_c_int, [_vp, _vp, _c_i64, _vp, _c_f, _vp, _c_int, _vp]),
+    "ms_ls_g_fwd": (_c_int, [_vp, _c_i64, _vp, _vp, _sz, _vp]),
+    "ms_ls_g_bwd": (_c_int, [_vp, _c_i64, _vp, _c_f, _vp, _vp]),
+    "ms_ls_d_fwd": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _sz, _vp]),
+    "ms_ls_d_bwd": (_c_int, [_vp, _vp, _c_i64, _vp, _c_f, _vp, _vp, _vp]),
+    "ms_weighted_sum": (_c_int, [_vp, _vp, _c_int, _vp, _vp]),
+    "ms_adam_step": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _vp, _vp]),
+    "ms_audio2mel_frames": (_c_int, [_c_int, _c_int, _c_int]),
+    "ms_audio2mel_fwd": (_c_int, [_vp, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _c_int, _vp, _vp]),
+}
+
+_LIB = None
+
+
+def load():
+    """Loads libmsynth_hip.so (after torch, so both share torch's HIP runtime)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "featuresynth (MI355X build): %s is missing; build it with "
+                "`make -C music-synthesis_amd/csrc` or __graft_entry__.build(). There is no CPU "
+                "or PyTorch fallback for the hot path." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ms_status_string(rc)
+        raise RuntimeError("%s failed: %s (ms_status %d)" % (what, msg.decode() if msg else "?", rc))
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def require(t, name):
+    """The hot path takes contiguous fp32 tensors resident on a HIP device, nothing else."""
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError("%s: expected a torch.Tensor, got %r" % (name, type(t)))
+    if not t.is_cuda:
+        raise RuntimeError(
+            "%s: featuresynth (MI355X build) only runs on a HIP device tensor; got device %s. "
+            "There is no CPU fallback." % (name, t.device))
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s: expected float32, got %s" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("%s: expected a contiguous tensor" % name)
+    return t
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(nbytes, device):
+    """Scratch for one call, from torch's caching allocator (stream-ordered, and when a hipGraph
+    is being captured it comes from that graph's private pool, so replays stay valid)."""
+    if nbytes <= 0:
+        return None
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+# ---- optional per-launch timing (bench.py's roofline leg; off in normal operation)
+PROFILE = None      # list of (symbol, cost dict, start event, end event) while enabled
+
+
+def profile_begin():
+    global PROFILE
+    PROFILE = []
+
+
+def profile_end():
+    """-> list of (symbol, cost, milliseconds); synchronises the device."""
+    global PROFILE
+    rec, PROFILE = PROFILE, None
+    torch.cuda.synchronize()
+    return [(name, cost, e0.elapsed_time(e1)) for name, cost, e0, e1 in rec]
+
+
+def call(name, cost_fn, *args):
+    """Launches C-ABI entry `name` on the current stream; raises on a non-zero status."""
+    fn = getattr(load(), name)
+    if PROFILE is None:
+        check(fn(*args), name)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    check(rc, name)
+    PROFILE.append((name, cost_fn() if cost_fn else {}, e0, e1))

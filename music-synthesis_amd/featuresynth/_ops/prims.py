@@ -1,0 +1,283 @@
+"""Tensor-level wrappers of the C-ABI kernels: shape checks, output allocation, launch on the
+current stream.  No autograd here (see functional.py)."""
+import torch
+
+from . import lib as L
+from .. import _workload as W
+
+
+_WHICH = {"fwd": 0, "bwd_data": 1, "bwd_weight": 2}
+
+
+def _ccost(d, which, **kw):
+    return lambda: dict(W.conv_cost(d.B, d.Cin, d.Lin, d.Cout, d.K, d.stride, d.pad, d.dil, d.groups,
+                                    which, **kw),
+                        geom=(d.B, d.Cin, d.Lin, d.Cout, d.K, d.stride, d.dil, d.groups),
+                        kernel=L.load().ms_conv1d_kernel_name(d, _WHICH[which]).decode())
+
+
+def _tcost(d, which, abi_which, **kw):
+    m = W.convt_as_conv(d.B, d.Cin, d.Lin, d.Cout, d.K, d.stride, d.pad)
+    return lambda: dict(W.conv_cost(which=which, **m, **kw),
+                        geom=(d.B, d.Cin, d.Lin, d.Cout, d.K, d.stride, 1, 1),
+                        kernel=L.load().ms_convt1d_kernel_name(d, abi_which).decode())
+
+
+def _scost(n, reads, writes, flops_per=1):
+    return lambda: {"flops": flops_per * n, "bytes": 4 * n * (reads + writes)}
+
+SLOPE = 0.2
+
+
+def conv_desc(x_shape, w_shape, stride=1, pad=0, dil=1, groups=1, pad_mode=L.PAD_ZERO,
+              act=L.ACT_NONE):
+    B, Cin, Lin = x_shape
+    Cout, Cg, K = w_shape
+    if Cg * groups != Cin:
+        raise RuntimeError("conv1d: weight %s does not match input channels %d / groups %d" %
+                           (tuple(w_shape), Cin, groups))
+    d = L.ConvDesc(B, Cin, Lin, Cout, K, stride, pad, dil, groups, pad_mode, act, SLOPE)
+    lout = L.load().ms_conv1d_out_len(d)
+    if lout <= 0:
+        raise RuntimeError("conv1d: invalid geometry x=%s w=%s stride=%d pad=%d dil=%d" %
+                           (tuple(x_shape), tuple(w_shape), stride, pad, dil))
+    return d, lout
+
+
+def conv1d_fwd(x, w, b, d, lout, residual=None, want_y_act=False):
+    L.require(x, "conv1d input"); L.require(w, "conv1d weight")
+    if b is not None:
+        L.require(b, "conv1d bias")
+    y = torch.empty((d.B, d.Cout, lout), dtype=torch.float32, device=x.device)
+    y_act = None
+    if residual is not None:
+        L.require(residual, "conv1d residual")
+        if residual.shape != y.shape:
+            raise RuntimeError("conv1d: residual shape %s != output shape %s" %
+                               (tuple(residual.shape), tuple(y.shape)))
+        if want_y_act:
+            y_act = torch.empty_like(y)
+    lib = L.load()
+    nws = lib.ms_conv1d_workspace_bytes(d, 0)
+    ws = L.workspace(nws, x.device)
+    L.call("ms_conv1d_fwd", _ccost(d, "fwd", extra_reads=int(residual is not None),
+                                   extra_writes=int(y_act is not None)),
+           d, x.data_ptr(), w.data_ptr(), L.ptr(b), L.ptr(residual), y.data_ptr(), L.ptr(y_act),
+           L.ptr(ws), nws, L.stream())
+    return y, (y_act if y_act is not None else y)
+
+
+def conv1d_bwd_data(gy, y_act, w, d, gx_add=None):
+    L.require(gy, "conv1d grad_output")
+    gx = torch.empty((d.B, d.Cin, d.Lin), dtype=torch.float32, device=gy.device)
+    if gx_add is not None:
+        L.require(gx_add, "conv1d gx_add")
+        assert gx_add.shape == gx.shape
+    lib = L.load()
+    nws = lib.ms_conv1d_workspace_bytes(d, 1)
+    ws = L.workspace(nws, gy.device)
+    L.call("ms_conv1d_bwd_data", _ccost(d, "bwd_data", act_read=y_act is not None,
+                                        extra_reads=int(gx_add is not None)),
+           d, gy.data_ptr(), L.ptr(y_act), w.data_ptr(), L.ptr(gx_add), gx.data_ptr(), L.ptr(ws), nws,
+           L.stream())
+    return gx
+
+
+def conv1d_bwd_weight(x, gy, y_act, d, w_shape, gw=None, gb=None, accumulate=False, want_bias=True):
+    L.require(gy, "conv1d grad_output")
+    if gw is None:
+        gw = torch.empty(tuple(w_shape), dtype=torch.float32, device=gy.device)
+        accumulate = False
+    if gb is None and want_bias:
+        gb = (torch.zeros if accumulate else torch.empty)((d.Cout,), dtype=torch.float32, device=gy.device)
+    lib = L.load()
+    nws = lib.ms_conv1d_workspace_bytes(d, 2)
+    ws = L.workspace(nws, gy.device)
+    L.call("ms_conv1d_bwd_weight", _ccost(d, "bwd_weight", act_read=y_act is not None),
+           d, x.data_ptr(), gy.data_ptr(), L.ptr(y_act), gw.data_ptr(), L.ptr(gb),
+           1.0 if accumulate else 0.0, L.ptr(ws), nws, L.stream())
+    return gw, gb
+
+
+def convt_desc(x_shape, w_shape, stride, pad, act=L.ACT_NONE):
+    B, Cin, Lin = x_shape
+    Cin2, Cout, K = w_shape
+    if Cin2 != Cin:
+        raise RuntimeError("conv_transpose1d: weight %s does not match input channels %d" %
+                           (tuple(w_shape), Cin))
+    d = L.ConvTDesc(B, Cin, Lin, Cout, K, stride, pad, act, SLOPE)
+    lout = L.load().ms_convt1d_out_len(d)
+    if lout <= 0:
+        raise RuntimeError("conv_transpose1d: invalid geometry")
+    return d, lout
+
+
+def convt1d_fwd(x, w, b, d, lout):
+    L.require(x, "conv_transpose1d input"); L.require(w, "conv_transpose1d weight")
+    y = torch.empty((d.B, d.Cout, lout), dtype=torch.float32, device=x.device)
+    lib = L.load()
+    nws = lib.ms_convt1d_workspace_bytes(d, 0)
+    ws = L.workspace(nws, x.device)
+    L.call("ms_convt1d_fwd", _tcost(d, "bwd_data", 0), d, x.data_ptr(), w.data_ptr(), L.ptr(b),
+           y.data_ptr(), L.ptr(ws), nws, L.stream())
+    return y
+
+
+def convt1d_bwd_data(gy, y_act, w, d):
+    L.require(gy, "conv_transpose1d grad_output")
+    gx = torch.empty((d.B, d.Cin, d.Lin), dtype=torch.float32, device=gy.device)
+    lib = L.load()
+    nws = lib.ms_convt1d_workspace_bytes(d, 1)
+    ws = L.workspace(nws, gy.device)
+    L.call("ms_convt1d_bwd_data", _tcost(d, "fwd", 1, extra_reads=int(y_act is not None)),
+           d, gy.data_ptr(), L.ptr(y_act), w.data_ptr(), gx.data_ptr(), L.ptr(ws), nws, L.stream())
+    return gx
+
+
+def convt1d_bwd_weight(x, gy, y_act, d, w_shape, gw=None, gb=None, accumulate=False):
+    L.require(gy, "conv_transpose1d grad_output")
+    if gw is None:
+        gw = torch.empty(tuple(w_shape), dtype=torch.float32, device=gy.device)
+        accumulate = False
+    if gb is None:
+        gb = (torch.zeros if accumulate else torch.empty)((d.Cout,), dtype=torch.float32, device=gy.device)
+    lib = L.load()
+    nws = lib.ms_convt1d_workspace_bytes(d, 2)
+    ws = L.workspace(nws, gy.device)
+    L.call("ms_convt1d_bwd_weight", _tcost(d, "bwd_weight", 2, act_read=y_act is not None),
+           d, x.data_ptr(), gy.data_ptr(), L.ptr(y_act), gw.data_ptr(), gb.data_ptr(),
+           1.0 if accumulate else 0.0, L.ptr(ws), nws, L.stream())
+    return gw, gb
+
+
+def pool_out_len(lin):
+    return (lin + 4 - 4) // 2 + 1
+
+
+def avg_pool_fwd(x):
+    L.require(x, "avg_pool1d input")
+    B, C, Lin = x.shape
+    y = torch.empty((B, C, pool_out_len(Lin)), dtype=torch.float32, device=x.device)
+    L.call("ms_avg_pool1d_4_2_2_fwd", _scost(x.numel(), 1, 0.5), x.data_ptr(), y.data_ptr(), B * C, Lin,
+           L.stream())
+    return y
+
+
+def avg_pool_bwd(gy, x_shape, gx_add=None):
+    L.require(gy, "avg_pool1d grad_output")
+    B, C, Lin = x_shape
+    gx = torch.empty((B, C, Lin), dtype=torch.float32, device=gy.device)
+    L.call("ms_avg_pool1d_4_2_2_bwd", _scost(gx.numel(), 0.5 + int(gx_add is not None), 1),
+           gy.data_ptr(), L.ptr(gx_add), gx.data_ptr(), B * C, Lin, L.stream())
+    return gx
+
+
+def add(a, b):
+    L.require(a, "add lhs"); L.require(b, "add rhs")
+    out = torch.empty_like(a)
+    L.call("ms_add", _scost(a.numel(), 2, 1), a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), L.stream())
+    return out
+
+
+def _reduce(fn_name, a, b, out=None):
+    lib = L.load()
+    n = a.numel()
+    if out is None:
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+    nws = lib.ms_reduce_workspace_bytes(n)
+    ws = L.workspace(nws, a.device)
+    if b is None:
+        L.call(fn_name, _scost(n, 1, 0, 2), a.data_ptr(), n, out.data_ptr(), L.ptr(ws), nws, L.stream())
+    else:
+        L.call(fn_name, _scost(n, 2, 0, 3), a.data_ptr(), b.data_ptr(), n, out.data_ptr(), L.ptr(ws), nws,
+               L.stream())
+    return out
+
+
+def hinge_d_fwd(r, f, out=None):
+    return _reduce("ms_hinge_d_fwd", L.require(r, "real judgement"), L.require(f, "fake judgement"), out)
+
+
+def neg_mean_fwd(f, out=None):
+    return _reduce("ms_neg_mean_fwd", L.require(f, "judgement"), None, out)
+
+
+def l1_mean_fwd(r, f, out=None):
+    return _reduce("ms_l1_mean_fwd", L.require(r, "real feature"), L.require(f, "fake feature"), out)
+
+
+def ls_g_fwd(j, out=None):
+    return _reduce("ms_ls_g_fwd", L.require(j, "judgement"), None, out)
+
+
+def ls_d_fwd(r, f, out=None):
+    return _reduce("ms_ls_d_fwd", L.require(r, "real judgement"), L.require(f, "fake judgement"), out)
+
+
+def hinge_d_bwd(r, f, gout, scale=1.0, want_r=True, want_f=True):
+    gr = torch.empty_like(r) if want_r else None
+    gf = torch.empty_like(f) if want_f else None
+    L.call("ms_hinge_d_bwd", _scost(r.numel(), 2, 2), r.data_ptr(), f.data_ptr(), r.numel(),
+           gout.data_ptr(), scale, L.ptr(gr), L.ptr(gf), L.stream())
+    return gr, gf
+
+
+def neg_mean_bwd(f, gout, scale=1.0):
+    gf = torch.empty_like(f)
+    L.call("ms_neg_mean_bwd", _scost(f.numel(), 0, 1), f.numel(), gout.data_ptr(), scale, gf.data_ptr(),
+           L.stream())
+    return gf
+
+
+def l1_mean_bwd(r, f, gout, scale=1.0, gf=None):
+    acc = gf is not None
+    if gf is None:
+        gf = torch.empty_like(f)
+    L.call("ms_l1_mean_bwd", _scost(f.numel(), 2 + int(acc), 1, 2), r.data_ptr(), f.data_ptr(), f.numel(),
+           gout.data_ptr(), scale, gf.data_ptr(), 1 if acc else 0, L.stream())
+    return gf
+
+
+def ls_g_bwd(j, gout, scale=1.0):
+    gj = torch.empty_like(j)
+    L.call("ms_ls_g_bwd", _scost(j.numel(), 1, 1), j.data_ptr(), j.numel(), gout.data_ptr(), scale,
+           gj.data_ptr(), L.stream())
+    return gj
+
+
+def ls_d_bwd(r, f, gout, scale=1.0):
+    gr, gf = torch.empty_like(r), torch.empty_like(f)
+    L.call("ms_ls_d_bwd", _scost(r.numel(), 2, 2), r.data_ptr(), f.data_ptr(), r.numel(),
+           gout.data_ptr(), scale, gr.data_ptr(), gf.data_ptr(), L.stream())
+    return gr, gf
+
+
+def weighted_sum(terms, coef):
+    """terms, coef: 1-D fp32 device tensors of equal length -> 0-d tensor sum(coef*terms)."""
+    out = torch.empty((), dtype=torch.float32, device=terms.device)
+    L.call("ms_weighted_sum", None, terms.data_ptr(), coef.data_ptr(), terms.numel(), out.data_ptr(),
+           L.stream())
+    return out
+
+
+def adam_step(p, g, m, v, step, lr, b1, b2, eps, grad_scale=1.0):
+    for t, nm in ((p, "param"), (g, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
+        L.require(t, "adam " + nm)
+    if step.dtype != torch.int32 or not step.is_cuda:
+        raise RuntimeError("adam: step must be an int32 device tensor")
+    L.call("ms_adam_step", _scost(p.numel(), 4, 3, 12), p.data_ptr(), g.data_ptr(), m.data_ptr(),
+           v.data_ptr(), p.numel(), lr, b1, b2, eps, grad_scale, step.data_ptr(), L.stream())
+
+
+def audio2mel(audio, window, basis, n_fft, hop):
+    L.require(audio, "audio"); L.require(window, "window"); L.require(basis, "mel_basis")
+    B, N = audio.shape
+    n_mel = basis.shape[0]
+    lib = L.load()
+    frames = lib.ms_audio2mel_frames(N, n_fft, hop)
+    if frames <= 0:
+        raise RuntimeError("Audio2Mel: %d samples are too few for one %d-sample frame" % (N, n_fft))
+    out = torch.empty((B, n_mel, frames), dtype=torch.float32, device=audio.device)
+    L.call("ms_audio2mel_fwd", None, audio.data_ptr(), B, N, window.data_ptr(), n_fft, hop,
+           basis.data_ptr(), n_mel, out.data_ptr(), L.stream())
+    return out

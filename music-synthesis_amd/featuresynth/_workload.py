@@ -1,0 +1,183 @@
+"""Algorithmic work (FLOPs, HBM bytes) of every kernel launch in the native D-step / G-step.
+
+Pure arithmetic, no device code: bench.py prices each launch with these figures (roofline),
+tools/layer_spec.py prints the table quoted in DESIGN.md / SURVEY.md 8(d).
+
+Byte model (layer-granular, fp32): every conv reads its input once and writes its output once;
+a fused residual / gradient add reads one more activation-sized tensor; a fused activation
+derivative reads the saved activation; weights (and weight grads) are counted once per launch.
+FLOPs = 2 * MACs of the dense arithmetic actually required.
+"""
+
+G_UPS = ((512, 256, 16, 8, 4), (256, 128, 16, 8, 4), (128, 64, 4, 2, 1), (64, 32, 4, 2, 1))
+D_MAIN = ((1, 16, 15, 1, 7, 1), (16, 64, 41, 4, 20, 4), (64, 256, 41, 4, 20, 16),
+          (256, 1024, 41, 4, 20, 64), (1024, 1024, 41, 4, 20, 256), (1024, 1024, 5, 1, 2, 1))
+F32 = 4
+
+
+def conv_out_len(lin, k, stride, pad, dil=1):
+    return (lin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def conv_cost(B, Cin, Lin, Cout, K, stride, pad, dil, groups, which, extra_reads=0, extra_writes=0,
+              act_read=False):
+    """which: 'fwd' | 'bwd_data' | 'bwd_weight'.  extra_reads/extra_writes: additional
+    activation-sized tensors of the OUTPUT side of that launch (residual, y_act, gx_add)."""
+    Lout = conv_out_len(Lin, K, stride, pad, dil)
+    macs = B * Cout * Lout * (Cin // groups) * K
+    nin, nout, nw = B * Cin * Lin, B * Cout * Lout, Cout * (Cin // groups) * K + Cout
+    if which == "fwd":
+        elems = nin + nout + nw + (extra_reads + extra_writes) * nout
+    elif which == "bwd_data":   # reads gy (+y_act), writes gx (+gx_add read)
+        elems = nout + (nout if act_read else 0) + nin + nw + extra_reads * nin
+    else:                        # bwd_weight: reads x, gy (+y_act), writes gw
+        elems = nin + nout + (nout if act_read else 0) + nw
+    return {"flops": 2 * macs, "bytes": F32 * elems}
+
+
+def convt_as_conv(B, Cin, Lin, Cout, K, stride, pad):
+    """Geometry of the mirrored conv whose backward-data is the transposed conv."""
+    Lout = (Lin - 1) * stride - 2 * pad + K
+    return dict(B=B, Cin=Cout, Lin=Lout, Cout=Cin, K=K, stride=stride, pad=pad, dil=1, groups=1)
+
+
+def _atom(B, C, L, d, mode, out):
+    c0 = dict(B=B, Cin=C, Lin=L, Cout=C, K=3, stride=1, pad=d, dil=d, groups=1)
+    c1 = dict(B=B, Cin=C, Lin=L, Cout=C, K=3, stride=1, pad=1, dil=1, groups=1)
+    if mode == "fwd":
+        out.append(("atom%d.conv0.fwd" % C, conv_cost(which="fwd", **c0)))
+        out.append(("atom%d.conv1.fwd" % C, conv_cost(which="fwd", extra_reads=1, **c1)))
+    elif mode == "fwd_train":   # also writes the pre-residual activation for the LeakyReLU mask
+        out.append(("atom%d.conv0.fwd" % C, conv_cost(which="fwd", **c0)))
+        out.append(("atom%d.conv1.fwd" % C, conv_cost(which="fwd", extra_reads=1, extra_writes=1, **c1)))
+    else:
+        out.append(("atom%d.conv1.bwd_weight" % C, conv_cost(which="bwd_weight", act_read=True, **c1)))
+        out.append(("atom%d.conv1.bwd_data" % C, conv_cost(which="bwd_data", act_read=True, **c1)))
+        out.append(("atom%d.conv0.bwd_weight" % C, conv_cost(which="bwd_weight", act_read=True, **c0)))
+        out.append(("atom%d.conv0.bwd_data" % C, conv_cost(which="bwd_data", act_read=True, extra_reads=1, **c0)))
+
+
+def generator_launches(B, mels, T, mode):
+    """mode: 'fwd' (inference / D-step), 'fwd_train' (G-step forward), 'bwd'."""
+    out = []
+    L = T
+    first = dict(B=B, Cin=mels, Lin=L, Cout=512, K=7, stride=1, pad=3, dil=1, groups=1)
+    stages = []
+    for cin, cout, k, s, p in G_UPS:
+        stages.append((cin, cout, k, s, p, L))
+        L = (L - 1) * s - 2 * p + k
+    last = dict(B=B, Cin=32, Lin=L, Cout=1, K=7, stride=1, pad=3, dil=1, groups=1)
+    if mode != "bwd":
+        out.append(("g.first.fwd", conv_cost(which="fwd", **first)))
+        for cin, cout, k, s, p, lin in stages:
+            m = convt_as_conv(B, cin, lin, cout, k, s, p)
+            out.append(("g.convT%d.fwd" % cout, conv_cost(which="bwd_data", **m)))
+            for d in (1, 3, 9):
+                _atom(B, cout, m["Lin"], d, mode, out)
+        out.append(("g.last.fwd", conv_cost(which="fwd", **last)))
+    else:
+        out.append(("g.last.bwd_weight", conv_cost(which="bwd_weight", act_read=True, **last)))
+        out.append(("g.last.bwd_data", conv_cost(which="bwd_data", act_read=True, **last)))
+        for cin, cout, k, s, p, lin in reversed(stages):
+            m = convt_as_conv(B, cin, lin, cout, k, s, p)
+            for d in (9, 3, 1):
+                _atom(B, cout, m["Lin"], d, "bwd", out)
+            out.append(("g.convT%d.bwd_weight" % cout, conv_cost(which="bwd_weight", act_read=True, **m)))
+            out.append(("g.convT%d.bwd_data" % cout, conv_cost(which="fwd", extra_reads=1, **m)))
+        out.append(("g.first.bwd_weight", conv_cost(which="bwd_weight", act_read=True, **first)))
+    return out
+
+
+def discriminator_launches(B, L0, mode, need_gx=False, feat_grads=False):
+    """mode 'fwd' | 'bwd' over the 3 scales (the pooling kernels are priced as pure streams)."""
+    out = []
+    L = L0
+    for s in range(3):
+        if s:
+            lp = (L + 4 - 4) // 2 + 1
+            out.append(("d.pool.%s" % mode, {"flops": 4 * B * lp, "bytes": F32 * B * (L + lp)}))
+            L = lp
+        l = L
+        geo = []
+        for cin, cout, k, st, p, g in D_MAIN:
+            geo.append(dict(B=B, Cin=cin, Lin=l, Cout=cout, K=k, stride=st, pad=p, dil=1, groups=g))
+            l = conv_out_len(l, k, st, p)
+        judge = dict(B=B, Cin=1024, Lin=l, Cout=1, K=3, stride=1, pad=1, dil=1, groups=1)
+        if mode == "fwd":
+            for i, c in enumerate(geo):
+                out.append(("d.main%d.fwd" % i, conv_cost(which="fwd", **c)))
+            out.append(("d.judge.fwd", conv_cost(which="fwd", **judge)))
+        else:
+            out.append(("d.judge.bwd_data", conv_cost(which="bwd_data", extra_reads=int(feat_grads), **judge)))
+            for i in range(5, -1, -1):
+                if not need_gx or True:
+                    pass
+                if i > 0 or need_gx:
+                    out.append(("d.main%d.bwd_data" % i,
+                                conv_cost(which="bwd_data", act_read=True,
+                                          extra_reads=int(feat_grads and i > 0), **geo[i])))
+    return out
+
+
+def discriminator_wgrad_launches(B, L0):
+    out = []
+    L = L0
+    for s in range(3):
+        if s:
+            L = (L + 4 - 4) // 2 + 1
+        l = L
+        for i, (cin, cout, k, st, p, g) in enumerate(D_MAIN):
+            out.append(("d.main%d.bwd_weight" % i,
+                        conv_cost(B, cin, l, cout, k, st, p, 1, g, "bwd_weight", act_read=True)))
+            l = conv_out_len(l, k, st, p)
+        out.append(("d.judge.bwd_weight", conv_cost(B, 1024, l, 1, 3, 1, 1, 1, 1, "bwd_weight")))
+    return out
+
+
+def feature_elems(B, L0):
+    tot, L = 0, L0
+    for s in range(3):
+        if s:
+            L = (L + 4 - 4) // 2 + 1
+        l = L
+        for cin, cout, k, st, p, g in D_MAIN:
+            l = conv_out_len(l, k, st, p)
+            tot += B * cout * l
+    return tot
+
+
+def d_step_launches(B, mels=80, T=32):
+    L0 = T * 256
+    out = generator_launches(B, mels, T, "fwd")
+    for _ in range(2):   # fake pass, real pass
+        out += discriminator_launches(B, L0, "fwd")
+    for _ in range(2):
+        out += discriminator_launches(B, L0, "bwd", need_gx=False)
+        out += discriminator_wgrad_launches(B, L0)
+    nparam = 5637953
+    out.append(("adam.D", {"flops": 12 * nparam, "bytes": 7 * F32 * nparam}))
+    return out
+
+
+def g_step_launches(B, mels=80, T=32):
+    L0 = T * 256
+    out = generator_launches(B, mels, T, "fwd_train")
+    out += discriminator_launches(B, L0, "fwd")
+    out += discriminator_launches(B, L0, "fwd")
+    fe = feature_elems(B, L0)
+    out.append(("loss.l1.fwd", {"flops": 3 * fe, "bytes": 2 * F32 * fe}))
+    out.append(("loss.l1.bwd", {"flops": 2 * fe, "bytes": 3 * F32 * fe}))
+    out += discriminator_launches(B, L0, "bwd", need_gx=True, feat_grads=True)
+    out += generator_launches(B, mels, T, "bwd")
+    nparam = 4519937 + (mels - 80) * 512 * 7
+    out.append(("adam.G", {"flops": 12 * nparam, "bytes": 7 * F32 * nparam}))
+    return out
+
+
+def totals(launches):
+    return {"flops": sum(c["flops"] for _, c in launches), "bytes": sum(c["bytes"] for _, c in launches)}
+
+
+def roofline_seconds(launches, hbm_bytes_per_s, flops_per_s):
+    """Sum over launches of max(bytes / BW, flops / peak): the per-layer roofline of the step."""
+    return sum(max(c["bytes"] / hbm_bytes_per_s, c["flops"] / flops_per_s) for _, c in launches)

@@ -1,0 +1,229 @@
+"""The alternating D / G train step, drop-in for the reference's featuresynth/train/train.py
+(GeneratorTrainer :8-42, DiscriminatorTrainer :45-74, training_loop :77-106): same constructor
+signatures, same `train(samples, features)` return dicts.
+
+Two execution paths, same numbers:
+  * reference order of operations (any generator / discriminator / optimizer objects);
+  * native path, taken when both networks are this package's HIP modules: work that cannot
+    change the result is skipped (D-step: no backward through the generator, which the reference
+    performs only because `fake` is not detached, train.py:66-71; G-step: no real-path backward
+    and no discriminator weight grads, train.py:36), and when both optimizers are FlatAdam the
+    whole step (zero_grad, forwards, backward, Adam) is captured once into a hipGraph and replayed.
+    Under torch.distributed the stepped network's flat gradient bucket is all-reduced (RCCL)
+    between the backward graph and the Adam graph.
+"""
+import os
+import sys
+from datetime import datetime
+
+import torch
+
+from .. import _dist
+from ..loss import hinge_discriminator_loss, hinge_generator_loss
+from ..optim import FlatAdam
+from ..util.modules import zero_grad
+
+
+def _native(*modules):
+    return all(getattr(m, "_ms_native", False) for m in modules)
+
+
+def _use_graph():
+    return os.environ.get("MSYNTH_GRAPH", "1") != "0"
+
+
+class _GraphedStep:
+    """Runs `body(samples, features) -> dict of device tensors`: first call eager (loads the
+    code objects, sizes the buckets), second call captures into a hipGraph, later calls copy the
+    inputs into the static buffers and replay."""
+
+    def __init__(self, body, post=None):
+        self.body = body
+        self.post = post          # optional eager tail (all-reduce + second graph)
+        self.seen = {}
+        self.graphs = {}
+        self.disabled = False
+
+    def __call__(self, samples, features):
+        key = (tuple(samples.shape), tuple(features.shape), samples.device)
+        entry = self.graphs.get(key)
+        if entry is None:
+            n = self.seen.get(key, 0)
+            self.seen[key] = n + 1
+            if n == 0 or self.disabled or not _use_graph():
+                return self.body(samples, features)
+            try:
+                s_in, f_in = samples.clone(), features.clone()
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self.body(s_in, f_in)
+                entry = (g, s_in, f_in, out)
+                self.graphs[key] = entry
+            except Exception as e:  # perf-only fallback, reported loudly
+                self.disabled = True
+                torch.cuda.synchronize()
+                print("featuresynth: hipGraph capture failed (%s: %s); running the step eagerly"
+                      % (type(e).__name__, e), file=sys.stderr)
+                return self.body(samples, features)
+        g, s_in, f_in, out = entry
+        s_in.copy_(samples)
+        f_in.copy_(features)
+        g.replay()
+        return out
+
+
+class _TrainerBase(object):
+    def __init__(self, generator, g_optim, discriminator, d_optim, loss, sub_loss):
+        super().__init__()
+        self.sub_loss = sub_loss
+        self.loss = loss
+        self.d_optim = d_optim
+        self.discriminator = discriminator
+        self.g_optim = g_optim
+        self.generator = generator
+        self._runner = None
+        self._tail = None
+
+    def _native_ok(self, samples, features):
+        return (_native(self.generator, self.discriminator) and isinstance(samples, torch.Tensor)
+                and samples.is_cuda and isinstance(features, torch.Tensor))
+
+    def _stepped_optim(self):
+        raise NotImplementedError
+
+    def _fwd_bwd(self, samples, features):
+        raise NotImplementedError
+
+    def _native_step(self, samples, features):
+        """fwd+bwd graph -> (RCCL all-reduce of the stepped bucket) -> Adam graph."""
+        opt = self._stepped_optim()
+        flat = isinstance(opt, FlatAdam) and isinstance(self.g_optim, FlatAdam) and \
+            isinstance(self.d_optim, FlatAdam)
+        world = _dist.world_size()
+        if not flat:
+            out = self._fwd_bwd(samples, features)
+            if world > 1:
+                for p in opt.param_groups[0]["params"]:
+                    if p.grad is not None:
+                        _dist.allreduce_sum_(p.grad)
+                        p.grad.div_(world)
+            opt.step()
+            return out
+        opt.grad_scale = 1.0 / world
+        if world == 1:
+            if self._runner is None:
+                def body(s, f):
+                    out = self._fwd_bwd(s, f)
+                    opt.step()
+                    return out
+                self._runner = _GraphedStep(body)
+            return self._runner(samples, features)
+        if self._runner is None:
+            self._runner = _GraphedStep(self._fwd_bwd)
+            self._tail = _GraphedStep(lambda s, f: (opt.step(), {})[1])
+        out = self._runner(samples, features)
+        _dist.allreduce_sum_(opt.flat_grads)
+        self._tail(samples[:0], features[:0])
+        return out
+
+
+class GeneratorTrainer(_TrainerBase):
+    def __init__(self, generator, g_optim, discriminator, d_optim, loss,
+                 sub_loss=hinge_generator_loss):
+        super().__init__(generator, g_optim, discriminator, d_optim, loss, sub_loss)
+
+    def _stepped_optim(self):
+        return self.g_optim
+
+    def _fwd_bwd(self, samples, features):
+        zero_grad(self.g_optim, self.d_optim)
+        d_params = [p for p in self.discriminator.parameters() if p.requires_grad]
+        for p in d_params:          # discriminator weight grads are never used by a G-step
+            p.requires_grad_(False)
+        try:
+            fake = self.generator(features)
+            f_features, f_score = self.discriminator(fake, features)
+            with torch.no_grad():   # the real path does not depend on the generator
+                r_features, r_score = self.discriminator(samples, features)
+            loss = self.loss(r_features, f_features, r_score, f_score, gan_loss=self.sub_loss)
+            loss.backward()
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
+        return {"loss": loss.detach(), "fake": fake.detach()}
+
+    def train(self, samples, features):
+        if self._native_ok(samples, features):
+            out = self._native_step(samples, features)
+            return {'g_loss': out["loss"].item(), 'fake': out["fake"].cpu().numpy()}
+        # reference order of operations (train.py:26-42)
+        zero_grad(self.g_optim, self.d_optim)
+        fake = self.generator(features)
+        f_features, f_score = self.discriminator(fake, features)
+        r_features, r_score = self.discriminator(samples, features)
+        loss = self.loss(r_features, f_features, r_score, f_score, gan_loss=self.sub_loss)
+        loss.backward()
+        self.g_optim.step()
+        if isinstance(fake, dict):
+            fake = {k: v.data.cpu().numpy() for k, v in fake.items()}
+        else:
+            fake = fake.data.cpu().numpy()
+        return {'g_loss': loss.item(), 'fake': fake}
+
+
+class DiscriminatorTrainer(_TrainerBase):
+    def __init__(self, generator, g_optim, discriminator, d_optim, loss,
+                 sub_loss=hinge_discriminator_loss):
+        super().__init__(generator, g_optim, discriminator, d_optim, loss, sub_loss)
+
+    def _stepped_optim(self):
+        return self.d_optim
+
+    def _fwd_bwd(self, samples, features):
+        zero_grad(self.g_optim, self.d_optim)
+        with torch.no_grad():       # generator grads of a D-step are discarded by the reference
+            fake = self.generator(features)
+        _, f_score = self.discriminator(fake, features)
+        _, r_score = self.discriminator(samples, features)
+        loss = self.loss(r_score, f_score, gan_loss=self.sub_loss)
+        loss.backward()
+        return {"loss": loss.detach()}
+
+    def train(self, samples, features):
+        if self._native_ok(samples, features):
+            out = self._native_step(samples, features)
+            return {'d_loss': out["loss"].item()}
+        # reference order of operations (train.py:63-74)
+        zero_grad(self.g_optim, self.d_optim)
+        fake = self.generator(features)
+        _, f_score = self.discriminator(fake, features)
+        _, r_score = self.discriminator(samples, features)
+        loss = self.loss(r_score, f_score, gan_loss=self.sub_loss)
+        loss.backward()
+        self.d_optim.step()
+        return {'d_loss': loss.item()}
+
+
+def training_loop(batch_stream, experiment, device, loggers):
+    """Driver with the contract of the reference's train.py:77-106: numpy batch -> float tensors
+    on `device` -> next training step -> loggers; yields (i, elapsed, log_results)."""
+    started = datetime.utcnow()
+
+    def to_device(x):
+        if isinstance(x, dict):
+            return {k: torch.from_numpy(v).to(device).float() for k, v in x.items()}
+        return torch.from_numpy(x).to(device).float()
+
+    for i, batch in enumerate(batch_stream):
+        preprocessed = experiment.preprocess_batch(batch)
+        tensors = [to_device(x) for x in preprocessed]
+        step = next(experiment.training_steps)
+        step_result = step(*tensors)
+        elapsed = datetime.utcnow() - started
+        log_results = {}
+        for logger in loggers:
+            result = logger(experiment, preprocessed, step_result, i, elapsed)
+            if result is not None:
+                log_results.update(result)
+        yield i, elapsed, log_results

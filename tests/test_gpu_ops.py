@@ -1,0 +1,291 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every kernel family through the C ABI
+against the golden fixtures (imported reference) and the CPU oracle on seeded inputs.
+
+Tolerances: all arithmetic is fp32; forward results must be within 1e-4 rel-L2 of the
+reference (the north-star bound for the generator output; single ops land at ~1e-6),
+gradients within 1e-3 rel-L2 per tensor."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+FWD_TOL = 1e-5   # single op, fp32 accumulation order only
+GRAD_TOL = 1e-4
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ops(golden):
+    return golden("ops_tiny")
+
+
+def _conv_cases():
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ops_tiny.npz"))
+    return sorted({k.split("/")[0] for k in z.files if k.endswith("/cfg") and k.startswith("conv_")})
+
+
+def test_library_is_in_tree_and_loaded():
+    import os
+    from featuresynth._ops import lib
+    L = lib.load()
+    assert L.ms_version() >= 100
+    assert os.path.realpath(lib.LIB_PATH).startswith(os.path.realpath(os.path.join(os.path.dirname(__file__), "..")))
+    maps = open("/proc/self/maps").read()
+    assert "libmsynth_hip.so" in maps
+    assert len({ln.split()[-1] for ln in maps.splitlines() if "libamdhip64" in ln}) == 1, "two HIP runtimes loaded"
+
+
+@pytest.mark.parametrize("name", _conv_cases())
+def test_conv_golden(ops, name):
+    from featuresynth._ops import functional as F_
+    z = ops
+    stride, pad, dil, groups, act, reflect = [int(v) for v in z[name + "/cfg"]]
+    x = dev(z[name + "/x"]).requires_grad_(True)
+    w = dev(z[name + "/w"]).requires_grad_(True)
+    b = dev(z[name + "/b"]).requires_grad_(True)
+    y = F_.Conv1dFn.apply(x, w, b, stride, pad, dil, groups, 1 if reflect else 0, act)
+    assert tuple(y.shape) == z[name + "/y"].shape
+    assert rel_l2(host(y), z[name + "/y"]) < FWD_TOL
+    if reflect:   # input gradient through a reflection pad is not on the hot path
+        gw, gb = torch.autograd.grad(y, (w, b), dev(z[name + "/gy"]))
+    else:
+        gx, gw, gb = torch.autograd.grad(y, (x, w, b), dev(z[name + "/gy"]))
+        assert rel_l2(host(gx), z[name + "/gx"]) < GRAD_TOL
+    assert rel_l2(host(gw), z[name + "/gw"]) < GRAD_TOL
+    assert rel_l2(host(gb), z[name + "/gb"]) < GRAD_TOL
+
+
+@pytest.mark.parametrize("name", ["convt_k16_s8", "convt_k4_s2", "convt_k16_s8_l1"])
+def test_convt_golden(ops, name):
+    from featuresynth._ops import functional as F_
+    z = ops
+    stride, pad = [int(v) for v in z[name + "/cfg"]]
+    x = dev(z[name + "/x"]).requires_grad_(True)
+    w = dev(z[name + "/w"]).requires_grad_(True)
+    b = dev(z[name + "/b"]).requires_grad_(True)
+    y = F_.ConvTranspose1dFn.apply(x, w, b, stride, pad, 1)
+    assert tuple(y.shape) == z[name + "/y"].shape
+    assert rel_l2(host(y), z[name + "/y"]) < FWD_TOL
+    gx, gw, gb = torch.autograd.grad(y, (x, w, b), dev(z[name + "/gy"]))
+    assert rel_l2(host(gx), z[name + "/gx"]) < GRAD_TOL
+    assert rel_l2(host(gw), z[name + "/gw"]) < GRAD_TOL
+    assert rel_l2(host(gb), z[name + "/gb"]) < GRAD_TOL
+
+
+@pytest.mark.parametrize("d", [1, 3, 9])
+def test_residual_atom_golden(ops, d):
+    from featuresynth.util.modules import ResidualAtom
+    z = ops
+    nm = "atom_d%d" % d
+    atom = ResidualAtom(8, d).cuda()
+    atom.load_state_dict({k: torch.from_numpy(z[nm + "/sd/" + k]) for k in
+                          ("main.0.weight", "main.0.bias", "main.1.weight", "main.1.bias")})
+    x = dev(z[nm + "/x"]).requires_grad_(True)
+    y = atom(x)
+    assert rel_l2(host(y), z[nm + "/y"]) < FWD_TOL
+    y.backward(dev(z[nm + "/gy"]))
+    assert rel_l2(host(x.grad), z[nm + "/gx"]) < GRAD_TOL
+    for k, p in atom.named_parameters():
+        assert rel_l2(host(p.grad), z[nm + "/grad/" + k]) < GRAD_TOL, k
+
+
+def test_residual_stack_golden(ops):
+    from featuresynth.util.modules import ResidualStack
+    z = ops
+    st = ResidualStack(8, [1, 3, 9]).cuda()
+    st.load_state_dict({k[len("stack/sd/"):]: torch.from_numpy(z[k]) for k in z.files
+                        if k.startswith("stack/sd/")})
+    assert rel_l2(host(st(dev(z["stack/x"]))), z["stack/y"]) < FWD_TOL
+
+
+@pytest.mark.parametrize("L", [67, 64, 5])
+def test_avg_pool_golden(ops, L):
+    from featuresynth._ops import functional as F_
+    z = ops
+    p = "pool_L%d/" % L
+    x = dev(z[p + "x"]).requires_grad_(True)
+    y = F_.AvgPoolFn.apply(x)
+    assert tuple(y.shape) == z[p + "y"].shape
+    assert rel_l2(host(y), z[p + "y"]) < 1e-6
+    y.backward(dev(z[p + "gy"]))
+    assert rel_l2(host(x.grad), z[p + "gx"]) < 1e-6
+
+
+def test_scalar_losses_golden(ops):
+    from featuresynth import loss as LS
+    z = ops
+    r = dev(z["hinge_d/r"]).requires_grad_(True)
+    f = dev(z["hinge_d/f"]).requires_grad_(True)
+    v = LS.hinge_discriminator_loss(r, f)
+    assert abs(v.item() - float(z["hinge_d/loss"])) < 1e-6
+    v.backward()
+    assert np.allclose(host(r.grad), z["hinge_d/gr"], atol=1e-8)
+    assert np.allclose(host(f.grad), z["hinge_d/gf"], atol=1e-8)
+    f2 = dev(z["hinge_g/f"]).requires_grad_(True)
+    v = LS.hinge_generator_loss(f2)
+    assert abs(v.item() - float(z["hinge_g/loss"])) < 1e-6
+    v.backward()
+    assert np.allclose(host(f2.grad), z["hinge_g/gf"], atol=1e-8)
+    assert abs(LS.least_squares_generator_loss(dev(z["hinge_g/f"])).item() - float(z["ls/g"])) < 1e-6
+    assert abs(LS.least_squares_disc_loss(dev(z["hinge_d/r"]), dev(z["hinge_d/f"])).item() - float(z["ls/d"])) < 1e-6
+
+
+def test_composite_losses_golden(ops):
+    from featuresynth import loss as LS
+    z = ops
+    rf = [[dev(z["genloss/rf%d_%d" % (s, i)]) for i in range(6)] for s in range(3)]
+    ff = [[dev(z["genloss/ff%d_%d" % (s, i)]).requires_grad_(True) for i in range(6)] for s in range(3)]
+    rj = [dev(z["genloss/rj%d" % s]).requires_grad_(True) for s in range(3)]
+    fj = [dev(z["genloss/fj%d" % s]).requires_grad_(True) for s in range(3)]
+    gl = LS.mel_gan_gen_loss(rf, ff, rj, fj, gan_loss=LS.hinge_generator_loss)
+    ref = float(z["genloss/loss"])
+    assert abs(gl.item() - ref) <= 1e-5 * abs(ref)
+    gl.backward()
+    for s in range(3):
+        assert np.allclose(host(fj[s].grad), z["genloss/gfj%d" % s], atol=1e-8)
+        for i in range(6):
+            assert np.allclose(host(ff[s][i].grad), z["genloss/gff%d_%d" % (s, i)], rtol=1e-5, atol=1e-9)
+    for t in fj:
+        t.grad = None
+    dl = LS.mel_gan_disc_loss(rj, fj, gan_loss=LS.hinge_discriminator_loss)
+    assert abs(dl.item() - float(z["discloss/loss"])) < 1e-6
+    dl.backward()
+    for s in range(3):
+        assert np.allclose(host(rj[s].grad), z["discloss/grj%d" % s], atol=1e-8)
+        assert np.allclose(host(fj[s].grad), z["discloss/gfj%d" % s], atol=1e-8)
+    # unfused fallbacks (arbitrary gan_loss callables) agree with the fused nodes
+    gl2 = LS.mel_gan_gen_loss(rf, ff, rj, fj, gan_loss=lambda j: LS.hinge_generator_loss(j))
+    assert abs(gl2.item() - ref) <= 1e-5 * abs(ref)
+    fl = LS.mel_gan_feature_loss(rf, ff)
+    assert fl.dim() == 0
+
+
+def test_adam_golden(ops):
+    from featuresynth._ops import prims as P
+    z = ops
+    n = z["adam/p0"].size
+    pad = (n + 3) // 4 * 4
+    p = torch.zeros(pad, device="cuda"); p[:n] = dev(z["adam/p0"])
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for i in range(3):
+        g = torch.zeros(pad, device="cuda"); g[:n] = dev(z["adam/g%d" % i])
+        P.adam_step(p, g, m, v, step, 1e-4, 0.5, 0.9, 1e-8)
+        assert rel_l2(host(p[:n]), z["adam/p%d" % (i + 1)]) < 1e-6
+    assert int(step.item()) == 3
+
+
+def test_audio2mel_golden(golden):
+    from featuresynth.feature.feature import Audio2Mel
+    z = golden("audio2mel")
+    x = np.random.default_rng(0).uniform(-0.95, 0.95, 22050).astype(np.float32)
+    for n_mel in (80, 128):
+        a2m = Audio2Mel(n_mel_channels=n_mel).cuda()
+        assert np.abs(host(a2m.mel_basis) - z["basis%d" % n_mel]).max() < 1e-6
+        y = a2m(x)                                   # numpy in, as feature/feature.py:41-42 allows
+        assert tuple(y.shape) == (1, n_mel, 84)
+        assert np.abs(host(y) - z["logmel%d" % n_mel]).max() < 2e-4
+        y2 = a2m(torch.from_numpy(x).view(1, 1, -1).cuda())
+        assert torch.equal(y, y2)
+    with pytest.raises(RuntimeError):
+        Audio2Mel().cuda()(np.zeros(100, np.float32))   # shorter than one frame
+
+
+# ---------------------------------------------------------------- hot-path layer shapes vs oracle
+
+HOT_CONVS = [
+    # name, B, Cin, L, Cout, K, stride, pad, dil, groups, act, reflect
+    ("g_first_k7", 2, 80, 32, 512, 7, 1, 3, 1, 1, 1, True),
+    ("atom_c256_d9", 2, 256, 70, 256, 3, 1, 9, 9, 1, 1, False),
+    ("atom_c128_d3", 1, 128, 300, 128, 3, 1, 3, 3, 1, 1, False),
+    ("atom_c64_d1", 1, 64, 515, 64, 3, 1, 1, 1, 1, 1, False),
+    ("atom_c32_d9", 2, 32, 1031, 32, 3, 1, 9, 9, 1, 1, False),
+    ("g_last_k7_tanh", 2, 32, 1000, 1, 7, 1, 3, 1, 1, 2, False),
+    ("d_k15", 2, 1, 2049, 16, 15, 1, 7, 1, 1, 1, False),
+    ("d_k41_g4", 2, 16, 2049, 64, 41, 4, 20, 1, 4, 1, False),
+    ("d_k41_g16", 2, 64, 513, 256, 41, 4, 20, 1, 16, 1, False),
+    ("d_k41_g64", 1, 256, 129, 1024, 41, 4, 20, 1, 64, 1, False),
+    ("d_k41_g256", 2, 1024, 33, 1024, 41, 4, 20, 1, 256, 1, False),
+    ("d_k5", 2, 1024, 17, 1024, 5, 1, 2, 1, 1, 1, False),
+    ("d_judge", 2, 1024, 9, 1, 3, 1, 1, 1, 1, 0, False),
+]
+
+
+@pytest.mark.parametrize("case", HOT_CONVS, ids=[c[0] for c in HOT_CONVS])
+def test_conv_hot_shapes_vs_oracle(case):
+    from featuresynth._ops import functional as F_
+    from oracle import oracle as O
+    name, B, Cin, L, Cout, K, stride, pad, dil, groups, act, reflect = case
+    rng = np.random.default_rng(abs(hash(name)) % (2 ** 31))
+    x = rng.standard_normal((B, Cin, L)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin // groups, K)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal((Cout,)) * 0.1).astype(np.float32)
+    pm = O.PAD_REFLECT if reflect else O.PAD_ZERO
+    y_ref = O.conv1d_fwd(x, w, b, stride, pad, dil, groups, pm, act)
+    gy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    gp = O.act_bwd(y_ref, gy, act)
+    gw_ref, gb_ref = O.conv1d_bwd_weight(x, gp, w.shape, stride, pad, dil, groups, pm)
+    xt, wt, bt = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    y = F_.Conv1dFn.apply(xt, wt, bt, stride, pad, dil, groups, 1 if reflect else 0, act)
+    assert rel_l2(host(y), y_ref) < FWD_TOL
+    if reflect:
+        gw, gb = torch.autograd.grad(y, (wt, bt), dev(gy))
+    else:
+        gx, gw, gb = torch.autograd.grad(y, (xt, wt, bt), dev(gy))
+        gx_ref = O.conv1d_bwd_data(gp, w, x.shape, stride, pad, dil, groups, pm)
+        assert rel_l2(host(gx), gx_ref) < GRAD_TOL
+    assert rel_l2(host(gw), gw_ref) < GRAD_TOL
+    assert rel_l2(host(gb), gb_ref) < GRAD_TOL
+
+
+HOT_CONVT = [("ct_512_256", 2, 512, 9, 256, 16, 8, 4), ("ct_256_128", 1, 256, 70, 128, 16, 8, 4),
+             ("ct_128_64", 2, 128, 130, 64, 4, 2, 1), ("ct_64_32", 1, 64, 1027, 32, 4, 2, 1)]
+
+
+@pytest.mark.parametrize("case", HOT_CONVT, ids=[c[0] for c in HOT_CONVT])
+def test_convt_hot_shapes_vs_oracle(case):
+    from featuresynth._ops import functional as F_
+    from oracle import oracle as O
+    name, B, Cin, L, Cout, K, stride, pad = case
+    rng = np.random.default_rng(abs(hash(name)) % (2 ** 31))
+    x = rng.standard_normal((B, Cin, L)).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout, K)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal((Cout,)) * 0.1).astype(np.float32)
+    y_ref = O.conv_transpose1d_fwd(x, w, b, stride, pad, O.ACT_LRELU)
+    gy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    gp = O.act_bwd(y_ref, gy, O.ACT_LRELU)
+    xt, wt, bt = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    y = F_.ConvTranspose1dFn.apply(xt, wt, bt, stride, pad, 1)
+    assert rel_l2(host(y), y_ref) < FWD_TOL
+    gx, gw, gb = torch.autograd.grad(y, (xt, wt, bt), dev(gy))
+    assert rel_l2(host(gx), O.conv_transpose1d_bwd_data(gp, w, x.shape, stride, pad)) < GRAD_TOL
+    gw_ref, gb_ref = O.conv_transpose1d_bwd_weight(x, gp, w.shape, stride, pad)
+    assert rel_l2(host(gw), gw_ref) < GRAD_TOL
+    assert rel_l2(host(gb), gb_ref) < GRAD_TOL
+
+
+def test_bad_arguments_raise():
+    from featuresynth._ops import functional as F_
+    x = torch.zeros(1, 4, 16, device="cuda")
+    w = torch.zeros(4, 3, 3, device="cuda")          # channel mismatch
+    with pytest.raises(RuntimeError):
+        F_.Conv1dFn.apply(x, w, None, 1, 1, 1, 1, 0, 0)
+    with pytest.raises(RuntimeError):                  # CPU tensor: no fallback
+        F_.Conv1dFn.apply(x.cpu(), torch.zeros(4, 4, 3), None, 1, 1, 1, 1, 0, 0)
+    with pytest.raises(RuntimeError):                  # kernel longer than the padded input
+        F_.Conv1dFn.apply(x, torch.zeros(4, 4, 41, device="cuda"), None, 1, 0, 1, 1, 0, 0)
+    with pytest.raises(RuntimeError):                  # non-contiguous
+        F_.Conv1dFn.apply(torch.zeros(1, 16, 4, device="cuda").transpose(1, 2),
+                          torch.zeros(4, 4, 3, device="cuda"), None, 1, 1, 1, 1, 0, 0)

@@ -253,3 +253,35 @@ def test_mel_basis_analytic():
     for row in b:
         nz = np.nonzero(row)[0]
         assert nz.size and (np.diff(nz) == 1).all()
+
+
+def test_torch_graph_matches_golden(golden):
+    """The torch-functional CPU restatement (cpu_baseline / full-size checker) against the
+    imported reference: generator, discriminator and two trainer steps."""
+    import torch
+    from featuresynth._synthetic import (synthetic_features, synthetic_samples,
+                                         synthetic_state_dict, strided_sample)
+    from oracle import torch_graph as TG
+    z = golden("g_fwd")
+    gp = TG.to_params(synthetic_state_dict(O.generator_param_shapes(80), seed=7), False)
+    feat = np.random.default_rng(1).standard_normal((1, 80, 32)).astype(np.float32)
+    with torch.no_grad():
+        y = TG.generator(gp, torch.from_numpy(feat)).numpy()
+    assert rel_l2(y, z["cfg2/y_ref32"]) < 1e-6
+    zd = golden("d_fwd")
+    dp = TG.to_params(synthetic_state_dict(O.discriminator_param_shapes(), seed=7), False)
+    with torch.no_grad():
+        _, judges = TG.discriminator(dp, torch.from_numpy(synthetic_samples(1)))
+    for s in range(3):
+        assert rel_l2(judges[s].numpy(), zd["cfg/j%d_ref32" % s]) < 1e-6
+    zt = golden("train")
+    B, T, _ = [int(v) for v in zt["small/cfg"]]
+    tr = TG.Trainer(synthetic_state_dict(O.generator_param_shapes(80), seed=7, bias_scale=0.02),
+                    synthetic_state_dict(O.discriminator_param_shapes(), seed=8, bias_scale=0.02))
+    r0 = tr.d_step(torch.from_numpy(synthetic_samples(B, T * 256, rank=0)),
+                   torch.from_numpy(synthetic_features(B, 80, T, rank=0)))
+    r1 = tr.g_step(torch.from_numpy(synthetic_samples(B, T * 256, rank=1)),
+                   torch.from_numpy(synthetic_features(B, 80, T, rank=1)))
+    assert abs(r0["d_loss"] - zt["small/losses"][0]) < 1e-6
+    assert abs(r1["g_loss"] - zt["small/losses"][1]) < 1e-5 * abs(zt["small/losses"][1]) + 1e-7
+    assert rel_l2(strided_sample(r1["fake"]), zt["small/fake_smp"]) < 1e-5
