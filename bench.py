@@ -41,6 +41,24 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def host_cpu_share(cap=16):
+    """Threads this process may really use: affinity mask, cgroup CPU quota, and the GPU box's
+    per-GPU share (16) -- os.cpu_count() reports the whole host and oversubscribes."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,14 +204,18 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import torch_graph as TG
-        cores = os.cpu_count() or 1
+        cores = host_cpu_share()
         torch.set_num_threads(cores)
+        log("[bench] cpu baseline on %d threads (os.cpu_count()=%s) ..." % (cores, os.cpu_count()))
         tr = TG.Trainer(gsd, dsd)
         s_cpu = torch.from_numpy(synthetic_samples(B, WINDOW, rank=0))
         f_cpu = torch.from_numpy(synthetic_features(B, args.mels, T, rank=0))
+        c0 = time.perf_counter()
         tr.d_step(s_cpu, f_cpu)                      # warm-up (allocator, MKLDNN primitives)
+        log("[bench]   warm-up D-step %.1f s" % (time.perf_counter() - c0))
         c0 = time.perf_counter()
         tr.d_step(s_cpu, f_cpu)
+        log("[bench]   D-step %.1f s" % (time.perf_counter() - c0))
         tr.g_step(s_cpu, f_cpu)
         cpu_s = time.perf_counter() - c0
         result["cpu_baseline"] = {

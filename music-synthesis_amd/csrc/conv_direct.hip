@@ -386,12 +386,19 @@ WgPlan plan_bwd_weight(const ConvP& p) {
     else if (p.Og >= 32) { q.cot = 32; q.jt = 128; }
     else if (p.Og >= 8) { q.cot = 16; q.jt = 256; }
     else { q.cot = 4; q.jt = 1024; }
-    q.TC = 64;
     const int J = p.Cg * p.K;
     int nci = q.jt / p.K + 2;
     if (nci > p.Cg) nci = p.Cg;
     q.nci = nci;
-    q.xspan = (q.TC - 1) * p.stride + (p.K - 1) * p.dil + 1;
+    // time chunk per LDS fill: as long as fits the LDS budget (wide J tiles of many-channel,
+    // few-output layers such as the 1024->1 judge conv need a short chunk)
+    q.TC = 64;
+    for (;;) {
+        q.xspan = (q.TC - 1) * p.stride + (p.K - 1) * p.dil + 1;
+        const size_t lds = (size_t)(q.TC * (q.cot + 1) + q.nci * q.xspan) * sizeof(float);
+        if (lds <= (size_t)kLdsBudgetBytes || q.TC <= 4) break;
+        q.TC >>= 1;
+    }
     q.jtiles = ms_ceil_div(J, q.jt);
     q.cotiles = ms_ceil_div(p.Og, q.cot);
     const int tiles = q.jtiles * q.cotiles * p.groups;

@@ -52,7 +52,7 @@ def test_conv_golden(ops, name):
     from featuresynth._ops import functional as F_
     z = ops
     stride, pad, dil, groups, act, reflect = [int(v) for v in z[name + "/cfg"]]
-    x = dev(z[name + "/x"]).requires_grad_(True)
+    x = dev(z[name + "/x"]).requires_grad_(not reflect)
     w = dev(z[name + "/w"]).requires_grad_(True)
     b = dev(z[name + "/b"]).requires_grad_(True)
     y = F_.Conv1dFn.apply(x, w, b, stride, pad, dil, groups, 1 if reflect else 0, act)
@@ -237,7 +237,7 @@ def test_conv_hot_shapes_vs_oracle(case):
     gy = rng.standard_normal(y_ref.shape).astype(np.float32)
     gp = O.act_bwd(y_ref, gy, act)
     gw_ref, gb_ref = O.conv1d_bwd_weight(x, gp, w.shape, stride, pad, dil, groups, pm)
-    xt, wt, bt = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    xt, wt, bt = dev(x).requires_grad_(not reflect), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
     y = F_.Conv1dFn.apply(xt, wt, bt, stride, pad, dil, groups, 1 if reflect else 0, act)
     assert rel_l2(host(y), y_ref) < FWD_TOL
     if reflect:
