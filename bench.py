@@ -173,10 +173,19 @@ def main():
         tot_ms = sum(a["ms"] for a in agg.values())
         top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
         log("[bench] instrumented eager D+G pass: %.2f ms of kernels in %d launches" % (tot_ms, len(rec)))
-        for k, a in top[:12]:
+        for k, a in top[:40]:
             log("    %-46s x%-4d %8.3f ms  %7.2f TFLOP/s  %7.1f GB/s" % (
                 k, a["n"], a["ms"], a["flops"] / a["ms"] / 1e9 if a["ms"] else 0,
                 a["bytes"] / a["ms"] / 1e6 if a["ms"] else 0))
+        by_geom = {}
+        for name, cost, ms in rec:
+            kk = (cost.get("kernel") or name, name, cost.get("geom"))
+            g_ = by_geom.setdefault(kk, [0.0, 0, 0.0])
+            g_[0] += ms; g_[1] += 1; g_[2] += cost.get("flops", 0)
+        log("[bench] per-layer (kernel, C-ABI entry, (B,Cin,Lin,Cout,K,stride,dil,groups)):")
+        for kk, g_ in sorted(by_geom.items(), key=lambda kv: -kv[1][0])[:45]:
+            log("    %-40s %-22s %-44s x%-3d %7.3f ms %7.2f TF/s" % (
+                kk[0], kk[1], str(kk[2]), g_[1], g_[0], g_[2] / g_[0] / 1e9 if g_[0] else 0))
         k, a = top[0]
         avg_s = a["ms"] / a["n"] / 1e3
         fl, by = a["flops"] / a["n"], a["bytes"] / a["n"]

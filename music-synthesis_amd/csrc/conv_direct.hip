@@ -42,9 +42,12 @@ __global__ __launch_bounds__(256) void k_conv1d_fwd_direct(
 #pragma unroll
         for (int j = 0; j < RT; ++j) acc[i][j] = 0.f;
 
+    // only the columns that valid outputs of this tile read are filled (short rows: L << TT)
+    const int tvalid = min(TT, p.Lout - t0);
+    const int span_used = min(span, (tvalid - 1) * p.stride + (K - 1) * p.dil + 1);
     for (int ci0 = 0; ci0 < p.Cg; ci0 += cic) {
-        for (int idx = tid; idx < cic * span; idx += 256) {
-            const int ci = idx / span, pos = idx - ci * span;
+        for (int idx = tid; idx < cic * span_used; idx += 256) {
+            const int ci = idx / span_used, pos = idx - ci * span_used;
             float v = 0.f;
             if (ci0 + ci < p.Cg) {
                 const int s = ms_src_index(t0 * p.stride - p.pad + pos, p.Lin, p.pad_mode);
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void k_conv1d_fwd_direct(
                     if (x_act) v = ms_act_grad(v, x_act[off], x_act_kind, p.slope);
                 }
             }
-            xs[idx] = v;
+            xs[ci * span + pos] = v;
         }
         const int rk = cic * K;
         for (int idx = tid; idx < rk * CT; idx += 256) {
@@ -74,7 +77,8 @@ __global__ __launch_bounds__(256) void k_conv1d_fwd_direct(
 #pragma unroll
                 for (int i = 0; i < RC; ++i) wv[i] = wr[k * CTP + i];
 #pragma unroll
-                for (int j = 0; j < RT; ++j) xv[j] = xr[j * NTX * p.stride + k * p.dil];
+                for (int j = 0; j < RT; ++j)   // columns past span_used belong to masked outputs
+                    xv[j] = (tx + j * NTX < tvalid) ? xr[j * NTX * p.stride + k * p.dil] : 0.f;
 #pragma unroll
                 for (int i = 0; i < RC; ++i)
 #pragma unroll
@@ -100,6 +104,43 @@ __global__ __launch_bounds__(256) void k_conv1d_fwd_direct(
             if (res) v = res[o] + v;
             y[o] = v;
         }
+    }
+}
+
+
+// ---------------------------------------------- forward, few output channels, many inputs
+// The discriminator's judge conv (1024 -> 1, k3) has 1024*3 MACs per output and only B*L outputs:
+// it is a reduction, not a tiling problem.  32 time lanes x 8 channel slices per workgroup, each
+// slice sums its channels (coalesced row reads), slices are combined through LDS.
+__global__ __launch_bounds__(256) void k_conv1d_fwd_cred(ConvP p, const float* __restrict__ x,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ y) {
+    __shared__ float red[8][33];
+    const int tl = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int t = blockIdx.x * 32 + tl;
+    const int co = blockIdx.y, b = blockIdx.z;
+    const int g = co / p.Og;
+    const int cper = (p.Cg + 7) / 8;
+    const int c_lo = part * cper, c_hi = min(p.Cg, c_lo + cper);
+    float acc = 0.f;
+    if (t < p.Lout) {
+        for (int c = c_lo; c < c_hi; ++c) {
+            const float* xr = x + ((size_t)b * p.Cin + (size_t)g * p.Cg + c) * p.Lin;
+            const float* wr = w + ((size_t)co * p.Cg + c) * p.K;
+            for (int k = 0; k < p.K; ++k) {
+                const int s = ms_src_index(t * p.stride + k * p.dil - p.pad, p.Lin, p.pad_mode);
+                if (s >= 0) acc = fmaf(wr[k], xr[s], acc);
+            }
+        }
+    }
+    red[part][tl] = acc;
+    __syncthreads();
+    if (part == 0 && t < p.Lout) {
+        float v = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v += red[i][tl];
+        y[((size_t)b * p.Cout + co) * p.Lout + t] = ms_apply_act(v, p.act, p.slope);
     }
 }
 
@@ -417,6 +458,7 @@ WgPlan plan_bwd_weight(const ConvP& p) {
 }  // namespace
 
 const char* msk_conv1d_fwd_direct_name(const ConvP& p) {
+    if (p.Cout <= 4 && p.Cg >= 256) return "k_conv1d_fwd_cred";
     if (p.Og >= 32) return "k_conv1d_fwd_direct<64, 64, 4, 4>";
     if (p.Og >= 8) return "k_conv1d_fwd_direct<16, 256, 4, 4>";
     return "k_conv1d_fwd_direct<4, 256, 1, 4>";
@@ -436,9 +478,19 @@ const char* msk_conv1d_bwd_weight_direct_name(const ConvP& p) {
     return "k_conv1d_bwd_weight_direct<4, 1024>";
 }
 
+static bool use_cred(const ConvP& p, const float* x_act, const float* residual, const float* y_act) {
+    return p.Cout <= 4 && p.Cg >= 256 && !x_act && !residual && !y_act;
+}
+
 int msk_conv1d_fwd_direct(const ConvP& p, const float* x, const float* x_act, int x_act_kind,
                           const float* w, const float* bias, const float* residual, float* y,
                           float* y_act, hipStream_t s) {
+    if (use_cred(p, x_act, residual, y_act)) {
+        dim3 grid(ms_ceil_div(p.Lout, 32), p.Cout, p.B);
+        hipLaunchKernelGGL(k_conv1d_fwd_cred, grid, dim3(256), 0, s, p, x, w, bias, y);
+        MS_CHECK_LAUNCH();
+        return MS_OK;
+    }
     if (p.Og >= 32) return launch_fwd<64, 64, 4, 4>(p, x, x_act, x_act_kind, w, bias, residual, y, y_act, s);
     if (p.Og >= 8) return launch_fwd<16, 256, 4, 4>(p, x, x_act, x_act_kind, w, bias, residual, y, y_act, s);
     return launch_fwd<4, 256, 1, 4>(p, x, x_act, x_act_kind, w, bias, residual, y, y_act, s);

@@ -1,24 +1,844 @@
-// f32-MFMA implicit-GEMM convolution kernels for gfx950 (placeholder: predicates return false
-// until the kernels land, so every layer runs on the direct kernels).
+// f32-MFMA implicit-GEMM convolution kernels for gfx950 (CDNA4).
+//
+// The dense stride-1 convolutions of the hot path (the 24 dilated k3 convs of the generator's
+// residual atoms, its k7 input conv, the discriminator's 1024->1024 k5 conv) carry ~3/4 of the
+// train step's FLOPs at 48..250 FLOP/B: in exact fp32 they are bound by the matrix pipe, not by
+// HBM.  They are lowered to an im2col x weight contraction executed with v_mfma_f32_32x32x2_f32
+// (fp32 in / fp32 accumulate, bit-identical to an fmaf chain, 64 FLOP/clk/SIMD):
+//
+//   forward        Y[m, (b,t)]  = sum_{(c,j)}  W[m, c, j]        * X[b, c, t + j*dil - pad]
+//   backward data  dX[m, (b,t)] = sum_{(c,j')} W[c, m, K-1-j']   * dY'[b, c, t + j'*dil - pad]
+//   backward wgt   dW[m, (c,j)] = sum_{(b,t)}  dY'[b, m, t]      * X[b, c, t + j*dil - pad]
+//
+// (dY' = dY * act'(Y) is formed in the operand loader.)  A 256-thread workgroup (4 waves of 64)
+// owns a BM x BN output tile; each wave a TM x TN grid of 32x32 MFMA tiles.  Per K-chunk the A
+// (weights or dY') and B (im2col of the activations, built on the fly: nothing is materialised
+// in HBM) tiles are staged in LDS; time is the lane-fast index of every global access, so
+// activation traffic is coalesced along contiguous audio frames.  Global loads of chunk c+1 are
+// in flight while the MFMAs of chunk c run.
 #include "conv_mfma.h"
+#include <stdio.h>
 
-bool msm_fwd_applicable(const ConvP&) { return false; }
-bool msm_bwd_data_applicable(const ConvP&) { return false; }
-bool msm_bwd_weight_applicable(const ConvP&) { return false; }
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KC = 16;        // GEMM-K elements staged per chunk
+constexpr int KCP = KC + 1;   // odd LDS row stride: conflict-free 32-lane column reads
+
+struct IgP {
+    int B, CK, L, M, dil, off0, pad_mode, act, in_act, N, KG;
+    float slope;
+};
+
+template <int K>
+__device__ __forceinline__ float load_im2col(const IgP& p, const float* __restrict__ X,
+                                             const float* __restrict__ Xact, int b, int t, int kg) {
+    // element (kg = c*K + j, n = (b, t)) of the im2col matrix
+    if (kg >= p.KG) return 0.f;
+    const int c = kg / K, j = kg - c * K;
+    const int s = ms_src_index(t + j * p.dil + p.off0, p.L, p.pad_mode);
+    if (s < 0) return 0.f;
+    const size_t off = ((size_t)b * p.CK + c) * p.L + s;
+    float v = X[off];
+    if (Xact) v = ms_act_grad(v, Xact[off], p.in_act, p.slope);
+    return v;
+}
+
+// ------------------------------------------------------------ forward / backward data
+template <int WGM, int WGN, int TM, int TN, int K, bool TRANS>
+__global__ __launch_bounds__(256) void k_igemm_conv(IgP p, const float* __restrict__ X,
+                                                   const float* __restrict__ Xact,
+                                                   const float* __restrict__ W,
+                                                   const float* __restrict__ bias,
+                                                   const float* __restrict__ res,
+                                                   float* __restrict__ Y,
+                                                   float* __restrict__ Yact) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int RA = BM * KC / 256, RB = BN * KC / 256;
+    constexpr int NCOL = BN > 256 ? BN / 256 : 1;         // columns a loader thread owns
+    constexpr int ROWSTEP = BN > 256 ? 1 : 256 / BN;      // B-tile rows covered per pass
+    static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(RB % NCOL == 0, "loader mapping");
+    __shared__ float As[BM * KCP];
+    __shared__ float Bs[KC * BN];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    // B loader: fixed column(s) per thread
+    int cb[NCOL], ct[NCOL];
+    bool cvalid[NCOL];
+#pragma unroll
+    for (int q = 0; q < NCOL; ++q) {
+        const int n = n0 + (tid % BN) + q * 256;
+        cvalid[q] = n < p.N;
+        const int nn = cvalid[q] ? n : 0;
+        cb[q] = nn / p.L;
+        ct[q] = nn - cb[q] * p.L;
+    }
+    const int brow0 = BN > 256 ? 0 : tid / BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float ra[RA], rb[RB];
+    auto gload = [&](int kc0) {
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            const int e = r * 256 + tid;
+            float v = 0.f;
+            if (!TRANS) {
+                const int kk = e % KC, m = e / KC;
+                if (m0 + m < p.M && kc0 + kk < p.KG) v = W[(size_t)(m0 + m) * p.KG + kc0 + kk];
+            } else {
+                const int m = e % BM, kk = e / BM;
+                const int kg = kc0 + kk;
+                if (m0 + m < p.M && kg < p.KG) {
+                    const int c = kg / K, j = kg - c * K;
+                    v = W[((size_t)c * p.M + m0 + m) * K + (K - 1 - j)];
+                }
+            }
+            ra[r] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < RB / NCOL; ++r) {
+            const int kk = brow0 + r * ROWSTEP;
+#pragma unroll
+            for (int q = 0; q < NCOL; ++q)
+                rb[r * NCOL + q] = cvalid[q] ? load_im2col<K>(p, X, Xact, cb[q], ct[q], kc0 + kk) : 0.f;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            const int e = r * 256 + tid;
+            if (!TRANS) As[(e / KC) * KCP + (e % KC)] = ra[r];
+            else As[(e % BM) * KCP + (e / BM)] = ra[r];
+        }
+#pragma unroll
+        for (int r = 0; r < RB / NCOL; ++r) {
+            const int kk = brow0 + r * ROWSTEP;
+#pragma unroll
+            for (int q = 0; q < NCOL; ++q) Bs[kk * BN + (tid % BN) + q * 256] = rb[r * NCOL + q];
+        }
+    };
+
+    const int nchunks = (p.KG + KC - 1) / KC;
+    gload(0);
+    lstore();
+    __syncthreads();
+    const int arow = (wm * TM * 32 + (lane & 31)) * KCP + (lane >> 5);
+    const int bcol = (lane >> 5) * BN + wn * TN * 32 + (lane & 31);
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        if (more) gload((c + 1) * KC);
+#pragma unroll
+        for (int k2 = 0; k2 < KC / 2; ++k2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[arow + i * 32 * KCP + 2 * k2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[bcol + 2 * k2 * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            lstore();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: D[row][col]: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+        if (n >= p.N) continue;
+        const int b = n / p.L, t = n - b * p.L;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
+                const size_t o = ((size_t)b * p.M + m) * p.L + t;
+                float v = acc[i][j][r] + (bias ? bias[m] : 0.f);
+                v = ms_apply_act(v, p.act, p.slope);
+                if (Yact) Yact[o] = v;
+                if (res) v += res[o];
+                Y[o] = v;
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------ forward / backward data, row-tile form
+// Same contraction as k_igemm_conv, but the activation tile is staged ONCE per channel chunk
+// as raw rows with their dilation halo (no im2col duplication, no per-element index math in the
+// K loop): a workgroup owns either a BN-long segment of one (b) row (L >= BN) or R = BN / L whole
+// rows (short L: the discriminator's 1024->1024 k5 conv at L = 32 / 17 / 9).  The B fragment of
+// tap j is the same LDS row read at a +j*dil column offset.  Weights arrive as 16-byte loads of
+// the contiguous (c, j) run of each output-channel row; for backward-data they are first
+// re-laid-out (transposed + tap-flipped) into the workspace by k_transpose_flip_w.
+struct RowP {
+    int B, CK, L, M, dil, off0, pad_mode, act, in_act, KG;
+    int Lt, R, SS, RSZ, tiles_per_row;   // segment length, rows per tile, LDS segment/row strides
+    float slope;
+};
+
+template <int WGM, int WGN, int TM, int TN, int K, int CC>
+__global__ __launch_bounds__(256) void k_conv_mfma_rows(RowP p, const float* __restrict__ X,
+                                                       const float* __restrict__ Xact,
+                                                       const float* __restrict__ W,
+                                                       const float* __restrict__ bias,
+                                                       const float* __restrict__ res,
+                                                       float* __restrict__ Y,
+                                                       float* __restrict__ Yact) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int KK = CC * K;               // GEMM-K elements per chunk
+    constexpr int AS = KK + 1;               // odd LDS stride of the weight tile
+    constexpr int A4 = BM * (KK / 4);        // float4 loads per weight tile
+    constexpr int RA4 = (A4 + 255) / 256;
+    constexpr int MAXCOL = 2;                // LDS columns a loader thread owns (RSZ <= 512)
+    static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(KK % 4 == 0 && KK % 2 == 0, "chunk must be float4- and k-pair-sized");
+    extern __shared__ float smem[];
+    float* As = smem;                        // [BM][AS]
+    float* Xs = smem + BM * AS;              // [CC][RSZ]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int m0 = blockIdx.y * BM;
+    int b0, t0;
+    if (p.R == 1) { b0 = blockIdx.x / p.tiles_per_row; t0 = (blockIdx.x - b0 * p.tiles_per_row) * BN; }
+    else { b0 = blockIdx.x * p.R; t0 = 0; }
+
+    // X loader: per-thread LDS columns -> global offset of channel 0 (or -1: zero padding)
+    long long goff[MAXCOL];
+#pragma unroll
+    for (int q = 0; q < MAXCOL; ++q) {
+        const int col = tid + q * 256;
+        goff[q] = -1;
+        if (col < p.RSZ) {
+            const int r = col / p.SS, pos = col - r * p.SS;
+            const int b = b0 + r;
+            if (b < p.B) {
+                const int s = ms_src_index(t0 + pos + p.off0, p.L, p.pad_mode);
+                if (s >= 0) goff[q] = (long long)b * p.CK * p.L + s;
+            }
+        }
+    }
+    const bool has_col1 = p.RSZ > 256;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // B-fragment base column of this lane for each N sub-tile (output column -> LDS column)
+    int bbase[TN];
+    bool nvalid[TN];
+    int ob[TN], ot[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = wn * TN * 32 + j * 32 + (lane & 31);
+        const int r = nl / p.Lt, tc = nl - r * p.Lt;
+        nvalid[j] = r < p.R && b0 + r < p.B && t0 + tc < p.L;
+        bbase[j] = nvalid[j] ? r * p.SS + tc : 0;
+        ob[j] = b0 + r;
+        ot[j] = t0 + tc;
+    }
+
+    float4 ra[RA4];
+    float rx[MAXCOL][CC];
+    auto gload = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < RA4; ++i) {
+            const int e = i * 256 + tid;
+            const int row = e / (KK / 4), q4 = e - row * (KK / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < A4 && m0 + row < p.M)
+                v = *reinterpret_cast<const float4*>(W + (size_t)(m0 + row) * p.KG + (size_t)c0 * K + q4 * 4);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < MAXCOL; ++q) {
+            if (q == 1 && !has_col1) break;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                float v = 0.f;
+                if (goff[q] >= 0) {
+                    const size_t off = (size_t)goff[q] + (size_t)(c0 + c) * p.L;
+                    v = X[off];
+                    if (Xact) v = ms_act_grad(v, Xact[off], p.in_act, p.slope);
+                }
+                rx[q][c] = v;
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < RA4; ++i) {
+            const int e = i * 256 + tid;
+            if (e < A4) {
+                const int row = e / (KK / 4), q4 = e - row * (KK / 4);
+                float* d = As + row * AS + q4 * 4;
+                d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < MAXCOL; ++q) {
+            if (q == 1 && !has_col1) break;
+            const int col = tid + q * 256;
+            if (col < p.RSZ) {
+#pragma unroll
+                for (int c = 0; c < CC; ++c) Xs[c * p.RSZ + col] = rx[q][c];
+            }
+        }
+    };
+
+    const int nchunks = p.CK / CC;
+    gload(0);
+    lstore();
+    __syncthreads();
+    const int arow = (wm * TM * 32 + (lane & 31)) * AS + h;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const bool more = ch + 1 < nchunks;
+        if (more) gload((ch + 1) * CC);
+#pragma unroll
+        for (int q = 0; q < KK / 2; ++q) {
+            constexpr int dummy = 0; (void)dummy;
+            const int kk0 = 2 * q, kk1 = 2 * q + 1;
+            const int off_lo = (kk0 / K) * p.RSZ + (kk0 % K) * p.dil;
+            const int off_hi = (kk1 / K) * p.RSZ + (kk1 % K) * p.dil;
+            const int off = h ? off_hi : off_lo;
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[arow + i * 32 * AS + 2 * q];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Xs[off + bbase[j]];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            lstore();
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        if (!nvalid[j]) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= p.M) continue;
+                const size_t o = ((size_t)ob[j] * p.M + m) * p.L + ot[j];
+                float v = acc[i][j][r] + (bias ? bias[m] : 0.f);
+                v = ms_apply_act(v, p.act, p.slope);
+                if (Yact) Yact[o] = v;
+                if (res) v += res[o];
+                Y[o] = v;
+            }
+        }
+    }
+}
+
+// Wt[ci][co*K + j'] = W[co][ci][K-1-j']  (weights of the conv that computes backward-data)
+__global__ __launch_bounds__(256) void k_transpose_flip_w(const float* __restrict__ W,
+                                                         float* __restrict__ Wt, int Co, int Ci,
+                                                         int K) {
+    const size_t total = (size_t)Co * Ci * K;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int jp = (int)(i % K);
+        const size_t r = i / K;
+        const int co = (int)(r % Co);
+        const int ci = (int)(r / Co);
+        Wt[i] = W[((size_t)co * Ci + ci) * K + (K - 1 - jp)];
+    }
+}
+
+// ------------------------------------------------------------------ backward weight
+// partial[z][m][n] = sum over this block's kk = (b,t) range of A[m,kk] * Bm[kk,n]
+//   A[m, kk] = dY'[b, m, t],  Bm[kk, n=(c,j)] = X[b, c, t + j*dil + off0]
+// Both operands are contiguous along kk (time), so both LDS tiles are [row][kk].
+template <int WGM, int WGN, int TM, int TN, int K>
+__global__ __launch_bounds__(256) void k_igemm_wgrad(IgP p, int chunks_per_split,
+                                                    const float* __restrict__ X,
+                                                    const float* __restrict__ Xact,
+                                                    const float* __restrict__ G,
+                                                    const float* __restrict__ Gact, int g_act,
+                                                    float* __restrict__ partial,
+                                                    size_t partial_stride) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int RA = BM * KC / 256, RB = BN * KC / 256;
+    static_assert(WGM * WGN == 4, "4 waves");
+    __shared__ float As[BM * KCP];
+    __shared__ float Bs[BN * KCP];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int NG = p.CK * K;                 // GEMM-N = (c, j) pairs
+    const int KT = p.B * p.L;                // GEMM-K = (b, t) pairs
+    const int kk_l = tid % KC, row0 = tid / KC;   // loader: fixed kk lane, rows row0 + 16*r
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float asum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asum[i] = 0.f;
+
+    // per-thread row descriptors are chunk-invariant: A rows m (offset m*L), B rows n = (c, j)
+    // (offset c*L, tap shift j*dil + off0 for the padding test)
+    int aoff[RA], boff[RB], bsh[RB];
+    bool avalid[RA], bvalid[RB];
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+        const int m = m0 + row0 + 16 * r;
+        avalid[r] = m < p.M;
+        aoff[r] = (avalid[r] ? m : 0) * p.L;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int n = n0 + row0 + 16 * r;
+        bvalid[r] = n < NG;
+        const int nn = bvalid[r] ? n : 0;
+        const int c = nn / K, j = nn - c * K;
+        bsh[r] = j * p.dil + p.off0;
+        boff[r] = c * p.L;
+    }
+
+    const int c_begin = blockIdx.z * chunks_per_split;
+    int c_end = c_begin + chunks_per_split;
+    const int nchunks = (KT + KC - 1) / KC;
+    if (c_end > nchunks) c_end = nchunks;
+
+    float ra[RA], rb[RB];
+    auto gload = [&](int chunk) {
+        const int kg = chunk * KC + kk_l;
+        const bool kv = kg < KT;
+        const int b = kv ? kg / p.L : 0;
+        const int t = kv ? kg - b * p.L : 0;
+        const float* Ga = G + (size_t)b * p.M * p.L + t;
+        const float* Gy = Gact ? Gact + (size_t)b * p.M * p.L + t : nullptr;
+        const float* Xb = X + (size_t)b * p.CK * p.L;
+        const float* Xa = Xact ? Xact + (size_t)b * p.CK * p.L : nullptr;
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            float v = 0.f;
+            if (kv && avalid[r]) {
+                v = Ga[aoff[r]];
+                if (Gy) v = ms_act_grad(v, Gy[aoff[r]], g_act, p.slope);
+            }
+            ra[r] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            float v = 0.f;
+            int sidx = t + bsh[r];
+            if (p.pad_mode == MS_PAD_REFLECT) sidx = ms_src_index(sidx, p.L, MS_PAD_REFLECT);
+            if (kv && bvalid[r] && (unsigned)sidx < (unsigned)p.L) {
+                v = Xb[boff[r] + sidx];
+                if (Xa) v = ms_act_grad(v, Xa[boff[r] + sidx], p.in_act, p.slope);
+            }
+            rb[r] = v;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int r = 0; r < RA; ++r) As[(row0 + 16 * r) * KCP + kk_l] = ra[r];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) Bs[(row0 + 16 * r) * KCP + kk_l] = rb[r];
+    };
+
+    const int arow = (wm * TM * 32 + (lane & 31)) * KCP + (lane >> 5);
+    const int brow = (wn * TN * 32 + (lane & 31)) * KCP + (lane >> 5);
+    if (c_begin < c_end) {
+        gload(c_begin);
+        lstore();
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = c + 1 < c_end;
+        if (more) gload(c + 1);
+#pragma unroll
+        for (int k2 = 0; k2 < KC / 2; ++k2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                a[i] = As[arow + i * 32 * KCP + 2 * k2];
+                asum[i] += a[i];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[brow + j * 32 * KCP + 2 * k2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            lstore();
+            __syncthreads();
+        }
+    }
+
+    float* part = partial + (size_t)blockIdx.z * partial_stride;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+        if (n >= NG) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) part[(size_t)m * NG + n] = acc[i][j][r];
+            }
+        }
+    }
+    // bias grad = row sums of A: lanes (i, k=0) and (i, k=1) each saw half of the kk's
+    if (blockIdx.x == 0 && wn == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float s = asum[i] + __shfl_xor(asum[i], 32, 64);
+            const int m = m0 + wm * TM * 32 + i * 32 + (lane & 31);
+            if (lane < 32 && m < p.M) part[(size_t)p.M * NG + m] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial,
+                                                     size_t partial_stride, int nsplit,
+                                                     size_t wsize, int nbias,
+                                                     float* __restrict__ gw,
+                                                     float* __restrict__ gb, float beta) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= wsize + (size_t)nbias) return;
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += partial[(size_t)z * partial_stride + i];
+    if (i < wsize) gw[i] = (beta != 0.f ? beta * gw[i] : 0.f) + s;
+    else if (gb) gb[i - wsize] = (beta != 0.f ? beta * gb[i - wsize] : 0.f) + s;
+}
+
+// ------------------------------------------------------------------------ host side
+bool dense_same(const ConvP& p) {
+    return p.groups == 1 && p.stride == 1 && p.Lout == p.Lin && (p.K == 3 || p.K == 5 || p.K == 7) &&
+           (long long)p.B * p.Lin < (1LL << 31) && (long long)p.Cin * p.K < (1 << 30);
+}
+
+enum Cfg { CFG_128x128, CFG_64x64, CFG_32x256, CFG_32x128 };
+
+Cfg pick_cfg(int M, long long N) {
+    if (M <= 32) return CFG_32x256;
+    if (M >= 128 && (N / 128) * (M / 128) >= 384) return CFG_128x128;
+    return CFG_64x64;
+}
+
+void cfg_tile(Cfg c, int* bm, int* bn) {
+    if (c == CFG_128x128) { *bm = 128; *bn = 128; }
+    else if (c == CFG_64x64) { *bm = 64; *bn = 64; }
+    else if (c == CFG_32x128) { *bm = 32; *bn = 128; }
+    else { *bm = 32; *bn = 256; }
+}
+
+template <int K, bool TRANS>
+int launch_conv_k(Cfg cfg, const IgP& p, const float* X, const float* Xact, const float* W,
+                  const float* bias, const float* res, float* Y, float* Yact, hipStream_t s) {
+    int bm, bn;
+    cfg_tile(cfg, &bm, &bn);
+    dim3 grid((unsigned)((p.N + bn - 1) / bn), (unsigned)((p.M + bm - 1) / bm));
+    if (cfg == CFG_128x128)
+        hipLaunchKernelGGL((k_igemm_conv<2, 2, 2, 2, K, TRANS>), grid, dim3(256), 0, s, p, X, Xact, W, bias, res, Y, Yact);
+    else if (cfg == CFG_64x64)
+        hipLaunchKernelGGL((k_igemm_conv<2, 2, 1, 1, K, TRANS>), grid, dim3(256), 0, s, p, X, Xact, W, bias, res, Y, Yact);
+    else
+        hipLaunchKernelGGL((k_igemm_conv<1, 4, 1, 2, K, TRANS>), grid, dim3(256), 0, s, p, X, Xact, W, bias, res, Y, Yact);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+template <bool TRANS>
+int launch_conv(int K, Cfg cfg, const IgP& p, const float* X, const float* Xact, const float* W,
+                const float* bias, const float* res, float* Y, float* Yact, hipStream_t s) {
+    if (K == 3) return launch_conv_k<3, TRANS>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
+    if (K == 5) return launch_conv_k<5, TRANS>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
+    if (K == 7) return launch_conv_k<7, TRANS>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
+    return MS_ERR_UNSUPPORTED;
+}
+
+struct WgradPlan {
+    Cfg cfg;
+    int bm, bn, nsplit, cps;
+    size_t stride_floats;
+};
+
+WgradPlan plan_wgrad(const ConvP& p) {
+    WgradPlan q;
+    const int NG = p.Cin * p.K;
+    if (p.Cout <= 32) q.cfg = NG <= 128 ? CFG_32x128 : CFG_32x256;
+    else q.cfg = (p.Cout >= 128 && NG >= 128) ? CFG_128x128 : CFG_64x64;
+    cfg_tile(q.cfg, &q.bm, &q.bn);
+    const int tiles = ms_ceil_div(p.Cout, q.bm) * ms_ceil_div(NG, q.bn);
+    const long long KT = (long long)p.B * p.Lin;
+    const int nchunks = (int)((KT + KC - 1) / KC);
+    int ns = ms_ceil_div(768, tiles);                // ~3 workgroups per CU
+    const int max_by_work = nchunks / 8 > 0 ? nchunks / 8 : 1;   // >= 8 chunks per split
+    if (ns > max_by_work) ns = max_by_work;
+    q.stride_floats = (size_t)p.Cout * NG + p.Cout;
+    const size_t cap = (size_t)96 << 20;
+    while (ns > 1 && (size_t)ns * q.stride_floats * 4 > cap) --ns;
+    q.cps = ms_ceil_div(nchunks, ns);
+    q.nsplit = ms_ceil_div(nchunks, q.cps);
+    return q;
+}
+
+
+// ---- row-tile kernel dispatch
+enum RowCfg { ROW_128x128, ROW_64x128, ROW_64x64, ROW_32x256 };
+
+constexpr int row_cc(int K) { return K == 7 ? 4 : 8; }
+
+bool rows_applicable(int M, int CK, int K, int L) {
+    if (!(K == 3 || K == 5 || K == 7)) return false;
+    if (CK % row_cc(K)) return false;
+    if (M < 32) return false;
+    return L >= 1;
+}
+
+RowCfg pick_row_cfg(int M, int B, int L) {
+    if (M <= 32) return ROW_32x256;
+    if (L < 128) return ROW_64x64;
+    const long long N = (long long)B * L;
+    if (M >= 128 && (N / 128) * (M / 128) >= 384) return ROW_128x128;
+    return ROW_64x128;
+}
+
+void row_tile(RowCfg c, int* bm, int* bn) {
+    switch (c) {
+        case ROW_128x128: *bm = 128; *bn = 128; break;
+        case ROW_64x128: *bm = 64; *bn = 128; break;
+        case ROW_64x64: *bm = 64; *bn = 64; break;
+        default: *bm = 32; *bn = 256; break;
+    }
+}
+
+bool make_rowp(RowP* q, RowCfg cfg, int B, int CK, int L, int M, int K, int dil, int off0,
+               int pad_mode, int act, int in_act, float slope) {
+    int bm, bn;
+    row_tile(cfg, &bm, &bn);
+    q->B = B; q->CK = CK; q->L = L; q->M = M; q->dil = dil; q->off0 = off0; q->pad_mode = pad_mode;
+    q->act = act; q->in_act = in_act; q->KG = CK * K; q->slope = slope;
+    const int H = (K - 1) * dil;
+    if (L >= bn) { q->Lt = bn; q->R = 1; q->tiles_per_row = (L + bn - 1) / bn; }
+    else { q->Lt = L; q->R = bn / L; q->tiles_per_row = 1; }
+    q->SS = q->Lt + H;
+    q->RSZ = q->R * q->SS;
+    return q->RSZ <= 512;
+}
+
+template <int K>
+int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, const float* W,
+                  const float* bias, const float* res, float* Y, float* Yact, hipStream_t s) {
+    constexpr int CC = row_cc(K);
+    int bm, bn;
+    row_tile(cfg, &bm, &bn);
+    const unsigned gx = p.R == 1 ? (unsigned)(p.B * p.tiles_per_row) : (unsigned)((p.B + p.R - 1) / p.R);
+    dim3 grid(gx, (unsigned)((p.M + bm - 1) / bm));
+    const size_t lds = (size_t)(bm * (CC * K + 1) + CC * p.RSZ) * sizeof(float);
+    if (lds > 64 * 1024) return MS_ERR_UNSUPPORTED;
+    switch (cfg) {
+        case ROW_128x128:
+            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 2, 2, K, CC>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            break;
+        case ROW_64x128:
+            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 1, 2, K, CC>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            break;
+        case ROW_64x64:
+            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 1, 1, K, CC>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            break;
+        default:
+            hipLaunchKernelGGL((k_conv_mfma_rows<1, 4, 1, 2, K, CC>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            break;
+    }
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int launch_rows(int K, RowCfg cfg, const RowP& p, const float* X, const float* Xact, const float* W,
+                const float* bias, const float* res, float* Y, float* Yact, hipStream_t s) {
+    if (K == 3) return launch_rows_k<3>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
+    if (K == 5) return launch_rows_k<5>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
+    if (K == 7) return launch_rows_k<7>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
+    return MS_ERR_UNSUPPORTED;
+}
+
+const char* row_kname(RowCfg c, int K) {
+    static thread_local char buf[96];
+    const char* tile = c == ROW_128x128 ? "2, 2, 2, 2" : (c == ROW_64x128 ? "2, 2, 1, 2" :
+                       (c == ROW_64x64 ? "2, 2, 1, 1" : "1, 4, 1, 2"));
+    snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, %d, %d>", tile, K, row_cc(K));
+    return buf;
+}
+
+bool rows_ok(const ConvP& p, bool bwd) {
+    const int M = bwd ? p.Cin : p.Cout, CK = bwd ? p.Cout : p.Cin;
+    if (!rows_applicable(M, CK, p.K, p.Lin)) return false;
+    if (((size_t)CK * p.K) % 4) return false;
+    RowP q;
+    return make_rowp(&q, pick_row_cfg(M, p.B, p.Lin), p.B, CK, p.Lin, M, p.K, p.dil, 0, 0, 0, 0, 0.f);
+}
+
+const char* kname(const char* kernel, Cfg c, int K, const char* tail) {
+    static thread_local char buf[96];
+    const char* tile = c == CFG_128x128 ? "2, 2, 2, 2" : (c == CFG_64x64 ? "2, 2, 1, 1" :
+                       (c == CFG_32x128 ? "1, 4, 1, 1" : "1, 4, 1, 2"));
+    snprintf(buf, sizeof(buf), "%s<%s, %d%s>", kernel, tile, K, tail);
+    return buf;
+}
+
+}  // namespace
+
+bool msm_fwd_applicable(const ConvP& p) {
+    return dense_same(p) && p.Cout >= 32 && p.Cin * p.K >= 32;
+}
+bool msm_bwd_data_applicable(const ConvP& p) {
+    return dense_same(p) && p.pad_mode == MS_PAD_ZERO && p.Cin >= 32 && p.Cout * p.K >= 32;
+}
+bool msm_bwd_weight_applicable(const ConvP& p) {
+    const bool kok = p.K == 3 || p.K == 5 || p.K == 7 || p.K == 15;
+    return p.groups == 1 && p.stride == 1 && p.Lout == p.Lin && kok &&
+           (long long)p.B * p.Lin < (1LL << 31) && (long long)p.B * p.Cout * p.Lin < (1LL << 31) &&
+           (long long)p.B * p.Cin * p.Lin < (1LL << 31) && p.Cout >= 16 && p.Cin * p.K >= 15;
+}
 bool msm_convt_fwd_applicable(const ConvP&) { return false; }
 size_t msm_fwd_ws(const ConvP&) { return 0; }
-size_t msm_bwd_data_ws(const ConvP&) { return 0; }
-size_t msm_bwd_weight_ws(const ConvP&) { return 0; }
+size_t msm_bwd_data_ws(const ConvP& p) {
+    return rows_ok(p, true) ? (size_t)p.Cin * p.Cout * p.K * sizeof(float) : 0;
+}
+size_t msm_bwd_weight_ws(const ConvP& p) {
+    const WgradPlan q = plan_wgrad(p);
+    return (size_t)q.nsplit * q.stride_floats * sizeof(float);
+}
 size_t msm_convt_fwd_ws(const ConvP&) { return 0; }
-int msm_conv1d_fwd(const ConvP&, const float*, const float*, int, const float*, const float*,
-                   const float*, float*, float*, void*, size_t, hipStream_t) { return MS_ERR_UNSUPPORTED; }
-int msm_conv1d_bwd_data(const ConvP&, const float*, const float*, const float*, const float*,
-                        float*, void*, size_t, hipStream_t) { return MS_ERR_UNSUPPORTED; }
-int msm_conv1d_bwd_weight(const ConvP&, const float*, const float*, int, const float*,
-                          const float*, int, float*, float*, float, void*, size_t, hipStream_t) { return MS_ERR_UNSUPPORTED; }
-int msm_convt1d_fwd(const ConvP&, const float*, const float*, const float*, float*, void*, size_t,
-                    hipStream_t) { return MS_ERR_UNSUPPORTED; }
-const char* msm_fwd_name(const ConvP&) { return ""; }
-const char* msm_bwd_data_name(const ConvP&) { return ""; }
-const char* msm_bwd_weight_name(const ConvP&) { return ""; }
+
+const char* msm_fwd_name(const ConvP& p) {
+    if (rows_ok(p, false)) return row_kname(pick_row_cfg(p.Cout, p.B, p.Lin), p.K);
+    return kname("k_igemm_conv", pick_cfg(p.Cout, (long long)p.B * p.Lin), p.K, ", false");
+}
+const char* msm_bwd_data_name(const ConvP& p) {
+    if (rows_ok(p, true)) return row_kname(pick_row_cfg(p.Cin, p.B, p.Lin), p.K);
+    return kname("k_igemm_conv", pick_cfg(p.Cin, (long long)p.B * p.Lin), p.K, ", true");
+}
+const char* msm_bwd_weight_name(const ConvP& p) {
+    return kname("k_igemm_wgrad", plan_wgrad(p).cfg, p.K, "");
+}
 const char* msm_convt_fwd_name(const ConvP&) { return ""; }
+
+int msm_conv1d_fwd(const ConvP& p, const float* x, const float* x_act, int x_act_kind,
+                   const float* w, const float* bias, const float* residual, float* y,
+                   float* y_act, void*, size_t, hipStream_t s) {
+    if (rows_ok(p, false) && (((uintptr_t)w) & 15) == 0) {
+        RowP r;
+        const RowCfg cfg = pick_row_cfg(p.Cout, p.B, p.Lin);
+        make_rowp(&r, cfg, p.B, p.Cin, p.Lin, p.Cout, p.K, p.dil, -p.pad, p.pad_mode, p.act,
+                  x_act_kind, p.slope);
+        return launch_rows(p.K, cfg, r, x, x_act, w, bias, residual, y, y_act, s);
+    }
+    IgP q;
+    q.B = p.B; q.CK = p.Cin; q.L = p.Lin; q.M = p.Cout; q.dil = p.dil; q.off0 = -p.pad;
+    q.pad_mode = p.pad_mode; q.act = p.act; q.in_act = x_act_kind; q.slope = p.slope;
+    q.N = p.B * p.Lin; q.KG = p.Cin * p.K;
+    return launch_conv<false>(p.K, pick_cfg(q.M, q.N), q, x, x_act, w, bias, residual, y, y_act, s);
+}
+
+int msm_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, const float* w,
+                        const float* gx_add, float* gx, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (rows_ok(p, true) && ws && ws_bytes >= msm_bwd_data_ws(p) && (((uintptr_t)ws) & 15) == 0) {
+        float* wt = (float*)ws;
+        const size_t total = (size_t)p.Cin * p.Cout * p.K;
+        unsigned nb = (unsigned)((total + 255) / 256);
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(k_transpose_flip_w, dim3(nb), dim3(256), 0, s, w, wt, p.Cout, p.Cin, p.K);
+        MS_CHECK_LAUNCH();
+        RowP r;
+        const RowCfg cfg = pick_row_cfg(p.Cin, p.B, p.Lin);
+        make_rowp(&r, cfg, p.B, p.Cout, p.Lin, p.Cin, p.K, p.dil, p.pad - (p.K - 1) * p.dil,
+                  MS_PAD_ZERO, MS_ACT_NONE, p.act, p.slope);
+        return launch_rows(p.K, cfg, r, gy, y_act, wt, nullptr, gx_add, gx, nullptr, s);
+    }
+    IgP q;
+    q.B = p.B; q.CK = p.Cout; q.L = p.Lin; q.M = p.Cin; q.dil = p.dil;
+    q.off0 = p.pad - (p.K - 1) * p.dil;   // flipped taps: j' = K-1-j
+    q.pad_mode = MS_PAD_ZERO; q.act = MS_ACT_NONE; q.in_act = p.act; q.slope = p.slope;
+    q.N = p.B * p.Lin; q.KG = p.Cout * p.K;
+    return launch_conv<true>(p.K, pick_cfg(q.M, q.N), q, gy, y_act, w, nullptr, gx_add, gx, nullptr, s);
+}
+
+int msm_conv1d_bwd_weight(const ConvP& p, const float* x, const float* x_act, int x_act_kind,
+                          const float* gy, const float* y_act, int y_act_kind, float* gw,
+                          float* gb, float beta, void* ws, size_t ws_bytes, hipStream_t s) {
+    const WgradPlan pl = plan_wgrad(p);
+    const size_t need = (size_t)pl.nsplit * pl.stride_floats * sizeof(float);
+    if (!ws || ws_bytes < need) return MS_ERR_WORKSPACE;
+    IgP q;
+    q.B = p.B; q.CK = p.Cin; q.L = p.Lin; q.M = p.Cout; q.dil = p.dil; q.off0 = -p.pad;
+    q.pad_mode = p.pad_mode; q.act = MS_ACT_NONE; q.in_act = x_act_kind; q.slope = p.slope;
+    q.N = p.B * p.Lin; q.KG = p.Cin * p.K;
+    const int NG = p.Cin * p.K;
+    dim3 grid((unsigned)ms_ceil_div(NG, pl.bn), (unsigned)ms_ceil_div(p.Cout, pl.bm), (unsigned)pl.nsplit);
+    float* partial = (float*)ws;
+#define MS_WG(WGM, WGN, TM, TN, KK)                                                                 \
+    hipLaunchKernelGGL((k_igemm_wgrad<WGM, WGN, TM, TN, KK>), grid, dim3(256), 0, s, q, pl.cps, x,  \
+                       x_act, gy, y_act, y_act_kind, partial, pl.stride_floats)
+#define MS_WG_K(KK)                                                                                 \
+    do {                                                                                            \
+        if (pl.cfg == CFG_128x128) MS_WG(2, 2, 2, 2, KK);                                           \
+        else if (pl.cfg == CFG_64x64) MS_WG(2, 2, 1, 1, KK);                                        \
+        else if (pl.cfg == CFG_32x128) MS_WG(1, 4, 1, 1, KK);                                       \
+        else MS_WG(1, 4, 1, 2, KK);                                                                 \
+    } while (0)
+    if (p.K == 3) MS_WG_K(3);
+    else if (p.K == 5) MS_WG_K(5);
+    else if (p.K == 7) MS_WG_K(7);
+    else if (p.K == 15) MS_WG_K(15);
+    else return MS_ERR_UNSUPPORTED;
+#undef MS_WG_K
+#undef MS_WG
+    MS_CHECK_LAUNCH();
+    const size_t wsize = (size_t)p.Cout * NG;
+    const size_t total = wsize + p.Cout;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial,
+                       pl.stride_floats, pl.nsplit, wsize, p.Cout, gw, gb, beta);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int msm_convt1d_fwd(const ConvP&, const float*, const float*, const float*, float*, void*, size_t,
+                    hipStream_t) {
+    return MS_ERR_UNSUPPORTED;
+}

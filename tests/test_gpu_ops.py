@@ -220,6 +220,11 @@ HOT_CONVS = [
     ("d_k41_g256", 2, 1024, 33, 1024, 41, 4, 20, 1, 256, 1, False),
     ("d_k5", 2, 1024, 17, 1024, 5, 1, 2, 1, 1, 1, False),
     ("d_judge", 2, 1024, 9, 1, 3, 1, 1, 1, 1, 0, False),
+    # MFMA implicit-GEMM edge cases: M / N / K-dimension tails, the 128x128 tile, no activation
+    ("mfma_m48_k120", 3, 40, 77, 48, 3, 1, 3, 3, 1, 1, False),
+    ("mfma_m96_k5", 2, 36, 41, 96, 5, 1, 2, 1, 1, 0, False),
+    ("mfma_tile128", 4, 128, 12288, 128, 3, 1, 9, 9, 1, 1, False),
+    ("mfma_m160_k7_reflect", 2, 24, 50, 160, 7, 1, 3, 1, 1, 2, True),
 ]
 
 
@@ -235,11 +240,13 @@ def test_conv_hot_shapes_vs_oracle(case):
     pm = O.PAD_REFLECT if reflect else O.PAD_ZERO
     y_ref = O.conv1d_fwd(x, w, b, stride, pad, dil, groups, pm, act)
     gy = rng.standard_normal(y_ref.shape).astype(np.float32)
-    gp = O.act_bwd(y_ref, gy, act)
-    gw_ref, gb_ref = O.conv1d_bwd_weight(x, gp, w.shape, stride, pad, dil, groups, pm)
     xt, wt, bt = dev(x).requires_grad_(not reflect), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
     y = F_.Conv1dFn.apply(xt, wt, bt, stride, pad, dil, groups, 1 if reflect else 0, act)
     assert rel_l2(host(y), y_ref) < FWD_TOL
+    # the LeakyReLU mask is taken from the device's own activations: an output within rounding of
+    # zero may carry the other sign in the double-precision oracle, which would flip its slope
+    gp = O.act_bwd(host(y), gy, act)
+    gw_ref, gb_ref = O.conv1d_bwd_weight(x, gp, w.shape, stride, pad, dil, groups, pm)
     if reflect:
         gw, gb = torch.autograd.grad(y, (wt, bt), dev(gy))
     else:
@@ -265,10 +272,10 @@ def test_convt_hot_shapes_vs_oracle(case):
     b = (rng.standard_normal((Cout,)) * 0.1).astype(np.float32)
     y_ref = O.conv_transpose1d_fwd(x, w, b, stride, pad, O.ACT_LRELU)
     gy = rng.standard_normal(y_ref.shape).astype(np.float32)
-    gp = O.act_bwd(y_ref, gy, O.ACT_LRELU)
     xt, wt, bt = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
     y = F_.ConvTranspose1dFn.apply(xt, wt, bt, stride, pad, 1)
     assert rel_l2(host(y), y_ref) < FWD_TOL
+    gp = O.act_bwd(host(y), gy, O.ACT_LRELU)      # mask from the device's activations (see above)
     gx, gw, gb = torch.autograd.grad(y, (xt, wt, bt), dev(gy))
     assert rel_l2(host(gx), O.conv_transpose1d_bwd_data(gp, w, x.shape, stride, pad)) < GRAD_TOL
     gw_ref, gb_ref = O.conv_transpose1d_bwd_weight(x, gp, w.shape, stride, pad)
