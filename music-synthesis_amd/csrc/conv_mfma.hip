@@ -31,18 +31,12 @@ struct IgP {
     float slope;
 };
 
-template <int K>
-__device__ __forceinline__ float load_im2col(const IgP& p, const float* __restrict__ X,
-                                             const float* __restrict__ Xact, int b, int t, int kg) {
-    // element (kg = c*K + j, n = (b, t)) of the im2col matrix
-    if (kg >= p.KG) return 0.f;
-    const int c = kg / K, j = kg - c * K;
-    const int s = ms_src_index(t + j * p.dil + p.off0, p.L, p.pad_mode);
-    if (s < 0) return 0.f;
-    const size_t off = ((size_t)b * p.CK + c) * p.L + s;
-    float v = X[off];
-    if (Xact) v = ms_act_grad(v, Xact[off], p.in_act, p.slope);
-    return v;
+// branch-free source index: every load below is issued unconditionally from a clamped (always
+// valid) address and masked afterwards, so hipcc batches the loads of a chunk instead of waiting
+// for each one (a load under a run-time branch costs a full memory round trip per element)
+__device__ __forceinline__ int src_index_sel(int t, int L, int reflect) {
+    const int r = t < 0 ? -t : (t >= L ? 2 * (L - 1) - t : t);
+    return reflect ? r : t;
 }
 
 // ------------------------------------------------------------ forward / backward data
@@ -87,32 +81,48 @@ __global__ __launch_bounds__(256) void k_igemm_conv(IgP p, const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // absent activation operand: alias the data (second load hits L1) with a pass-through kind
+    const float* Xa = Xact ? Xact : X;
+    const int in_act = Xact ? p.in_act : MS_ACT_NONE;
     float ra[RA], rb[RB];
     auto gload = [&](int kc0) {
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
             const int e = r * 256 + tid;
-            float v = 0.f;
+            bool ok;
+            size_t off;
             if (!TRANS) {
                 const int kk = e % KC, m = e / KC;
-                if (m0 + m < p.M && kc0 + kk < p.KG) v = W[(size_t)(m0 + m) * p.KG + kc0 + kk];
+                ok = m0 + m < p.M && kc0 + kk < p.KG;
+                off = (size_t)(m0 + m) * p.KG + kc0 + kk;
             } else {
                 const int m = e % BM, kk = e / BM;
                 const int kg = kc0 + kk;
-                if (m0 + m < p.M && kg < p.KG) {
-                    const int c = kg / K, j = kg - c * K;
-                    v = W[((size_t)c * p.M + m0 + m) * K + (K - 1 - j)];
-                }
+                const int c = kg / K, j = kg - c * K;
+                ok = m0 + m < p.M && kg < p.KG;
+                off = ((size_t)c * p.M + m0 + m) * K + (K - 1 - j);
             }
-            ra[r] = v;
+            const float v = W[ok ? off : 0];
+            ra[r] = ok ? v : 0.f;
         }
+        float xv[RB], av[RB];
+        bool ok[RB];
 #pragma unroll
         for (int r = 0; r < RB / NCOL; ++r) {
-            const int kk = brow0 + r * ROWSTEP;
+            const int kg = kc0 + brow0 + r * ROWSTEP;
+            const int c = kg / K, j = kg - c * K;
 #pragma unroll
-            for (int q = 0; q < NCOL; ++q)
-                rb[r * NCOL + q] = cvalid[q] ? load_im2col<K>(p, X, Xact, cb[q], ct[q], kc0 + kk) : 0.f;
+            for (int q = 0; q < NCOL; ++q) {
+                const int sidx = src_index_sel(ct[q] + j * p.dil + p.off0, p.L, p.pad_mode == MS_PAD_REFLECT);
+                const bool v = cvalid[q] && kg < p.KG && (unsigned)sidx < (unsigned)p.L;
+                const size_t off = v ? ((size_t)cb[q] * p.CK + c) * p.L + sidx : 0;
+                ok[r * NCOL + q] = v;
+                xv[r * NCOL + q] = X[off];
+                av[r * NCOL + q] = Xa[off];
+            }
         }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) rb[r] = ok[r] ? ms_act_grad(xv[r], av[r], in_act, p.slope) : 0.f;
     };
     auto lstore = [&]() {
 #pragma unroll
@@ -196,7 +206,7 @@ struct RowP {
     float slope;
 };
 
-template <int WGM, int WGN, int TM, int TN, int K, int CC>
+template <int WGM, int WGN, int TM, int TN, int K, int CC, bool HAS_ACT>
 __global__ __launch_bounds__(256) void k_conv_mfma_rows(RowP p, const float* __restrict__ X,
                                                        const float* __restrict__ Xact,
                                                        const float* __restrict__ W,
@@ -268,23 +278,29 @@ __global__ __launch_bounds__(256) void k_conv_mfma_rows(RowP p, const float* __r
         for (int i = 0; i < RA4; ++i) {
             const int e = i * 256 + tid;
             const int row = e / (KK / 4), q4 = e - row * (KK / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < A4 && m0 + row < p.M)
-                v = *reinterpret_cast<const float4*>(W + (size_t)(m0 + row) * p.KG + (size_t)c0 * K + q4 * 4);
+            const bool ok = e < A4 && m0 + row < p.M;
+            const size_t off = ok ? (size_t)(m0 + row) * p.KG + (size_t)c0 * K + q4 * 4 : 0;
+            float4 v = *reinterpret_cast<const float4*>(W + off);
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             ra[i] = v;
         }
 #pragma unroll
         for (int q = 0; q < MAXCOL; ++q) {
             if (q == 1 && !has_col1) break;
+            const bool ok = goff[q] >= 0;
+            const size_t base = ok ? (size_t)goff[q] + (size_t)c0 * p.L : 0;
+            const size_t step = ok ? (size_t)p.L : 0;
+            float av[CC];
 #pragma unroll
             for (int c = 0; c < CC; ++c) {
-                float v = 0.f;
-                if (goff[q] >= 0) {
-                    const size_t off = (size_t)goff[q] + (size_t)(c0 + c) * p.L;
-                    v = X[off];
-                    if (Xact) v = ms_act_grad(v, Xact[off], p.in_act, p.slope);
-                }
-                rx[q][c] = v;
+                rx[q][c] = X[base + c * step];
+                if (HAS_ACT) av[c] = Xact[base + c * step];
+            }
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                float v = rx[q][c];
+                if (HAS_ACT) v = ms_act_grad(v, av[c], p.in_act, p.slope);
+                rx[q][c] = ok ? v : 0.f;
             }
         }
     };
@@ -436,6 +452,11 @@ __global__ __launch_bounds__(256) void k_igemm_wgrad(IgP p, int chunks_per_split
     const int nchunks = (KT + KC - 1) / KC;
     if (c_end > nchunks) c_end = nchunks;
 
+    // absent activation operands alias the data with a pass-through kind (keeps loads branch-free)
+    const float* Gq = Gact ? Gact : G;
+    const float* Xq = Xact ? Xact : X;
+    const int g_kind = Gact ? g_act : MS_ACT_NONE;
+    const int x_kind = Xact ? p.in_act : MS_ACT_NONE;
     float ra[RA], rb[RB];
     auto gload = [&](int chunk) {
         const int kg = chunk * KC + kk_l;
@@ -443,29 +464,29 @@ __global__ __launch_bounds__(256) void k_igemm_wgrad(IgP p, int chunks_per_split
         const int b = kv ? kg / p.L : 0;
         const int t = kv ? kg - b * p.L : 0;
         const float* Ga = G + (size_t)b * p.M * p.L + t;
-        const float* Gy = Gact ? Gact + (size_t)b * p.M * p.L + t : nullptr;
+        const float* Gy = Gq + (size_t)b * p.M * p.L + t;
         const float* Xb = X + (size_t)b * p.CK * p.L;
-        const float* Xa = Xact ? Xact + (size_t)b * p.CK * p.L : nullptr;
+        const float* Xy = Xq + (size_t)b * p.CK * p.L;
+        float gv[RA], ga[RA], xv[RB], xa[RB];
+        bool xok[RB];
 #pragma unroll
-        for (int r = 0; r < RA; ++r) {
-            float v = 0.f;
-            if (kv && avalid[r]) {
-                v = Ga[aoff[r]];
-                if (Gy) v = ms_act_grad(v, Gy[aoff[r]], g_act, p.slope);
-            }
-            ra[r] = v;
+        for (int r = 0; r < RA; ++r) {   // rows past M read row 0 and are masked below
+            gv[r] = Ga[aoff[r]];
+            ga[r] = Gy[aoff[r]];
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            float v = 0.f;
-            int sidx = t + bsh[r];
-            if (p.pad_mode == MS_PAD_REFLECT) sidx = ms_src_index(sidx, p.L, MS_PAD_REFLECT);
-            if (kv && bvalid[r] && (unsigned)sidx < (unsigned)p.L) {
-                v = Xb[boff[r] + sidx];
-                if (Xa) v = ms_act_grad(v, Xa[boff[r] + sidx], p.in_act, p.slope);
-            }
-            rb[r] = v;
+            const int sidx = src_index_sel(t + bsh[r], p.L, p.pad_mode == MS_PAD_REFLECT);
+            xok[r] = kv && bvalid[r] && (unsigned)sidx < (unsigned)p.L;
+            const int off = xok[r] ? boff[r] + sidx : 0;
+            xv[r] = Xb[off];
+            xa[r] = Xy[off];
         }
+#pragma unroll
+        for (int r = 0; r < RA; ++r)
+            ra[r] = (kv && avalid[r]) ? ms_act_grad(gv[r], ga[r], g_kind, p.slope) : 0.f;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) rb[r] = xok[r] ? ms_act_grad(xv[r], xa[r], x_kind, p.slope) : 0.f;
     };
     auto lstore = [&]() {
 #pragma unroll
@@ -661,7 +682,7 @@ bool make_rowp(RowP* q, RowCfg cfg, int B, int CK, int L, int M, int K, int dil,
     return q->RSZ <= 512;
 }
 
-template <int K>
+template <int K, bool HAS_ACT>
 int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, const float* W,
                   const float* bias, const float* res, float* Y, float* Yact, hipStream_t s) {
     constexpr int CC = row_cc(K);
@@ -673,16 +694,16 @@ int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, 
     if (lds > 64 * 1024) return MS_ERR_UNSUPPORTED;
     switch (cfg) {
         case ROW_128x128:
-            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 2, 2, K, CC>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 2, 2, K, CC, HAS_ACT>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
             break;
         case ROW_64x128:
-            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 1, 2, K, CC>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 1, 2, K, CC, HAS_ACT>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
             break;
         case ROW_64x64:
-            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 1, 1, K, CC>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 1, 1, K, CC, HAS_ACT>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
             break;
         default:
-            hipLaunchKernelGGL((k_conv_mfma_rows<1, 4, 1, 2, K, CC>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            hipLaunchKernelGGL((k_conv_mfma_rows<1, 4, 1, 2, K, CC, HAS_ACT>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
             break;
     }
     MS_CHECK_LAUNCH();
@@ -691,17 +712,23 @@ int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, 
 
 int launch_rows(int K, RowCfg cfg, const RowP& p, const float* X, const float* Xact, const float* W,
                 const float* bias, const float* res, float* Y, float* Yact, hipStream_t s) {
-    if (K == 3) return launch_rows_k<3>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
-    if (K == 5) return launch_rows_k<5>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
-    if (K == 7) return launch_rows_k<7>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
+    if (Xact) {
+        if (K == 3) return launch_rows_k<3, true>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
+        if (K == 5) return launch_rows_k<5, true>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
+        if (K == 7) return launch_rows_k<7, true>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
+    } else {
+        if (K == 3) return launch_rows_k<3, false>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
+        if (K == 5) return launch_rows_k<5, false>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
+        if (K == 7) return launch_rows_k<7, false>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
+    }
     return MS_ERR_UNSUPPORTED;
 }
 
-const char* row_kname(RowCfg c, int K) {
+const char* row_kname(RowCfg c, int K, bool act) {
     static thread_local char buf[96];
     const char* tile = c == ROW_128x128 ? "2, 2, 2, 2" : (c == ROW_64x128 ? "2, 2, 1, 2" :
                        (c == ROW_64x64 ? "2, 2, 1, 1" : "1, 4, 1, 2"));
-    snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, %d, %d>", tile, K, row_cc(K));
+    snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, %d, %d, %s>", tile, K, row_cc(K), act ? "true" : "false");
     return buf;
 }
 
@@ -747,11 +774,11 @@ size_t msm_bwd_weight_ws(const ConvP& p) {
 size_t msm_convt_fwd_ws(const ConvP&) { return 0; }
 
 const char* msm_fwd_name(const ConvP& p) {
-    if (rows_ok(p, false)) return row_kname(pick_row_cfg(p.Cout, p.B, p.Lin), p.K);
+    if (rows_ok(p, false)) return row_kname(pick_row_cfg(p.Cout, p.B, p.Lin), p.K, false);
     return kname("k_igemm_conv", pick_cfg(p.Cout, (long long)p.B * p.Lin), p.K, ", false");
 }
 const char* msm_bwd_data_name(const ConvP& p) {
-    if (rows_ok(p, true)) return row_kname(pick_row_cfg(p.Cin, p.B, p.Lin), p.K);
+    if (rows_ok(p, true)) return row_kname(pick_row_cfg(p.Cin, p.B, p.Lin), p.K, p.act != MS_ACT_NONE);
     return kname("k_igemm_conv", pick_cfg(p.Cin, (long long)p.B * p.Lin), p.K, ", true");
 }
 const char* msm_bwd_weight_name(const ConvP& p) {
