@@ -206,7 +206,7 @@ struct RowP {
     float slope;
 };
 
-template <int WGM, int WGN, int TM, int TN, int K, int CC, bool HAS_ACT>
+template <int WGM, int WGN, int TM, int TN, int K, int CC, bool HAS_ACT, int EPI_S>
 __global__ __launch_bounds__(256) void k_conv_mfma_rows(RowP p, const float* __restrict__ X,
                                                        const float* __restrict__ Xact,
                                                        const float* __restrict__ W,
@@ -358,23 +358,82 @@ __global__ __launch_bounds__(256) void k_conv_mfma_rows(RowP p, const float* __r
         }
     }
 
+    if (EPI_S == 0) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        if (!nvalid[j]) continue;
+        for (int j = 0; j < TN; ++j) {
+            if (!nvalid[j]) continue;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= p.M) continue;
-                const size_t o = ((size_t)ob[j] * p.M + m) * p.L + ot[j];
-                float v = acc[i][j][r] + (bias ? bias[m] : 0.f);
-                v = ms_apply_act(v, p.act, p.slope);
-                if (Yact) Yact[o] = v;
-                if (res) v += res[o];
-                Y[o] = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m >= p.M) continue;
+                    const size_t o = ((size_t)ob[j] * p.M + m) * p.L + ot[j];
+                    float v = acc[i][j][r] + (bias ? bias[m] : 0.f);
+                    v = ms_apply_act(v, p.act, p.slope);
+                    if (Yact) Yact[o] = v;
+                    if (res) v += res[o];
+                    Y[o] = v;
+                }
             }
         }
+    } else {
+        // transposed conv: GEMM row m' = co*S + r is output phase r of channel co; a lane's 4
+        // consecutive accumulator rows are 4 consecutive output samples (S = 8) or 2 x 2 (S = 2),
+        // written as one 16-byte / two 8-byte stores along contiguous audio frames
+        const int Cout = p.M / EPI_S;
+        const size_t Lo = (size_t)p.L * EPI_S;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (!nvalid[j]) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int mb = m0 + wm * TM * 32 + i * 32 + 8 * rg + 4 * h;
+                    if (mb >= p.M) continue;
+                    if (EPI_S >= 4) {
+                        const int co = mb / EPI_S, ph = mb - co * EPI_S;
+                        const float bv = bias ? bias[co] : 0.f;
+                        float4 v;
+                        v.x = ms_apply_act(acc[i][j][4 * rg + 0] + bv, p.act, p.slope);
+                        v.y = ms_apply_act(acc[i][j][4 * rg + 1] + bv, p.act, p.slope);
+                        v.z = ms_apply_act(acc[i][j][4 * rg + 2] + bv, p.act, p.slope);
+                        v.w = ms_apply_act(acc[i][j][4 * rg + 3] + bv, p.act, p.slope);
+                        *reinterpret_cast<float4*>(Y + ((size_t)ob[j] * Cout + co) * Lo + (size_t)ot[j] * EPI_S + ph) = v;
+                    } else {
+                        const int co = mb / 2;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const float bv = bias ? bias[co + u] : 0.f;
+                            float2 v;
+                            v.x = ms_apply_act(acc[i][j][4 * rg + 2 * u + 0] + bv, p.act, p.slope);
+                            v.y = ms_apply_act(acc[i][j][4 * rg + 2 * u + 1] + bv, p.act, p.slope);
+                            *reinterpret_cast<float2*>(Y + ((size_t)ob[j] * Cout + co + u) * Lo + (size_t)ot[j] * 2) = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Packed weights of the 3-tap polyphase form of ConvTranspose1d(K = 2S, padding = S/2):
+//   y[b, co, q*S + r] = sum_ci sum_{d=-1..1} W[ci, co, r + pad - d*S] * x[b, ci, q + d]
+// Wp[(co*S + r)][ci*3 + (d+1)], zero where the tap index falls outside [0, K).
+__global__ __launch_bounds__(256) void k_pack_convt_w(const float* __restrict__ W,
+                                                     float* __restrict__ Wp, int Cin, int Cout,
+                                                     int K, int S, int pad) {
+    const size_t total = (size_t)Cout * S * Cin * 3;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int d = (int)(i % 3) - 1;
+        size_t r0 = i / 3;
+        const int ci = (int)(r0 % Cin);
+        r0 /= Cin;
+        const int r = (int)(r0 % S);
+        const int co = (int)(r0 / S);
+        const int k = r + pad - d * S;
+        Wp[i] = (k >= 0 && k < K) ? W[((size_t)ci * Cout + co) * K + k] : 0.f;
     }
 }
 
@@ -682,7 +741,7 @@ bool make_rowp(RowP* q, RowCfg cfg, int B, int CK, int L, int M, int K, int dil,
     return q->RSZ <= 512;
 }
 
-template <int K, bool HAS_ACT>
+template <int K, bool HAS_ACT, int EPI_S = 0>
 int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, const float* W,
                   const float* bias, const float* res, float* Y, float* Yact, hipStream_t s) {
     constexpr int CC = row_cc(K);
@@ -694,16 +753,16 @@ int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, 
     if (lds > 64 * 1024) return MS_ERR_UNSUPPORTED;
     switch (cfg) {
         case ROW_128x128:
-            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 2, 2, K, CC, HAS_ACT>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 2, 2, K, CC, HAS_ACT, EPI_S>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
             break;
         case ROW_64x128:
-            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 1, 2, K, CC, HAS_ACT>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 1, 2, K, CC, HAS_ACT, EPI_S>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
             break;
         case ROW_64x64:
-            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 1, 1, K, CC, HAS_ACT>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 1, 1, K, CC, HAS_ACT, EPI_S>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
             break;
         default:
-            hipLaunchKernelGGL((k_conv_mfma_rows<1, 4, 1, 2, K, CC, HAS_ACT>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            hipLaunchKernelGGL((k_conv_mfma_rows<1, 4, 1, 2, K, CC, HAS_ACT, EPI_S>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
             break;
     }
     MS_CHECK_LAUNCH();
@@ -762,7 +821,15 @@ bool msm_bwd_weight_applicable(const ConvP& p) {
            (long long)p.B * p.Lin < (1LL << 31) && (long long)p.B * p.Cout * p.Lin < (1LL << 31) &&
            (long long)p.B * p.Cin * p.Lin < (1LL << 31) && p.Cout >= 16 && p.Cin * p.K >= 15;
 }
-bool msm_convt_fwd_applicable(const ConvP&) { return false; }
+// p = mirrored conv of the transposed conv: Cin_T = p.Cout, Cout_T = p.Cin, Lin_T = p.Lout
+bool msm_convt_fwd_applicable(const ConvP& p) {
+    const int S = p.stride;
+    if (!(S == 2 || S == 8) || p.K != 2 * S || 2 * p.pad != S || p.dil != 1 || p.groups != 1) return false;
+    if (p.Cout % 8 || p.Cin < 32 || (p.Cin * S) % 32) return false;
+    if ((long long)p.B * p.Lin >= (1LL << 31)) return false;
+    RowP q;
+    return make_rowp(&q, pick_row_cfg(p.Cin * S, p.B, p.Lout), p.B, p.Cout, p.Lout, p.Cin * S, 3, 1, -1, 0, 0, 0, 0.f);
+}
 size_t msm_fwd_ws(const ConvP&) { return 0; }
 size_t msm_bwd_data_ws(const ConvP& p) {
     return rows_ok(p, true) ? (size_t)p.Cin * p.Cout * p.K * sizeof(float) : 0;
@@ -771,7 +838,9 @@ size_t msm_bwd_weight_ws(const ConvP& p) {
     const WgradPlan q = plan_wgrad(p);
     return (size_t)q.nsplit * q.stride_floats * sizeof(float);
 }
-size_t msm_convt_fwd_ws(const ConvP&) { return 0; }
+size_t msm_convt_fwd_ws(const ConvP& p) {
+    return (size_t)p.Cin * p.stride * p.Cout * 3 * sizeof(float);
+}
 
 const char* msm_fwd_name(const ConvP& p) {
     if (rows_ok(p, false)) return row_kname(pick_row_cfg(p.Cout, p.B, p.Lin), p.K, false);
@@ -784,7 +853,14 @@ const char* msm_bwd_data_name(const ConvP& p) {
 const char* msm_bwd_weight_name(const ConvP& p) {
     return kname("k_igemm_wgrad", plan_wgrad(p).cfg, p.K, "");
 }
-const char* msm_convt_fwd_name(const ConvP&) { return ""; }
+const char* msm_convt_fwd_name(const ConvP& p) {
+    static thread_local char buf[96];
+    const RowCfg c = pick_row_cfg(p.Cin * p.stride, p.B, p.Lout);
+    const char* tile = c == ROW_128x128 ? "2, 2, 2, 2" : (c == ROW_64x128 ? "2, 2, 1, 2" :
+                       (c == ROW_64x64 ? "2, 2, 1, 1" : "1, 4, 1, 2"));
+    snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, 3, 8, false, %d>", tile, p.stride);
+    return buf;
+}
 
 int msm_conv1d_fwd(const ConvP& p, const float* x, const float* x_act, int x_act_kind,
                    const float* w, const float* bias, const float* residual, float* y,
@@ -865,7 +941,19 @@ int msm_conv1d_bwd_weight(const ConvP& p, const float* x, const float* x_act, in
     return MS_OK;
 }
 
-int msm_convt1d_fwd(const ConvP&, const float*, const float*, const float*, float*, void*, size_t,
-                    hipStream_t) {
-    return MS_ERR_UNSUPPORTED;
+int msm_convt1d_fwd(const ConvP& p, const float* x, const float* w, const float* bias, float* y,
+                    void* ws, size_t ws_bytes, hipStream_t s) {
+    const int S = p.stride, CinT = p.Cout, CoutT = p.Cin, LinT = p.Lout;
+    if (!ws || ws_bytes < msm_convt_fwd_ws(p) || (((uintptr_t)ws) & 15)) return MS_ERR_WORKSPACE;
+    float* wp = (float*)ws;
+    const size_t total = (size_t)CoutT * S * CinT * 3;
+    unsigned nb = (unsigned)((total + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_pack_convt_w, dim3(nb), dim3(256), 0, s, w, wp, CinT, CoutT, p.K, S, p.pad);
+    MS_CHECK_LAUNCH();
+    RowP r;
+    const RowCfg cfg = pick_row_cfg(CoutT * S, p.B, LinT);
+    make_rowp(&r, cfg, p.B, CinT, LinT, CoutT * S, 3, 1, -1, MS_PAD_ZERO, p.act, MS_ACT_NONE, p.slope);
+    if (S == 8) return launch_rows_k<3, false, 8>(cfg, r, x, nullptr, wp, bias, nullptr, y, nullptr, s);
+    return launch_rows_k<3, false, 2>(cfg, r, x, nullptr, wp, bias, nullptr, y, nullptr, s);
 }

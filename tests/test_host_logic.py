@@ -1,0 +1,112 @@
+"""Host-side logic of the featuresynth surface (CPU only, no kernels launched)."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_state_dict_contract_matches_reference_shapes():
+    """Keys and shapes as probed from the reference; the oracle's shape tables
+    were checked against the imported reference when the fixtures were made."""
+    import featuresynth as fs
+    from oracle import oracle as O
+    for mels in (80, 128):
+        g = fs.MelGanGenerator(32, mels)
+        assert [(k, tuple(v.shape)) for k, v in g.state_dict().items()] == O.generator_param_shapes(mels)
+    d = fs.MelGanDiscriminator()
+    assert [(k, tuple(v.shape)) for k, v in d.state_dict().items()] == O.discriminator_param_shapes()
+    assert sum(p.numel() for p in fs.MelGanGenerator(32, 80).parameters()) == 4519937
+    assert sum(p.numel() for p in d.parameters()) == 5637953
+    assert len(list(g.main)) == 17 and d.scales == 2
+    fd = fs.FullDiscriminator()
+    assert list(fd.state_dict().keys())[0] == "main.0.weight" and "judge.bias" in fd.state_dict()
+
+
+def test_golden_param_names(golden):
+    import featuresynth as fs
+    assert list(fs.MelGanGenerator(32, 80).state_dict().keys()) == list(golden("g_fwd")["param_names"])
+    assert list(fs.MelGanDiscriminator().state_dict().keys()) == list(golden("d_fwd")["param_names"])
+
+
+def test_weights_init_semantics():
+    import featuresynth as fs
+    from featuresynth.experiment.init import weights_init
+    torch.manual_seed(0)
+    g = fs.MelGanGenerator(32, 80).apply(weights_init)
+    for name, p in g.named_parameters():
+        if name.endswith("bias"):
+            assert float(p.abs().max()) == 0.0
+        elif p.numel() > 10000:
+            assert abs(float(p.std()) - 0.02) < 2e-3 and abs(float(p.mean())) < 1e-3
+    lin = torch.nn.Linear(4, 4)
+    before = lin.weight.clone()
+    weights_init(lin)                      # class name without "Conv": untouched
+    assert torch.equal(before, lin.weight)
+
+
+def test_no_cpu_fallback():
+    import featuresynth as fs
+    from featuresynth import loss as LS
+    g, d = fs.MelGanGenerator(32, 80), fs.MelGanDiscriminator()
+    with pytest.raises(RuntimeError, match="HIP device"):
+        g(torch.zeros(1, 80, 32))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        d(torch.zeros(1, 1, 8192))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        LS.hinge_generator_loss(torch.zeros(2, 1, 9))
+    with pytest.raises(RuntimeError):
+        fs.FlatAdam(g.parameters(), lr=1e-4, betas=(0.5, 0.9)).step()
+    from featuresynth.feature.feature import Audio2Mel
+    with pytest.raises(RuntimeError, match="HIP device"):
+        Audio2Mel()(np.zeros(22050, np.float32))
+
+
+def test_audio2mel_buffers_and_basis(golden):
+    from featuresynth.feature.feature import Audio2Mel, slaney_mel_basis
+    z = golden("audio2mel")
+    a = Audio2Mel()
+    assert set(dict(a.named_buffers())) == {"mel_basis", "window"}
+    assert tuple(a.mel_basis.shape) == (80, 513) and tuple(a.window.shape) == (1024,)
+    assert np.abs(a.window.numpy() - z["hann1024"]).max() < 1e-6
+    for n in (80, 128):
+        assert np.abs(slaney_mel_basis(22050, 1024, n) - z["basis%d" % n]).max() < 1e-6
+    with pytest.raises(NotImplementedError):
+        Audio2Mel(win_length=512)
+
+
+def test_workload_spec_matches_survey():
+    """10.56 GFLOP per element per call from the layer spec."""
+    from featuresynth import _workload as W
+    d1, g1 = W.totals(W.d_step_launches(1)), W.totals(W.g_step_launches(1))
+    assert abs(d1["flops"] / 1e9 - 8.51) < 0.15 and abs(g1["flops"] / 1e9 - 12.62) < 0.15
+    d32 = W.totals(W.d_step_launches(32))
+    assert abs(d32["flops"] / 32 / d1["flops"] - 1.0) < 0.01
+    assert W.feature_elems(1, 8192) == 1039008             # loss.py feature-matching elements
+    assert W.roofline_seconds(W.g_step_launches(32), 8e12, 157.3e12) > 0
+
+
+def test_synthetic_inputs_are_deterministic():
+    from featuresynth._synthetic import synthetic_features, synthetic_samples, synthetic_state_dict
+    a, b = synthetic_samples(2, 64, rank=3), synthetic_samples(2, 64, rank=3)
+    assert np.array_equal(a, b) and np.abs(a).max() <= 0.95
+    assert not np.array_equal(a, synthetic_samples(2, 64, rank=4))
+    assert synthetic_features(2, 80, 4).shape == (2, 80, 4)
+    sd = synthetic_state_dict([("w.weight", (4, 3, 3)), ("w.bias", (4,))])
+    assert float(np.abs(sd["w.bias"]).max()) == 0.0 and sd["w.weight"].dtype == np.float32
+
+
+def test_losses_generic_composition_signature():
+    import inspect
+    from featuresynth import loss as LS
+    assert "gan_loss" in inspect.signature(LS.mel_gan_disc_loss).parameters
+    sig = inspect.signature(LS.mel_gan_gen_loss).parameters
+    assert list(sig)[:4] == ["real_features", "fake_features", "real_judgements", "fake_judgements"]
+    assert sig["feature_loss_weight"].default == 10
+
+
+def test_trainer_surface():
+    import inspect
+    from featuresynth.train import DiscriminatorTrainer, GeneratorTrainer, training_loop
+    for cls in (GeneratorTrainer, DiscriminatorTrainer):
+        assert list(inspect.signature(cls.__init__).parameters)[1:] == [
+            "generator", "g_optim", "discriminator", "d_optim", "loss", "sub_loss"]
+    assert inspect.isgeneratorfunction(training_loop)
