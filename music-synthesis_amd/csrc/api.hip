@@ -2,6 +2,7 @@
 // dispatch between the direct (vector FMA) kernels and the f32-MFMA implicit-GEMM kernels.
 #include "ms_common.h"
 #include "conv_mfma.h"
+#include "gconv_mfma.h"
 
 namespace {
 
@@ -74,6 +75,7 @@ int ms_conv1d_fwd(const ms_conv1d_desc* d, const float* x, const float* w, const
     hipStream_t s = (hipStream_t)stream;
     if (msm_fwd_applicable(p))
         return msm_conv1d_fwd(p, x, nullptr, 0, w, bias, residual, y, y_act, workspace, workspace_bytes, s);
+    if (msg_fwd_applicable(p) && !residual && !y_act) return msg_conv1d_fwd(p, x, w, bias, y, s);
     return msk_conv1d_fwd_direct(p, x, nullptr, 0, w, bias, residual, y, y_act, s);
 }
 
@@ -86,6 +88,7 @@ int ms_conv1d_bwd_data(const ms_conv1d_desc* d, const float* gy, const float* y_
     hipStream_t s = (hipStream_t)stream;
     if (msm_bwd_data_applicable(p))
         return msm_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, workspace, workspace_bytes, s);
+    if (msg_bwd_data_applicable(p)) return msg_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, s);
     return msk_conv1d_bwd_data_direct(p, gy, y_act, w, nullptr, MS_ACT_NONE, gx_add, gx, s);
 }
 
@@ -115,8 +118,12 @@ size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which) {
 const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which) {
     ConvP p;
     if (!make_conv(d, &p)) return "";
-    if (which == 0) return msm_fwd_applicable(p) ? msm_fwd_name(p) : msk_conv1d_fwd_direct_name(p);
-    if (which == 1) return msm_bwd_data_applicable(p) ? msm_bwd_data_name(p) : msk_conv1d_bwd_data_direct_name(p);
+    if (which == 0)
+        return msm_fwd_applicable(p) ? msm_fwd_name(p)
+                                     : (msg_fwd_applicable(p) ? msg_fwd_name(p) : msk_conv1d_fwd_direct_name(p));
+    if (which == 1)
+        return msm_bwd_data_applicable(p) ? msm_bwd_data_name(p)
+               : (msg_bwd_data_applicable(p) ? msg_bwd_data_name(p) : msk_conv1d_bwd_data_direct_name(p));
     if (which == 2) return msm_bwd_weight_applicable(p) ? msm_bwd_weight_name(p) : msk_conv1d_bwd_weight_direct_name(p);
     return "";
 }

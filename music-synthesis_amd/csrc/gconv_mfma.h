@@ -1,0 +1,13 @@
+// Grouped k41/stride-4 conv kernels on the fp32 matrix cores (gconv_mfma.hip).
+#pragma once
+#include "ms_common.h"
+
+bool msg_fwd_applicable(const ConvP& p);
+const char* msg_fwd_name(const ConvP& p);
+int msg_conv1d_fwd(const ConvP& p, const float* x, const float* w, const float* bias, float* y,
+                   hipStream_t s);
+
+bool msg_bwd_data_applicable(const ConvP& p);
+const char* msg_bwd_data_name(const ConvP& p);
+int msg_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, const float* w,
+                        const float* gx_add, float* gx, hipStream_t s);
