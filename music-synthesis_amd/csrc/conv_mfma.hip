@@ -612,17 +612,233 @@ __global__ __launch_bounds__(256) void k_igemm_wgrad(IgP p, int chunks_per_split
     }
 }
 
+template <int WGM, int WGN, int TM, int TN, int K>
+__global__ __launch_bounds__(256) void k_igemm_wgrad_v4(IgP p, int chunks_per_split,
+                                                    const float* __restrict__ X,
+                                                    const float* __restrict__ Xact,
+                                                    const float* __restrict__ G,
+                                                    const float* __restrict__ Gact, int g_act,
+                                                    float* __restrict__ partial,
+                                                    size_t partial_stride) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    static_assert(WGM * WGN == 4, "4 waves");
+    __shared__ float As[BM * KCP];
+    __shared__ float Bs[BN * KCP];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int NG = p.CK * K;                 // GEMM-N = (c, j) pairs
+    const int KT = p.B * p.L;                // GEMM-K = (b, t) pairs
+    // loader: a thread owns 4 consecutive kk (= 4 consecutive time steps of one batch row; the
+    // host guarantees L % 4 == 0) of rows row0 + 64*r: 16-byte loads along contiguous audio frames
+    const int kq = tid & 3, row0 = tid >> 2;
+    constexpr int RA4 = (BM + 63) / 64, RB4 = (BN + 63) / 64;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float asum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asum[i] = 0.f;
+
+    int aoff[RA4], boff[RB4], bsh[RB4];
+    bool avalid[RA4], bvalid[RB4];
+#pragma unroll
+    for (int r = 0; r < RA4; ++r) {
+        const int row = row0 + 64 * r;
+        const int m = m0 + row;
+        avalid[r] = row < BM && m < p.M;
+        aoff[r] = (avalid[r] ? m : 0) * p.L;
+    }
+#pragma unroll
+    for (int r = 0; r < RB4; ++r) {
+        const int row = row0 + 64 * r;
+        const int n = n0 + row;
+        bvalid[r] = row < BN && n < NG;
+        const int nn = bvalid[r] ? n : 0;
+        const int c = nn / K, j = nn - c * K;
+        bsh[r] = j * p.dil + p.off0;
+        boff[r] = c * p.L;
+    }
+
+    const int c_begin = blockIdx.z * chunks_per_split;
+    int c_end = c_begin + chunks_per_split;
+    const int nchunks = (KT + KC - 1) / KC;
+    if (c_end > nchunks) c_end = nchunks;
+
+    // absent activation operands alias the data with a pass-through kind (keeps loads branch-free)
+    const float* Gq = Gact ? Gact : G;
+    const float* Xq = Xact ? Xact : X;
+    const int g_kind = Gact ? g_act : MS_ACT_NONE;
+    const int x_kind = Xact ? p.in_act : MS_ACT_NONE;
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    float4 ra[RA4], rb[RB4];
+    auto gload = [&](int chunk) {
+        const int kg = chunk * KC + 4 * kq;
+        const bool kv = kg < KT;                  // KT % 4 == 0: all 4 or none
+        const int b = kv ? kg / p.L : 0;
+        const int t = kv ? kg - b * p.L : 0;
+        const float* Ga = G + (size_t)b * p.M * p.L + t;
+        const float* Gy = Gq + (size_t)b * p.M * p.L + t;
+        const float* Xb = X + (size_t)b * p.CK * p.L;
+        const float* Xy = Xq + (size_t)b * p.CK * p.L;
+        float4 gv[RA4], ga[RA4];
+        f4u xv[RB4], xa[RB4];
+        int s0[RB4];
+#pragma unroll
+        for (int r = 0; r < RA4; ++r) {
+            gv[r] = *reinterpret_cast<const float4*>(Ga + aoff[r]);
+            ga[r] = *reinterpret_cast<const float4*>(Gy + aoff[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RB4; ++r) {
+            s0[r] = t + bsh[r];
+            // the 4 taps sit in one row; a window hanging over a row end is re-read element-wise below
+            const bool inside = s0[r] >= 0 && s0[r] + 3 < p.L;
+            const int off = inside ? boff[r] + s0[r] : boff[r];
+            xv[r] = *reinterpret_cast<const f4u*>(Xb + off);
+            xa[r] = *reinterpret_cast<const f4u*>(Xy + off);
+        }
+#pragma unroll
+        for (int r = 0; r < RB4; ++r) {
+            const bool inside = s0[r] >= 0 && s0[r] + 3 < p.L;
+            if (!inside && kv && bvalid[r]) {      // rare: row edges only
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int sidx = s0[r] + i;
+                    const bool ok = (unsigned)sidx < (unsigned)p.L;
+                    xv[r][i] = ok ? Xb[boff[r] + sidx] : 0.f;
+                    xa[r][i] = ok ? Xy[boff[r] + sidx] : 1.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RA4; ++r) {
+            const bool ok = kv && avalid[r];
+            ra[r].x = ok ? ms_act_grad(gv[r].x, ga[r].x, g_kind, p.slope) : 0.f;
+            ra[r].y = ok ? ms_act_grad(gv[r].y, ga[r].y, g_kind, p.slope) : 0.f;
+            ra[r].z = ok ? ms_act_grad(gv[r].z, ga[r].z, g_kind, p.slope) : 0.f;
+            ra[r].w = ok ? ms_act_grad(gv[r].w, ga[r].w, g_kind, p.slope) : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < RB4; ++r) {
+            const bool ok = kv && bvalid[r];
+            rb[r].x = ok ? ms_act_grad(xv[r][0], xa[r][0], x_kind, p.slope) : 0.f;
+            rb[r].y = ok ? ms_act_grad(xv[r][1], xa[r][1], x_kind, p.slope) : 0.f;
+            rb[r].z = ok ? ms_act_grad(xv[r][2], xa[r][2], x_kind, p.slope) : 0.f;
+            rb[r].w = ok ? ms_act_grad(xv[r][3], xa[r][3], x_kind, p.slope) : 0.f;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int r = 0; r < RA4; ++r) {
+            const int row = row0 + 64 * r;
+            if (row < BM) {
+                float* d = As + row * KCP + 4 * kq;
+                d[0] = ra[r].x; d[1] = ra[r].y; d[2] = ra[r].z; d[3] = ra[r].w;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB4; ++r) {
+            const int row = row0 + 64 * r;
+            if (row < BN) {
+                float* d = Bs + row * KCP + 4 * kq;
+                d[0] = rb[r].x; d[1] = rb[r].y; d[2] = rb[r].z; d[3] = rb[r].w;
+            }
+        }
+    };
+
+    const int arow = (wm * TM * 32 + (lane & 31)) * KCP + (lane >> 5);
+    const int brow = (wn * TN * 32 + (lane & 31)) * KCP + (lane >> 5);
+    if (c_begin < c_end) {
+        gload(c_begin);
+        lstore();
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool more = c + 1 < c_end;
+        if (more) gload(c + 1);
+#pragma unroll
+        for (int k2 = 0; k2 < KC / 2; ++k2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                a[i] = As[arow + i * 32 * KCP + 2 * k2];
+                asum[i] += a[i];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[brow + j * 32 * KCP + 2 * k2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            lstore();
+            __syncthreads();
+        }
+    }
+
+    float* part = partial + (size_t)blockIdx.z * partial_stride;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+        if (n >= NG) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) part[(size_t)m * NG + n] = acc[i][j][r];
+            }
+        }
+    }
+    // bias grad = row sums of A: lanes (i, k=0) and (i, k=1) each saw half of the kk's
+    if (blockIdx.x == 0 && wn == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float s = asum[i] + __shfl_xor(asum[i], 32, 64);
+            const int m = m0 + wm * TM * 32 + i * 32 + (lane & 31);
+            if (lane < 32 && m < p.M) part[(size_t)p.M * NG + m] = s;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial,
                                                      size_t partial_stride, int nsplit,
                                                      size_t wsize, int nbias,
                                                      float* __restrict__ gw,
                                                      float* __restrict__ gb, float beta) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= wsize + (size_t)nbias) return;
-    float s = 0.f;
-    for (int z = 0; z < nsplit; ++z) s += partial[(size_t)z * partial_stride + i];
-    if (i < wsize) gw[i] = (beta != 0.f ? beta * gw[i] : 0.f) + s;
-    else if (gb) gb[i - wsize] = (beta != 0.f ? beta * gb[i - wsize] : 0.f) + s;
+    // 64 consecutive outputs per workgroup (coalesced 256-byte rows of every slab); the slabs are
+    // dealt round-robin to the 4 waves, whose partial sums meet in LDS: fixed order, deterministic
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    const bool ok = i < wsize + (size_t)nbias;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (ok) {
+        int z = wv;
+        for (; z + 12 < nsplit; z += 16) {
+            s0 += partial[(size_t)z * partial_stride + i];
+            s1 += partial[(size_t)(z + 4) * partial_stride + i];
+            s2 += partial[(size_t)(z + 8) * partial_stride + i];
+            s3 += partial[(size_t)(z + 12) * partial_stride + i];
+        }
+        for (; z < nsplit; z += 4) s0 += partial[(size_t)z * partial_stride + i];
+    }
+    red[wv][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wv == 0 && ok) {
+        const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (i < wsize) gw[i] = (beta != 0.f ? beta * gw[i] : 0.f) + s;
+        else if (gb) gb[i - wsize] = (beta != 0.f ? beta * gb[i - wsize] : 0.f) + s;
+    }
 }
 
 // ------------------------------------------------------------------------ host side
@@ -680,18 +896,23 @@ struct WgradPlan {
 WgradPlan plan_wgrad(const ConvP& p) {
     WgradPlan q;
     const int NG = p.Cin * p.K;
+    const int t128 = ms_ceil_div(p.Cout, 128) * ms_ceil_div(NG, 128);
     if (p.Cout <= 32) q.cfg = NG <= 128 ? CFG_32x128 : CFG_32x256;
-    else q.cfg = (p.Cout >= 128 && NG >= 128) ? CFG_128x128 : CFG_64x64;
+    else if (p.Cout >= 128 && NG >= 128 && t128 >= 192) q.cfg = CFG_128x128;   // enough tiles without split-K
+    else q.cfg = CFG_64x64;
     cfg_tile(q.cfg, &q.bm, &q.bn);
     const int tiles = ms_ceil_div(p.Cout, q.bm) * ms_ceil_div(NG, q.bn);
     const long long KT = (long long)p.B * p.Lin;
     const int nchunks = (int)((KT + KC - 1) / KC);
-    int ns = ms_ceil_div(768, tiles);                // ~3 workgroups per CU
-    const int max_by_work = nchunks / 8 > 0 ? nchunks / 8 : 1;   // >= 8 chunks per split
-    if (ns > max_by_work) ns = max_by_work;
     q.stride_floats = (size_t)p.Cout * NG + p.Cout;
-    const size_t cap = (size_t)96 << 20;
-    while (ns > 1 && (size_t)ns * q.stride_floats * 4 > cap) --ns;
+    // split-K: ~2 workgroups per CU, >= 16 chunks per split, partial slabs <= 12 MiB in total
+    int ns = ms_ceil_div(512, tiles);
+    const int max_by_work = nchunks / 16 > 0 ? nchunks / 16 : 1;
+    if (ns > max_by_work) ns = max_by_work;
+    const size_t cap = (size_t)12 << 20;
+    const size_t max_by_bytes = cap / (q.stride_floats * 4);
+    if ((size_t)ns > max_by_bytes) ns = max_by_bytes > 0 ? (int)max_by_bytes : 1;
+    if (ns < 1) ns = 1;
     q.cps = ms_ceil_div(nchunks, ns);
     q.nsplit = ms_ceil_div(nchunks, q.cps);
     return q;
@@ -851,7 +1072,8 @@ const char* msm_bwd_data_name(const ConvP& p) {
     return kname("k_igemm_conv", pick_cfg(p.Cin, (long long)p.B * p.Lin), p.K, ", true");
 }
 const char* msm_bwd_weight_name(const ConvP& p) {
-    return kname("k_igemm_wgrad", plan_wgrad(p).cfg, p.K, "");
+    const bool v4 = (p.Lin % 4 == 0) && p.pad_mode == MS_PAD_ZERO;
+    return kname(v4 ? "k_igemm_wgrad_v4" : "k_igemm_wgrad", plan_wgrad(p).cfg, p.K, "");
 }
 const char* msm_convt_fwd_name(const ConvP& p) {
     static thread_local char buf[96];
@@ -915,9 +1137,17 @@ int msm_conv1d_bwd_weight(const ConvP& p, const float* x, const float* x_act, in
     const int NG = p.Cin * p.K;
     dim3 grid((unsigned)ms_ceil_div(NG, pl.bn), (unsigned)ms_ceil_div(p.Cout, pl.bm), (unsigned)pl.nsplit);
     float* partial = (float*)ws;
+    const bool v4 = (p.Lin % 4 == 0) && p.pad_mode == MS_PAD_ZERO &&
+                    ((((uintptr_t)x) | ((uintptr_t)gy) | ((uintptr_t)(y_act ? y_act : gy))) & 15) == 0;
 #define MS_WG(WGM, WGN, TM, TN, KK)                                                                 \
-    hipLaunchKernelGGL((k_igemm_wgrad<WGM, WGN, TM, TN, KK>), grid, dim3(256), 0, s, q, pl.cps, x,  \
-                       x_act, gy, y_act, y_act_kind, partial, pl.stride_floats)
+    do {                                                                                            \
+        if (v4)                                                                                     \
+            hipLaunchKernelGGL((k_igemm_wgrad_v4<WGM, WGN, TM, TN, KK>), grid, dim3(256), 0, s, q,  \
+                               pl.cps, x, x_act, gy, y_act, y_act_kind, partial, pl.stride_floats); \
+        else                                                                                        \
+            hipLaunchKernelGGL((k_igemm_wgrad<WGM, WGN, TM, TN, KK>), grid, dim3(256), 0, s, q,     \
+                               pl.cps, x, x_act, gy, y_act, y_act_kind, partial, pl.stride_floats); \
+    } while (0)
 #define MS_WG_K(KK)                                                                                 \
     do {                                                                                            \
         if (pl.cfg == CFG_128x128) MS_WG(2, 2, 2, 2, KK);                                           \
@@ -935,7 +1165,7 @@ int msm_conv1d_bwd_weight(const ConvP& p, const float* x, const float* x_act, in
     MS_CHECK_LAUNCH();
     const size_t wsize = (size_t)p.Cout * NG;
     const size_t total = wsize + p.Cout;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, partial,
                        pl.stride_floats, pl.nsplit, wsize, p.Cout, gw, gb, beta);
     MS_CHECK_LAUNCH();
     return MS_OK;
