@@ -133,11 +133,15 @@ const char* ms_convt1d_kernel_name(const ms_convt1d_desc* d, int which) {
     if (!make_convt(d, &p)) return "";
     if (which == 0) return msm_convt_fwd_applicable(p) ? msm_convt_fwd_name(p) : msk_conv1d_bwd_data_direct_name(p);
     if (which == 1) {
+        if (msm_convt_bwd_applicable(p)) return msm_convt_bwd_data_name(p);
         ConvP q = p;
         q.act = MS_ACT_NONE;
         return msm_fwd_applicable(q) ? msm_fwd_name(q) : msk_conv1d_fwd_direct_name(q);
     }
-    if (which == 2) return msm_bwd_weight_applicable(p) ? msm_bwd_weight_name(p) : msk_conv1d_bwd_weight_direct_name(p);
+    if (which == 2) {
+        if (msm_convt_bwd_applicable(p)) return msm_convt_bwd_weight_name(p);
+        return msm_bwd_weight_applicable(p) ? msm_bwd_weight_name(p) : msk_conv1d_bwd_weight_direct_name(p);
+    }
     return "";
 }
 
@@ -164,6 +168,8 @@ int ms_convt1d_bwd_data(const ms_convt1d_desc* d, const float* gy, const float* 
     ConvP p;
     if (!make_convt(d, &p) || !gy || !w || !gx) return MS_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (msm_convt_bwd_applicable(p))
+        return msm_convt1d_bwd_data(p, gy, y_act, w, gx, workspace, workspace_bytes, s);
     ConvP q = p;
     q.act = MS_ACT_NONE;
     if (msm_fwd_applicable(q))
@@ -182,7 +188,9 @@ int ms_convt1d_bwd_weight(const ms_convt1d_desc* d, const float* x, const float*
     if (beta != 0.f && beta != 1.f) return MS_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (msm_bwd_weight_applicable(p))
+    if (msm_convt_bwd_applicable(p))
+        rc = msm_convt1d_bwd_weight(p, x, gy, y_act, gw, beta, workspace, workspace_bytes, s);
+    else if (msm_bwd_weight_applicable(p))
         rc = msm_conv1d_bwd_weight(p, gy, y_act, p.act, x, nullptr, 0, gw, nullptr, beta, workspace,
                                    workspace_bytes, s);
     else
@@ -198,11 +206,15 @@ size_t ms_convt1d_workspace_bytes(const ms_convt1d_desc* d, int which) {
     if (!make_convt(d, &p)) return 0;
     if (which == 0) return msm_convt_fwd_applicable(p) ? msm_convt_fwd_ws(p) : 0;
     if (which == 1) {
+        if (msm_convt_bwd_applicable(p)) return msm_convt_bwd_data_ws(p);
         ConvP q = p;
         q.act = MS_ACT_NONE;
         return msm_fwd_applicable(q) ? msm_fwd_ws(q) : 0;
     }
-    if (which == 2) return msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p);
+    if (which == 2) {
+        if (msm_convt_bwd_applicable(p)) return msm_convt_bwd_weight_ws(p);
+        return msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p);
+    }
     return 0;
 }
 

@@ -27,3 +27,14 @@ int msm_conv1d_bwd_weight(const ConvP& p, const float* x, const float* x_act, in
                           float* gb, float beta, void* ws, size_t ws_bytes, hipStream_t s);
 int msm_convt1d_fwd(const ConvP& p, const float* x, const float* w, const float* bias, float* y,
                     void* ws, size_t ws_bytes, hipStream_t s);
+
+// ConvTranspose1d backward passes in phase-split form (p = mirrored conv of the transposed conv)
+bool msm_convt_bwd_applicable(const ConvP& p);
+size_t msm_convt_bwd_data_ws(const ConvP& p);
+size_t msm_convt_bwd_weight_ws(const ConvP& p);
+const char* msm_convt_bwd_data_name(const ConvP& p);
+const char* msm_convt_bwd_weight_name(const ConvP& p);
+int msm_convt1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, const float* w,
+                         float* gx, void* ws, size_t ws_bytes, hipStream_t s);
+int msm_convt1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act,
+                           float* gw, float beta, void* ws, size_t ws_bytes, hipStream_t s);

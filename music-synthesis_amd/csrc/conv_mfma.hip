@@ -29,6 +29,7 @@ constexpr int KCP = KC + 1;   // odd LDS row stride: conflict-free 32-lane colum
 struct IgP {
     int B, CK, L, M, dil, off0, pad_mode, act, in_act, N, KG;
     float slope;
+    int in_s;   // weight-grad B operand: channel c' = co*in_s + r is phase r of a stride-in_s signal
 };
 
 // branch-free source index: every load below is issued unconditionally from a clamped (always
@@ -206,7 +207,7 @@ struct RowP {
     float slope;
 };
 
-template <int WGM, int WGN, int TM, int TN, int K, int CC, bool HAS_ACT, int EPI_S>
+template <int WGM, int WGN, int TM, int TN, int K, int CC, bool HAS_ACT, int EPI_S, int IN_S>
 __global__ __launch_bounds__(256) void k_conv_mfma_rows(RowP p, const float* __restrict__ X,
                                                        const float* __restrict__ Xact,
                                                        const float* __restrict__ W,
@@ -243,7 +244,9 @@ __global__ __launch_bounds__(256) void k_conv_mfma_rows(RowP p, const float* __r
             const int b = b0 + r;
             if (b < p.B) {
                 const int s = ms_src_index(t0 + pos + p.off0, p.L, p.pad_mode);
-                if (s >= 0) goff[q] = (long long)b * p.CK * p.L + s;
+                // IN_S > 1: channel c' = co*IN_S + r is phase r of a stride-IN_S signal (row length
+                // L*IN_S) -- the input of a transposed conv's backward passes
+                if (s >= 0) goff[q] = (long long)b * p.CK * p.L + (long long)s * IN_S;
             }
         }
     }
@@ -288,13 +291,14 @@ __global__ __launch_bounds__(256) void k_conv_mfma_rows(RowP p, const float* __r
         for (int q = 0; q < MAXCOL; ++q) {
             if (q == 1 && !has_col1) break;
             const bool ok = goff[q] >= 0;
-            const size_t base = ok ? (size_t)goff[q] + (size_t)c0 * p.L : 0;
-            const size_t step = ok ? (size_t)p.L : 0;
+            const size_t base = ok ? (size_t)goff[q] + (size_t)(c0 / IN_S) * p.L * IN_S : 0;
+            const size_t step = ok ? (size_t)p.L * IN_S : 0;
             float av[CC];
 #pragma unroll
             for (int c = 0; c < CC; ++c) {
-                rx[q][c] = X[base + c * step];
-                if (HAS_ACT) av[c] = Xact[base + c * step];
+                const size_t off = base + (c / IN_S) * step + (ok ? (c % IN_S) : 0);
+                rx[q][c] = X[off];
+                if (HAS_ACT) av[c] = Xact[off];
             }
 #pragma unroll
             for (int c = 0; c < CC; ++c) {
@@ -451,6 +455,41 @@ __global__ __launch_bounds__(256) void k_transpose_flip_w(const float* __restric
     }
 }
 
+// Weights of the 3-tap phase-split form of ConvTranspose1d's backward-data:
+//   gx[b, ci, q] = sum_{co, r, d} W[ci, co, r + pad + d*S] * G'[b, (co, r), q + d],  G'[b,(co,r),q] = gp[b,co,qS+r]
+// Wq[ci][(co*S + r)*3 + (d+1)], zero where the tap index falls outside [0, K).
+__global__ __launch_bounds__(256) void k_pack_convt_bwd_w(const float* __restrict__ W,
+                                                         float* __restrict__ Wq, int Cin, int Cout,
+                                                         int K, int S, int pad) {
+    const size_t total = (size_t)Cin * Cout * S * 3;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int d = (int)(i % 3) - 1;
+        size_t r0 = i / 3;
+        const int r = (int)(r0 % S);
+        r0 /= S;
+        const int co = (int)(r0 % Cout);
+        const int ci = (int)(r0 / Cout);
+        const int k = r + pad + d * S;
+        Wq[i] = (k >= 0 && k < K) ? W[((size_t)ci * Cout + co) * K + k] : 0.f;
+    }
+}
+
+// gw[ci, co, k] = beta*gw + dWq[ci][(co*S + r)*3 + (d+1)] with k = r + pad + d*S
+__global__ __launch_bounds__(256) void k_unpack_convt_gw(const float* __restrict__ dWq,
+                                                        float* __restrict__ gw, int Cin, int Cout,
+                                                        int K, int S, int pad, float beta) {
+    const size_t total = (size_t)Cin * Cout * K;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i % K);
+        const size_t cc = i / K;               // ci*Cout + co
+        const int kp = k - pad;
+        int d = kp >= 0 ? kp / S : -((-kp + S - 1) / S);
+        const int r = kp - d * S;
+        const float v = dWq[(cc * S + r) * 3 + (d + 1)];
+        gw[i] = (beta != 0.f ? beta * gw[i] : 0.f) + v;
+    }
+}
+
 // ------------------------------------------------------------------ backward weight
 // partial[z][m][n] = sum over this block's kk = (b,t) range of A[m,kk] * Bm[kk,n]
 //   A[m, kk] = dY'[b, m, t],  Bm[kk, n=(c,j)] = X[b, c, t + j*dil + off0]
@@ -503,7 +542,7 @@ __global__ __launch_bounds__(256) void k_igemm_wgrad(IgP p, int chunks_per_split
         const int nn = bvalid[r] ? n : 0;
         const int c = nn / K, j = nn - c * K;
         bsh[r] = j * p.dil + p.off0;
-        boff[r] = c * p.L;
+        boff[r] = (c / p.in_s) * p.L * p.in_s + (c % p.in_s);
     }
 
     const int c_begin = blockIdx.z * chunks_per_split;
@@ -537,7 +576,7 @@ __global__ __launch_bounds__(256) void k_igemm_wgrad(IgP p, int chunks_per_split
         for (int r = 0; r < RB; ++r) {
             const int sidx = src_index_sel(t + bsh[r], p.L, p.pad_mode == MS_PAD_REFLECT);
             xok[r] = kv && bvalid[r] && (unsigned)sidx < (unsigned)p.L;
-            const int off = xok[r] ? boff[r] + sidx : 0;
+            const int off = xok[r] ? boff[r] + sidx * p.in_s : 0;
             xv[r] = Xb[off];
             xa[r] = Xy[off];
         }
@@ -962,7 +1001,7 @@ bool make_rowp(RowP* q, RowCfg cfg, int B, int CK, int L, int M, int K, int dil,
     return q->RSZ <= 512;
 }
 
-template <int K, bool HAS_ACT, int EPI_S = 0>
+template <int K, bool HAS_ACT, int EPI_S = 0, int IN_S = 1>
 int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, const float* W,
                   const float* bias, const float* res, float* Y, float* Yact, hipStream_t s) {
     constexpr int CC = row_cc(K);
@@ -974,16 +1013,16 @@ int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, 
     if (lds > 64 * 1024) return MS_ERR_UNSUPPORTED;
     switch (cfg) {
         case ROW_128x128:
-            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 2, 2, K, CC, HAS_ACT, EPI_S>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 2, 2, K, CC, HAS_ACT, EPI_S, IN_S>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
             break;
         case ROW_64x128:
-            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 1, 2, K, CC, HAS_ACT, EPI_S>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 1, 2, K, CC, HAS_ACT, EPI_S, IN_S>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
             break;
         case ROW_64x64:
-            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 1, 1, K, CC, HAS_ACT, EPI_S>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 1, 1, K, CC, HAS_ACT, EPI_S, IN_S>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
             break;
         default:
-            hipLaunchKernelGGL((k_conv_mfma_rows<1, 4, 1, 2, K, CC, HAS_ACT, EPI_S>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            hipLaunchKernelGGL((k_conv_mfma_rows<1, 4, 1, 2, K, CC, HAS_ACT, EPI_S, IN_S>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
             break;
     }
     MS_CHECK_LAUNCH();
@@ -1097,7 +1136,7 @@ int msm_conv1d_fwd(const ConvP& p, const float* x, const float* x_act, int x_act
     IgP q;
     q.B = p.B; q.CK = p.Cin; q.L = p.Lin; q.M = p.Cout; q.dil = p.dil; q.off0 = -p.pad;
     q.pad_mode = p.pad_mode; q.act = p.act; q.in_act = x_act_kind; q.slope = p.slope;
-    q.N = p.B * p.Lin; q.KG = p.Cin * p.K;
+    q.N = p.B * p.Lin; q.KG = p.Cin * p.K; q.in_s = 1;
     return launch_conv<false>(p.K, pick_cfg(q.M, q.N), q, x, x_act, w, bias, residual, y, y_act, s);
 }
 
@@ -1120,7 +1159,7 @@ int msm_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, con
     q.B = p.B; q.CK = p.Cout; q.L = p.Lin; q.M = p.Cin; q.dil = p.dil;
     q.off0 = p.pad - (p.K - 1) * p.dil;   // flipped taps: j' = K-1-j
     q.pad_mode = MS_PAD_ZERO; q.act = MS_ACT_NONE; q.in_act = p.act; q.slope = p.slope;
-    q.N = p.B * p.Lin; q.KG = p.Cout * p.K;
+    q.N = p.B * p.Lin; q.KG = p.Cout * p.K; q.in_s = 1;
     return launch_conv<true>(p.K, pick_cfg(q.M, q.N), q, gy, y_act, w, nullptr, gx_add, gx, nullptr, s);
 }
 
@@ -1133,7 +1172,7 @@ int msm_conv1d_bwd_weight(const ConvP& p, const float* x, const float* x_act, in
     IgP q;
     q.B = p.B; q.CK = p.Cin; q.L = p.Lin; q.M = p.Cout; q.dil = p.dil; q.off0 = -p.pad;
     q.pad_mode = p.pad_mode; q.act = MS_ACT_NONE; q.in_act = x_act_kind; q.slope = p.slope;
-    q.N = p.B * p.Lin; q.KG = p.Cin * p.K;
+    q.N = p.B * p.Lin; q.KG = p.Cin * p.K; q.in_s = 1;
     const int NG = p.Cin * p.K;
     dim3 grid((unsigned)ms_ceil_div(NG, pl.bn), (unsigned)ms_ceil_div(p.Cout, pl.bm), (unsigned)pl.nsplit);
     float* partial = (float*)ws;
@@ -1186,4 +1225,111 @@ int msm_convt1d_fwd(const ConvP& p, const float* x, const float* w, const float*
     make_rowp(&r, cfg, p.B, CinT, LinT, CoutT * S, 3, 1, -1, MS_PAD_ZERO, p.act, MS_ACT_NONE, p.slope);
     if (S == 8) return launch_rows_k<3, false, 8>(cfg, r, x, nullptr, wp, bias, nullptr, y, nullptr, s);
     return launch_rows_k<3, false, 2>(cfg, r, x, nullptr, wp, bias, nullptr, y, nullptr, s);
+}
+
+// ---- ConvTranspose1d backward (p = mirrored conv: Cin_T = p.Cout, Cout_T = p.Cin, Lin_T = p.Lout)
+bool msm_convt_bwd_applicable(const ConvP& p) {
+    const int S = p.stride;
+    if (!(S == 2 || S == 8) || p.K != 2 * S || 2 * p.pad != S || p.dil != 1 || p.groups != 1) return false;
+    if (p.Cout < 32 || p.Cin % 8 || (p.Cin * S) % 8) return false;
+    if ((long long)p.B * p.Cin * p.Lin >= (1LL << 31) || (long long)p.B * p.Cout * p.Lout >= (1LL << 31)) return false;
+    RowP q;
+    return make_rowp(&q, pick_row_cfg(p.Cout, p.B, p.Lout), p.B, p.Cin * S, p.Lout, p.Cout, 3, 1, -1, 0, 0, 0, 0.f);
+}
+
+size_t msm_convt_bwd_data_ws(const ConvP& p) {
+    return (size_t)p.Cout * p.Cin * p.stride * 3 * sizeof(float);
+}
+
+const char* msm_convt_bwd_data_name(const ConvP& p) {
+    static thread_local char buf[96];
+    const RowCfg c = pick_row_cfg(p.Cout, p.B, p.Lout);
+    const char* tile = c == ROW_128x128 ? "2, 2, 2, 2" : (c == ROW_64x128 ? "2, 2, 1, 2" :
+                       (c == ROW_64x64 ? "2, 2, 1, 1" : "1, 4, 1, 2"));
+    snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, 3, 8, true, 0, %d>", tile, p.stride);
+    return buf;
+}
+
+// gx_T = conv over the phase-split gradient: M = Cin_T, channels (co, r), 3 taps
+int msm_convt1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, const float* w,
+                         float* gx, void* ws, size_t ws_bytes, hipStream_t s) {
+    const int S = p.stride, CinT = p.Cout, CoutT = p.Cin, LinT = p.Lout;
+    if (!ws || ws_bytes < msm_convt_bwd_data_ws(p) || (((uintptr_t)ws) & 15)) return MS_ERR_WORKSPACE;
+    float* wq = (float*)ws;
+    const size_t total = (size_t)CinT * CoutT * S * 3;
+    unsigned nb = (unsigned)((total + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_pack_convt_bwd_w, dim3(nb), dim3(256), 0, s, w, wq, CinT, CoutT, p.K, S, p.pad);
+    MS_CHECK_LAUNCH();
+    RowP r;
+    const RowCfg cfg = pick_row_cfg(CinT, p.B, LinT);
+    make_rowp(&r, cfg, p.B, CoutT * S, LinT, CinT, 3, 1, -1, MS_PAD_ZERO, MS_ACT_NONE, p.act, p.slope);
+    // the activation operand aliases the data when absent (pass-through kind)
+    const float* ya = y_act ? y_act : gy;
+    if (!y_act) r.in_act = MS_ACT_NONE;
+    if (S == 8) return launch_rows_k<3, true, 0, 8>(cfg, r, gy, ya, wq, nullptr, nullptr, gx, nullptr, s);
+    return launch_rows_k<3, true, 0, 2>(cfg, r, gy, ya, wq, nullptr, nullptr, gx, nullptr, s);
+}
+
+struct ConvtWgradPlan {
+    WgradPlan w;
+    size_t dwq_floats;
+};
+
+static ConvtWgradPlan plan_convt_wgrad(const ConvP& p) {
+    // weight-grad GEMM: M = Cin_T, N = Cout_T * S * 3, K = B * Lin_T
+    ConvP m = p;
+    m.Cout = p.Cout;                 // rows: x_T channels
+    m.Cin = p.Cin * p.stride;        // (co, r) phase channels
+    m.K = 3; m.Lin = p.Lout; m.Lout = p.Lout; m.stride = 1; m.pad = 1; m.dil = 1;
+    ConvtWgradPlan q;
+    q.w = plan_wgrad(m);
+    q.dwq_floats = (size_t)p.Cout * m.Cin * 3 + p.Cout;
+    return q;
+}
+
+size_t msm_convt_bwd_weight_ws(const ConvP& p) {
+    const ConvtWgradPlan q = plan_convt_wgrad(p);
+    return ((size_t)q.w.nsplit * q.w.stride_floats + q.dwq_floats) * sizeof(float);
+}
+
+const char* msm_convt_bwd_weight_name(const ConvP& p) {
+    return kname("k_igemm_wgrad", plan_convt_wgrad(p).w.cfg, 3, "");
+}
+
+// gw_T via the phase-split weight-grad GEMM, then un-packed into (Cin_T, Cout_T, K)
+int msm_convt1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act,
+                           float* gw, float beta, void* ws, size_t ws_bytes, hipStream_t s) {
+    const int S = p.stride, CinT = p.Cout, CoutT = p.Cin, LinT = p.Lout;
+    const ConvtWgradPlan pl = plan_convt_wgrad(p);
+    if (!ws || ws_bytes < msm_convt_bwd_weight_ws(p)) return MS_ERR_WORKSPACE;
+    float* partial = (float*)ws;
+    float* dwq = partial + (size_t)pl.w.nsplit * pl.w.stride_floats;
+    IgP q;
+    q.B = p.B; q.CK = CoutT * S; q.L = LinT; q.M = CinT; q.dil = 1; q.off0 = -1;
+    q.pad_mode = MS_PAD_ZERO; q.act = MS_ACT_NONE; q.in_act = p.act; q.slope = p.slope;
+    q.N = p.B * LinT; q.KG = q.CK * 3; q.in_s = S;
+    const int NG = q.CK * 3;
+    dim3 grid((unsigned)ms_ceil_div(NG, pl.w.bn), (unsigned)ms_ceil_div(CinT, pl.w.bm), (unsigned)pl.w.nsplit);
+    // A operand = x_T (no activation), B operand = phase-split gy with act'(y_T)
+#define MS_TWG(WGM, WGN, TM, TN)                                                                     \
+    hipLaunchKernelGGL((k_igemm_wgrad<WGM, WGN, TM, TN, 3>), grid, dim3(256), 0, s, q, pl.w.cps, gy, \
+                       y_act, x, (const float*)nullptr, 0, partial, pl.w.stride_floats)
+    if (pl.w.cfg == CFG_128x128) MS_TWG(2, 2, 2, 2);
+    else if (pl.w.cfg == CFG_64x64) MS_TWG(2, 2, 1, 1);
+    else if (pl.w.cfg == CFG_32x128) MS_TWG(1, 4, 1, 1);
+    else MS_TWG(1, 4, 1, 2);
+#undef MS_TWG
+    MS_CHECK_LAUNCH();
+    const size_t wsize = (size_t)CinT * NG;
+    const size_t total = wsize + CinT;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, partial,
+                       pl.w.stride_floats, pl.w.nsplit, wsize, CinT, dwq, (float*)nullptr, 0.f);
+    MS_CHECK_LAUNCH();
+    const size_t gtotal = (size_t)CinT * CoutT * p.K;
+    unsigned nb = (unsigned)((gtotal + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_unpack_convt_gw, dim3(nb), dim3(256), 0, s, dwq, gw, CinT, CoutT, p.K, S, p.pad, beta);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
 }
