@@ -102,6 +102,8 @@ int ms_conv1d_bwd_weight(const ms_conv1d_desc* d, const float* x, const float* g
     if (msm_bwd_weight_applicable(p))
         return msm_conv1d_bwd_weight(p, x, nullptr, 0, gy, y_act, p.act, gw, gb, beta, workspace,
                                      workspace_bytes, s);
+    if (msg_bwd_weight_applicable(p))
+        return msg_conv1d_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
     return msk_conv1d_bwd_weight_direct(p, x, nullptr, 0, gy, y_act, p.act, gw, gb, beta, workspace,
                                         workspace_bytes, s);
 }
@@ -111,7 +113,9 @@ size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which) {
     if (!make_conv(d, &p)) return 0;
     if (which == 0) return msm_fwd_applicable(p) ? msm_fwd_ws(p) : 0;
     if (which == 1) return msm_bwd_data_applicable(p) ? msm_bwd_data_ws(p) : 0;
-    if (which == 2) return msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p);
+    if (which == 2)
+        return msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p)
+               : (msg_bwd_weight_applicable(p) ? msg_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p));
     return 0;
 }
 
@@ -124,7 +128,9 @@ const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which) {
     if (which == 1)
         return msm_bwd_data_applicable(p) ? msm_bwd_data_name(p)
                : (msg_bwd_data_applicable(p) ? msg_bwd_data_name(p) : msk_conv1d_bwd_data_direct_name(p));
-    if (which == 2) return msm_bwd_weight_applicable(p) ? msm_bwd_weight_name(p) : msk_conv1d_bwd_weight_direct_name(p);
+    if (which == 2)
+        return msm_bwd_weight_applicable(p) ? msm_bwd_weight_name(p)
+               : (msg_bwd_weight_applicable(p) ? msg_bwd_weight_name(p) : msk_conv1d_bwd_weight_direct_name(p));
     return "";
 }
 

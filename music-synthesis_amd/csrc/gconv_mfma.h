@@ -11,3 +11,9 @@ bool msg_bwd_data_applicable(const ConvP& p);
 const char* msg_bwd_data_name(const ConvP& p);
 int msg_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, const float* w,
                         const float* gx_add, float* gx, hipStream_t s);
+
+bool msg_bwd_weight_applicable(const ConvP& p);
+size_t msg_bwd_weight_ws(const ConvP& p);
+const char* msg_bwd_weight_name(const ConvP& p);
+int msg_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act,
+                          float* gw, float* gb, float beta, void* ws, size_t ws_bytes, hipStream_t s);

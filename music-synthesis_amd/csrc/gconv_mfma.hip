@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_fwd(ConvP p, const float* __
     const int g = blockIdx.y, b = blockIdx.z;
     const int T0 = blockIdx.x * WTT;                 // first output of this workgroup
     const int u0 = T0 * GS - p.pad;                  // input index of padded position 0
-    const int span = WTT * GS + GK - 1;
+    const int tvalid = min(WTT, p.Lout - T0);          // short rows: stage only what is read
+    const int span = min(WTT * GS + GK - 1, (((tvalid + 15) & ~15) - 1) * GS + GK);
 
     // stage x[b, g*4 + ci, u0 .. u0+span) de-interleaved by phase
     for (int idx = tid; idx < GCG * span; idx += 256) {
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_bwd_data(ConvP p, const floa
     const int g = blockIdx.y, b = blockIdx.z;
     const int Q0 = blockIdx.x * WQ;
     const int tlo = Q0 + 5 - (JJ - 1);               // first gp index staged (may be < 0)
-    const int span = WQ + 2 * (JJ - 1);
+    const int qvalid = min(WQ, (p.Lin + GS - 1) / GS - Q0);
+    const int span = min(WQ + 2 * (JJ - 1), ((qvalid + 15) & ~15) + 2 * (JJ - 1));
     const float* ya = y_act ? y_act : gy;
     const int kind = y_act ? p.act : MS_ACT_NONE;
     for (int idx = tid; idx < OQ * 4 * span; idx += 256) {
@@ -156,6 +158,127 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_bwd_data(ConvP p, const floa
     }
 }
 
+
+// --------------------------------------------------------------- backward weight
+// gw[co, ci, k] = sum_{b,t} gp[b, co, t] * x[b, g*4+ci, 4t + k - 20] per group: M = co (16),
+// N = (ci, k) = 164 columns in 11 MFMA tiles, MFMA k index = 4 consecutive t.  Every wave sums
+// its own quarter of each 256-output chunk into registers (11 x f32x4) and writes ONE slab per
+// wave at the end; slabs are combined by the deterministic split-K reduce (k_reduce_slabs).
+constexpr int WC = 256;                       // outputs per chunk (4 waves x 64)
+constexpr int RSA = WC + 2;                   // == 2 (mod 32): (co, k) fragment reads conflict-free
+constexpr int XSPAN = WC * GS + GK - 1;       // 1064 inputs per channel and chunk
+constexpr int NT = (GCG * GK + 15) / 16;      // 11 column tiles
+
+__global__ __launch_bounds__(256) void k_gconv_mfma_wgrad(ConvP p, const float* __restrict__ x,
+                                                         const float* __restrict__ gy,
+                                                         const float* __restrict__ y_act,
+                                                         float* __restrict__ partial,
+                                                         size_t partial_stride) {
+    __shared__ float gs[16 * RSA];
+    __shared__ float xs[GCG * XSPAN];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = blockIdx.y;
+    const float* ya = y_act ? y_act : gy;
+    const int kind = y_act ? p.act : MS_ACT_NONE;
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    // B-fragment offsets of this lane: column nn = tile*16 + (lane&15) -> (ci, kk); k = lane>>4
+    int xo[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        int nn = i * 16 + (lane & 15);
+        if (nn >= GCG * GK) nn = 0;           // padded columns: computed, never stored
+        const int ci = nn / GK, kk = nn - ci * GK;
+        xo[i] = ci * XSPAN + kk + 4 * (lane >> 4) + wid * 64 * GS;
+    }
+    const int ao = (lane & 15) * RSA + (lane >> 4) + wid * 64;
+
+    const int tchunks = (p.Lout + WC - 1) / WC;
+    const int nchunks = p.B * tchunks;
+    for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const int b = ch / tchunks, t0 = (ch - b * tchunks) * WC;
+        const int tvalid = min(WC, p.Lout - t0);
+        const int tv4 = (tvalid + 3) & ~3;    // MFMA k-steps cover whole groups of 4 outputs
+        __syncthreads();                      // previous chunk fully consumed
+        for (int idx = tid; idx < 16 * tv4; idx += 256) {
+            const int co = idx / tv4, t = idx - co * tv4;
+            const bool ok = co < p.Og && t0 + t < p.Lout;
+            const size_t off = ok ? ((size_t)b * p.Cout + (size_t)g * p.Og + co) * p.Lout + t0 + t : 0;
+            const float v = gy[off], a = ya[off];
+            gs[co * RSA + t] = ok ? ms_act_grad(v, a, kind, p.slope) : 0.f;
+        }
+        const int u0 = t0 * GS - p.pad;
+        const int xspan = tv4 * GS + GK - 1;
+        for (int idx = tid; idx < GCG * xspan; idx += 256) {
+            const int ci = idx / xspan, u = idx - ci * xspan;
+            const int sidx = u0 + u;
+            const bool ok = sidx >= 0 && sidx < p.Lin;
+            const float v = x[ok ? ((size_t)b * p.Cin + (size_t)g * GCG + ci) * p.Lin + sidx : 0];
+            xs[ci * XSPAN + u] = ok ? v : 0.f;
+        }
+        __syncthreads();
+        const int isteps = min(16, max(0, (tv4 - wid * 64) >> 2));   // wave-uniform
+#pragma unroll 4
+        for (int i = 0; i < isteps; ++i) {    // MFMA k-steps of 4 outputs within this wave's 64 outputs
+            const float a = gs[ao + 4 * i];
+            bsum += a;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float bv = xs[xo[n] + 16 * i];
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[n], 0, 0, 0);
+            }
+        }
+    }
+
+    float* part = partial + (size_t)(blockIdx.x * 4 + wid) * partial_stride;
+    const int J = GCG * GK;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int nn = n * 16 + (lane & 15);
+        if (nn >= J) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = (lane >> 4) * 4 + r;
+            if (m < p.Og) part[(size_t)(g * p.Og + m) * J + nn] = acc[n][r];
+        }
+    }
+    // bias grad: lane (co, k) summed the outputs with t % 4 == k; combine the 4 k lanes
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lane < 16 && lane < p.Og) part[(size_t)p.Cout * J + g * p.Og + lane] = bsum;
+}
+
+__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ partial,
+                                                     size_t partial_stride, int nsplit,
+                                                     size_t wsize, int nbias,
+                                                     float* __restrict__ gw,
+                                                     float* __restrict__ gb, float beta) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    const bool ok = i < wsize + (size_t)nbias;
+    float s0 = 0.f, s1 = 0.f;
+    if (ok) {
+        int z = wv;
+        for (; z + 4 < nsplit; z += 8) {
+            s0 += partial[(size_t)z * partial_stride + i];
+            s1 += partial[(size_t)(z + 4) * partial_stride + i];
+        }
+        for (; z < nsplit; z += 4) s0 += partial[(size_t)z * partial_stride + i];
+    }
+    red[wv][lane] = s0 + s1;
+    __syncthreads();
+    if (wv == 0 && ok) {
+        const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (i < wsize) gw[i] = (beta != 0.f ? beta * gw[i] : 0.f) + s;
+        else if (gb) gb[i - wsize] = (beta != 0.f ? beta * gb[i - wsize] : 0.f) + s;
+    }
+}
+
 }  // namespace
 
 bool msg_fwd_applicable(const ConvP& p) {
@@ -190,6 +313,45 @@ int msg_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, con
         hipLaunchKernelGGL(k_gconv_mfma_bwd_data<4>, grid, dim3(256), 0, s, p, gy, y_act, w, gx_add, gx);
     else
         hipLaunchKernelGGL(k_gconv_mfma_bwd_data<1>, grid, dim3(256), 0, s, p, gy, y_act, w, gx_add, gx);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+bool msg_bwd_weight_applicable(const ConvP& p) {
+    return p.K == GK && p.stride == GS && p.Cg == GCG && p.dil == 1 && p.pad_mode == MS_PAD_ZERO &&
+           p.Og <= 16 && p.groups <= 65535;
+}
+
+static int wgrad_gridx(const ConvP& p) {
+    const size_t slab = ((size_t)p.Cout * GCG * GK + p.Cout) * sizeof(float);
+    const int nchunks = p.B * ms_ceil_div(p.Lout, WC);
+    int gx = ms_ceil_div(384, p.groups);                 // ~1.5 workgroups per CU
+    const size_t cap = (size_t)16 << 20;                 // slabs (4 per workgroup column) <= 16 MiB
+    while (gx > 1 && (size_t)gx * 4 * slab > cap) --gx;
+    if (gx > nchunks) gx = nchunks;
+    return gx < 1 ? 1 : gx;
+}
+
+size_t msg_bwd_weight_ws(const ConvP& p) {
+    return (size_t)wgrad_gridx(p) * 4 * ((size_t)p.Cout * GCG * GK + p.Cout) * sizeof(float);
+}
+
+const char* msg_bwd_weight_name(const ConvP&) { return "k_gconv_mfma_wgrad"; }
+
+int msg_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act,
+                          float* gw, float* gb, float beta, void* ws, size_t ws_bytes,
+                          hipStream_t s) {
+    if (!ws || ws_bytes < msg_bwd_weight_ws(p)) return MS_ERR_WORKSPACE;
+    const int gxn = wgrad_gridx(p);
+    const size_t stride = (size_t)p.Cout * GCG * GK + p.Cout;
+    float* partial = (float*)ws;
+    hipLaunchKernelGGL(k_gconv_mfma_wgrad, dim3(gxn, p.groups), dim3(256), 0, s, p, x, gy, y_act,
+                       partial, stride);
+    MS_CHECK_LAUNCH();
+    const size_t wsize = (size_t)p.Cout * GCG * GK;
+    const size_t total = wsize + p.Cout;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, partial,
+                       stride, gxn * 4, wsize, p.Cout, gw, gb, beta);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }
