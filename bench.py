@@ -158,11 +158,13 @@ def main():
     if rank == 0 and not args.no_roofline:
         # instrumented eager pass: HIP events around every C-ABI launch on the launch stream
         s, f = batches[0]
+        os.environ["MSYNTH_STREAMS"] = "0"      # serialise the discriminator scales: clean per-kernel times
         L.profile_begin()
         out_d = dt._fwd_bwd(s, f); d_optim.step()
         mark = len(L.PROFILE)
         out_g = gt._fwd_bwd(s, f); g_optim.step()
         rec = L.profile_end()
+        os.environ.pop("MSYNTH_STREAMS", None)
         del out_d, out_g
         agg = {}
         for name, cost, ms in rec:

@@ -9,6 +9,10 @@ derivative into the kernels' operand loaders (y_act), the skip/feature-gradient 
 backward-data epilogues (gx_add) and the cross-scale weight-grad sums into the weight-grad
 epilogue (accumulate), so no stand-alone elementwise pass remains.
 """
+import os
+
+import torch
+
 from . import lib as L
 from . import prims as P
 
@@ -179,32 +183,104 @@ def disc_backward(tape, params, g_feats, g_judge, sink, need_gx=True, need_wgrad
     return g
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device, n):
+    key = (device.index, n)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _SIDE_STREAMS[key]
+
+
+def _concurrent_scales():
+    return os.environ.get("MSYNTH_STREAMS", "1") != "0"
+
+
 def melgan_forward(x, params, scales=2):
-    """MelGanDiscriminator: the shared discriminator on x, pool(x), pool(pool(x))."""
-    feats, judges, tapes, xs = [], [], [], []
-    h = x
-    for s in range(scales + 1):
-        if s > 0:
-            h = P.avg_pool_fwd(h)
-        xs.append(h)
-        f, j, tape = disc_forward(h, params)
-        feats.append(f); judges.append(j); tapes.append(tape)
+    """MelGanDiscriminator: the shared discriminator on x, pool(x), pool(pool(x)).
+
+    The three scale passes are independent; the pooled scales are tiny (their 1024-channel layers
+    run at L = 17 / 9 and cannot fill 256 CUs on their own), so they are issued on side HIP
+    streams forked from / joined to the caller's stream -- under hipGraph capture they become
+    parallel branches of the graph."""
+    xs = [x]
+    for s in range(scales):
+        xs.append(P.avg_pool_fwd(xs[-1]))
+    res = [None] * (scales + 1)
+    if scales > 0 and _concurrent_scales():
+        main = torch.cuda.current_stream(x.device)
+        side = _side_streams(x.device, scales)
+        for s in range(1, scales + 1):
+            st = side[s - 1]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                res[s] = disc_forward(xs[s], params)
+        res[0] = disc_forward(xs[0], params)
+        for st in side:
+            main.wait_stream(st)
+    else:
+        for s in range(scales + 1):
+            res[s] = disc_forward(xs[s], params)
+    feats = [r[0] for r in res]
+    judges = [r[1] for r in res]
+    tapes = [r[2] for r in res]
     return feats, judges, (tapes, xs)
+
+
+def _scale_has_grad(g_feats, g_judges, s):
+    gf = None if g_feats is None else g_feats[s]
+    gj = None if g_judges is None else g_judges[s]
+    return gj is not None or (gf is not None and any(t is not None for t in gf)), gf, gj
 
 
 def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, need_wgrad=True):
     tapes, xs = ctx
+    n = len(tapes)
     sink = sink if sink is not None else GradSink(D_NPARAMS)
+    gxs = [None] * n
+    if n > 1 and _concurrent_scales():
+        dev = xs[0].device
+        main = torch.cuda.current_stream(dev)
+        side = _side_streams(dev, n - 1)
+        tmp = [None] * n
+        for s in range(1, n):
+            has, gf, gj = _scale_has_grad(g_feats, g_judges, s)
+            if not has:
+                continue
+            st = side[s - 1]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                tmp[s] = GradSink(D_NPARAMS)          # own slabs: no cross-stream accumulation
+                gxs[s] = disc_backward(tapes[s], params, gf, gj, tmp[s], need_gx=need_gx,
+                                       need_wgrad=need_wgrad)
+        has, gf, gj = _scale_has_grad(g_feats, g_judges, 0)
+        if has:
+            gxs[0] = disc_backward(tapes[0], params, gf, gj, sink, need_gx=need_gx,
+                                   need_wgrad=need_wgrad)
+        for st in side:
+            main.wait_stream(st)
+        for s in range(1, n):                          # fold the side-stream weight grads in
+            if tmp[s] is None:
+                continue
+            for i in range(D_NPARAMS):
+                if tmp[s].t[i] is None:
+                    continue
+                if sink.t[i] is None:
+                    sink.t[i] = tmp[s].t[i]
+                else:
+                    P.add_(sink.t[i], tmp[s].t[i])
+                sink.acc[i] = True
+    else:
+        for s in range(n - 1, -1, -1):
+            has, gf, gj = _scale_has_grad(g_feats, g_judges, s)
+            if has:
+                gxs[s] = disc_backward(tapes[s], params, gf, gj, sink, need_gx=need_gx,
+                                       need_wgrad=need_wgrad)
     gx_next = None
-    for s in range(len(tapes) - 1, -1, -1):
-        gf = None if g_feats is None else g_feats[s]
-        gj = None if g_judges is None else g_judges[s]
-        has_any = gj is not None or (gf is not None and any(t is not None for t in gf))
-        gx = None
-        if has_any:
-            gx = disc_backward(tapes[s], params, gf, gj, sink, need_gx=need_gx or s > 0,
-                               need_wgrad=need_wgrad)
-        if gx_next is not None and (need_gx or s > 0):
+    for s in range(n - 1, -1, -1):
+        gx = gxs[s]
+        if gx_next is not None and need_gx:
             gx = P.avg_pool_bwd(gx_next, xs[s].shape, gx_add=gx)
         gx_next = gx
-    return gx_next, sink
+    return (gx_next if need_gx else None), sink

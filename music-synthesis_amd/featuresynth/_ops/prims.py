@@ -179,6 +179,15 @@ def add(a, b):
     return out
 
 
+def add_(a, b):
+    """a += b (in place)."""
+    L.require(a, "add_ lhs"); L.require(b, "add_ rhs")
+    if a.shape != b.shape:
+        raise RuntimeError("add_: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+    L.call("ms_add", _scost(a.numel(), 2, 1), a.data_ptr(), b.data_ptr(), a.data_ptr(), a.numel(), L.stream())
+    return a
+
+
 def _reduce(fn_name, a, b, out=None):
     lib = L.load()
     n = a.numel()
