@@ -186,11 +186,23 @@ def disc_backward(tape, params, g_feats, g_judge, sink, need_gx=True, need_wgrad
 _SIDE_STREAMS = {}
 
 
+def aux_stream(device):
+    """Side stream for work that is independent of the caller's stream (the G-step's real pass)."""
+    key = (device.index, "aux")
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 def _side_streams(device, n):
     key = (device.index, n)
-    if key not in _SIDE_STREAMS:
+    if key not in _SIDE_STREAMS:   # created on the first (eager) call, never during graph capture
         _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
     return _SIDE_STREAMS[key]
+
+
+def _on_aux(device):
+    return torch.cuda.current_stream(device) == aux_stream(device)
 
 
 def _concurrent_scales():
@@ -208,7 +220,7 @@ def melgan_forward(x, params, scales=2):
     for s in range(scales):
         xs.append(P.avg_pool_fwd(xs[-1]))
     res = [None] * (scales + 1)
-    if scales > 0 and _concurrent_scales():
+    if scales > 0 and _concurrent_scales() and not _on_aux(x.device):   # forks are kept one level deep
         main = torch.cuda.current_stream(x.device)
         side = _side_streams(x.device, scales)
         for s in range(1, scales + 1):
@@ -239,7 +251,7 @@ def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, nee
     n = len(tapes)
     sink = sink if sink is not None else GradSink(D_NPARAMS)
     gxs = [None] * n
-    if n > 1 and _concurrent_scales():
+    if n > 1 and _concurrent_scales() and not _on_aux(xs[0].device):
         dev = xs[0].device
         main = torch.cuda.current_stream(dev)
         side = _side_streams(dev, n - 1)

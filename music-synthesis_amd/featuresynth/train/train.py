@@ -19,6 +19,7 @@ from datetime import datetime
 import torch
 
 from .. import _dist
+from .._ops import graph as _graph
 from ..loss import hinge_discriminator_loss, hinge_generator_loss
 from ..optim import FlatAdam
 from ..util.modules import zero_grad
@@ -142,10 +143,16 @@ class GeneratorTrainer(_TrainerBase):
         for p in d_params:          # discriminator weight grads are never used by a G-step
             p.requires_grad_(False)
         try:
+            # the real path neither depends on the generator nor needs gradients: it runs on a
+            # forked stream (a parallel branch of the captured graph) beside G and D(fake)
+            main = torch.cuda.current_stream(samples.device)
+            side = _graph.aux_stream(samples.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad():
+                r_features, r_score = self.discriminator(samples, features)
             fake = self.generator(features)
             f_features, f_score = self.discriminator(fake, features)
-            with torch.no_grad():   # the real path does not depend on the generator
-                r_features, r_score = self.discriminator(samples, features)
+            main.wait_stream(side)
             loss = self.loss(r_features, f_features, r_score, f_score, gan_loss=self.sub_loss)
             loss.backward()
         finally:
@@ -184,8 +191,13 @@ class DiscriminatorTrainer(_TrainerBase):
         zero_grad(self.g_optim, self.d_optim)
         with torch.no_grad():       # generator grads of a D-step are discarded by the reference
             fake = self.generator(features)
-        _, f_score = self.discriminator(fake, features)
-        _, r_score = self.discriminator(samples, features)
+        # one discriminator pass over [fake; real]: samples are independent (no batch coupling),
+        # so the judgements are the same and the shared weights' gradients are summed in-kernel
+        B = fake.shape[0]
+        both = torch.cat([fake, samples], 0)
+        _, scores = self.discriminator(both, features)
+        f_score = [j[:B] for j in scores]
+        r_score = [j[B:] for j in scores]
         loss = self.loss(r_score, f_score, gan_loss=self.sub_loss)
         loss.backward()
         return {"loss": loss.detach()}

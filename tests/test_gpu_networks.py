@@ -186,11 +186,19 @@ def test_reference_order_path_matches_native(monkeypatch):
         results[mode] = (r1["d_loss"], r2["g_loss"], {k: host(v) for k, v in g.state_dict().items()},
                          {k: host(v) for k, v in d.state_dict().items()})
     a, b = results["native"], results["generic"]
-    assert abs(a[0] - b[0]) < 1e-6 and abs(a[1] - b[1]) < 1e-6 * max(1.0, abs(b[1]))
+    # the D-step runs on identical parameters: same loss.  The native path sums the shared
+    # discriminator's weight grads in a different order (one pass over [fake; real]); after the Adam
+    # update, rounding-level gradient entries may step the other way (DESIGN.md "Adam sensitivity"),
+    # so post-update quantities are compared at the +-lr level.
+    assert abs(a[0] - b[0]) < 1e-6
+    assert abs(a[1] - b[1]) < 1e-2 * abs(b[1])
     for k in a[2]:
-        assert np.abs(a[2][k] - b[2][k]).max() < 1e-6, k
+        assert np.abs(a[2][k] - b[2][k]).max() <= 2.1e-4, k
     for k in a[3]:
-        assert np.abs(a[3][k] - b[3][k]).max() < 1e-6, k
+        d = np.abs(a[3][k] - b[3][k])
+        assert d.max() <= 2.1e-4, k
+        if k.endswith("weight"):
+            assert rel_l2(a[3][k], b[3][k]) < 5e-3, k
 
 
 def test_hipgraph_replay_matches_eager(monkeypatch):
