@@ -123,16 +123,26 @@ __global__ __launch_bounds__(256) void k_conv1d_fwd_cred(ConvP p, const float* _
     const int g = co / p.Og;
     const int cper = (p.Cg + 7) / 8;
     const int c_lo = part * cper, c_hi = min(p.Cg, c_lo + cper);
+    const float* xb = x + ((size_t)b * p.Cin + (size_t)g * p.Cg) * p.Lin;
+    const float* wb = w + (size_t)co * p.Cg * p.K;
     float acc = 0.f;
-    if (t < p.Lout) {
-        for (int c = c_lo; c < c_hi; ++c) {
-            const float* xr = x + ((size_t)b * p.Cin + (size_t)g * p.Cg + c) * p.Lin;
-            const float* wr = w + ((size_t)co * p.Cg + c) * p.K;
-            for (int k = 0; k < p.K; ++k) {
-                const int s = ms_src_index(t * p.stride + k * p.dil - p.pad, p.Lin, p.pad_mode);
-                if (s >= 0) acc = fmaf(wr[k], xr[s], acc);
-            }
+    // branch-free taps: clamped address + mask, 4 channels in flight per iteration
+    for (int k = 0; k < p.K; ++k) {
+        const int sidx = ms_src_index(t * p.stride + k * p.dil - p.pad, p.Lin, p.pad_mode);
+        const bool ok = t < p.Lout && sidx >= 0;
+        const int so = ok ? sidx : 0;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int c = c_lo;
+        for (; c + 3 < c_hi; c += 4) {
+            const float x0 = xb[(size_t)(c + 0) * p.Lin + so], x1 = xb[(size_t)(c + 1) * p.Lin + so];
+            const float x2 = xb[(size_t)(c + 2) * p.Lin + so], x3 = xb[(size_t)(c + 3) * p.Lin + so];
+            a0 = fmaf(wb[(c + 0) * p.K + k], x0, a0);
+            a1 = fmaf(wb[(c + 1) * p.K + k], x1, a1);
+            a2 = fmaf(wb[(c + 2) * p.K + k], x2, a2);
+            a3 = fmaf(wb[(c + 3) * p.K + k], x3, a3);
         }
+        for (; c < c_hi; ++c) a0 = fmaf(wb[c * p.K + k], xb[(size_t)c * p.Lin + so], a0);
+        if (ok) acc += (a0 + a1) + (a2 + a3);
     }
     red[part][tl] = acc;
     __syncthreads();

@@ -1047,7 +1047,7 @@ const char* row_kname(RowCfg c, int K, bool act) {
     static thread_local char buf[96];
     const char* tile = c == ROW_128x128 ? "2, 2, 2, 2" : (c == ROW_64x128 ? "2, 2, 1, 2" :
                        (c == ROW_64x64 ? "2, 2, 1, 1" : "1, 4, 1, 2"));
-    snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, %d, %d, %s>", tile, K, row_cc(K), act ? "true" : "false");
+    snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, %d, %d, %s, 0, 1>", tile, K, row_cc(K), act ? "true" : "false");
     return buf;
 }
 
@@ -1119,7 +1119,7 @@ const char* msm_convt_fwd_name(const ConvP& p) {
     const RowCfg c = pick_row_cfg(p.Cin * p.stride, p.B, p.Lout);
     const char* tile = c == ROW_128x128 ? "2, 2, 2, 2" : (c == ROW_64x128 ? "2, 2, 1, 2" :
                        (c == ROW_64x64 ? "2, 2, 1, 1" : "1, 4, 1, 2"));
-    snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, 3, 8, false, %d>", tile, p.stride);
+    snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, 3, 8, false, %d, 1>", tile, p.stride);
     return buf;
 }
 
