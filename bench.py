@@ -200,6 +200,18 @@ def main():
                     "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["traffic"] = None
+        # HBM bytes per launch of that kernel from the TCC counters (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate passes, gfx950 x2 fetch correction: tools/pmc_traffic.sh), collected
+        # on this same workload and committed under profiles/
+        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc_file):
+            with open(pmc_file) as fh:
+                pmc = json.load(fh)
+            for name, rec_ in pmc.items():
+                if (k + "(") in name:
+                    roof["traffic"] = rec_["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/r01_pmc_traffic.json (%d dispatches)" % rec_["dispatches"]
+                    break
         roof.update({"kernel": k, "launches_per_DG_pair": a["n"], "avg_launch_us": avg_s * 1e6,
                      "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
                      "share_of_kernel_time": a["ms"] / tot_ms})

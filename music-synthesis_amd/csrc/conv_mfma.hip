@@ -936,8 +936,9 @@ WgradPlan plan_wgrad(const ConvP& p) {
     WgradPlan q;
     const int NG = p.Cin * p.K;
     const int t128 = ms_ceil_div(p.Cout, 128) * ms_ceil_div(NG, 128);
+    (void)t128;
     if (p.Cout <= 32) q.cfg = NG <= 128 ? CFG_32x128 : CFG_32x256;
-    else if (p.Cout >= 128 && NG >= 128 && t128 >= 192) q.cfg = CFG_128x128;   // enough tiles without split-K
+    else if (p.Cout >= 128 && NG >= 128) q.cfg = CFG_128x128;   // 4 MFMAs per 4 LDS fragment reads
     else q.cfg = CFG_64x64;
     cfg_tile(q.cfg, &q.bm, &q.bn);
     const int tiles = ms_ceil_div(p.Cout, q.bm) * ms_ceil_div(NG, q.bn);
@@ -948,7 +949,7 @@ WgradPlan plan_wgrad(const ConvP& p) {
     int ns = ms_ceil_div(512, tiles);
     const int max_by_work = nchunks / 16 > 0 ? nchunks / 16 : 1;
     if (ns > max_by_work) ns = max_by_work;
-    const size_t cap = (size_t)12 << 20;
+    const size_t cap = (size_t)24 << 20;
     const size_t max_by_bytes = cap / (q.stride_floats * 4);
     if ((size_t)ns > max_by_bytes) ns = max_by_bytes > 0 ? (int)max_by_bytes : 1;
     if (ns < 1) ns = 1;
@@ -1001,10 +1002,13 @@ bool make_rowp(RowP* q, RowCfg cfg, int B, int CK, int L, int M, int K, int dil,
     return q->RSZ <= 512;
 }
 
-template <int K, bool HAS_ACT, int EPI_S = 0, int IN_S = 1>
+// deep contractions (>= 128 input channels) stage two channel chunks per barrier pair
+bool row_deep(int K, int CK) { return K != 7 && CK >= 128 && CK % (2 * row_cc(K)) == 0; }
+
+template <int K, bool HAS_ACT, int EPI_S = 0, int IN_S = 1, int CCMUL = 1>
 int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, const float* W,
                   const float* bias, const float* res, float* Y, float* Yact, hipStream_t s) {
-    constexpr int CC = row_cc(K);
+    constexpr int CC = row_cc(K) * CCMUL;
     int bm, bn;
     row_tile(cfg, &bm, &bn);
     const unsigned gx = p.R == 1 ? (unsigned)(p.B * p.tiles_per_row) : (unsigned)((p.B + p.R - 1) / p.R);
@@ -1031,23 +1035,29 @@ int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, 
 
 int launch_rows(int K, RowCfg cfg, const RowP& p, const float* X, const float* Xact, const float* W,
                 const float* bias, const float* res, float* Y, float* Yact, hipStream_t s) {
+    const bool deep = row_deep(K, p.CK);
+#define MS_ROWS(KK, ACT)                                                                              \
+    (deep ? launch_rows_k<KK, ACT, 0, 1, 2>(cfg, p, X, Xact, W, bias, res, Y, Yact, s)                \
+          : launch_rows_k<KK, ACT, 0, 1, 1>(cfg, p, X, Xact, W, bias, res, Y, Yact, s))
     if (Xact) {
-        if (K == 3) return launch_rows_k<3, true>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
-        if (K == 5) return launch_rows_k<5, true>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
+        if (K == 3) return MS_ROWS(3, true);
+        if (K == 5) return MS_ROWS(5, true);
         if (K == 7) return launch_rows_k<7, true>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
     } else {
-        if (K == 3) return launch_rows_k<3, false>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
-        if (K == 5) return launch_rows_k<5, false>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
+        if (K == 3) return MS_ROWS(3, false);
+        if (K == 5) return MS_ROWS(5, false);
         if (K == 7) return launch_rows_k<7, false>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
     }
+#undef MS_ROWS
     return MS_ERR_UNSUPPORTED;
 }
 
-const char* row_kname(RowCfg c, int K, bool act) {
+const char* row_kname(RowCfg c, int K, bool act, int CK) {
     static thread_local char buf[96];
     const char* tile = c == ROW_128x128 ? "2, 2, 2, 2" : (c == ROW_64x128 ? "2, 2, 1, 2" :
                        (c == ROW_64x64 ? "2, 2, 1, 1" : "1, 4, 1, 2"));
-    snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, %d, %d, %s, 0, 1>", tile, K, row_cc(K), act ? "true" : "false");
+    snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, %d, %d, %s, 0, 1>", tile, K,
+             row_cc(K) * (row_deep(K, CK) ? 2 : 1), act ? "true" : "false");
     return buf;
 }
 
@@ -1103,11 +1113,11 @@ size_t msm_convt_fwd_ws(const ConvP& p) {
 }
 
 const char* msm_fwd_name(const ConvP& p) {
-    if (rows_ok(p, false)) return row_kname(pick_row_cfg(p.Cout, p.B, p.Lin), p.K, false);
+    if (rows_ok(p, false)) return row_kname(pick_row_cfg(p.Cout, p.B, p.Lin), p.K, false, p.Cin);
     return kname("k_igemm_conv", pick_cfg(p.Cout, (long long)p.B * p.Lin), p.K, ", false");
 }
 const char* msm_bwd_data_name(const ConvP& p) {
-    if (rows_ok(p, true)) return row_kname(pick_row_cfg(p.Cin, p.B, p.Lin), p.K, p.act != MS_ACT_NONE);
+    if (rows_ok(p, true)) return row_kname(pick_row_cfg(p.Cin, p.B, p.Lin), p.K, p.act != MS_ACT_NONE, p.Cout);
     return kname("k_igemm_conv", pick_cfg(p.Cin, (long long)p.B * p.Lin), p.K, ", true");
 }
 const char* msm_bwd_weight_name(const ConvP& p) {
