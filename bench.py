@@ -185,7 +185,7 @@ def main():
             g_ = by_geom.setdefault(kk, [0.0, 0, 0.0])
             g_[0] += ms; g_[1] += 1; g_[2] += cost.get("flops", 0)
         log("[bench] per-layer (kernel, C-ABI entry, (B,Cin,Lin,Cout,K,stride,dil,groups)):")
-        for kk, g_ in sorted(by_geom.items(), key=lambda kv: -kv[1][0])[:45]:
+        for kk, g_ in sorted(by_geom.items(), key=lambda kv: -kv[1][0])[:200]:
             log("    %-40s %-22s %-44s x%-3d %7.3f ms %7.2f TF/s" % (
                 kk[0], kk[1], str(kk[2]), g_[1], g_[0], g_[2] / g_[0] / 1e9 if g_[0] else 0))
         k, a = top[0]

@@ -203,7 +203,14 @@ int ms_convt1d_bwd_weight(const ms_convt1d_desc* d, const float* x, const float*
         rc = msk_conv1d_bwd_weight_direct(p, gy, y_act, p.act, x, nullptr, 0, gw, nullptr, beta,
                                           workspace, workspace_bytes, s);
     if (rc != MS_OK) return rc;
-    if (gb) return msk_channel_sum(gy, y_act, p.act, p.slope, p.B, p.Cin, p.Lin, gb, beta, s);
+    if (gb) {   // bias grad: the slice partials live at the tail of the workspace
+        const size_t tail = msk_channel_sum_ws(p.Cin);
+        if (!workspace || workspace_bytes < tail) return MS_ERR_WORKSPACE;
+        char* wtail = (char*)workspace + (workspace_bytes - tail);
+        wtail -= ((uintptr_t)wtail) & 15;
+        if (wtail < (char*)workspace) return MS_ERR_WORKSPACE;
+        return msk_channel_sum(gy, y_act, p.act, p.slope, p.B, p.Cin, p.Lin, gb, beta, wtail, tail, s);
+    }
     return MS_OK;
 }
 
@@ -218,8 +225,9 @@ size_t ms_convt1d_workspace_bytes(const ms_convt1d_desc* d, int which) {
         return msm_fwd_applicable(q) ? msm_fwd_ws(q) : 0;
     }
     if (which == 2) {
-        if (msm_convt_bwd_applicable(p)) return msm_convt_bwd_weight_ws(p);
-        return msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p);
+        const size_t tail = msk_channel_sum_ws(p.Cin) + 32;   // bias-grad slice partials
+        if (msm_convt_bwd_applicable(p)) return msm_convt_bwd_weight_ws(p) + tail;
+        return (msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p)) + tail;
     }
     return 0;
 }

@@ -367,24 +367,34 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict
     }
 }
 
-// out[c] = beta*out[c] + sum_{b,t} g[b,c,t] * act'(y_act[b,c,t])
-__global__ __launch_bounds__(256) void k_channel_sum(const float* __restrict__ gsrc,
-                                                    const float* __restrict__ y_act, int act,
-                                                    float slope, int B, int C, int L,
-                                                    float* __restrict__ out, float beta) {
+// out[c] = beta*out[c] + sum_{b,t} g[b,c,t] * act'(y_act[b,c,t]); one workgroup per (channel, batch
+// slice) writes a partial, the last stage folds the slices in a fixed order (deterministic)
+constexpr int kChanSlices = 32;
+
+__global__ __launch_bounds__(256) void k_channel_sum_partial(const float* __restrict__ gsrc,
+                                                            const float* __restrict__ y_act,
+                                                            int act, float slope, int B, int C,
+                                                            int L, float* __restrict__ partial) {
     __shared__ float red[4];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, sl = blockIdx.y;
+    const float* ya = y_act ? y_act : gsrc;
+    const int kind = y_act ? act : MS_ACT_NONE;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) {
+    for (int b = sl; b < B; b += kChanSlices) {
         const size_t base = ((size_t)b * C + c) * L;
-        for (int t = threadIdx.x; t < L; t += 256) {
-            float v = gsrc[base + t];
-            if (y_act) v = ms_act_grad(v, y_act[base + t], act, slope);
-            s += v;
-        }
+        for (int t = threadIdx.x; t < L; t += 256) s += ms_act_grad(gsrc[base + t], ya[base + t], kind, slope);
     }
     const float tot = ms_block_sum(s, red);
-    if (threadIdx.x == 0) out[c] = (beta != 0.f ? beta * out[c] : 0.f) + tot;
+    if (threadIdx.x == 0) partial[(size_t)sl * C + c] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_channel_sum_final(const float* __restrict__ partial, int C,
+                                                          float* __restrict__ out, float beta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int i = 0; i < kChanSlices; ++i) s += partial[(size_t)i * C + c];
+    out[c] = (beta != 0.f ? beta * out[c] : 0.f) + s;
 }
 
 template <int CT>
@@ -549,10 +559,16 @@ int msk_conv1d_bwd_weight_direct(const ConvP& p, const float* x, const float* x_
     return MS_OK;
 }
 
+size_t msk_channel_sum_ws(int C) { return (size_t)kChanSlices * C * sizeof(float); }
+
 int msk_channel_sum(const float* g, const float* y_act, int act, float slope, int B, int C, int L,
-                    float* out, float beta, hipStream_t s) {
-    hipLaunchKernelGGL(k_channel_sum, dim3(C), dim3(256), 0, s, g, y_act, act, slope, B, C, L, out,
-                       beta);
+                    float* out, float beta, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!ws || ws_bytes < msk_channel_sum_ws(C)) return MS_ERR_WORKSPACE;
+    float* partial = (float*)ws;
+    hipLaunchKernelGGL(k_channel_sum_partial, dim3(C, kChanSlices), dim3(256), 0, s, g, y_act, act,
+                       slope, B, C, L, partial);
+    MS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_channel_sum_final, dim3((C + 255) / 256), dim3(256), 0, s, partial, C, out, beta);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }

@@ -973,7 +973,7 @@ bool rows_applicable(int M, int CK, int K, int L) {
 
 RowCfg pick_row_cfg(int M, int B, int L) {
     if (M <= 32) return ROW_32x256;
-    if (L < 128) return ROW_64x64;
+    if (L < 128) return (M >= 512 && (long long)B * L >= 512) ? ROW_64x128 : ROW_64x64;   // short rows: R = 128 / L rows per tile
     const long long N = (long long)B * L;
     if (M >= 128 && (N / 128) * (M / 128) >= 384) return ROW_128x128;
     return ROW_64x128;

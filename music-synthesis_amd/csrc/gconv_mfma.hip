@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_fwd(ConvP p, const float* __
                                                        const float* __restrict__ bias,
                                                        float* __restrict__ y) {
     __shared__ float xs[GCG * GS * PSP];
+    __shared__ float ws[16 * GCG * GK];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = blockIdx.y, b = blockIdx.z;
     const int T0 = blockIdx.x * WTT;                 // first output of this workgroup
@@ -41,19 +42,22 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_fwd(ConvP p, const float* __
         xs[ci * (GS * PSP) + (u & (GS - 1)) * PSP + (u >> 2)] = ok ? v : 0.f;
     }
 
+    // the group's weights (Og*4*41 contiguous floats) go through LDS: one coalesced read per
+    // workgroup instead of 41 row-strided loads per lane
+    for (int idx = tid; idx < p.Og * GCG * GK; idx += 256) ws[idx] = w[(size_t)g * p.Og * GCG * GK + idx];
+    __syncthreads();
     // weight fragments: lane (m = lane&15, ci = lane>>4) holds w[g*Og+m][ci][j] for every tap j
     const int m = lane & 15, ci = lane >> 4;
     float a[GK];
     {
         const bool ok = m < p.Og;
-        const float* wr = w + ((size_t)(g * p.Og + (ok ? m : 0)) * GCG + ci) * GK;
+        const float* wr = ws + ((ok ? m : 0) * GCG + ci) * GK;   // lane stride 41: conflict-free
 #pragma unroll
         for (int j = 0; j < GK; ++j) {
             const float v = wr[j];
             a[j] = ok ? v : 0.f;
         }
     }
-    __syncthreads();
 
     const float* xb = xs + ci * (GS * PSP) + wid * TT + (lane & 15);
 #pragma unroll
@@ -99,6 +103,7 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_bwd_data(ConvP p, const floa
                                                             const float* __restrict__ gx_add,
                                                             float* __restrict__ gx) {
     __shared__ float gs[OQ * 4 * GRS];
+    __shared__ float ws[OQ * 4 * GCG * GK];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = blockIdx.y, b = blockIdx.z;
     const int Q0 = blockIdx.x * WQ;
@@ -115,6 +120,8 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_bwd_data(ConvP p, const floa
         const float v = gy[off], a = ya[off];
         gs[co * GRS + tt] = ok ? ms_act_grad(v, a, kind, p.slope) : 0.f;
     }
+    for (int idx = tid; idx < OQ * 4 * GCG * GK; idx += 256) ws[idx] = w[(size_t)g * p.Og * GCG * GK + idx];
+    __syncthreads();
     // weight fragments: lane (m = (ci, r) = lane&15, k = lane>>4): w[g*Og + 4cq + k][ci][r + 4jj]
     const int mrow = lane & 15, ci = mrow >> 2, r = mrow & 3, kq = lane >> 4;
     float a[OQ * JJ];
@@ -124,10 +131,9 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_bwd_data(ConvP p, const floa
         for (int jj = 0; jj < JJ; ++jj) {
             const int k = r + 4 * jj;
             const bool ok = k < GK;
-            const float v = w[((size_t)(g * p.Og + cq * 4 + kq) * GCG + ci) * GK + (ok ? k : 0)];
+            const float v = ws[((cq * 4 + kq) * GCG + ci) * GK + (ok ? k : 0)];
             a[cq * JJ + jj] = ok ? v : 0.f;
         }
-    __syncthreads();
 
 #pragma unroll
     for (int tq = 0; tq < TQ / 16; ++tq) {

@@ -83,5 +83,6 @@ int msk_conv1d_bwd_weight_direct(const ConvP& p, const float* x, const float* x_
 const char* msk_conv1d_fwd_direct_name(const ConvP& p);
 const char* msk_conv1d_bwd_data_direct_name(const ConvP& p);
 const char* msk_conv1d_bwd_weight_direct_name(const ConvP& p);
+size_t msk_channel_sum_ws(int C);
 int msk_channel_sum(const float* g, const float* y_act, int act, float slope, int B, int C, int L,
-                    float* out, float beta, hipStream_t s);
+                    float* out, float beta, void* ws, size_t ws_bytes, hipStream_t s);

@@ -1,0 +1,99 @@
+"""Data-parallel trainer path on the GPU box: two ranks share cuda:0 (gloo backend, which stages
+device tensors through the host; RCCL refuses two ranks on one GPU).  Exercises exactly what
+bench.py --gpus N runs: [hipGraph fwd+bwd] -> all-reduce of the flat gradient bucket -> [hipGraph
+fused Adam with grad_scale = 1/world], and checks it against one process on the global batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _nets():
+    import featuresynth as fs
+    from featuresynth._synthetic import module_param_shapes, synthetic_state_dict
+    g, d = fs.MelGanGenerator(32, 80), fs.MelGanDiscriminator()
+    g.load_state_dict({k: torch.from_numpy(v) for k, v in
+                       synthetic_state_dict(module_param_shapes(g), seed=7, bias_scale=0.02).items()})
+    d.load_state_dict({k: torch.from_numpy(v) for k, v in
+                       synthetic_state_dict(module_param_shapes(d), seed=8, bias_scale=0.02).items()})
+    return g.cuda(), d.cuda()
+
+
+def _run_steps(samples, feats, ncalls):
+    import featuresynth as fs
+    from featuresynth import loss as LS
+    from featuresynth.train import DiscriminatorTrainer, GeneratorTrainer
+    g, d = _nets()
+    go = fs.FlatAdam(g.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    do = fs.FlatAdam(d.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    dt = DiscriminatorTrainer(g, go, d, do, LS.mel_gan_disc_loss)
+    gt = GeneratorTrainer(g, go, d, do, LS.mel_gan_gen_loss)
+    s, f = torch.from_numpy(samples).cuda(), torch.from_numpy(feats).cuda()
+    losses = []
+    for i in range(ncalls):                     # same batch every call: calls 3+ replay the graphs
+        losses.append(dt.train(s, f)["d_loss"] if i % 2 == 0 else gt.train(s, f)["g_loss"])
+    sd = {k: v.detach().cpu().numpy() for k, v in list(g.state_dict().items()) + list(d.state_dict().items())}
+    return losses, sd, (dt, gt)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "music-synthesis_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.cuda.set_device(0)
+    from featuresynth import _dist
+    from featuresynth._synthetic import synthetic_features, synthetic_samples
+    _dist.init_from_env("gloo")
+    B, T = 2, 4
+    losses, sd, (dt, gt) = _run_steps(synthetic_samples(B, T * 256, rank=rank),
+                                      synthetic_features(B, 80, T, rank=rank), 6)
+    assert dt._tail is not None and gt._tail is not None, "distributed two-graph path not taken"
+    assert dt._runner.graphs and dt._tail.graphs, "graphs not captured under data parallelism"
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=np.array(losses), **sd)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_match_global_batch(tmp_path):
+    import torch.multiprocessing as mp
+    from conftest import rel_l2
+    from featuresynth._synthetic import synthetic_features, synthetic_samples
+    world, B, T = 2, 2, 4
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(str(tmp_path / "rank0.npz")), np.load(str(tmp_path / "rank1.npz"))
+    # replicas stay in lock-step
+    for k in r0.files:
+        if k != "losses":
+            assert np.array_equal(r0[k], r1[k]), k
+    # one process on the concatenated batch: first D-step and G-step run on identical parameters
+    samples = np.concatenate([synthetic_samples(B, T * 256, rank=r) for r in range(world)])
+    feats = np.concatenate([synthetic_features(B, 80, T, rank=r) for r in range(world)])
+    losses, sd, _ = _run_steps(samples, feats, 6)
+    mean_losses = 0.5 * (r0["losses"] + r1["losses"])
+    assert abs(mean_losses[0] - losses[0]) <= 1e-5 * abs(losses[0])          # d_loss, same params
+    for i, (a, b) in enumerate(zip(mean_losses[1:], losses[1:]), 1):
+        # after Adam updates (DESIGN.md "Adam sensitivity"): d_loss ~ 6 stays tight, g_loss is a
+        # small number near zero whose judge term moves at the +-lr scale
+        tol = 1e-4 * abs(b) if i % 2 == 0 else 1e-3
+        assert abs(a - b) <= tol, (i, mean_losses, losses)
+    for k, v in sd.items():
+        d = np.abs(r0[k] - v)
+        assert d.max() <= 3 * 2.1e-4, (k, d.max())                           # 3 updates per net, +-lr each
+        if k.endswith("weight"):
+            assert rel_l2(r0[k], v) < 1e-2, k
