@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void k_igemm_conv(IgP p, const float* __restri
         }
     }
 
-    // epilogue: D[row][col]: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // epilogue: D[row][col]: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); bias and
+    // residual loads of a tile are batched ahead of its stores (no loads under per-element branches)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * TN * 32 + j * 32 + (lane & 31);
@@ -177,21 +178,36 @@ __global__ __launch_bounds__(256) void k_igemm_conv(IgP p, const float* __restri
         const int b = n / p.L, t = n - b * p.L;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * TM * 32 + i * 32 + 4 * (lane >> 5);
+            const size_t obase = ((size_t)b * p.M + mb) * p.L + t;
+            float bv[16], rv[16];
+            bool ok[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= p.M) continue;
-                const size_t o = ((size_t)b * p.M + m) * p.L + t;
-                float v = acc[i][j][r] + (bias ? bias[m] : 0.f);
-                v = ms_apply_act(v, p.act, p.slope);
+                const int dm = (r & 3) + 8 * (r >> 2);
+                ok[r] = mb + dm < p.M;
+                bv[r] = bias ? bias[ok[r] ? mb + dm : 0] : 0.f;
+            }
+            if (res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dm = (r & 3) + 8 * (r >> 2);
+                    rv[r] = res[ok[r] ? obase + (size_t)dm * p.L : 0];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dm = (r & 3) + 8 * (r >> 2);
+                if (!ok[r]) continue;
+                const size_t o = obase + (size_t)dm * p.L;
+                float v = ms_apply_act(acc[i][j][r] + bv[r], p.act, p.slope);
                 if (Yact) Yact[o] = v;
-                if (res) v += res[o];
+                if (res) v += rv[r];
                 Y[o] = v;
             }
         }
     }
 }
-
 
 // ------------------------------------------------ forward / backward data, row-tile form
 // Same contraction as k_igemm_conv, but the activation tile is staged ONCE per channel chunk
@@ -363,20 +379,39 @@ __global__ __launch_bounds__(256) void k_conv_mfma_rows(RowP p, const float* __r
     }
 
     if (EPI_S == 0) {
+        // All loads of a 16-row accumulator tile (bias, residual) are issued as one batch from
+        // clamped addresses before any store: loads under per-element branches serialise into one
+        // memory round trip each (measured: 40 us of a 109 us launch).
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             if (!nvalid[j]) continue;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + wm * TM * 32 + i * 32 + 4 * h;
+                const size_t obase = ((size_t)ob[j] * p.M + mb) * p.L + ot[j];
+                float bv[16], rv[16];
+                bool ok[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (m >= p.M) continue;
-                    const size_t o = ((size_t)ob[j] * p.M + m) * p.L + ot[j];
-                    float v = acc[i][j][r] + (bias ? bias[m] : 0.f);
-                    v = ms_apply_act(v, p.act, p.slope);
+                    const int dm = (r & 3) + 8 * (r >> 2);
+                    ok[r] = mb + dm < p.M;
+                    bv[r] = bias ? bias[ok[r] ? mb + dm : 0] : 0.f;
+                }
+                if (res) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dm = (r & 3) + 8 * (r >> 2);
+                        rv[r] = res[ok[r] ? obase + (size_t)dm * p.L : 0];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dm = (r & 3) + 8 * (r >> 2);
+                    if (!ok[r]) continue;
+                    const size_t o = obase + (size_t)dm * p.L;
+                    float v = ms_apply_act(acc[i][j][r] + bv[r], p.act, p.slope);
                     if (Yact) Yact[o] = v;
-                    if (res) v += res[o];
+                    if (res) v += rv[r];
                     Y[o] = v;
                 }
             }
@@ -385,31 +420,40 @@ __global__ __launch_bounds__(256) void k_conv_mfma_rows(RowP p, const float* __r
         // transposed conv: GEMM row m' = co*S + r is output phase r of channel co; a lane's 4
         // consecutive accumulator rows are 4 consecutive output samples (S = 8) or 2 x 2 (S = 2),
         // written as one 16-byte / two 8-byte stores along contiguous audio frames
-        const int Cout = p.M / EPI_S;
-        const size_t Lo = (size_t)p.L * EPI_S;
+        constexpr int ES = EPI_S > 0 ? EPI_S : 1;     // (EPI_S == 0 never reaches this branch)
+        const int Cout = p.M / ES;
+        const size_t Lo = (size_t)p.L * ES;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             if (!nvalid[j]) continue;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                float bq[4][2];
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {   // bias loads batched ahead of the stores
+                    const int mb = m0 + wm * TM * 32 + i * 32 + 8 * rg + 4 * h;
+                    const int co = (mb < p.M ? mb : 0) / ES;
+                    bq[rg][0] = bias ? bias[co] : 0.f;
+                    bq[rg][1] = (bias && EPI_S < 4) ? bias[co + 1 < Cout ? co + 1 : co] : 0.f;
+                }
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     const int mb = m0 + wm * TM * 32 + i * 32 + 8 * rg + 4 * h;
                     if (mb >= p.M) continue;
                     if (EPI_S >= 4) {
-                        const int co = mb / EPI_S, ph = mb - co * EPI_S;
-                        const float bv = bias ? bias[co] : 0.f;
+                        const int co = mb / ES, ph = mb - co * ES;
+                        const float bv = bq[rg][0];
                         float4 v;
                         v.x = ms_apply_act(acc[i][j][4 * rg + 0] + bv, p.act, p.slope);
                         v.y = ms_apply_act(acc[i][j][4 * rg + 1] + bv, p.act, p.slope);
                         v.z = ms_apply_act(acc[i][j][4 * rg + 2] + bv, p.act, p.slope);
                         v.w = ms_apply_act(acc[i][j][4 * rg + 3] + bv, p.act, p.slope);
-                        *reinterpret_cast<float4*>(Y + ((size_t)ob[j] * Cout + co) * Lo + (size_t)ot[j] * EPI_S + ph) = v;
+                        *reinterpret_cast<float4*>(Y + ((size_t)ob[j] * Cout + co) * Lo + (size_t)ot[j] * ES + ph) = v;
                     } else {
                         const int co = mb / 2;
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
-                            const float bv = bias ? bias[co + u] : 0.f;
+                            const float bv = bq[rg][u];
                             float2 v;
                             v.x = ms_apply_act(acc[i][j][4 * rg + 2 * u + 0] + bv, p.act, p.slope);
                             v.y = ms_apply_act(acc[i][j][4 * rg + 2 * u + 1] + bv, p.act, p.slope);
