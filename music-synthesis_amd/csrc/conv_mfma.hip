@@ -18,6 +18,7 @@
 // in flight while the MFMAs of chunk c run.
 #include "conv_mfma.h"
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -1004,7 +1005,17 @@ WgradPlan plan_wgrad(const ConvP& p) {
 
 
 // ---- row-tile kernel dispatch
-enum RowCfg { ROW_128x128, ROW_64x128, ROW_64x64, ROW_32x256 };
+enum RowCfg { ROW_128x128, ROW_64x128, ROW_64x64, ROW_32x256, ROW_64x256 };
+
+const char* row_tile_str(RowCfg c) {
+    switch (c) {
+        case ROW_128x128: return "2, 2, 2, 2";
+        case ROW_64x128: return "2, 2, 1, 2";
+        case ROW_64x64: return "2, 2, 1, 1";
+        case ROW_64x256: return "1, 4, 2, 2";
+        default: return "1, 4, 1, 2";
+    }
+}
 
 constexpr int row_cc(int K) { return K == 7 ? 4 : 8; }
 
@@ -1028,6 +1039,7 @@ void row_tile(RowCfg c, int* bm, int* bn) {
         case ROW_128x128: *bm = 128; *bn = 128; break;
         case ROW_64x128: *bm = 64; *bn = 128; break;
         case ROW_64x64: *bm = 64; *bn = 64; break;
+        case ROW_64x256: *bm = 64; *bn = 256; break;
         default: *bm = 32; *bn = 256; break;
     }
 }
@@ -1069,6 +1081,9 @@ int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, 
         case ROW_64x64:
             hipLaunchKernelGGL((k_conv_mfma_rows<2, 2, 1, 1, K, CC, HAS_ACT, EPI_S, IN_S>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
             break;
+        case ROW_64x256:
+            hipLaunchKernelGGL((k_conv_mfma_rows<1, 4, 2, 2, K, CC, HAS_ACT, EPI_S, IN_S>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
+            break;
         default:
             hipLaunchKernelGGL((k_conv_mfma_rows<1, 4, 1, 2, K, CC, HAS_ACT, EPI_S, IN_S>), grid, dim3(256), lds, s, p, X, Xact, W, bias, res, Y, Yact);
             break;
@@ -1098,8 +1113,7 @@ int launch_rows(int K, RowCfg cfg, const RowP& p, const float* X, const float* X
 
 const char* row_kname(RowCfg c, int K, bool act, int CK) {
     static thread_local char buf[96];
-    const char* tile = c == ROW_128x128 ? "2, 2, 2, 2" : (c == ROW_64x128 ? "2, 2, 1, 2" :
-                       (c == ROW_64x64 ? "2, 2, 1, 1" : "1, 4, 1, 2"));
+    const char* tile = row_tile_str(c);
     snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, %d, %d, %s, 0, 1>", tile, K,
              row_cc(K) * (row_deep(K, CK) ? 2 : 1), act ? "true" : "false");
     return buf;
@@ -1171,8 +1185,7 @@ const char* msm_bwd_weight_name(const ConvP& p) {
 const char* msm_convt_fwd_name(const ConvP& p) {
     static thread_local char buf[96];
     const RowCfg c = pick_row_cfg(p.Cin * p.stride, p.B, p.Lout);
-    const char* tile = c == ROW_128x128 ? "2, 2, 2, 2" : (c == ROW_64x128 ? "2, 2, 1, 2" :
-                       (c == ROW_64x64 ? "2, 2, 1, 1" : "1, 4, 1, 2"));
+    const char* tile = row_tile_str(c);
     snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, 3, 8, false, %d, 1>", tile, p.stride);
     return buf;
 }
@@ -1298,8 +1311,7 @@ size_t msm_convt_bwd_data_ws(const ConvP& p) {
 const char* msm_convt_bwd_data_name(const ConvP& p) {
     static thread_local char buf[96];
     const RowCfg c = pick_row_cfg(p.Cout, p.B, p.Lout);
-    const char* tile = c == ROW_128x128 ? "2, 2, 2, 2" : (c == ROW_64x128 ? "2, 2, 1, 2" :
-                       (c == ROW_64x64 ? "2, 2, 1, 1" : "1, 4, 1, 2"));
+    const char* tile = row_tile_str(c);
     snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, 3, 8, true, 0, %d>", tile, p.stride);
     return buf;
 }
