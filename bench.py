@@ -225,6 +225,29 @@ def main():
             "algorithmic_mb_per_DG_pair": W.totals(launches)["bytes"] / 1e6,
             "kernel_ms_per_DG_pair_eager": tot_ms}
 
+    if rank == 0 and not args.no_roofline:
+        # BASELINE config 2: generator forward only, B=1, 80-bin mel x 32 frames -> 8192 samples
+        feat1 = torch.from_numpy(np.random.default_rng(1).standard_normal((1, args.mels, T)).astype(np.float32)).to(device)
+        with torch.no_grad():
+            for _ in range(5):
+                g(feat1)
+            torch.cuda.synchronize()
+            gg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gg):
+                y1 = g(feat1)
+            gg.replay(); torch.cuda.synchronize()
+            n_it = 200
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n_it):
+                gg.replay()
+            e1.record(); torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / n_it
+        result["generator_forward_b1"] = {"latency_us": us, "samples_per_s": WINDOW / (us * 1e-6),
+                                          "note": "BASELINE config 2 (hipGraph replay of the 30-layer forward)"}
+        log("[bench] generator forward B=1: %.1f us -> %.4g samples/s" % (us, WINDOW / (us * 1e-6)))
+        del gg, y1
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import torch_graph as TG
         cores = host_cpu_share()
