@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--mels", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--model", default="melgan", choices=["melgan", "realmelgan"],
+                    help="melgan = the north-star variant (headline); realmelgan = the weight-normed "
+                         "variant of experiment/realmelgan.py (SURVEY.md 8(f) row 1, 128 mels)")
     args = ap.parse_args()
 
     import numpy as np
@@ -97,8 +100,16 @@ def main():
     L.load()
 
     B, T = args.batch, WINDOW // 256
-    g = fs.MelGanGenerator(T, args.mels)
-    d = fs.MelGanDiscriminator()
+    gen_loss = LS.mel_gan_gen_loss
+    if args.model == "realmelgan":
+        from featuresynth.experiment import realmelgan as R
+        args.mels = 128
+        g, d = R.Generator(args.mels, 32, 3), R.Discriminator(3, 16, 4, 4)
+        gen_loss = R.mel_gan_gen_loss
+        args.no_roofline = args.no_cpu_baseline = True     # priced for the headline model only
+    else:
+        g = fs.MelGanGenerator(T, args.mels)
+        d = fs.MelGanDiscriminator()
     gsd = synthetic_state_dict(module_param_shapes(g), seed=7)
     dsd = synthetic_state_dict(module_param_shapes(d), seed=7)
     g.load_state_dict({k: torch.from_numpy(v) for k, v in gsd.items()})
@@ -106,7 +117,7 @@ def main():
     g.to(device); d.to(device)
     g_optim = fs.FlatAdam(g.parameters(), lr=1e-4, betas=(0.5, 0.9))
     d_optim = fs.FlatAdam(d.parameters(), lr=1e-4, betas=(0.5, 0.9))
-    gt = GeneratorTrainer(g, g_optim, d, d_optim, LS.mel_gan_gen_loss)
+    gt = GeneratorTrainer(g, g_optim, d, d_optim, gen_loss)
     dt = DiscriminatorTrainer(g, g_optim, d, d_optim, LS.mel_gan_disc_loss)
 
     nbatches = 4   # distinct pre-staged batches, cycled
@@ -147,9 +158,11 @@ def main():
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "stage-2 GAN train step: alternating D/G trainer calls, MelGAN "
-                               "generator + 3-scale discriminator + feature-matching loss "
-                               "(BASELINE.json configs[2]%s)" % ("" if world == 1 else "/[3]"),
+        "config": {"workload": ("stage-2 GAN train step: alternating D/G trainer calls, MelGAN "
+                                "generator + 3-scale discriminator + feature-matching loss "
+                                "(BASELINE.json configs[2]%s)" % ("" if world == 1 else "/[3]"))
+                               if args.model == "melgan" else
+                               "weight-normed MelGAN of experiment/realmelgan.py (SURVEY.md 8(f) row 1), same step",
                    "per_gpu_batch": B, "global_batch": world * B, "window": WINDOW,
                    "mels": args.mels, "optimizer": "FlatAdam(1e-4,(0.5,0.9))",
                    "parallelism": "dp%d" % world, "hipgraph": graphs},

@@ -53,6 +53,9 @@ typedef struct ms_conv1d_desc {
     int32_t pad_mode; /* ms_pad_mode; REFLECT = nn.ReflectionPad1d(pad) fused in front */
     int32_t act;      /* ms_act fused behind the conv */
     float slope;      /* LeakyReLU negative slope */
+    int32_t in_act;   /* ms_act applied to x on load, i.e. an activation layer IN FRONT of the conv
+                         (NONE or LRELU; the pre-activation ResnetBlock / LeakyReLU -> ConvTranspose1d
+                         of experiment/realmelgan.py:35-37,63-66) */
 } ms_conv1d_desc;
 
 int ms_conv1d_out_len(const ms_conv1d_desc* d);
@@ -99,6 +102,7 @@ typedef struct ms_convt1d_desc {
     int32_t B, Cin, Lin, Cout, K, stride, pad;
     int32_t act;
     float slope;
+    int32_t in_act;   /* activation in front of the transposed conv (NONE or LRELU) */
 } ms_convt1d_desc;
 
 int ms_convt1d_out_len(const ms_convt1d_desc* d);
@@ -124,6 +128,24 @@ const char* ms_convt1d_kernel_name(const ms_convt1d_desc* d, int which);
 int ms_avg_pool1d_4_2_2_fwd(const float* x, float* y, int64_t rows, int32_t Lin, ms_stream_t stream);
 int ms_avg_pool1d_4_2_2_bwd(const float* gy, const float* gx_add, float* gx, int64_t rows,
                             int32_t Lin, ms_stream_t stream);
+
+/*
+ * nn.AvgPool1d(4, stride=2, padding=1, count_include_pad=False) (experiment/realmelgan.py:168-169):
+ * the divisor is the number of in-range samples of each window.  Lout = (Lin + 2 - 4)/2 + 1.
+ */
+int ms_avg_pool1d_4_2_1_fwd(const float* x, float* y, int64_t rows, int32_t Lin, ms_stream_t stream);
+int ms_avg_pool1d_4_2_1_bwd(const float* gy, const float* gx_add, float* gx, int64_t rows,
+                            int32_t Lin, ms_stream_t stream);
+
+/*
+ * torch.nn.utils.weight_norm (experiment/realmelgan.py:24-29): w[r, :] = g[r] * v[r, :] / ||v[r, :]||_2
+ * for a (rows, cols) view of the parameter (rows = dim 0 of the weight).  Backward:
+ * gv = (g/||v||) * (gw - (gw . v^) v^),  gg = gw . v^   with v^ = v/||v||.
+ */
+int ms_weight_norm_fwd(const float* v, const float* g, float* w, int32_t rows, int32_t cols,
+                       ms_stream_t stream);
+int ms_weight_norm_bwd(const float* v, const float* g, const float* gw, float* gv, float* gg,
+                       int32_t rows, int32_t cols, float beta, ms_stream_t stream);
 
 /* gpre = gy * act'(y_act), elementwise (stand-alone form of the fused modifier above) */
 int ms_act_bwd(const float* y_act, const float* gy, float* gpre, int64_t n, int32_t act,

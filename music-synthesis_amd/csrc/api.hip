@@ -22,6 +22,8 @@ bool make_conv(const ms_conv1d_desc* d, ConvP* p) {
     p->Cg = d->Cin / d->groups; p->Og = d->Cout / d->groups;
     p->Lout = eff / d->stride + 1;
     p->pad_mode = d->pad_mode; p->act = d->act; p->slope = d->slope;
+    if (d->in_act != MS_ACT_NONE && d->in_act != MS_ACT_LRELU) return false;
+    p->in_act = d->in_act;
     return true;
 }
 
@@ -40,6 +42,8 @@ bool make_convt(const ms_convt1d_desc* d, ConvP* p) {
     p->Cg = d->Cout; p->Og = d->Cin;
     p->Lout = d->Lin;
     p->pad_mode = MS_PAD_ZERO; p->act = d->act; p->slope = d->slope;
+    if (d->in_act != MS_ACT_NONE && d->in_act != MS_ACT_LRELU) return false;
+    p->in_act = d->in_act;   // activation in front of the TRANSPOSED conv (on its input x)
     // consistency: the conv's own output length for Lin=Lout_T must give back Lin_T
     const int chk = (Lout + 2 * d->pad - (d->K - 1) - 1) / d->stride + 1;
     return chk == d->Lin;
@@ -73,10 +77,13 @@ int ms_conv1d_fwd(const ms_conv1d_desc* d, const float* x, const float* w, const
     ConvP p;
     if (!make_conv(d, &p) || !x || !w || !y) return MS_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
+    // activation in front of the conv: applied to x on load (operand modifier "LeakyReLU of the value")
+    const float* xa = p.in_act ? x : nullptr;
+    const int xk = p.in_act ? MS_MOD_LRELU_FWD : 0;
     if (msm_fwd_applicable(p))
-        return msm_conv1d_fwd(p, x, nullptr, 0, w, bias, residual, y, y_act, workspace, workspace_bytes, s);
-    if (msg_fwd_applicable(p) && !residual && !y_act) return msg_conv1d_fwd(p, x, w, bias, y, s);
-    return msk_conv1d_fwd_direct(p, x, nullptr, 0, w, bias, residual, y, y_act, s);
+        return msm_conv1d_fwd(p, x, xa, xk, w, bias, residual, y, y_act, workspace, workspace_bytes, s);
+    if (msg_fwd_applicable(p) && !residual && !y_act && !p.in_act) return msg_conv1d_fwd(p, x, w, bias, y, s);
+    return msk_conv1d_fwd_direct(p, x, xa, xk, w, bias, residual, y, y_act, s);
 }
 
 int ms_conv1d_bwd_data(const ms_conv1d_desc* d, const float* gy, const float* y_act,
@@ -84,12 +91,21 @@ int ms_conv1d_bwd_data(const ms_conv1d_desc* d, const float* gy, const float* y_
                        size_t workspace_bytes, ms_stream_t stream) {
     ConvP p;
     if (!make_conv(d, &p) || !gy || !w || !gx) return MS_ERR_INVALID_ARG;
-    if (p.pad_mode != MS_PAD_ZERO) return MS_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    // reflection padding: the zero-padded backward gives the gradient of the in-range taps; the
+    // taps that read mirrored samples are folded back onto their sources by a small edge kernel
+    const bool reflect = p.pad_mode == MS_PAD_REFLECT;
+    if (reflect && (p.stride != 1 || p.groups != 1)) return MS_ERR_UNSUPPORTED;
+    p.pad_mode = MS_PAD_ZERO;
+    int rc;
     if (msm_bwd_data_applicable(p))
-        return msm_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, workspace, workspace_bytes, s);
-    if (msg_bwd_data_applicable(p)) return msg_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, s);
-    return msk_conv1d_bwd_data_direct(p, gy, y_act, w, nullptr, MS_ACT_NONE, gx_add, gx, s);
+        rc = msm_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, workspace, workspace_bytes, s);
+    else if (msg_bwd_data_applicable(p))
+        rc = msg_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, s);
+    else
+        rc = msk_conv1d_bwd_data_direct(p, gy, y_act, w, nullptr, MS_ACT_NONE, gx_add, gx, s);
+    if (rc != MS_OK || !reflect) return rc;
+    return msk_reflect_fold_bwd(p, gy, y_act, w, gx, s);
 }
 
 int ms_conv1d_bwd_weight(const ms_conv1d_desc* d, const float* x, const float* gy,
@@ -99,12 +115,14 @@ int ms_conv1d_bwd_weight(const ms_conv1d_desc* d, const float* x, const float* g
     if (!make_conv(d, &p) || !x || !gy || !gw) return MS_ERR_INVALID_ARG;
     if (beta != 0.f && beta != 1.f) return MS_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
+    const float* xa = p.in_act ? x : nullptr;
+    const int xk = p.in_act ? MS_MOD_LRELU_FWD : 0;
     if (msm_bwd_weight_applicable(p))
-        return msm_conv1d_bwd_weight(p, x, nullptr, 0, gy, y_act, p.act, gw, gb, beta, workspace,
+        return msm_conv1d_bwd_weight(p, x, xa, xk, gy, y_act, p.act, gw, gb, beta, workspace,
                                      workspace_bytes, s);
-    if (msg_bwd_weight_applicable(p))
+    if (msg_bwd_weight_applicable(p) && !p.in_act)
         return msg_conv1d_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
-    return msk_conv1d_bwd_weight_direct(p, x, nullptr, 0, gy, y_act, p.act, gw, gb, beta, workspace,
+    return msk_conv1d_bwd_weight_direct(p, x, xa, xk, gy, y_act, p.act, gw, gb, beta, workspace,
                                         workspace_bytes, s);
 }
 
@@ -164,7 +182,9 @@ int ms_convt1d_fwd(const ms_convt1d_desc* d, const float* x, const float* w, con
     hipStream_t s = (hipStream_t)stream;
     if (msm_convt_fwd_applicable(p))
         return msm_convt1d_fwd(p, x, w, bias, y, workspace, workspace_bytes, s);
-    return msk_conv1d_bwd_data_direct(p, x, nullptr, w, bias, p.act, nullptr, y, s);
+    ConvP q = p;     // direct path: the loader modifier kind rides in q.act, the epilogue gets p.act
+    q.act = p.in_act ? MS_MOD_LRELU_FWD : MS_ACT_NONE;
+    return msk_conv1d_bwd_data_direct(q, x, p.in_act ? x : nullptr, w, bias, p.act, nullptr, y, s);
 }
 
 // gx = conv(gy * act'(y_act), w) with the mirrored conv geometry (no bias / activation)
@@ -197,10 +217,12 @@ int ms_convt1d_bwd_weight(const ms_convt1d_desc* d, const float* x, const float*
     if (msm_convt_bwd_applicable(p))
         rc = msm_convt1d_bwd_weight(p, x, gy, y_act, gw, beta, workspace, workspace_bytes, s);
     else if (msm_bwd_weight_applicable(p))
-        rc = msm_conv1d_bwd_weight(p, gy, y_act, p.act, x, nullptr, 0, gw, nullptr, beta, workspace,
+        rc = msm_conv1d_bwd_weight(p, gy, y_act, p.act, x, p.in_act ? x : nullptr,
+                                   p.in_act ? MS_MOD_LRELU_FWD : 0, gw, nullptr, beta, workspace,
                                    workspace_bytes, s);
     else
-        rc = msk_conv1d_bwd_weight_direct(p, gy, y_act, p.act, x, nullptr, 0, gw, nullptr, beta,
+        rc = msk_conv1d_bwd_weight_direct(p, gy, y_act, p.act, x, p.in_act ? x : nullptr,
+                                          p.in_act ? MS_MOD_LRELU_FWD : 0, gw, nullptr, beta,
                                           workspace, workspace_bytes, s);
     if (rc != MS_OK) return rc;
     if (gb) {   // bias grad: the slice partials live at the tail of the workspace

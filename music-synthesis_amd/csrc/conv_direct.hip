@@ -250,6 +250,41 @@ __global__ __launch_bounds__(256) void k_conv1d_bwd_data_direct(
     }
 }
 
+
+// ------------------------------------------------- reflection-pad fold (backward data)
+// A conv behind nn.ReflectionPad1d(pad) reads mirrored samples at the row ends.  The zero-padded
+// backward-data pass covers the taps that read in-range samples; this kernel adds, for every padded
+// border position u (u < pad or u >= L + pad), the gradient that reached it,
+//   gpad[u] = sum_{co,j} w[co,ci,j] * gp[b,co,u - j*dil]      (0 <= u - j*dil < Lout),
+// onto its mirror source s = reflect(u - pad).  2*pad positions per (b, ci) row: tiny.
+__global__ __launch_bounds__(256) void k_reflect_fold_bwd(ConvP p, const float* __restrict__ gy,
+                                                         const float* __restrict__ y_act,
+                                                         const float* __restrict__ w,
+                                                         float* __restrict__ gx) {
+    const int nb = 2 * p.pad;
+    const long long total = (long long)p.B * p.Cin * nb;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i % nb);
+    const int ci = (int)((i / nb) % p.Cin);
+    const int b = (int)(i / ((long long)nb * p.Cin));
+    const int u = e < p.pad ? e : p.Lin + e;            // padded index (length Lin + 2*pad)
+    const int sidx = ms_src_index(u - p.pad, p.Lin, MS_PAD_REFLECT);
+    if (sidx < 0) return;
+    const float* ya = y_act ? y_act : gy;
+    const int kind = y_act ? p.act : MS_ACT_NONE;
+    float acc = 0.f;
+    for (int j = 0; j < p.K; ++j) {
+        const int t = u - j * p.dil;
+        if (t < 0 || t >= p.Lout) continue;             // uniform over co: no load under it diverges
+        for (int co = 0; co < p.Cout; ++co) {
+            const size_t off = ((size_t)b * p.Cout + co) * p.Lout + t;
+            acc = fmaf(w[((size_t)co * p.Cin + ci) * p.K + j], ms_act_grad(gy[off], ya[off], kind, p.slope), acc);
+        }
+    }
+    atomicAdd(&gx[((size_t)b * p.Cin + ci) * p.Lin + sidx], acc);
+}
+
 // ---------------------------------------------------------- backward weight
 // partial[z][co][j] = sum over this block's (b, t-chunk) slices of gp[b,co,t] * x[b, ci(j), t*stride + k(j)*dil - pad]
 // with j = ci*K + k inside the group.  Partials (and the bias column) are summed by k_reduce_partials.
@@ -569,6 +604,16 @@ int msk_channel_sum(const float* g, const float* y_act, int act, float slope, in
                        slope, B, C, L, partial);
     MS_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_channel_sum_final, dim3((C + 255) / 256), dim3(256), 0, s, partial, C, out, beta);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int msk_reflect_fold_bwd(const ConvP& p, const float* gy, const float* y_act, const float* w,
+                         float* gx, hipStream_t s) {
+    if (p.pad <= 0) return MS_OK;
+    const long long total = (long long)p.B * p.Cin * 2 * p.pad;
+    hipLaunchKernelGGL(k_reflect_fold_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, gy,
+                       y_act, w, gx);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }

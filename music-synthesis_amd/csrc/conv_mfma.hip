@@ -927,7 +927,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 
 // ------------------------------------------------------------------------ host side
 bool dense_same(const ConvP& p) {
-    return p.groups == 1 && p.stride == 1 && p.Lout == p.Lin && (p.K == 3 || p.K == 5 || p.K == 7) &&
+    return p.groups == 1 && p.stride == 1 && p.Lout == p.Lin && (p.K == 1 || p.K == 3 || p.K == 5 || p.K == 7) &&
            (long long)p.B * p.Lin < (1LL << 31) && (long long)p.Cin * p.K < (1 << 30);
 }
 
@@ -965,6 +965,7 @@ int launch_conv_k(Cfg cfg, const IgP& p, const float* X, const float* Xact, cons
 template <bool TRANS>
 int launch_conv(int K, Cfg cfg, const IgP& p, const float* X, const float* Xact, const float* W,
                 const float* bias, const float* res, float* Y, float* Yact, hipStream_t s) {
+    if (K == 1) return launch_conv_k<1, TRANS>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
     if (K == 3) return launch_conv_k<3, TRANS>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
     if (K == 5) return launch_conv_k<5, TRANS>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
     if (K == 7) return launch_conv_k<7, TRANS>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
@@ -1017,10 +1018,10 @@ const char* row_tile_str(RowCfg c) {
     }
 }
 
-constexpr int row_cc(int K) { return K == 7 ? 4 : 8; }
+constexpr int row_cc(int K) { return K == 7 ? 4 : (K == 1 ? 32 : 8); }
 
 bool rows_applicable(int M, int CK, int K, int L) {
-    if (!(K == 3 || K == 5 || K == 7)) return false;
+    if (!(K == 1 || K == 3 || K == 5 || K == 7)) return false;
     if (CK % row_cc(K)) return false;
     if (M < 32) return false;
     return L >= 1;
@@ -1060,7 +1061,7 @@ bool make_rowp(RowP* q, RowCfg cfg, int B, int CK, int L, int M, int K, int dil,
 }
 
 // deep contractions (>= 128 input channels) stage two channel chunks per barrier pair
-bool row_deep(int K, int CK) { return K != 7 && CK >= 128 && CK % (2 * row_cc(K)) == 0; }
+bool row_deep(int K, int CK) { return K != 7 && K != 1 && CK >= 128 && CK % (2 * row_cc(K)) == 0; }
 
 template <int K, bool HAS_ACT, int EPI_S = 0, int IN_S = 1, int CCMUL = 1>
 int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, const float* W,
@@ -1100,10 +1101,12 @@ int launch_rows(int K, RowCfg cfg, const RowP& p, const float* X, const float* X
     (deep ? launch_rows_k<KK, ACT, 0, 1, 2>(cfg, p, X, Xact, W, bias, res, Y, Yact, s)                \
           : launch_rows_k<KK, ACT, 0, 1, 1>(cfg, p, X, Xact, W, bias, res, Y, Yact, s))
     if (Xact) {
+        if (K == 1) return launch_rows_k<1, true>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
         if (K == 3) return MS_ROWS(3, true);
         if (K == 5) return MS_ROWS(5, true);
         if (K == 7) return launch_rows_k<7, true>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
     } else {
+        if (K == 1) return launch_rows_k<1, false>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
         if (K == 3) return MS_ROWS(3, false);
         if (K == 5) return MS_ROWS(5, false);
         if (K == 7) return launch_rows_k<7, false>(cfg, p, X, Xact, W, bias, res, Y, Yact, s);
@@ -1145,7 +1148,7 @@ bool msm_bwd_data_applicable(const ConvP& p) {
     return dense_same(p) && p.pad_mode == MS_PAD_ZERO && p.Cin >= 32 && p.Cout * p.K >= 32;
 }
 bool msm_bwd_weight_applicable(const ConvP& p) {
-    const bool kok = p.K == 3 || p.K == 5 || p.K == 7 || p.K == 15;
+    const bool kok = p.K == 1 || p.K == 3 || p.K == 5 || p.K == 7 || p.K == 15;
     return p.groups == 1 && p.stride == 1 && p.Lout == p.Lin && kok &&
            (long long)p.B * p.Lin < (1LL << 31) && (long long)p.B * p.Cout * p.Lin < (1LL << 31) &&
            (long long)p.B * p.Cin * p.Lin < (1LL << 31) && p.Cout >= 16 && p.Cin * p.K >= 15;
@@ -1262,7 +1265,8 @@ int msm_conv1d_bwd_weight(const ConvP& p, const float* x, const float* x_act, in
         else if (pl.cfg == CFG_32x128) MS_WG(1, 4, 1, 1, KK);                                       \
         else MS_WG(1, 4, 1, 2, KK);                                                                 \
     } while (0)
-    if (p.K == 3) MS_WG_K(3);
+    if (p.K == 1) MS_WG_K(1);
+    else if (p.K == 3) MS_WG_K(3);
     else if (p.K == 5) MS_WG_K(5);
     else if (p.K == 7) MS_WG_K(7);
     else if (p.K == 15) MS_WG_K(15);
@@ -1291,6 +1295,11 @@ int msm_convt1d_fwd(const ConvP& p, const float* x, const float* w, const float*
     RowP r;
     const RowCfg cfg = pick_row_cfg(CoutT * S, p.B, LinT);
     make_rowp(&r, cfg, p.B, CinT, LinT, CoutT * S, 3, 1, -1, MS_PAD_ZERO, p.act, MS_ACT_NONE, p.slope);
+    if (p.in_act) {   // LeakyReLU in front of the transposed conv: applied to x on load
+        r.in_act = MS_MOD_LRELU_FWD;
+        if (S == 8) return launch_rows_k<3, true, 8>(cfg, r, x, x, wp, bias, nullptr, y, nullptr, s);
+        return launch_rows_k<3, true, 2>(cfg, r, x, x, wp, bias, nullptr, y, nullptr, s);
+    }
     if (S == 8) return launch_rows_k<3, false, 8>(cfg, r, x, nullptr, wp, bias, nullptr, y, nullptr, s);
     return launch_rows_k<3, false, 2>(cfg, r, x, nullptr, wp, bias, nullptr, y, nullptr, s);
 }
@@ -1381,7 +1390,8 @@ int msm_convt1d_bwd_weight(const ConvP& p, const float* x, const float* gy, cons
     // A operand = x_T (no activation), B operand = phase-split gy with act'(y_T)
 #define MS_TWG(WGM, WGN, TM, TN)                                                                     \
     hipLaunchKernelGGL((k_igemm_wgrad<WGM, WGN, TM, TN, 3>), grid, dim3(256), 0, s, q, pl.w.cps, gy, \
-                       y_act, x, (const float*)nullptr, 0, partial, pl.w.stride_floats)
+                       y_act, x, p.in_act ? x : (const float*)nullptr,                               \
+                       p.in_act ? MS_MOD_LRELU_FWD : 0, partial, pl.w.stride_floats)
     if (pl.w.cfg == CFG_128x128) MS_TWG(2, 2, 2, 2);
     else if (pl.w.cfg == CFG_64x64) MS_TWG(2, 2, 1, 1);
     else if (pl.w.cfg == CFG_32x128) MS_TWG(1, 4, 1, 1);

@@ -58,6 +58,104 @@ __global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ gy,
     }
 }
 
+
+// ---- nn.AvgPool1d(4, 2, padding=1, count_include_pad=False): divisor = in-range samples
+__global__ __launch_bounds__(256) void k_pool421_fwd(const float* __restrict__ x,
+                                                    float* __restrict__ y, int64_t rows, int Lin,
+                                                    int Lout) {
+    const int64_t total = rows * Lout;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / Lout;
+        const int o = (int)(i - r * Lout);
+        const float* xr = x + r * Lin;
+        const int s = o * 2 - 1;
+        float a = 0.f;
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = s + j;
+            const bool ok = q >= 0 && q < Lin;
+            a += ok ? xr[q] : 0.f;
+            cnt += ok ? 1 : 0;
+        }
+        y[i] = a / (float)cnt;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pool421_bwd(const float* __restrict__ gy,
+                                                    const float* __restrict__ gx_add,
+                                                    float* __restrict__ gx, int64_t rows, int Lin,
+                                                    int Lout) {
+    const int64_t total = rows * Lin;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / Lin;
+        const int p = (int)(i - r * Lin);
+        const float* gr = gy + r * Lout;
+        // windows o with 2o-1 <= p <= 2o+2  ->  o in [ceil((p-2)/2), floor((p+1)/2)]
+        const int o_lo = p >= 2 ? (p - 1) >> 1 : 0;
+        const int o_hi = (p + 1) >> 1;
+        float a = 0.f;
+        for (int o = o_lo; o <= o_hi; ++o) {
+            if (o >= Lout) continue;
+            const int s = o * 2 - 1;
+            const int lo = s < 0 ? 0 : s, hi = s + 3 >= Lin ? Lin - 1 : s + 3;
+            a += gr[o] / (float)(hi - lo + 1);
+        }
+        if (gx_add) a += gx_add[i];
+        gx[i] = a;
+    }
+}
+
+// ---- weight normalisation: one workgroup per row of the (rows, cols) parameter view
+__global__ __launch_bounds__(256) void k_weight_norm_fwd(const float* __restrict__ v,
+                                                        const float* __restrict__ g,
+                                                        float* __restrict__ w, int cols) {
+    __shared__ float red[4];
+    __shared__ float scale;
+    const int r = blockIdx.x;
+    const float* vr = v + (size_t)r * cols;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) s += vr[c] * vr[c];
+    const float tot = ms_block_sum(s, red);
+    if (threadIdx.x == 0) scale = g[r] / sqrtf(tot);
+    __syncthreads();
+    const float sc = scale;
+    for (int c = threadIdx.x; c < cols; c += 256) w[(size_t)r * cols + c] = vr[c] * sc;
+}
+
+__global__ __launch_bounds__(256) void k_weight_norm_bwd(const float* __restrict__ v,
+                                                        const float* __restrict__ g,
+                                                        const float* __restrict__ gw,
+                                                        float* __restrict__ gv,
+                                                        float* __restrict__ gg, int cols,
+                                                        float beta) {
+    __shared__ float red[4];
+    __shared__ float sh[2];
+    const int r = blockIdx.x;
+    const float* vr = v + (size_t)r * cols;
+    const float* gr = gw + (size_t)r * cols;
+    float s2 = 0.f, dot = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        s2 += vr[c] * vr[c];
+        dot += gr[c] * vr[c];
+    }
+    const float t2 = ms_block_sum(s2, red);
+    const float td = ms_block_sum(dot, red);
+    if (threadIdx.x == 0) { sh[0] = t2; sh[1] = td; }
+    __syncthreads();
+    const float nrm = sqrtf(sh[0]);
+    const float gdot = sh[1] / nrm;              // gw . v^
+    const float gs = g[r] / nrm;
+    if (threadIdx.x == 0) gg[r] = (beta != 0.f ? beta * gg[r] : 0.f) + gdot;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float val = gs * (gr[c] - gdot * vr[c] / nrm);
+        const size_t o = (size_t)r * cols + c;
+        gv[o] = (beta != 0.f ? beta * gv[o] : 0.f) + val;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ ya,
                                                 const float* __restrict__ gy,
                                                 float* __restrict__ out, int64_t n, int act,
@@ -237,6 +335,43 @@ int ms_avg_pool1d_4_2_2_bwd(const float* gy, const float* gx_add, float* gx, int
     const int Lout = (Lin + 4 - 4) / 2 + 1;
     hipLaunchKernelGGL(k_pool_bwd, dim3(grid_for(rows * Lin)), dim3(256), 0, (hipStream_t)stream,
                        gy, gx_add, gx, rows, Lin, Lout);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_avg_pool1d_4_2_1_fwd(const float* x, float* y, int64_t rows, int32_t Lin, ms_stream_t stream) {
+    if (!x || !y || rows <= 0 || Lin < 2) return MS_ERR_INVALID_ARG;
+    const int Lout = (Lin + 2 - 4) / 2 + 1;
+    hipLaunchKernelGGL(k_pool421_fwd, dim3(grid_for(rows * Lout)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, rows, Lin, Lout);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_avg_pool1d_4_2_1_bwd(const float* gy, const float* gx_add, float* gx, int64_t rows,
+                            int32_t Lin, ms_stream_t stream) {
+    if (!gy || !gx || rows <= 0 || Lin < 2) return MS_ERR_INVALID_ARG;
+    const int Lout = (Lin + 2 - 4) / 2 + 1;
+    hipLaunchKernelGGL(k_pool421_bwd, dim3(grid_for(rows * Lin)), dim3(256), 0, (hipStream_t)stream,
+                       gy, gx_add, gx, rows, Lin, Lout);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_weight_norm_fwd(const float* v, const float* g, float* w, int32_t rows, int32_t cols,
+                       ms_stream_t stream) {
+    if (!v || !g || !w || rows <= 0 || cols <= 0) return MS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_weight_norm_fwd, dim3(rows), dim3(256), 0, (hipStream_t)stream, v, g, w, cols);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_weight_norm_bwd(const float* v, const float* g, const float* gw, float* gv, float* gg,
+                       int32_t rows, int32_t cols, float beta, ms_stream_t stream) {
+    if (!v || !g || !gw || !gv || !gg || rows <= 0 || cols <= 0) return MS_ERR_INVALID_ARG;
+    if (beta != 0.f && beta != 1.f) return MS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_weight_norm_bwd, dim3(rows), dim3(256), 0, (hipStream_t)stream, v, g, gw, gv,
+                       gg, cols, beta);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }

@@ -14,7 +14,12 @@
 struct ConvP {  // kernel-side copy of ms_conv1d_desc (+ derived sizes)
     int B, Cin, Lin, Cout, Lout, K, stride, pad, dil, groups, Cg, Og, pad_mode, act;
     float slope;
+    int in_act;   // activation applied to the conv input on load (NONE / LRELU)
 };
+
+// operand-modifier kind: "apply LeakyReLU to the loaded value itself" (pre-activation convs);
+// the kinds 0..2 (ms_act) mean "multiply by the derivative of that activation at ya"
+#define MS_MOD_LRELU_FWD 3
 
 static inline int ms_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int ms_floor_div(int a, int b) {  // b > 0
@@ -31,6 +36,7 @@ __device__ __forceinline__ float ms_apply_act(float v, int act, float slope) {
 
 // d act(pre)/d pre expressed through the saved post-activation value ya
 __device__ __forceinline__ float ms_act_grad(float g, float ya, int act, float slope) {
+    if (act == MS_MOD_LRELU_FWD) return g > 0.f ? g : g * slope;
     if (act == MS_ACT_LRELU) return ya > 0.f ? g : g * slope;
     if (act == MS_ACT_TANH) return g * (1.f - ya * ya);
     return g;
@@ -80,6 +86,8 @@ int msk_conv1d_bwd_weight_direct(const ConvP& p, const float* x, const float* x_
                                  int x_act_kind, const float* gy, const float* y_act,
                                  int y_act_kind, float* gw, float* gb, float beta, void* ws,
                                  size_t ws_bytes, hipStream_t s);
+int msk_reflect_fold_bwd(const ConvP& p, const float* gy, const float* y_act, const float* w,
+                         float* gx, hipStream_t s);
 const char* msk_conv1d_fwd_direct_name(const ConvP& p);
 const char* msk_conv1d_bwd_data_direct_name(const ConvP& p);
 const char* msk_conv1d_bwd_weight_direct_name(const ConvP& p);

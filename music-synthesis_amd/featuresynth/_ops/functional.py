@@ -303,3 +303,95 @@ class MelGanGenLossFn(Function):
         g_ff = [P.l1_mean_bwd(rf[i], ff[i], g, fscale) if need[nf + i] else None for i in range(nf)]
         g_fj = [P.neg_mean_bwd(fj[s], g) if need[2 * nf + s] else None for s in range(S)]
         return (None, None, None) + tuple(g_rf) + tuple(g_ff) + tuple(g_fj)
+
+
+# --------------------------------------------------------------- RealMelGan building blocks
+# (reference featuresynth/experiment/realmelgan.py: weight-normed convs, pre-activation
+#  ResnetBlock, reflection padding, AvgPool1d(4, 2, 1, count_include_pad=False))
+
+class WeightNormFn(Function):
+    """w = g * v / ||v||  (torch.nn.utils.weight_norm with dim=0, realmelgan.py:24-29)."""
+
+    @staticmethod
+    def forward(ctx, v, g):
+        ctx.save_for_backward(v, g)
+        return P.weight_norm_fwd(v, g)
+
+    @staticmethod
+    def backward(ctx, gw):
+        v, g = ctx.saved_tensors
+        gv, gg = P.weight_norm_bwd(v, g, _c(gw))
+        return gv, gg
+
+
+class Conv1dExFn(Function):
+    """conv1d with an optional activation IN FRONT (in_act, applied on load), reflection padding,
+    a fused activation behind and a fused residual add:  y = residual + act(conv(in_act(x)))."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual, stride, pad, dil, groups, pad_mode, act, in_act):
+        d, lo = P.conv_desc(x.shape, w.shape, stride, pad, dil, groups, pad_mode, act, in_act)
+        y, y_act = P.conv1d_fwd(x, w, b, d, lo, residual=residual,
+                                want_y_act=(residual is not None and act != L.ACT_NONE))
+        ctx.d = d
+        ctx.in_act = in_act
+        ctx.has = (b is not None, residual is not None)
+        ctx.save_for_backward(x, w, y_act)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y_act = ctx.saved_tensors
+        gy = _c(gy)
+        d = ctx.d
+        ya = y_act if d.act != L.ACT_NONE else None
+        gx = gw = gb = None
+        has_b, has_r = ctx.has
+        if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
+            gw, gb = P.conv1d_bwd_weight(x, gy, ya, d, w.shape, want_bias=has_b)
+        if ctx.needs_input_grad[0]:
+            gx = P.conv1d_bwd_data(gy, ya, w, d)            # d loss / d in_act(x)
+            if ctx.in_act != L.ACT_NONE:
+                gx = P.act_bwd(x, gx, ctx.in_act)            # through the activation in front
+        gr = gy if (has_r and ctx.needs_input_grad[3]) else None
+        return gx, gw, (gb if has_b else None), gr, None, None, None, None, None, None, None
+
+
+class ConvTranspose1dExFn(Function):
+    """y = act(conv_transpose1d(in_act(x)))."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, act, in_act):
+        d, lo = P.convt_desc(x.shape, w.shape, stride, pad, act, in_act)
+        y = P.convt1d_fwd(x, w, b, d, lo)
+        ctx.d = d
+        ctx.in_act = in_act
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        gy = _c(gy)
+        d = ctx.d
+        ya = y if d.act != L.ACT_NONE else None
+        gx = gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = P.convt1d_bwd_weight(x, gy, ya, d, w.shape)
+        if ctx.needs_input_grad[0]:
+            gx = P.convt1d_bwd_data(gy, ya, w, d)
+            if ctx.in_act != L.ACT_NONE:
+                gx = P.act_bwd(x, gx, ctx.in_act)
+        return gx, gw, (gb if ctx.has_bias else None), None, None, None, None
+
+
+class AvgPool421Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return P.avg_pool421_fwd(x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return P.avg_pool421_bwd(_c(gy), ctx.shape)

@@ -23,12 +23,12 @@ _sz = ctypes.c_size_t
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, _c_int) for n in ("B", "Cin", "Lin", "Cout", "K", "stride", "pad", "dil",
-                                      "groups", "pad_mode", "act")] + [("slope", _c_f)]
+                                      "groups", "pad_mode", "act")] + [("slope", _c_f), ("in_act", _c_int)]
 
 
 class ConvTDesc(ctypes.Structure):
     _fields_ = [(n, _c_int) for n in ("B", "Cin", "Lin", "Cout", "K", "stride", "pad", "act")] + \
-               [("slope", _c_f)]
+               [("slope", _c_f), ("in_act", _c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/msynth.h declares
@@ -49,6 +49,10 @@ SIGNATURES = {
     "ms_convt1d_workspace_bytes": (_sz, [ctypes.POINTER(ConvTDesc), _c_int]),
     "ms_avg_pool1d_4_2_2_fwd": (_c_int, [_vp, _vp, _c_i64, _c_int, _vp]),
     "ms_avg_pool1d_4_2_2_bwd": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _vp]),
+    "ms_avg_pool1d_4_2_1_fwd": (_c_int, [_vp, _vp, _c_i64, _c_int, _vp]),
+    "ms_avg_pool1d_4_2_1_bwd": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _vp]),
+    "ms_weight_norm_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _vp]),
+    "ms_weight_norm_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_f, _vp]),
     "ms_act_bwd": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _c_f, _vp]),
     "ms_add": (_c_int, [_vp, _vp, _vp, _c_i64, _vp]),
     "ms_reduce_workspace_bytes": (_sz, [_c_i64]),

@@ -30,13 +30,13 @@ SLOPE = 0.2
 
 
 def conv_desc(x_shape, w_shape, stride=1, pad=0, dil=1, groups=1, pad_mode=L.PAD_ZERO,
-              act=L.ACT_NONE):
+              act=L.ACT_NONE, in_act=L.ACT_NONE):
     B, Cin, Lin = x_shape
     Cout, Cg, K = w_shape
     if Cg * groups != Cin:
         raise RuntimeError("conv1d: weight %s does not match input channels %d / groups %d" %
                            (tuple(w_shape), Cin, groups))
-    d = L.ConvDesc(B, Cin, Lin, Cout, K, stride, pad, dil, groups, pad_mode, act, SLOPE)
+    d = L.ConvDesc(B, Cin, Lin, Cout, K, stride, pad, dil, groups, pad_mode, act, SLOPE, in_act)
     lout = L.load().ms_conv1d_out_len(d)
     if lout <= 0:
         raise RuntimeError("conv1d: invalid geometry x=%s w=%s stride=%d pad=%d dil=%d" %
@@ -99,13 +99,13 @@ def conv1d_bwd_weight(x, gy, y_act, d, w_shape, gw=None, gb=None, accumulate=Fal
     return gw, gb
 
 
-def convt_desc(x_shape, w_shape, stride, pad, act=L.ACT_NONE):
+def convt_desc(x_shape, w_shape, stride, pad, act=L.ACT_NONE, in_act=L.ACT_NONE):
     B, Cin, Lin = x_shape
     Cin2, Cout, K = w_shape
     if Cin2 != Cin:
         raise RuntimeError("conv_transpose1d: weight %s does not match input channels %d" %
                            (tuple(w_shape), Cin))
-    d = L.ConvTDesc(B, Cin, Lin, Cout, K, stride, pad, act, SLOPE)
+    d = L.ConvTDesc(B, Cin, Lin, Cout, K, stride, pad, act, SLOPE, in_act)
     lout = L.load().ms_convt1d_out_len(d)
     if lout <= 0:
         raise RuntimeError("conv_transpose1d: invalid geometry")
@@ -170,6 +170,60 @@ def avg_pool_bwd(gy, x_shape, gx_add=None):
     L.call("ms_avg_pool1d_4_2_2_bwd", _scost(gx.numel(), 0.5 + int(gx_add is not None), 1),
            gy.data_ptr(), L.ptr(gx_add), gx.data_ptr(), B * C, Lin, L.stream())
     return gx
+
+
+def pool421_out_len(lin):
+    return (lin + 2 - 4) // 2 + 1
+
+
+def avg_pool421_fwd(x):
+    """nn.AvgPool1d(4, stride=2, padding=1, count_include_pad=False)."""
+    L.require(x, "avg_pool1d input")
+    B, C, Lin = x.shape
+    y = torch.empty((B, C, pool421_out_len(Lin)), dtype=torch.float32, device=x.device)
+    L.call("ms_avg_pool1d_4_2_1_fwd", _scost(x.numel(), 1, 0.5), x.data_ptr(), y.data_ptr(), B * C, Lin,
+           L.stream())
+    return y
+
+
+def avg_pool421_bwd(gy, x_shape, gx_add=None):
+    L.require(gy, "avg_pool1d grad_output")
+    B, C, Lin = x_shape
+    gx = torch.empty((B, C, Lin), dtype=torch.float32, device=gy.device)
+    L.call("ms_avg_pool1d_4_2_1_bwd", _scost(gx.numel(), 0.5 + int(gx_add is not None), 1),
+           gy.data_ptr(), L.ptr(gx_add), gx.data_ptr(), B * C, Lin, L.stream())
+    return gx
+
+
+def weight_norm_fwd(v, g):
+    """w = g * v / ||v|| over all dims but 0 (torch.nn.utils.weight_norm, dim=0)."""
+    L.require(v, "weight_v"); L.require(g, "weight_g")
+    rows, cols = v.shape[0], v.numel() // v.shape[0]
+    w = torch.empty_like(v)
+    L.call("ms_weight_norm_fwd", _scost(v.numel(), 2, 1, 3), v.data_ptr(), g.data_ptr(), w.data_ptr(), rows,
+           cols, L.stream())
+    return w
+
+
+def weight_norm_bwd(v, g, gw, gv=None, gg=None):
+    L.require(gw, "weight grad")
+    acc = gv is not None
+    if gv is None:
+        gv = torch.empty_like(v)
+        gg = torch.empty_like(g)
+    rows, cols = v.shape[0], v.numel() // v.shape[0]
+    L.call("ms_weight_norm_bwd", _scost(v.numel(), 3, 1, 6), v.data_ptr(), g.data_ptr(), gw.data_ptr(),
+           gv.data_ptr(), gg.data_ptr(), rows, cols, 1.0 if acc else 0.0, L.stream())
+    return gv, gg
+
+
+def act_bwd(y_act, gy, act):
+    """gy * act'(.) evaluated from y_act (for LeakyReLU: the sign of y_act)."""
+    L.require(y_act, "activation"); L.require(gy, "grad")
+    out = torch.empty_like(gy)
+    L.call("ms_act_bwd", _scost(gy.numel(), 2, 1), y_act.data_ptr(), gy.data_ptr(), out.data_ptr(),
+           gy.numel(), act, SLOPE, L.stream())
+    return out
 
 
 def add(a, b):

@@ -22,6 +22,8 @@ def synthetic_state_dict(param_shapes, seed=WEIGHT_SEED, weight_scale=0.02, bias
                 out[name] = (rng.standard_normal(shape) * bias_scale).astype(np.float32)
             else:
                 out[name] = np.zeros(shape, np.float32)
+        elif name.endswith("weight_g"):      # weight-norm gain: positive, around 1
+            out[name] = (0.5 + rng.random(shape)).astype(np.float32)
         else:
             out[name] = (rng.standard_normal(shape) * weight_scale).astype(np.float32)
     return out

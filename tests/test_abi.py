@@ -41,23 +41,23 @@ def test_host_side_queries(lib):
     assert b"ok" == L.ms_status_string(0)
     assert b"unsupported" in L.ms_status_string(-2) or b"not supported" in L.ms_status_string(-2)
     # geometry of the hot-path layers (no kernel is launched)
-    d = lib.ConvDesc(32, 16, 8192, 64, 41, 4, 20, 1, 4, 0, 1, 0.2)
+    d = lib.ConvDesc(32, 16, 8192, 64, 41, 4, 20, 1, 4, 0, 1, 0.2, 0)
     assert L.ms_conv1d_out_len(d) == 2048
-    d = lib.ConvDesc(1, 1, 8192, 16, 15, 1, 7, 1, 1, 0, 1, 0.2)
+    d = lib.ConvDesc(1, 1, 8192, 16, 15, 1, 7, 1, 1, 0, 1, 0.2, 0)
     assert L.ms_conv1d_out_len(d) == 8192
-    bad = lib.ConvDesc(1, 6, 10, 4, 3, 1, 1, 1, 4, 0, 0, 0.2)      # 6 channels, 4 groups
+    bad = lib.ConvDesc(1, 6, 10, 4, 3, 1, 1, 1, 4, 0, 0, 0.2, 0)      # 6 channels, 4 groups
     assert L.ms_conv1d_out_len(bad) < 0
-    t = lib.ConvTDesc(32, 512, 32, 256, 16, 8, 4, 1, 0.2)
+    t = lib.ConvTDesc(32, 512, 32, 256, 16, 8, 4, 1, 0.2, 0)
     assert L.ms_convt1d_out_len(t) == 256
-    t = lib.ConvTDesc(1, 64, 4096, 32, 4, 2, 1, 1, 0.2)
+    t = lib.ConvTDesc(1, 64, 4096, 32, 4, 2, 1, 1, 0.2, 0)
     assert L.ms_convt1d_out_len(t) == 8192
     assert L.ms_audio2mel_frames(22050, 1024, 256) == 84
     assert L.ms_audio2mel_frames(100, 1024, 256) == 0
     assert L.ms_reduce_workspace_bytes(10) >= 4
     # the dispatch names a kernel for every hot-path geometry
-    for args, which in (((32, 128, 2048, 128, 3, 1, 3, 3, 1, 0, 1, 0.2), 0),
-                        ((32, 1024, 32, 1024, 5, 1, 2, 1, 1, 0, 1, 0.2), 1),
-                        ((32, 256, 512, 1024, 41, 4, 20, 1, 64, 0, 1, 0.2), 2)):
+    for args, which in (((32, 128, 2048, 128, 3, 1, 3, 3, 1, 0, 1, 0.2, 0), 0),
+                        ((32, 1024, 32, 1024, 5, 1, 2, 1, 1, 0, 1, 0.2, 0), 1),
+                        ((32, 256, 512, 1024, 41, 4, 20, 1, 64, 0, 1, 0.2, 0), 2)):
         assert L.ms_conv1d_kernel_name(lib.ConvDesc(*args), which)
     # null pointers are rejected before anything is launched
     assert L.ms_conv1d_fwd(d, None, None, None, None, None, None, None, 0, None) == -1
@@ -65,5 +65,5 @@ def test_host_side_queries(lib):
 
 
 def test_struct_layout(lib):
-    assert ctypes.sizeof(lib.ConvDesc) == 12 * 4
-    assert ctypes.sizeof(lib.ConvTDesc) == 9 * 4
+    assert ctypes.sizeof(lib.ConvDesc) == 13 * 4
+    assert ctypes.sizeof(lib.ConvTDesc) == 10 * 4

@@ -1,0 +1,198 @@
+"""GPU parity of the weight-normed MelGAN (reference experiment/realmelgan.py)
+and of the ops it adds: activation in front of a conv, 1x1 convs, reflection-pad backward,
+AvgPool1d(4,2,1,count_include_pad=False), weight norm."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def _ref_conv(x, w, b, pad, dil, in_act, act, reflect, residual=None):
+    import torch.nn.functional as F
+    h = F.leaky_relu(x, 0.2) if in_act else x
+    if reflect and pad:
+        h = F.pad(h, (pad, pad), mode="reflect")
+        y = F.conv1d(h, w, b, dilation=dil)
+    else:
+        y = F.conv1d(h, w, b, padding=pad, dilation=dil)
+    if act == 1:
+        y = F.leaky_relu(y, 0.2)
+    elif act == 2:
+        y = torch.tanh(y)
+    return y if residual is None else y + residual
+
+
+CASES = [  # name, B, Cin, L, Cout, K, pad, dil, in_act, act, reflect, residual
+    ("res_conv3_c64", 2, 64, 300, 64, 3, 3, 3, 1, 1, True, False),
+    ("res_conv3_c256_d9", 2, 256, 70, 256, 3, 9, 9, 1, 1, True, False),
+    ("res_conv1x1_c128", 2, 128, 257, 128, 1, 0, 1, 0, 0, False, True),
+    ("shortcut_1x1_c32", 3, 32, 1031, 32, 1, 0, 1, 0, 0, False, False),
+    ("first_k7_reflect", 2, 128, 9, 512, 7, 3, 1, 0, 0, True, False),
+    ("last_k7_reflect_tanh", 2, 32, 515, 1, 7, 3, 1, 1, 2, True, False),
+    ("d_first_k15_reflect", 2, 1, 1025, 16, 15, 7, 1, 0, 1, True, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_ex_vs_torch_cpu(case):
+    from featuresynth._ops import functional as F_
+    name, B, Cin, L, Cout, K, pad, dil, in_act, act, reflect, with_res = case
+    rng = np.random.default_rng(abs(hash(name)) % (2 ** 31))
+    x = rng.standard_normal((B, Cin, L)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal((Cout,)) * 0.1).astype(np.float32)
+    res = rng.standard_normal((B, Cout, L)).astype(np.float32) if with_res else None
+    xt, wt, bt = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    rt = dev(res).requires_grad_(True) if with_res else None
+    y = F_.Conv1dExFn.apply(xt, wt, bt, rt, 1, pad, dil, 1, 1 if reflect else 0, act, in_act)
+    gy = rng.standard_normal(y.shape).astype(np.float32)
+    y.backward(dev(gy))
+    # double-precision CPU reference; LeakyReLU masks can only differ at rounding-level activations
+    xc, wc, bc = [torch.from_numpy(a).double().requires_grad_(True) for a in (x, w, b)]
+    rc = torch.from_numpy(res).double().requires_grad_(True) if with_res else None
+    yc = _ref_conv(xc, wc, bc, pad, dil, in_act, act, reflect, rc)
+    yc.backward(torch.from_numpy(gy).double())
+    assert rel_l2(host(y), yc.detach().numpy()) < 1e-5
+    assert rel_l2(host(xt.grad), xc.grad.numpy()) < 1e-3, "gx"
+    assert rel_l2(host(wt.grad), wc.grad.numpy()) < 1e-3, "gw"
+    assert rel_l2(host(bt.grad), bc.grad.numpy()) < 1e-3, "gb"
+    if with_res:
+        assert rel_l2(host(rt.grad), rc.grad.numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("L", [64, 67, 5])
+def test_avg_pool_421(L):
+    import torch.nn.functional as F
+    from featuresynth._ops import functional as F_
+    rng = np.random.default_rng(L)
+    x = rng.standard_normal((2, 3, L)).astype(np.float32)
+    xt = dev(x).requires_grad_(True)
+    y = F_.AvgPool421Fn.apply(xt)
+    xc = torch.from_numpy(x).requires_grad_(True)
+    yc = F.avg_pool1d(xc, 4, stride=2, padding=1, count_include_pad=False)
+    assert tuple(y.shape) == tuple(yc.shape)
+    gy = rng.standard_normal(yc.shape).astype(np.float32)
+    y.backward(dev(gy)); yc.backward(torch.from_numpy(gy))
+    assert rel_l2(host(y), yc.detach().numpy()) < 1e-6
+    assert rel_l2(host(xt.grad), xc.grad.numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(16, 1, 15), (256, 256, 3), (512, 256, 16), (1, 32, 7)])
+def test_weight_norm(shape):
+    from featuresynth._ops import functional as F_
+    rng = np.random.default_rng(sum(shape))
+    v = rng.standard_normal(shape).astype(np.float32)
+    g = (0.5 + rng.random((shape[0], 1, 1))).astype(np.float32)
+    vt, gt = dev(v).requires_grad_(True), dev(g).requires_grad_(True)
+    w = F_.WeightNormFn.apply(vt, gt)
+    vc, gc = torch.from_numpy(v).double().requires_grad_(True), torch.from_numpy(g).double().requires_grad_(True)
+    wc = gc * vc / vc.reshape(shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
+    gw = rng.standard_normal(shape).astype(np.float32)
+    w.backward(dev(gw)); wc.backward(torch.from_numpy(gw).double())
+    assert rel_l2(host(w), wc.detach().numpy()) < 1e-6
+    assert rel_l2(host(vt.grad), vc.grad.numpy()) < 1e-5
+    assert rel_l2(host(gt.grad), gc.grad.numpy()) < 1e-5
+
+
+def _nets():
+    from featuresynth._synthetic import module_param_shapes, synthetic_state_dict
+    from featuresynth.experiment import realmelgan as R
+    g, d = R.Generator(128, 32, 3), R.Discriminator(3, 16, 4, 4)
+    gsd = synthetic_state_dict(module_param_shapes(g), seed=21, weight_scale=0.3, bias_scale=0.05)
+    dsd = synthetic_state_dict(module_param_shapes(d), seed=22, weight_scale=0.3, bias_scale=0.05)
+    g.load_state_dict({k: torch.from_numpy(v) for k, v in gsd.items()})
+    d.load_state_dict({k: torch.from_numpy(v) for k, v in dsd.items()})
+    return g.cuda(), d.cuda(), gsd, dsd
+
+
+def test_realmelgan_forward_golden(golden):
+    from featuresynth._synthetic import strided_sample, synthetic_samples
+    z = golden("realmelgan")
+    g, d, _, _ = _nets()
+    assert list(g.state_dict().keys()) == list(z["g_param_names"])
+    assert list(d.state_dict().keys()) == list(z["d_param_names"])
+    feat = np.random.default_rng(5).standard_normal((2, 128, 6)).astype(np.float32)
+    with torch.no_grad():
+        y = g(dev(feat))
+        feats, judges = d(dev(synthetic_samples(2, 2048, rank=9)), None)
+    assert tuple(y.shape) == z["g/y_ref32"].shape
+    e = rel_l2(host(y), z["g/y_ref32"])
+    print("RealMelGan generator rel-L2 vs reference: %.3e" % e)
+    assert e < 1e-4
+    assert len(feats) == 3 and all(len(f) == 6 for f in feats)
+    for s in range(3):
+        assert rel_l2(host(judges[s]), z["d/j%d_ref32" % s]) < 1e-4
+        for i in range(6):
+            assert tuple(feats[s][i].shape) == tuple(z["d/f%d_%d_shape" % (s, i)])
+            assert rel_l2(strided_sample(host(feats[s][i])), z["d/f%d_%d_smp_ref32" % (s, i)]) < 1e-4
+
+
+def test_realmelgan_train_steps_golden(golden):
+    """One D-step and one G-step through featuresynth.train (the variant that trains at the
+    reference's HEAD) against the reference's trainers: losses and every parameter gradient."""
+    from featuresynth import loss as LS
+    from featuresynth._synthetic import strided_sample, synthetic_features, synthetic_samples
+    from featuresynth.experiment import realmelgan as R
+    from featuresynth.train import DiscriminatorTrainer, GeneratorTrainer
+    z = golden("realmelgan")
+    B, T = 2, 8
+    samples, feats = dev(synthetic_samples(B, T * 256, rank=3)), dev(synthetic_features(B, 128, T, rank=3))
+    for kind in ("d", "g"):
+        g, d, _, _ = _nets()
+        go = torch.optim.Adam(g.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        do = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        if kind == "d":
+            r = DiscriminatorTrainer(g, go, d, do, LS.mel_gan_disc_loss).train(samples, feats)
+            assert abs(r["d_loss"] - float(z["step/d_loss"][0])) < 1e-4
+            net = d
+        else:
+            r = GeneratorTrainer(g, go, d, do, R.mel_gan_gen_loss).train(samples, feats)
+            ref = float(z["step/g_loss"][0])
+            assert abs(r["g_loss"] - ref) < 1e-4 * abs(ref)
+            assert rel_l2(strided_sample(r["fake"]), z["step/fake_smp"]) < 1e-4
+            net = g
+        worst = 0.0
+        for k, p in net.named_parameters():
+            e = rel_l2(strided_sample(host(p.grad)), z["step/%sgrad_smp/%s" % (kind, k)])
+            worst = max(worst, e)
+            assert e < 1e-2, (kind, k, e)      # deep LeakyReLU-mask flips, see oracle test
+        print("RealMelGan %s-step worst grad rel-L2 %.2e" % (kind, worst))
+
+
+def test_realmelgan_native_graph_path(monkeypatch):
+    """FlatAdam + hipGraph replay of the weight-normed variant walks the eager trajectory."""
+    import featuresynth as fs
+    from featuresynth import loss as LS
+    from featuresynth._synthetic import synthetic_features, synthetic_samples
+    from featuresynth.experiment import realmelgan as R
+    from featuresynth.train import DiscriminatorTrainer, GeneratorTrainer
+    B, T = 2, 4
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MSYNTH_GRAPH", mode)
+        g, d, _, _ = _nets()
+        go = fs.FlatAdam(g.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        do = fs.FlatAdam(d.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        dt = DiscriminatorTrainer(g, go, d, do, LS.mel_gan_disc_loss)
+        gt = GeneratorTrainer(g, go, d, do, R.mel_gan_gen_loss)
+        losses = []
+        for step in range(6):
+            s = dev(synthetic_samples(B, T * 256, rank=step))
+            f = dev(synthetic_features(B, 128, T, rank=step))
+            losses.append(dt.train(s, f)["d_loss"] if step % 2 == 0 else gt.train(s, f)["g_loss"])
+        if mode == "1":
+            assert dt._runner.graphs and gt._runner.graphs and not dt._runner.disabled
+        out[mode] = losses
+    for a, b in zip(out["0"], out["1"]):
+        assert abs(a - b) <= 1e-4 * abs(a) + 1e-6, (out["0"], out["1"])

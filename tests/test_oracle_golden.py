@@ -285,3 +285,53 @@ def test_torch_graph_matches_golden(golden):
     assert abs(r0["d_loss"] - zt["small/losses"][0]) < 1e-6
     assert abs(r1["g_loss"] - zt["small/losses"][1]) < 1e-5 * abs(zt["small/losses"][1]) + 1e-7
     assert rel_l2(strided_sample(r1["fake"]), zt["small/fake_smp"]) < 1e-5
+
+
+def test_realmelgan_oracle_matches_golden(golden):
+    """the torch-functional restatement of experiment/realmelgan.py against the
+    imported reference (forward passes, D-step / G-step losses and gradients)."""
+    import torch
+    from featuresynth._synthetic import (strided_sample, synthetic_features, synthetic_samples,
+                                         synthetic_state_dict)
+    from oracle import torch_graph_real as TR
+    z = golden("realmelgan")
+    from featuresynth.experiment import realmelgan as R
+    g, d = R.Generator(128, 32, 3), R.Discriminator(3, 16, 4, 4)
+    gshapes = [(k, tuple(v.shape)) for k, v in g.state_dict().items()]
+    dshapes = [(k, tuple(v.shape)) for k, v in d.state_dict().items()]
+    assert [k for k, _ in gshapes] == list(z["g_param_names"])      # drop-in state_dict keys
+    assert [k for k, _ in dshapes] == list(z["d_param_names"])
+    gsd = synthetic_state_dict(gshapes, seed=21, weight_scale=0.3, bias_scale=0.05)
+    dsd = synthetic_state_dict(dshapes, seed=22, weight_scale=0.3, bias_scale=0.05)
+    feat = np.random.default_rng(5).standard_normal((2, 128, 6)).astype(np.float32)
+    with torch.no_grad():
+        y = TR.generator(TR.to_params(gsd, False), torch.from_numpy(feat)).numpy()
+        feats, judges = TR.discriminator(TR.to_params(dsd, False), torch.from_numpy(synthetic_samples(2, 2048, rank=9)))
+    assert rel_l2(y, z["g/y_ref32"]) < 1e-5
+    for s in range(3):
+        assert rel_l2(judges[s].numpy(), z["d/j%d_ref32" % s]) < 1e-5
+        for i in range(6):
+            assert tuple(feats[s][i].shape) == tuple(z["d/f%d_%d_shape" % (s, i)])
+            assert rel_l2(strided_sample(feats[s][i].numpy()), z["d/f%d_%d_smp_ref32" % (s, i)]) < 1e-5
+    B, T = 2, 8
+    samples = torch.from_numpy(synthetic_samples(B, T * 256, rank=3))
+    feats_in = torch.from_numpy(synthetic_features(B, 128, T, rank=3))
+    gp, dp = TR.to_params(gsd), TR.to_params(dsd)
+    fake = TR.generator(gp, feats_in)
+    ff, fj = TR.discriminator(dp, fake)
+    rf, rj = TR.discriminator(dp, samples)
+    dl = TR.disc_loss(rj, fj)
+    assert abs(dl.item() - float(z["step/d_loss"][0])) < 1e-5
+    dl.backward()
+    for k in dp:
+        assert rel_l2(strided_sample(dp[k].grad.numpy()), z["step/dgrad_smp/" + k]) < 2e-3, k
+    gp, dp = TR.to_params(gsd), TR.to_params(dsd)
+    fake = TR.generator(gp, feats_in)
+    ff, fj = TR.discriminator(dp, fake)
+    rf, rj = TR.discriminator(dp, samples)
+    gl = TR.gen_loss(rf, ff, fj)
+    assert abs(gl.item() - float(z["step/g_loss"][0])) < 1e-5 * abs(float(z["step/g_loss"][0]))
+    gl.backward()
+    for k in gp:
+        # LeakyReLU-mask flips at rounding-level activations accumulate through ~30 layers
+        assert rel_l2(strided_sample(gp[k].grad.numpy()), z["step/ggrad_smp/" + k]) < 1e-2, k

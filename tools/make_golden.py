@@ -369,10 +369,67 @@ def audio2mel():
     print("audio2mel: logmel80", out["logmel80"].shape)
 
 
+# ------------------------------------------------------------------ realmelgan
+
+def realmelgan():
+    """experiment/realmelgan.py (weight-normed MelGAN): forward passes and one
+    D-step + one G-step of the reference's own trainers."""
+    rm = ref_import.load_realmelgan()
+    ns = ref_import.load_reference()
+    out = {}
+    g = rm.Generator(128, 32, 3)
+    d = rm.Discriminator(3, 16, 4, 4)
+    gshapes, dshapes = SYN.module_param_shapes(g), SYN.module_param_shapes(d)
+    out["g_param_names"] = np.array([k for k, _ in gshapes])
+    out["d_param_names"] = np.array([k for k, _ in dshapes])
+    load_sd(g, SYN.synthetic_state_dict(gshapes, seed=21, weight_scale=0.3, bias_scale=0.05))
+    load_sd(d, SYN.synthetic_state_dict(dshapes, seed=22, weight_scale=0.3, bias_scale=0.05))
+    feat = np.random.default_rng(5).standard_normal((2, 128, 6)).astype(np.float32)
+    with torch.no_grad():
+        y = g(torch.from_numpy(feat))
+        out["g/y_ref32"] = t2n(y)
+        out["g/y_ref64"] = t2n(copy.deepcopy(g).double()(torch.from_numpy(feat).double()))
+        x = SYN.synthetic_samples(2, 2048, rank=9)
+        feats, judges = d(torch.from_numpy(x), None)
+        feats64, judges64 = copy.deepcopy(d).double()(torch.from_numpy(x).double(), None)
+    for s in range(3):
+        out["d/j%d_ref32" % s] = t2n(judges[s])
+        out["d/j%d_ref64" % s] = t2n(judges64[s])
+        for i in range(6):
+            out["d/f%d_%d_shape" % (s, i)] = np.array(feats[s][i].shape, np.int64)
+            out["d/f%d_%d_smp_ref32" % (s, i)] = SYN.strided_sample(t2n(feats[s][i]))
+            out["d/f%d_%d_smp_ref64" % (s, i)] = SYN.strided_sample(t2n(feats64[s][i]))
+    # one D-step and one G-step from the same parameters (fresh copies), reference trainers
+    B, T = 2, 8
+    samples = torch.from_numpy(SYN.synthetic_samples(B, T * 256, rank=3))
+    feats_in = torch.from_numpy(SYN.synthetic_features(B, 128, T, rank=3))
+    for kind in ("d", "g"):
+        g2, d2 = copy.deepcopy(g), copy.deepcopy(d)
+        go = torch.optim.Adam(g2.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        do = torch.optim.Adam(d2.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        if kind == "d":
+            tr = ns.train.DiscriminatorTrainer(g2, go, d2, do, rm.mel_gan_disc_loss)
+            r = tr.train(samples, feats_in)
+            out["step/d_loss"] = np.array([r["d_loss"]])
+            net = d2
+        else:
+            tr = ns.train.GeneratorTrainer(g2, go, d2, do, rm.mel_gan_gen_loss)
+            r = tr.train(samples, feats_in)
+            out["step/g_loss"] = np.array([r["g_loss"]])
+            out["step/fake_smp"] = SYN.strided_sample(r["fake"])
+            net = g2
+        for k, p in net.named_parameters():
+            out["step/%sgrad_sum/%s" % (kind, k)] = summary(t2n(p.grad))
+            out["step/%sgrad_smp/%s" % (kind, k)] = SYN.strided_sample(t2n(p.grad))
+    np.savez_compressed(os.path.join(OUT, "realmelgan.npz"), **out)
+    print("realmelgan: |y|max %.4g, d_loss %.6f, g_loss %.6f" % (np.abs(out["g/y_ref32"]).max(),
+                                                                 out["step/d_loss"][0], out["step/g_loss"][0]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_import.load_reference()
-    which = sys.argv[1:] or ["ops", "g", "d", "train", "mel"]
+    which = sys.argv[1:] or ["ops", "g", "d", "train", "mel", "real"]
     if "ops" in which:
         ops_tiny(ns)
     if "g" in which:
@@ -383,6 +440,8 @@ def main():
         train(ns)
     if "mel" in which:
         audio2mel()
+    if "real" in which:
+        realmelgan()
 
 
 if __name__ == "__main__":

@@ -72,6 +72,23 @@ def load_reference():
     return ns
 
 
+def load_realmelgan():
+    """The reference's experiment/realmelgan.py.  Its module-level imports of
+    the data layer (..audio, .experiment, ..feature, zounds.SR22050) are satisfied with inert stubs;
+    the model classes and losses are the unmodified reference code."""
+    load_reference()
+    for name, attrs in (("featuresynth.audio", {"RawAudio": object}),
+                        ("featuresynth.experiment.experiment", {"Experiment": object}),
+                        ("featuresynth.feature", {"audio": None, "spectrogram": None})):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for k, v in attrs.items():
+                setattr(m, k, v)
+            sys.modules[name] = m
+    sys.modules["zounds"].SR22050 = lambda: 22050
+    return importlib.import_module("featuresynth.experiment.realmelgan")
+
+
 def unload_reference():
     for k in [k for k in sys.modules if k == "featuresynth" or k.startswith("featuresynth.")]:
         del sys.modules[k]
