@@ -268,3 +268,71 @@ def test_full_size_properties():
         _, fj = d(fake)
         dl = LS.mel_gan_disc_loss(j_all, fj)
         assert abs(dl.item() - 6.0) < 1e-2
+
+
+@pytest.mark.parametrize("B,T", [(1, 4), (3, 5), (2, 128)])
+def test_generator_lengths_vs_oracle(B, T):
+    """Fully-convolutional generator at the shortest input the reflection pad allows, an odd
+    batch/length, and the 4x inference length (experiment/experiment.py:223-229)."""
+    import torch as th
+    from featuresynth._synthetic import synthetic_features
+    from oracle import torch_graph as TG
+    g, _, gsd, _ = make_nets(dict(seed=7, weight_scale=0.05, bias_scale=0.05), dict(seed=7))
+    feats = synthetic_features(B, 80, T, rank=T)
+    with th.no_grad():
+        y = g(dev(feats))
+        ref = TG.generator(TG.to_params(gsd, False), th.from_numpy(feats)).numpy()
+    assert tuple(y.shape) == (B, 1, 256 * T)
+    assert rel_l2(host(y), ref) < 1e-4
+
+
+@pytest.mark.parametrize("B,L", [(1, 64), (3, 300), (2, 1000)])
+def test_discriminator_short_and_odd_inputs_vs_oracle(B, L):
+    """Very short / odd windows: pooled scales go down to a handful of samples (K=41 > L)."""
+    import torch as th
+    from featuresynth._synthetic import synthetic_samples
+    from oracle import torch_graph as TG
+    _, d, _, dsd = make_nets(dict(seed=7), dict(seed=13, weight_scale=0.08, bias_scale=0.1))
+    x = synthetic_samples(B, L, rank=L)
+    with th.no_grad():
+        feats, judges = d(dev(x))
+        rf, rj = TG.discriminator(TG.to_params(dsd, False), th.from_numpy(x))
+    for s in range(3):
+        assert tuple(judges[s].shape) == tuple(rj[s].shape)
+        assert rel_l2(host(judges[s]), rj[s].numpy()) < 1e-4
+        for i in range(6):
+            assert tuple(feats[s][i].shape) == tuple(rf[s][i].shape)
+            assert rel_l2(host(feats[s][i]), rf[s][i].numpy()) < 1e-4
+
+
+def test_train_step_mel128_odd_batch_vs_torch_graph():
+    """A D-step and a G-step with 128 mel channels (experiment/melgan.py:23) and B=3 against the
+    torch-functional oracle's autograd."""
+    import torch as th
+    import featuresynth as fs
+    from featuresynth import loss as LS
+    from featuresynth._synthetic import synthetic_features, synthetic_samples
+    from featuresynth.train import DiscriminatorTrainer, GeneratorTrainer
+    from oracle import torch_graph as TG
+    B, T = 3, 5
+    samples, feats = synthetic_samples(B, T * 256, rank=1), synthetic_features(B, 128, T, rank=1)
+    for kind in ("d", "g"):
+        g, d, gsd, dsd = make_nets(dict(seed=7, bias_scale=0.02), dict(seed=8, bias_scale=0.02), mels=128)
+        go = fs.FlatAdam(g.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        do = fs.FlatAdam(d.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        gp, dp = TG.to_params(gsd), TG.to_params(dsd)
+        fake = TG.generator(gp, th.from_numpy(feats))
+        ff, fj = TG.discriminator(dp, fake)
+        rf, rj = TG.discriminator(dp, th.from_numpy(samples))
+        if kind == "d":
+            ref = TG.disc_loss(rj, fj); ref.backward()
+            loss = DiscriminatorTrainer(g, go, d, do, LS.mel_gan_disc_loss).train(dev(samples), dev(feats))["d_loss"]
+            net, refp = d, dp
+        else:
+            ref = TG.gen_loss(rf, ff, fj); ref.backward()
+            loss = GeneratorTrainer(g, go, d, do, LS.mel_gan_gen_loss).train(dev(samples), dev(feats))["g_loss"]
+            net, refp = g, gp
+        assert abs(loss - ref.item()) <= 1e-4 * abs(ref.item())
+        for k, p in net.named_parameters():
+            r = refp[k].grad.numpy()
+            assert rel_l2(host(p.grad), r) < 2e-3 or np.linalg.norm(r) < 1e-12, (kind, k)
