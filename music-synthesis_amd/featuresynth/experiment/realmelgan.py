@@ -24,6 +24,7 @@ from .._ops import lib as L
 from ..loss import hinge_generator_loss, mel_gan_disc_loss  # noqa: F401  (re-exported like the reference)
 from ..loss.loss import mel_gan_feature_loss as _unused  # noqa: F401
 from ..util.modules import Fused
+from .experiment import Experiment as _Experiment
 
 import torch
 
@@ -216,3 +217,25 @@ def mel_gan_gen_loss(real_features, fake_features, real_judgements, fake_judgeme
         term = gan_loss(f)
         j_loss = term if j_loss is None else j_loss + term
     return j_loss + feature_loss_weight * real_mel_gan_feature_loss(real_features, fake_features)
+
+
+class RealMelGanExperiment(_Experiment):
+    """Hyper-parameters of realmelgan.py:223-253 (128 mels, ngf 32, 3 residual layers, 3 x
+    NLayerDiscriminator(16, 4, 4), Adam 1e-4) minus the file-based feature functions."""
+
+    def __init__(self, optimizer="flat"):
+        n_mels, size, total_samples = 128, 32, 8192
+        super().__init__(
+            Generator(n_mels, size, n_residual_layers=3),
+            Discriminator(num_D=3, ndf=16, n_layers=4, downsampling_factor=4),
+            learning_rate=1e-4,
+            feature_size=size,
+            generator_loss=mel_gan_gen_loss,
+            discriminator_loss=mel_gan_disc_loss,
+            g_init=weights_init,
+            d_init=weights_init,
+            total_samples=total_samples,
+            feature_channels=n_mels,
+            samplerate=22050,
+            inference_sequence_factor=4,
+            optimizer=optimizer)

@@ -336,3 +336,36 @@ def test_train_step_mel128_odd_batch_vs_torch_graph():
         for k, p in net.named_parameters():
             r = refp[k].grad.numpy()
             assert rel_l2(host(p.grad), r) < 2e-3 or np.linalg.norm(r) < 1e-12, (kind, k)
+
+
+def test_training_loop_checkpoint_resume(tmp_path, monkeypatch):
+    """featuresynth.train.training_loop over an Experiment: alternating D/G
+    steps, logger plumbing, checkpoint + resume including the optimizer state."""
+    import torch as th
+    import featuresynth.experiment as E
+    from featuresynth.train import training_loop
+    monkeypatch.chdir(tmp_path)
+    device = th.device("cuda", 0)
+    th.manual_seed(0)
+    exp = E.MultiScaleMelGanExperiment(n_mels=80).to(device)
+    seen = []
+
+    def logger(experiment, batch, result, i, elapsed):
+        seen.append(sorted(result))
+        return {"iter": i}
+
+    logs = list(training_loop(exp.synthetic_batch_stream(2, n_batches=6), exp, device, [logger]))
+    assert [l[0] for l in logs] == list(range(6)) and logs[-1][2] == {"iter": 5}
+    assert seen == [["d_loss"], ["fake", "g_loss"]] * 3
+    exp.checkpoint("ck_", with_optimizers=True)
+    th.manual_seed(1)
+    exp2 = E.MultiScaleMelGanExperiment(n_mels=80).to(device)
+    exp2.resume("ck_", with_optimizers=True)
+    assert exp2._d_optim.step_count() == 3 and exp2._g_optim.step_count() == 3
+    s, f = next(exp.synthetic_batch_stream(2))
+    s, f = dev(s), dev(f)
+    a = exp.discriminator_trainer(s, f)["d_loss"]
+    b = exp2.discriminator_trainer(s, f)["d_loss"]
+    assert abs(a - b) < 1e-6
+    for (k, p), (_, q) in zip(exp.discriminator.state_dict().items(), exp2.discriminator.state_dict().items()):
+        assert np.abs(host(p) - host(q)).max() < 1e-7, k

@@ -110,3 +110,36 @@ def test_trainer_surface():
         assert list(inspect.signature(cls.__init__).parameters)[1:] == [
             "generator", "g_optim", "discriminator", "d_optim", "loss", "sub_loss"]
     assert inspect.isgeneratorfunction(training_loop)
+
+
+def test_experiment_surface(tmp_path, monkeypatch):
+    """the experiment object evaluate.py instantiates by name
+    (evaluate.py:52 `getattr(featuresynth.experiment, name)()`)."""
+    import featuresynth.experiment as E
+    from featuresynth.optim import FlatAdam
+    exp = getattr(E, "MultiScaleMelGanExperiment")()
+    assert exp._name() == "multiscalemelgan"
+    assert exp._gen_name("p_") == "trained_models/p_multiscalemelgan_gen.dat"
+    assert exp.feature_spec == {"audio": (8192, 1), "spectrogram": (32, 128)}
+    assert exp.inference_spec == {"audio": (32768, 1), "spectrogram": (128, 128)}
+    assert isinstance(exp._g_optim, FlatAdam) and exp._g_optim.param_groups[0]["betas"] == (0.5, 0.9)
+    assert exp._g_optim.param_groups[0]["lr"] == 1e-4
+    steps = [next(exp.training_steps) for _ in range(4)]
+    assert steps[0] == exp.discriminator_trainer and steps[1] == exp.generator_trainer   # D first
+    assert steps[2] == steps[0]
+    w = exp.generator.main[1].weight
+    assert abs(float(w.std()) - 0.02) < 2e-3                     # weights_init applied
+    with pytest.raises(NotImplementedError):
+        exp.batch_stream("/data", "*.wav", 4)
+    s, f = next(exp.synthetic_batch_stream(3))
+    assert s.shape == (3, 1, 8192) and f.shape == (3, 128, 32) and s.dtype == np.float32
+    ps, pf = exp.preprocess_batch((s, f))
+    assert ps.shape == s.shape and pf.shape == f.shape
+    monkeypatch.chdir(tmp_path)
+    exp.checkpoint("t_")                                           # CPU state_dicts round-trip
+    exp2 = E.MultiScaleMelGanExperiment()
+    exp2.resume("t_")
+    for (k, a), (_, b) in zip(exp.generator.state_dict().items(), exp2.generator.state_dict().items()):
+        assert torch.equal(a, b), k
+    real = E.RealMelGanExperiment(optimizer="torch")
+    assert real._name() == "realmelgan" and isinstance(real._d_optim, torch.optim.Adam)
