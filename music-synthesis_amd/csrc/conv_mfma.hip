@@ -16,6 +16,7 @@
 // in HBM) tiles are staged in LDS; time is the lane-fast index of every global access, so
 // activation traffic is coalesced along contiguous audio frames.  Global loads of chunk c+1 are
 // in flight while the MFMAs of chunk c run.
+#include <cstdlib>
 #include "conv_mfma.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -222,6 +223,8 @@ struct RowP {
     int B, CK, L, M, dil, off0, pad_mode, act, in_act, KG;
     int Lt, R, SS, RSZ, tiles_per_row;   // segment length, rows per tile, LDS segment/row strides
     float slope;
+    int CKs;                             // input channels per split-K slice (== CK: no split)
+    long long zstride;                   // floats between the partial-output slabs of two slices
 };
 
 template <int WGM, int WGN, int TM, int TN, int K, int CC, bool HAS_ACT, int EPI_S, int IN_S>
@@ -346,14 +349,17 @@ __global__ __launch_bounds__(256) void k_conv_mfma_rows(RowP p, const float* __r
         }
     };
 
-    const int nchunks = p.CK / CC;
-    gload(0);
+    // split-K: slice z contracts channels [z*CKs, min((z+1)*CKs, CK)) into its own output slab
+    const int cbeg = blockIdx.z * p.CKs;
+    const int nchunks = ((cbeg + p.CKs < p.CK ? cbeg + p.CKs : p.CK) - cbeg) / CC;
+    Y += (size_t)blockIdx.z * p.zstride;
+    gload(cbeg);
     lstore();
     __syncthreads();
     const int arow = (wm * TM * 32 + (lane & 31)) * AS + h;
     for (int ch = 0; ch < nchunks; ++ch) {
         const bool more = ch + 1 < nchunks;
-        if (more) gload((ch + 1) * CC);
+        if (more) gload(cbeg + (ch + 1) * CC);
 #pragma unroll
         for (int q = 0; q < KK / 2; ++q) {
             constexpr int dummy = 0; (void)dummy;
@@ -464,6 +470,27 @@ __global__ __launch_bounds__(256) void k_conv_mfma_rows(RowP p, const float* __r
                 }
             }
         }
+    }
+}
+
+// Epilogue of a split-K row-tile launch: sums the slices' slabs in slice order (deterministic) and
+// applies what the fused epilogue would have: bias (channel = (i / rowlen) % nch), activation,
+// the pre-residual copy and the residual add.
+__global__ __launch_bounds__(256) void k_rows_split_finish(const float* __restrict__ slabs, int ns,
+                                                          size_t zstride,
+                                                          const float* __restrict__ bias, int nch,
+                                                          int rowlen, int act, float slope,
+                                                          const float* __restrict__ res,
+                                                          float* __restrict__ Y,
+                                                          float* __restrict__ Yact, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        float v = slabs[i];
+        for (int z = 1; z < ns; ++z) v += slabs[(size_t)z * zstride + i];
+        if (bias) v += bias[(i / rowlen) % nch];
+        v = ms_apply_act(v, act, slope);
+        if (Yact) Yact[i] = v;
+        if (res) v += res[i];
+        Y[i] = v;
     }
 }
 
@@ -1057,6 +1084,7 @@ bool make_rowp(RowP* q, RowCfg cfg, int B, int CK, int L, int M, int K, int dil,
     else { q->Lt = L; q->R = bn / L; q->tiles_per_row = 1; }
     q->SS = q->Lt + H;
     q->RSZ = q->R * q->SS;
+    q->CKs = CK; q->zstride = 0;
     return q->RSZ <= 512;
 }
 
@@ -1070,7 +1098,7 @@ int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, 
     int bm, bn;
     row_tile(cfg, &bm, &bn);
     const unsigned gx = p.R == 1 ? (unsigned)(p.B * p.tiles_per_row) : (unsigned)((p.B + p.R - 1) / p.R);
-    dim3 grid(gx, (unsigned)((p.M + bm - 1) / bm));
+    dim3 grid(gx, (unsigned)((p.M + bm - 1) / bm), (unsigned)((p.CK + p.CKs - 1) / p.CKs));
     const size_t lds = (size_t)(bm * (CC * K + 1) + CC * p.RSZ) * sizeof(float);
     if (lds > 64 * 1024) return MS_ERR_UNSUPPORTED;
     switch (cfg) {
@@ -1123,6 +1151,73 @@ const char* row_kname(RowCfg c, int K, bool act, int CK) {
     return buf;
 }
 
+// ---- split-K for row-tile launches whose (M, N) tiling alone leaves most of the 256 CUs idle
+// (the discriminator's 1024->1024 k5 conv at L = 32 / 17 / 9, the generator's first transposed
+// conv): the contraction is cut into ns channel slices (grid.z), each slice writes a raw partial
+// slab into the workspace and k_rows_split_finish sums them in slice order and applies the epilogue.
+struct RowSplit {
+    int ns, cks;
+    size_t out_floats;
+};
+
+int rows_wgs(RowCfg cfg, const RowP& p) {
+    int bm, bn;
+    row_tile(cfg, &bm, &bn);
+    const int gx = p.R == 1 ? p.B * p.tiles_per_row : (p.B + p.R - 1) / p.R;
+    return gx * ((p.M + bm - 1) / bm);
+}
+
+int split_max_wgs() {
+    const char* e = getenv("MSYNTH_SPLIT_WGS");   // tuning / test switch (0 disables split-K)
+    return e ? atoi(e) : 192;
+}
+
+RowSplit plan_rows_split(RowCfg cfg, const RowP& p, int CC) {
+    RowSplit q;
+    q.ns = 1; q.cks = p.CK; q.out_floats = (size_t)p.B * p.M * p.L;
+    const int wgs = rows_wgs(cfg, p);
+    const int nchunks = p.CK / CC;
+    if (wgs > split_max_wgs() || nchunks < 8) return q;
+    int ns = ms_ceil_div(512, wgs);
+    if (ns > nchunks / 4) ns = nchunks / 4;
+    if (ns > 16) ns = 16;
+    while (ns > 1 && (size_t)ns * q.out_floats * sizeof(float) > ((size_t)64 << 20)) --ns;
+    if (ns <= 1) return q;
+    q.cks = ms_ceil_div(nchunks, ns) * CC;
+    q.ns = ms_ceil_div(p.CK, q.cks);
+    return q;
+}
+
+size_t rows_split_ws(RowCfg cfg, const RowP& p, int CC) {
+    const RowSplit q = plan_rows_split(cfg, p, CC);
+    return q.ns > 1 ? (size_t)q.ns * q.out_floats * sizeof(float) : 0;
+}
+
+// launch(rowp, bias, res, Y, Yact) runs the row-tile kernel; nch / rowlen describe the bias index
+template <class F>
+int rows_maybe_split(RowCfg cfg, const RowP& r, int CC, int nch, int rowlen, const float* bias,
+                     const float* res, float* Y, float* Yact, void* slab_ws, size_t slab_bytes,
+                     hipStream_t s, F launch) {
+    const RowSplit q = plan_rows_split(cfg, r, CC);
+    if (q.ns <= 1 || !slab_ws || slab_bytes < (size_t)q.ns * q.out_floats * sizeof(float))
+        return launch(r, bias, res, Y, Yact);
+    RowP z = r;
+    z.CKs = q.cks; z.zstride = (long long)q.out_floats; z.act = MS_ACT_NONE;
+    float* slabs = (float*)slab_ws;
+    const int rc = launch(z, (const float*)nullptr, (const float*)nullptr, slabs, (float*)nullptr);
+    if (rc != MS_OK) return rc;
+    unsigned nb = (unsigned)((q.out_floats + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_rows_split_finish, dim3(nb), dim3(256), 0, s, slabs, q.ns, q.out_floats,
+                       bias, nch, rowlen, r.act, r.slope, res, Y, Yact, q.out_floats);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int rows_cc_eff(int K, int CK) { return row_cc(K) * (row_deep(K, CK) ? 2 : 1); }
+
+size_t align16(size_t n) { return (n + 15) & ~(size_t)15; }
+
 bool rows_ok(const ConvP& p, bool bwd) {
     const int M = bwd ? p.Cin : p.Cout, CK = bwd ? p.Cout : p.Cin;
     if (!rows_applicable(M, CK, p.K, p.Lin)) return false;
@@ -1162,16 +1257,29 @@ bool msm_convt_fwd_applicable(const ConvP& p) {
     RowP q;
     return make_rowp(&q, pick_row_cfg(p.Cin * S, p.B, p.Lout), p.B, p.Cout, p.Lout, p.Cin * S, 3, 1, -1, 0, 0, 0, 0.f);
 }
-size_t msm_fwd_ws(const ConvP&) { return 0; }
+size_t msm_fwd_ws(const ConvP& p) {
+    if (!rows_ok(p, false)) return 0;
+    RowP r;
+    const RowCfg cfg = pick_row_cfg(p.Cout, p.B, p.Lin);
+    make_rowp(&r, cfg, p.B, p.Cin, p.Lin, p.Cout, p.K, p.dil, -p.pad, p.pad_mode, 0, 0, 0.f);
+    return rows_split_ws(cfg, r, rows_cc_eff(p.K, p.Cin));
+}
 size_t msm_bwd_data_ws(const ConvP& p) {
-    return rows_ok(p, true) ? (size_t)p.Cin * p.Cout * p.K * sizeof(float) : 0;
+    if (!rows_ok(p, true)) return 0;
+    RowP r;
+    const RowCfg cfg = pick_row_cfg(p.Cin, p.B, p.Lin);
+    make_rowp(&r, cfg, p.B, p.Cout, p.Lin, p.Cin, p.K, p.dil, 0, 0, 0, 0, 0.f);
+    return align16((size_t)p.Cin * p.Cout * p.K * sizeof(float)) + rows_split_ws(cfg, r, rows_cc_eff(p.K, p.Cout));
 }
 size_t msm_bwd_weight_ws(const ConvP& p) {
     const WgradPlan q = plan_wgrad(p);
     return (size_t)q.nsplit * q.stride_floats * sizeof(float);
 }
 size_t msm_convt_fwd_ws(const ConvP& p) {
-    return (size_t)p.Cin * p.stride * p.Cout * 3 * sizeof(float);
+    RowP r;
+    const RowCfg cfg = pick_row_cfg(p.Cin * p.stride, p.B, p.Lout);
+    make_rowp(&r, cfg, p.B, p.Cout, p.Lout, p.Cin * p.stride, 3, 1, -1, 0, 0, 0, 0.f);
+    return align16((size_t)p.Cin * p.stride * p.Cout * 3 * sizeof(float)) + rows_split_ws(cfg, r, row_cc(3));
 }
 
 const char* msm_fwd_name(const ConvP& p) {
@@ -1196,13 +1304,18 @@ const char* msm_convt_fwd_name(const ConvP& p) {
 
 int msm_conv1d_fwd(const ConvP& p, const float* x, const float* x_act, int x_act_kind,
                    const float* w, const float* bias, const float* residual, float* y,
-                   float* y_act, void*, size_t, hipStream_t s) {
+                   float* y_act, void* ws, size_t ws_bytes, hipStream_t s) {
     if (rows_ok(p, false) && (((uintptr_t)w) & 15) == 0) {
         RowP r;
         const RowCfg cfg = pick_row_cfg(p.Cout, p.B, p.Lin);
         make_rowp(&r, cfg, p.B, p.Cin, p.Lin, p.Cout, p.K, p.dil, -p.pad, p.pad_mode, p.act,
                   x_act_kind, p.slope);
-        return launch_rows(p.K, cfg, r, x, x_act, w, bias, residual, y, y_act, s);
+        const int K = p.K;
+        return rows_maybe_split(cfg, r, rows_cc_eff(K, p.Cin), p.Cout, p.Lin, bias, residual, y, y_act,
+                                ws, ws_bytes, s,
+                                [&](const RowP& rp, const float* b_, const float* r_, float* y_, float* ya_) {
+                                    return launch_rows(K, cfg, rp, x, x_act, w, b_, r_, y_, ya_, s);
+                                });
     }
     IgP q;
     q.B = p.B; q.CK = p.Cin; q.L = p.Lin; q.M = p.Cout; q.dil = p.dil; q.off0 = -p.pad;
@@ -1216,6 +1329,7 @@ int msm_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, con
     if (rows_ok(p, true) && ws && ws_bytes >= msm_bwd_data_ws(p) && (((uintptr_t)ws) & 15) == 0) {
         float* wt = (float*)ws;
         const size_t total = (size_t)p.Cin * p.Cout * p.K;
+        const size_t wbytes = align16(total * sizeof(float));
         unsigned nb = (unsigned)((total + 255) / 256);
         if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(k_transpose_flip_w, dim3(nb), dim3(256), 0, s, w, wt, p.Cout, p.Cin, p.K);
@@ -1224,7 +1338,12 @@ int msm_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, con
         const RowCfg cfg = pick_row_cfg(p.Cin, p.B, p.Lin);
         make_rowp(&r, cfg, p.B, p.Cout, p.Lin, p.Cin, p.K, p.dil, p.pad - (p.K - 1) * p.dil,
                   MS_PAD_ZERO, MS_ACT_NONE, p.act, p.slope);
-        return launch_rows(p.K, cfg, r, gy, y_act, wt, nullptr, gx_add, gx, nullptr, s);
+        const int K = p.K;
+        return rows_maybe_split(cfg, r, rows_cc_eff(K, p.Cout), p.Cin, p.Lin, nullptr, gx_add, gx, nullptr,
+                                (char*)ws + wbytes, ws_bytes - wbytes, s,
+                                [&](const RowP& rp, const float* b_, const float* r_, float* y_, float* ya_) {
+                                    return launch_rows(K, cfg, rp, gy, y_act, wt, b_, r_, y_, ya_, s);
+                                });
     }
     IgP q;
     q.B = p.B; q.CK = p.Cout; q.L = p.Lin; q.M = p.Cin; q.dil = p.dil;
@@ -1295,13 +1414,19 @@ int msm_convt1d_fwd(const ConvP& p, const float* x, const float* w, const float*
     RowP r;
     const RowCfg cfg = pick_row_cfg(CoutT * S, p.B, LinT);
     make_rowp(&r, cfg, p.B, CinT, LinT, CoutT * S, 3, 1, -1, MS_PAD_ZERO, p.act, MS_ACT_NONE, p.slope);
-    if (p.in_act) {   // LeakyReLU in front of the transposed conv: applied to x on load
-        r.in_act = MS_MOD_LRELU_FWD;
-        if (S == 8) return launch_rows_k<3, true, 8>(cfg, r, x, x, wp, bias, nullptr, y, nullptr, s);
-        return launch_rows_k<3, true, 2>(cfg, r, x, x, wp, bias, nullptr, y, nullptr, s);
-    }
-    if (S == 8) return launch_rows_k<3, false, 8>(cfg, r, x, nullptr, wp, bias, nullptr, y, nullptr, s);
-    return launch_rows_k<3, false, 2>(cfg, r, x, nullptr, wp, bias, nullptr, y, nullptr, s);
+    const size_t wbytes = align16(total * sizeof(float));
+    const bool ia = p.in_act != 0;   // LeakyReLU in front of the transposed conv: applied to x on load
+    if (ia) r.in_act = MS_MOD_LRELU_FWD;
+    return rows_maybe_split(cfg, r, row_cc(3), CoutT, LinT * S, bias, nullptr, y, nullptr,
+                            (char*)ws + wbytes, ws_bytes - wbytes, s,
+                            [&](const RowP& rp, const float* b_, const float* r_, float* y_, float* ya_) {
+                                if (ia) {
+                                    if (S == 8) return launch_rows_k<3, true, 8>(cfg, rp, x, x, wp, b_, r_, y_, ya_, s);
+                                    return launch_rows_k<3, true, 2>(cfg, rp, x, x, wp, b_, r_, y_, ya_, s);
+                                }
+                                if (S == 8) return launch_rows_k<3, false, 8>(cfg, rp, x, nullptr, wp, b_, r_, y_, ya_, s);
+                                return launch_rows_k<3, false, 2>(cfg, rp, x, nullptr, wp, b_, r_, y_, ya_, s);
+                            });
 }
 
 // ---- ConvTranspose1d backward (p = mirrored conv: Cin_T = p.Cout, Cout_T = p.Cin, Lin_T = p.Lout)
@@ -1315,7 +1440,10 @@ bool msm_convt_bwd_applicable(const ConvP& p) {
 }
 
 size_t msm_convt_bwd_data_ws(const ConvP& p) {
-    return (size_t)p.Cout * p.Cin * p.stride * 3 * sizeof(float);
+    RowP r;
+    const RowCfg cfg = pick_row_cfg(p.Cout, p.B, p.Lout);
+    make_rowp(&r, cfg, p.B, p.Cin * p.stride, p.Lout, p.Cout, 3, 1, -1, 0, 0, 0, 0.f);
+    return align16((size_t)p.Cout * p.Cin * p.stride * 3 * sizeof(float)) + rows_split_ws(cfg, r, row_cc(3));
 }
 
 const char* msm_convt_bwd_data_name(const ConvP& p) {
@@ -1343,8 +1471,13 @@ int msm_convt1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, co
     // the activation operand aliases the data when absent (pass-through kind)
     const float* ya = y_act ? y_act : gy;
     if (!y_act) r.in_act = MS_ACT_NONE;
-    if (S == 8) return launch_rows_k<3, true, 0, 8>(cfg, r, gy, ya, wq, nullptr, nullptr, gx, nullptr, s);
-    return launch_rows_k<3, true, 0, 2>(cfg, r, gy, ya, wq, nullptr, nullptr, gx, nullptr, s);
+    const size_t wbytes = align16(total * sizeof(float));
+    return rows_maybe_split(cfg, r, row_cc(3), CinT, LinT, nullptr, nullptr, gx, nullptr,
+                            (char*)ws + wbytes, ws_bytes - wbytes, s,
+                            [&](const RowP& rp, const float* b_, const float* r_, float* y_, float* ya_) {
+                                if (S == 8) return launch_rows_k<3, true, 0, 8>(cfg, rp, gy, ya, wq, b_, r_, y_, ya_, s);
+                                return launch_rows_k<3, true, 0, 2>(cfg, rp, gy, ya, wq, b_, r_, y_, ya_, s);
+                            });
 }
 
 struct ConvtWgradPlan {
