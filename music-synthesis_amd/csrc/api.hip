@@ -3,6 +3,7 @@
 #include "ms_common.h"
 #include "conv_mfma.h"
 #include "gconv_mfma.h"
+#include "conv_thin.h"
 
 namespace {
 
@@ -83,6 +84,7 @@ int ms_conv1d_fwd(const ms_conv1d_desc* d, const float* x, const float* w, const
     if (msm_fwd_applicable(p))
         return msm_conv1d_fwd(p, x, xa, xk, w, bias, residual, y, y_act, workspace, workspace_bytes, s);
     if (msg_fwd_applicable(p) && !residual && !y_act && !p.in_act) return msg_conv1d_fwd(p, x, w, bias, y, s);
+    if (mst_fwd_applicable(p) && !y_act) return mst_conv1d_fwd(p, x, w, bias, residual, y, s);
     return msk_conv1d_fwd_direct(p, x, xa, xk, w, bias, residual, y, y_act, s);
 }
 
@@ -102,6 +104,8 @@ int ms_conv1d_bwd_data(const ms_conv1d_desc* d, const float* gy, const float* y_
         rc = msm_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, workspace, workspace_bytes, s);
     else if (msg_bwd_data_applicable(p))
         rc = msg_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, s);
+    else if (mst_bwd_data_applicable(p) && !reflect)
+        rc = mst_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, s);
     else
         rc = msk_conv1d_bwd_data_direct(p, gy, y_act, w, nullptr, MS_ACT_NONE, gx_add, gx, s);
     if (rc != MS_OK || !reflect) return rc;
@@ -117,6 +121,8 @@ int ms_conv1d_bwd_weight(const ms_conv1d_desc* d, const float* x, const float* g
     hipStream_t s = (hipStream_t)stream;
     const float* xa = p.in_act ? x : nullptr;
     const int xk = p.in_act ? MS_MOD_LRELU_FWD : 0;
+    if (mst_bwd_weight_applicable(p))   // one-channel side: HBM-bound stream kernels
+        return mst_conv1d_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
     if (msm_bwd_weight_applicable(p))
         return msm_conv1d_bwd_weight(p, x, xa, xk, gy, y_act, p.act, gw, gb, beta, workspace,
                                      workspace_bytes, s);
@@ -131,9 +137,11 @@ size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which) {
     if (!make_conv(d, &p)) return 0;
     if (which == 0) return msm_fwd_applicable(p) ? msm_fwd_ws(p) : 0;
     if (which == 1) return msm_bwd_data_applicable(p) ? msm_bwd_data_ws(p) : 0;
-    if (which == 2)
+    if (which == 2) {
+        if (mst_bwd_weight_applicable(p)) return mst_bwd_weight_ws(p);
         return msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p)
                : (msg_bwd_weight_applicable(p) ? msg_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p));
+    }
     return 0;
 }
 
@@ -142,10 +150,14 @@ const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which) {
     if (!make_conv(d, &p)) return "";
     if (which == 0)
         return msm_fwd_applicable(p) ? msm_fwd_name(p)
-                                     : (msg_fwd_applicable(p) ? msg_fwd_name(p) : msk_conv1d_fwd_direct_name(p));
+               : (msg_fwd_applicable(p) ? msg_fwd_name(p)
+                  : (mst_fwd_applicable(p) ? mst_fwd_name(p) : msk_conv1d_fwd_direct_name(p)));
     if (which == 1)
         return msm_bwd_data_applicable(p) ? msm_bwd_data_name(p)
-               : (msg_bwd_data_applicable(p) ? msg_bwd_data_name(p) : msk_conv1d_bwd_data_direct_name(p));
+               : (msg_bwd_data_applicable(p) ? msg_bwd_data_name(p)
+                  : (mst_bwd_data_applicable(p) && p.pad_mode == MS_PAD_ZERO ? mst_bwd_data_name(p)
+                                                                              : msk_conv1d_bwd_data_direct_name(p)));
+    if (which == 2 && mst_bwd_weight_applicable(p)) return mst_bwd_weight_name(p);
     if (which == 2)
         return msm_bwd_weight_applicable(p) ? msm_bwd_weight_name(p)
                : (msg_bwd_weight_applicable(p) ? msg_bwd_weight_name(p) : msk_conv1d_bwd_weight_direct_name(p));

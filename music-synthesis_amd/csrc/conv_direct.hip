@@ -402,6 +402,37 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict
     }
 }
 
+// Same reduction for FEW outputs and MANY partial slabs (the 1-output-channel convs: 225 outputs,
+// up to 2048 slabs): one wave per output, lanes stride over the slabs (independent loads), fixed
+// shuffle tree.  The one-thread-per-output loop above is a serial chain of nsplit dependent
+// iterations -- 125 us for 225 outputs.
+__global__ __launch_bounds__(256) void k_reduce_partials_wave(const float* __restrict__ partial,
+                                                             size_t partial_stride, int nsplit,
+                                                             size_t wsize, int nbias,
+                                                             float* __restrict__ gw,
+                                                             float* __restrict__ gb, float beta) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 4 + wv;
+    if (i >= wsize + (size_t)nbias) return;          // wave-uniform
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = lane;
+    for (; z + 192 < nsplit; z += 256) {
+        const float a = partial[(size_t)z * partial_stride + i];
+        const float b = partial[(size_t)(z + 64) * partial_stride + i];
+        const float c = partial[(size_t)(z + 128) * partial_stride + i];
+        const float d = partial[(size_t)(z + 192) * partial_stride + i];
+        s0 += a; s1 += b; s2 += c; s3 += d;
+    }
+    for (; z < nsplit; z += 64) s0 += partial[(size_t)z * partial_stride + i];
+    float s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+        if (i < wsize) gw[i] = (beta != 0.f ? beta * gw[i] : 0.f) + s;
+        else if (gb) gb[i - wsize] = (beta != 0.f ? beta * gb[i - wsize] : 0.f) + s;
+    }
+}
+
 // out[c] = beta*out[c] + sum_{b,t} g[b,c,t] * act'(y_act[b,c,t]); one workgroup per (channel, batch
 // slice) writes a partial, the last stage folds the slices in a fixed order (deterministic)
 constexpr int kChanSlices = 32;
@@ -587,9 +618,18 @@ int msk_conv1d_bwd_weight_direct(const ConvP& p, const float* x, const float* x_
 #undef MS_LAUNCH_WG
     MS_CHECK_LAUNCH();
     const size_t wsize = (size_t)p.Cout * p.Cg * p.K;
-    const size_t total = wsize + p.Cout;
-    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       partial, q.stride_floats, q.nsplit, wsize, p.Cout, gw, gb, beta);
+    return msk_reduce_partials(partial, q.stride_floats, q.nsplit, wsize, p.Cout, gw, gb, beta, s);
+}
+
+int msk_reduce_partials(const float* partial, size_t partial_stride, int nsplit, size_t wsize,
+                        int nbias, float* gw, float* gb, float beta, hipStream_t s) {
+    const size_t total = wsize + (size_t)nbias;
+    if (total <= 8192 && nsplit >= 64)
+        hipLaunchKernelGGL(k_reduce_partials_wave, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s,
+                           partial, partial_stride, nsplit, wsize, nbias, gw, gb, beta);
+    else
+        hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                           partial, partial_stride, nsplit, wsize, nbias, gw, gb, beta);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }

@@ -1,0 +1,18 @@
+// One-channel-side ("thin") convolution kernels (conv_thin.hip): applicability, names, launchers.
+#pragma once
+#include "ms_common.h"
+
+bool mst_fwd_applicable(const ConvP& p);
+bool mst_bwd_data_applicable(const ConvP& p);
+bool mst_bwd_weight_applicable(const ConvP& p);
+const char* mst_fwd_name(const ConvP& p);
+const char* mst_bwd_data_name(const ConvP& p);
+const char* mst_bwd_weight_name(const ConvP& p);
+size_t mst_bwd_weight_ws(const ConvP& p);
+int mst_conv1d_fwd(const ConvP& p, const float* x, const float* w, const float* bias,
+                   const float* residual, float* y, hipStream_t s);
+int mst_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, const float* w,
+                        const float* gx_add, float* gx, hipStream_t s);
+int mst_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act,
+                          float* gw, float* gb, float beta, void* ws, size_t ws_bytes,
+                          hipStream_t s);

@@ -1,0 +1,395 @@
+// "Thin" convolutions: one side of the layer has a single channel, so the layer is a stream over
+// the many-channel tensor and bound by HBM, not by the matrix cores:
+//   * the generator's last conv   Conv1d(32, 1, 7, padding=3) + tanh  (reference generator/full.py:43-44)
+//   * the discriminator's first   Conv1d(1, 16, 15, padding=7)        (reference discriminator/full.py:14)
+// Three kernels cover their passes (stride 1, dilation 1, zero padding, Lout == Lin):
+//   k_thin_reduce  many -> 1 : forward of Cout == 1, backward-data of Cin == 1
+//   k_thin_expand  1 -> many : backward-data of Cout == 1, forward of Cin == 1
+//   k_thin_wgrad            : weight/bias gradients of both
+// Every thread owns 4 consecutive samples; the one-channel operand ("thin") is read as a window of
+// K + 3 samples, the many-channel operand ("stream") as one 16-byte access per channel.
+#include "ms_common.h"
+#include "conv_thin.h"
+
+namespace {
+
+constexpr int TS = 1024;                 // stream samples per workgroup chunk (weight-grad kernel)
+
+// ------------------------------------------------------------------ many -> 1
+// out[b, 0, t] = act(bias + res + sum_c sum_j wt[c, j] * S'[b, c, t + j - off]),  S' = S * act'(Sact)
+// (forward: wt = w[0, c, j];  backward-data of Cin == 1: wt = w[c, 0, K-1-j];  off = (K-1)/2 both ways)
+// A workgroup owns 256 consecutive samples of one batch row; its 4 waves each sum a quarter of the
+// channels (CW channels, all loads of a wave issued as one batch) and are combined through LDS.
+template <int K, bool FLIP, bool VEC, int CW>
+__global__ __launch_bounds__(256) void k_thin_reduce(int B, int C, int L, int s_kind, int act,
+                                                    float slope, const float* __restrict__ S,
+                                                    const float* __restrict__ Sact,
+                                                    const float* __restrict__ w,
+                                                    const float* __restrict__ bias,
+                                                    const float* __restrict__ res,
+                                                    float* __restrict__ out) {
+    constexpr int OFF = (K - 1) / 2;
+    constexpr int HV = (OFF + 3) / 4;                   // 16-byte vectors on each side of the centre one
+    constexpr int NV = 2 * HV + 1;
+    constexpr int NW = VEC ? NV * 4 : K + 3;            // window floats per channel
+    constexpr int W0 = VEC ? 4 * HV : OFF;              // window index of S'[t]
+    __shared__ float red[4][256 + 4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int tiles = (L + 255) / 256;
+    const int b = blockIdx.x / tiles, t = (blockIdx.x - b * tiles) * 256 + lane * 4;
+    const float* Sq = Sact ? Sact : S;
+    const int kind = Sact ? s_kind : MS_ACT_NONE;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float win[CW][NW];
+#pragma unroll
+    for (int cc = 0; cc < CW; ++cc) {
+        const int c = wid * CW + cc;
+        const size_t row = ((size_t)b * C + (c < C ? c : 0)) * L;
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int tq = t + 4 * (q - HV);
+                const bool ok = tq >= 0 && tq < L;     // L % 4 == 0: a vector is all in or all out
+                const float4 v = *reinterpret_cast<const float4*>(S + row + (ok ? tq : 0));
+                win[cc][4 * q + 0] = v.x; win[cc][4 * q + 1] = v.y; win[cc][4 * q + 2] = v.z; win[cc][4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < K + 3; ++i) {
+                const int ti = t + i - OFF;
+                const bool ok = ti >= 0 && ti < L;
+                win[cc][i] = S[row + (ok ? ti : 0)];
+            }
+        }
+    }
+    if (Sact) {       // activation-derivative operand (wave-uniform branch; second batch of loads)
+        float wa[CW][NW];
+#pragma unroll
+        for (int cc = 0; cc < CW; ++cc) {
+            const int c = wid * CW + cc;
+            const size_t row = ((size_t)b * C + (c < C ? c : 0)) * L;
+            if (VEC) {
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    const int tq = t + 4 * (q - HV);
+                    const bool ok = tq >= 0 && tq < L;
+                    const float4 v = *reinterpret_cast<const float4*>(Sq + row + (ok ? tq : 0));
+                    wa[cc][4 * q + 0] = v.x; wa[cc][4 * q + 1] = v.y; wa[cc][4 * q + 2] = v.z; wa[cc][4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < K + 3; ++i) {
+                    const int ti = t + i - OFF;
+                    const bool ok = ti >= 0 && ti < L;
+                    wa[cc][i] = Sq[row + (ok ? ti : 0)];
+                }
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < CW; ++cc)
+#pragma unroll
+            for (int i = 0; i < NW; ++i) win[cc][i] = ms_act_grad(win[cc][i], wa[cc][i], kind, slope);
+    }
+#pragma unroll
+    for (int cc = 0; cc < CW; ++cc) {
+        const int c = wid * CW + cc;
+        if (c >= C) continue;                         // wave-uniform
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {                // zero padding outside the row
+            const int ti = t + i - W0;
+            if (ti < 0 || ti >= L) win[cc][i] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float wv = w[c * K + (FLIP ? K - 1 - j : j)];     // wave-uniform: scalar load
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(wv, win[cc][W0 + e + j - OFF], acc[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wid][lane * 4 + e] = acc[e];
+    __syncthreads();
+    const int to = (blockIdx.x - b * tiles) * 256 + threadIdx.x;
+    if (to < L) {
+        const int i = threadIdx.x;
+        float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        v = ms_apply_act(v + (bias ? bias[0] : 0.f), act, slope);
+        const size_t o = (size_t)b * L + to;
+        if (res) v += res[o];
+        out[o] = v;
+    }
+}
+
+// ------------------------------------------------------------------ 1 -> many
+// out[b, c, s] = act(bias[c] + sum_j wt[c, j] * T'[b, 0, s + j - off]) + add,  T' = T * act'(Tact)
+// (backward-data of Cout == 1: wt = w[0, c, K-1-j];  forward of Cin == 1: wt = w[c, 0, j])
+// Same tiling: every wave reads the (tiny) window itself and writes a quarter of the channels.
+template <int K, bool FLIP, bool VEC, int CW>
+__global__ __launch_bounds__(256) void k_thin_expand(int B, int C, int L, int t_kind, int act,
+                                                    float slope, const float* __restrict__ T,
+                                                    const float* __restrict__ Tact,
+                                                    const float* __restrict__ w,
+                                                    const float* __restrict__ bias,
+                                                    const float* __restrict__ add,
+                                                    float* __restrict__ out) {
+    constexpr int OFF = (K - 1) / 2;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int tiles = (L + 255) / 256;
+    const int b = blockIdx.x / tiles, s = (blockIdx.x - b * tiles) * 256 + lane * 4;
+    if (s >= L) return;
+    const float* Tq = Tact ? Tact : T;
+    const int kind = Tact ? t_kind : MS_ACT_NONE;
+    float v[K + 3], a[K + 3], win[K + 3];
+#pragma unroll
+    for (int i = 0; i < K + 3; ++i) {
+        const int ti = s + i - OFF;
+        const bool ok = ti >= 0 && ti < L;
+        v[i] = T[(size_t)b * L + (ok ? ti : 0)];
+        a[i] = Tq[(size_t)b * L + (ok ? ti : 0)];
+    }
+#pragma unroll
+    for (int i = 0; i < K + 3; ++i) {
+        const int ti = s + i - OFF;
+        const bool ok = ti >= 0 && ti < L;
+        win[i] = ok ? ms_act_grad(v[i], a[i], kind, slope) : 0.f;
+    }
+    float4 av[CW];
+    if (add && VEC) {
+#pragma unroll
+        for (int cc = 0; cc < CW; ++cc) {
+            const int c = wid * CW + cc;
+            av[cc] = *reinterpret_cast<const float4*>(add + ((size_t)b * C + (c < C ? c : 0)) * L + s);
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < CW; ++cc) {
+        const int c = wid * CW + cc;
+        if (c >= C) continue;                         // wave-uniform
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float wv = w[c * K + (FLIP ? K - 1 - j : j)];     // wave-uniform: scalar load
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(wv, win[e + j], acc[e]);
+        }
+        const float bv = bias ? bias[c] : 0.f;
+        const size_t o = ((size_t)b * C + c) * L + s;
+        float r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = ms_apply_act(acc[e] + bv, act, slope);
+        if (VEC) {
+            if (add) { r[0] += av[cc].x; r[1] += av[cc].y; r[2] += av[cc].z; r[3] += av[cc].w; }
+            *reinterpret_cast<float4*>(out + o) = make_float4(r[0], r[1], r[2], r[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (s + e < L) out[o + e] = r[e] + (add ? add[o + e] : 0.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ weight / bias gradients
+// ROLE 0 (Cout == 1): stream = x (C = Cin), thin = gy * act'(y):  gw[0, c, j] = sum S[b,c,s] T'[b, s - j + pad]
+// ROLE 1 (Cin  == 1): stream = gy * act'(y) (C = Cout), thin = x: gw[c, 0, j] = sum S'[b,c,s] T[b, s + j - pad]
+// A workgroup owns one (batch row, 1024-sample chunk): the thin window goes to LDS once, wave w
+// accumulates channels [w*CPW, (w+1)*CPW) over the chunk in registers (CPW*K accumulators per lane),
+// and the lanes are combined once at the end.  One partial row per workgroup; k_reduce_partials_wave
+// sums the rows.
+template <int K, int ROLE, int CPW, bool VEC>
+__global__ __launch_bounds__(256) void k_thin_wgrad(int B, int C, int L, int pad, int act, float slope,
+                                                   int schunks, const float* __restrict__ S,
+                                                   const float* __restrict__ Sact,
+                                                   const float* __restrict__ T,
+                                                   const float* __restrict__ Tact,
+                                                   float* __restrict__ partial, size_t pstride) {
+    constexpr int TW = TS + K - 1;
+    constexpr int NT = (TW + 255) / 256;
+    __shared__ float Tl[NT * 256];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.x / schunks, s0 = (blockIdx.x - b * schunks) * TS;
+    const int lo = ROLE == 0 ? s0 - (K - 1) + pad : s0 - pad;
+    const float* Tq = Tact ? Tact : T;
+    const int t_kind = Tact ? act : MS_ACT_NONE;
+    const float* Sq = Sact ? Sact : S;
+    const int s_kind = Sact ? act : MS_ACT_NONE;
+    float bs = 0.f;
+    {
+        float tv[NT], ta[NT];
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+            const int i = tid + it * 256, t = lo + i;
+            const bool ok = i < TW && t >= 0 && t < L;
+            tv[it] = T[(size_t)b * L + (ok ? t : 0)];
+            ta[it] = Tq[(size_t)b * L + (ok ? t : 0)];
+        }
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+            const int i = tid + it * 256, t = lo + i;
+            const bool ok = i < TW && t >= 0 && t < L;
+            const float v = ok ? ms_act_grad(tv[it], ta[it], t_kind, slope) : 0.f;
+            Tl[i] = v;
+            if (ROLE == 0 && ok && t >= s0 && t < s0 + TS) bs += v;     // bias grad: each sample once
+        }
+    }
+    __syncthreads();
+    float acc[CPW][K];
+    float bsum[CPW];
+#pragma unroll
+    for (int cc = 0; cc < CPW; ++cc) {
+        bsum[cc] = 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[cc][j] = 0.f;
+    }
+    const int c0 = wid * CPW;
+#pragma unroll 1
+    for (int pass = 0; pass < TS / 256; ++pass) {
+        const int sl = pass * 256 + lane * 4, s = s0 + sl;
+        float win[K + 3];
+#pragma unroll
+        for (int i = 0; i < K + 3; ++i) win[i] = Tl[sl + i];
+        float4 sv[CPW], sa[CPW];
+#pragma unroll
+        for (int cc = 0; cc < CPW; ++cc) {
+            const int c = c0 + cc;
+            const bool ok = c < C && s < L;
+            const size_t o = ok ? ((size_t)b * C + c) * L + s : 0;
+            if (VEC) {                           // L % 4 == 0: 4 samples all in or all out
+                sv[cc] = *reinterpret_cast<const float4*>(S + o);
+                sa[cc] = *reinterpret_cast<const float4*>(Sq + o);
+            } else {
+                const size_t o1 = ok && s + 1 < L ? o + 1 : o, o2 = ok && s + 2 < L ? o + 2 : o,
+                             o3 = ok && s + 3 < L ? o + 3 : o;
+                sv[cc] = make_float4(S[o], S[o1], S[o2], S[o3]);
+                sa[cc] = make_float4(Sq[o], Sq[o1], Sq[o2], Sq[o3]);
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < CPW; ++cc) {
+            const int c = c0 + cc;
+            const float xv[4] = {sv[cc].x, sv[cc].y, sv[cc].z, sv[cc].w};
+            const float xa[4] = {sa[cc].x, sa[cc].y, sa[cc].z, sa[cc].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = c < C && s + e < L;
+                const float v = ok ? ms_act_grad(xv[e], xa[e], s_kind, slope) : 0.f;
+                bsum[cc] += v;
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+                    acc[cc][j] = fmaf(v, win[ROLE == 0 ? e + K - 1 - j : e + j], acc[cc][j]);
+            }
+        }
+    }
+    float* prow = partial + (size_t)blockIdx.x * pstride;
+#pragma unroll
+    for (int cc = 0; cc < CPW; ++cc) {
+        const int c = c0 + cc;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float r = ms_wave_sum(acc[cc][j]);
+            if (lane == 0 && c < C) prow[c * K + j] = r;
+        }
+        if (ROLE == 1) {
+            const float r = ms_wave_sum(bsum[cc]);
+            if (lane == 0 && c < C) prow[(size_t)C * K + c] = r;
+        }
+    }
+    if (ROLE == 0) {
+        const float tot = ms_block_sum(bs, red);
+        if (tid == 0) prow[(size_t)C * K] = tot;
+    }
+}
+
+bool thin_common(const ConvP& p) {
+    return p.groups == 1 && p.stride == 1 && p.dil == 1 && p.pad_mode == MS_PAD_ZERO &&
+           p.Lout == p.Lin && !p.in_act && 2 * p.pad == p.K - 1 && p.B <= 65535;
+}
+bool role0(const ConvP& p) { return thin_common(p) && p.Cout == 1 && p.K == 7 && p.Cin <= 32 && p.Cin >= 4; }
+bool role1(const ConvP& p) { return thin_common(p) && p.Cin == 1 && p.K == 15 && p.Cout <= 16 && p.Cout >= 4; }
+bool aligned16(const void* a) { return (((uintptr_t)a) & 15) == 0; }
+
+}  // namespace
+
+bool mst_fwd_applicable(const ConvP& p) { return role0(p); }
+bool mst_bwd_data_applicable(const ConvP& p) { return role0(p) || role1(p); }
+bool mst_bwd_weight_applicable(const ConvP& p) { return role0(p) || role1(p); }
+
+const char* mst_fwd_name(const ConvP&) { return "k_thin_reduce<7, false>"; }
+const char* mst_bwd_data_name(const ConvP& p) { return role0(p) ? "k_thin_expand<7, true>" : "k_thin_reduce<15, true>"; }
+const char* mst_bwd_weight_name(const ConvP& p) { return role0(p) ? "k_thin_wgrad<7, 0, 8>" : "k_thin_wgrad<15, 1, 4>"; }
+
+static unsigned thin_grid(const ConvP& p) { return (unsigned)(p.B * ms_ceil_div(p.Lin, 256)); }
+
+int mst_conv1d_fwd(const ConvP& p, const float* x, const float* w, const float* bias,
+                   const float* residual, float* y, hipStream_t s) {
+    const bool vec = p.Lin % 4 == 0 && aligned16(x);
+    const dim3 grid(thin_grid(p));
+    if (vec)
+        hipLaunchKernelGGL((k_thin_reduce<7, false, true, 8>), grid, dim3(256), 0, s, p.B, p.Cin, p.Lin,
+                           MS_ACT_NONE, p.act, p.slope, x, (const float*)nullptr, w, bias, residual, y);
+    else
+        hipLaunchKernelGGL((k_thin_reduce<7, false, false, 8>), grid, dim3(256), 0, s, p.B, p.Cin, p.Lin,
+                           MS_ACT_NONE, p.act, p.slope, x, (const float*)nullptr, w, bias, residual, y);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int mst_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, const float* w,
+                        const float* gx_add, float* gx, hipStream_t s) {
+    const dim3 grid(thin_grid(p));
+    if (role0(p)) {      // 1 -> Cin
+        const bool vec = p.Lin % 4 == 0 && aligned16(gx) && (!gx_add || aligned16(gx_add));
+        if (vec)
+            hipLaunchKernelGGL((k_thin_expand<7, true, true, 8>), grid, dim3(256), 0, s, p.B, p.Cin, p.Lin,
+                               p.act, MS_ACT_NONE, p.slope, gy, y_act, w, (const float*)nullptr, gx_add, gx);
+        else
+            hipLaunchKernelGGL((k_thin_expand<7, true, false, 8>), grid, dim3(256), 0, s, p.B, p.Cin, p.Lin,
+                               p.act, MS_ACT_NONE, p.slope, gy, y_act, w, (const float*)nullptr, gx_add, gx);
+    } else {             // Cout -> 1
+        const bool vec = p.Lin % 4 == 0 && aligned16(gy) && (!y_act || aligned16(y_act));
+        if (vec)
+            hipLaunchKernelGGL((k_thin_reduce<15, true, true, 4>), grid, dim3(256), 0, s, p.B, p.Cout, p.Lin,
+                               p.act, MS_ACT_NONE, p.slope, gy, y_act, w, (const float*)nullptr, gx_add, gx);
+        else
+            hipLaunchKernelGGL((k_thin_reduce<15, true, false, 4>), grid, dim3(256), 0, s, p.B, p.Cout, p.Lin,
+                               p.act, MS_ACT_NONE, p.slope, gy, y_act, w, (const float*)nullptr, gx_add, gx);
+    }
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+static int thin_nchunks(const ConvP& p) { return p.B * ms_ceil_div(p.Lin, TS); }
+static size_t thin_pstride(const ConvP& p) { return (size_t)p.Cout * p.Cin * p.K + p.Cout; }
+
+size_t mst_bwd_weight_ws(const ConvP& p) {
+    return (size_t)thin_nchunks(p) * thin_pstride(p) * sizeof(float);
+}
+
+int mst_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act,
+                          float* gw, float* gb, float beta, void* ws, size_t ws_bytes,
+                          hipStream_t s) {
+    if (!ws || ws_bytes < mst_bwd_weight_ws(p)) return MS_ERR_WORKSPACE;
+    float* partial = (float*)ws;
+    const int nch = thin_nchunks(p), sch = ms_ceil_div(p.Lin, TS);
+    const size_t ps = thin_pstride(p);
+    const dim3 grid(nch);
+    if (role0(p)) {
+        const bool vec = p.Lin % 4 == 0 && aligned16(x);
+        if (vec)
+            hipLaunchKernelGGL((k_thin_wgrad<7, 0, 8, true>), grid, dim3(256), 0, s, p.B, p.Cin, p.Lin, p.pad,
+                               p.act, p.slope, sch, x, (const float*)nullptr, gy, y_act, partial, ps);
+        else
+            hipLaunchKernelGGL((k_thin_wgrad<7, 0, 8, false>), grid, dim3(256), 0, s, p.B, p.Cin, p.Lin, p.pad,
+                               p.act, p.slope, sch, x, (const float*)nullptr, gy, y_act, partial, ps);
+    } else {
+        const bool vec = p.Lin % 4 == 0 && aligned16(gy) && (!y_act || aligned16(y_act));
+        if (vec)
+            hipLaunchKernelGGL((k_thin_wgrad<15, 1, 4, true>), grid, dim3(256), 0, s, p.B, p.Cout, p.Lin, p.pad,
+                               p.act, p.slope, sch, gy, y_act, x, (const float*)nullptr, partial, ps);
+        else
+            hipLaunchKernelGGL((k_thin_wgrad<15, 1, 4, false>), grid, dim3(256), 0, s, p.B, p.Cout, p.Lin, p.pad,
+                               p.act, p.slope, sch, gy, y_act, x, (const float*)nullptr, partial, ps);
+    }
+    MS_CHECK_LAUNCH();
+    return msk_reduce_partials(partial, ps, nch, (size_t)p.Cout * p.Cin * p.K, p.Cout, gw, gb, beta, s);
+}

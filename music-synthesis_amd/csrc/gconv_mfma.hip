@@ -9,45 +9,125 @@
 // of tap j becomes a unit-stride, conflict-free ds_read for every lane.
 #include "ms_common.h"
 #include "gconv_mfma.h"
+#include <stdint.h>
+#include <stdlib.h>
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GK = 41, GS = 4, GCG = 4;      // taps, stride, input channels per group
-constexpr int TT = 64;                        // outputs per wave  (4 MFMA column tiles)
-constexpr int WTT = 4 * TT;                   // outputs per workgroup
-constexpr int PS = (WTT * GS + GK - 1 + GS - 1) / GS + 1;   // entries per phase row
-constexpr int PSP = ((PS + 7) / 8) * 8 + 4;   // == 4 (mod 8): the 4 ci rows land 16 banks apart
 
-__global__ __launch_bounds__(256) void k_gconv_mfma_fwd(ConvP p, const float* __restrict__ x,
+// Batched staging: every global load of a fill is issued before the first LDS store that consumes
+// one (clamped address + mask, fixed trip count).  A `for (idx = tid; idx < n; idx += 256)` fill
+// waits for each load before its store: one memory round trip per iteration, which made these
+// HBM-sized layers latency-bound (41 us for a 33 MB layer).
+template <int MAXIT>
+__device__ inline void stage_weights(const float* __restrict__ w, float* __restrict__ ws, int n, int tid) {
+    float v[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int idx = tid + it * 256;
+        v[it] = w[idx < n ? idx : 0];
+    }
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < n) ws[idx] = v[it];
+    }
+}
+
+// ---------------------------------------------------------------- forward
+// Work unit of a WAVE: 64 consecutive outputs of one (batch row, group).  The wave stages the
+// 4 x 293 inputs the unit reads into its private LDS region (phase-split: [ci][u mod 4][u / 4],
+// so the stride-4 gather of tap j is a unit-stride conflict-free ds_read), runs 4 independent
+// 16-output MFMA chains of 41 taps, and prefetches the next unit's inputs into registers while
+// the matrix cores work.  No workgroup barrier after the weight fill: short rows (L = 9 .. 65 at
+// the coarse scales) keep all four waves busy on different batch rows.
+//
+// Memory instructions are 16 bytes per lane wherever the tensors allow it (dword loads / stores
+// are issue-bound at ~7 B/cycle/CU, MI355X_MICROARCH.md "store tail"):
+//  * inputs: 16-byte-ALIGNED vectors of the flat tensor; a row that starts off a 16-byte boundary
+//    (the odd lengths 4097 / 1025 / .. of the pooled scales) just shifts where each of the four
+//    elements lands in LDS (sh = element offset of the row start within its vector);
+//  * outputs: bias + activation, then a transpose through the wave's LDS region so that a lane
+//    stores 4 consecutive samples of one channel (rows of 256 contiguous bytes per 16 lanes).
+constexpr int UT = 64;                               // outputs per unit
+constexpr int USPAN = (UT - 1) * GS + GK;            // 293 inputs per channel
+constexpr int UK = (USPAN + 63) / 64;                // 5 dword loads per lane and channel
+constexpr int UV = (USPAN + 3 + 3) / 4;              // 75 aligned vectors cover a shifted row
+constexpr int UVI = (GCG * UV + 63) / 64;            // 5 vector loads per lane
+constexpr int UPS = 76;                              // phase-row pitch: >= 74, == 4 (mod 8)
+constexpr int UWS = GCG * GS * UPS;                  // floats per wave region
+constexpr int OPITCH = 68;                           // output-transpose pitch: == 4 (mod 8), 16 B rows
+static_assert(16 * OPITCH <= UWS, "output transpose reuses the input region");
+
+template <int NTT>
+__device__ inline void gfwd_tiles(const float (&a)[GK], const float* __restrict__ xb, f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int j = 0; j < GK; ++j) {
+        float bv[NTT];
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) bv[tt] = xb[(j & (GS - 1)) * UPS + tt * 16 + (j >> 2)];
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt)
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bv[tt], acc[tt], 0, 0, 0);
+    }
+}
+
+template <bool VIN, bool VOUT>
+__global__ __launch_bounds__(256) void k_gconv_mfma_fwd(ConvP p, int tiles, int nunits,
+                                                       const float* __restrict__ x,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias,
                                                        float* __restrict__ y) {
-    __shared__ float xs[GCG * GS * PSP];
+    __shared__ __attribute__((aligned(16))) float xs[4 * UWS];
     __shared__ float ws[16 * GCG * GK];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int g = blockIdx.y, b = blockIdx.z;
-    const int T0 = blockIdx.x * WTT;                 // first output of this workgroup
-    const int u0 = T0 * GS - p.pad;                  // input index of padded position 0
-    const int tvalid = min(WTT, p.Lout - T0);          // short rows: stage only what is read
-    const int span = min(WTT * GS + GK - 1, (((tvalid + 15) & ~15) - 1) * GS + GK);
-
-    // stage x[b, g*4 + ci, u0 .. u0+span) de-interleaved by phase
-    for (int idx = tid; idx < GCG * span; idx += 256) {
-        const int ci = idx / span, u = idx - ci * span;
-        const int s = u0 + u;
-        const bool ok = s >= 0 && s < p.Lin;
-        const float v = x[ok ? ((size_t)b * p.Cin + (size_t)g * GCG + ci) * p.Lin + s : 0];
-        xs[ci * (GS * PSP) + (u & (GS - 1)) * PSP + (u >> 2)] = ok ? v : 0.f;
-    }
-
-    // the group's weights (Og*4*41 contiguous floats) go through LDS: one coalesced read per
-    // workgroup instead of 41 row-strided loads per lane
-    for (int idx = tid; idx < p.Og * GCG * GK; idx += 256) ws[idx] = w[(size_t)g * p.Og * GCG * GK + idx];
+    const int g = blockIdx.y;
+    const int m = lane & 15, ci = lane >> 4;
+    float* xw = xs + wid * UWS;
+    const float* xb = xw + ci * (GS * UPS) + (lane & 15);
+    const int wstride = gridDim.x * 4;
+    const long long total4 = (long long)p.B * p.Cin * p.Lin / 4;
+    constexpr int NLD = VIN ? UVI : GCG * UK;
+    float4 xv[VIN ? UVI : 1];
+    float xr[VIN ? 1 : GCG * UK];
+    // element index (in the flat tensor) of the unit's first input of channel c
+    auto row_e0 = [&](int b, int t0, int c) {
+        return ((long long)b * p.Cin + (long long)g * GCG + c) * p.Lin + (long long)t0 * GS - p.pad;
+    };
+    auto gload = [&](int unit) {
+        const int b = unit / tiles, t0 = (unit - b * tiles) * UT;
+        if (VIN) {
+#pragma unroll
+            for (int it = 0; it < UVI; ++it) {
+                const int idx = lane + 64 * it;
+                const int c = idx / UV, k = idx - c * UV;
+                const long long va = (row_e0(b, t0, c < GCG ? c : 0) >> 2) + k;
+                const bool ok = c < GCG && va >= 0 && va < total4;
+                xv[it] = reinterpret_cast<const float4*>(x)[ok ? va : 0];
+            }
+        } else {
+            const int u0 = t0 * GS - p.pad;
+            const float* xrow = x + ((size_t)b * p.Cin + (size_t)g * GCG) * p.Lin;
+#pragma unroll
+            for (int k = 0; k < UK; ++k) {
+                const int u = lane + 64 * k, sidx = u0 + u;
+                const bool ok = u < USPAN && sidx >= 0 && sidx < p.Lin;
+                const int so = ok ? sidx : 0;
+#pragma unroll
+                for (int c = 0; c < GCG; ++c) xr[c * UK + k] = xrow[(size_t)c * p.Lin + so];
+            }
+        }
+    };   // (masking happens at the LDS store, so the loads stay in flight across the MFMA loop)
+    (void)NLD;
+    int unit = blockIdx.x * 4 + wid;
+    if (unit < nunits) gload(unit);      // in flight while the weights are staged
+    const int nwf = p.Og * GCG * GK;
+    stage_weights<(16 * GCG * GK + 255) / 256>(w + (size_t)g * nwf, ws, nwf, tid);
     __syncthreads();
     // weight fragments: lane (m = lane&15, ci = lane>>4) holds w[g*Og+m][ci][j] for every tap j
-    const int m = lane & 15, ci = lane >> 4;
     float a[GK];
     {
         const bool ok = m < p.Og;
@@ -58,30 +138,98 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_fwd(ConvP p, const float* __
             a[j] = ok ? v : 0.f;
         }
     }
+    float bq[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int mo = ci * 4 + r;
+        bq[r] = bias ? bias[g * p.Og + (mo < p.Og ? mo : 0)] : 0.f;
+    }
 
-    const float* xb = xs + ci * (GS * PSP) + wid * TT + (lane & 15);
+    for (; unit < nunits; unit += wstride) {
+        const int b = unit / tiles, t0 = (unit - b * tiles) * UT;
+        const int u0 = t0 * GS - p.pad;
+        if (VIN) {
 #pragma unroll
-    for (int tt = 0; tt < TT / 16; ++tt) {
-        const int tbase = T0 + wid * TT + tt * 16;
-        if (tbase >= p.Lout) break;                  // wave-uniform
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int it = 0; it < UVI; ++it) {
+                const int idx = lane + 64 * it;
+                const int c = idx / UV, k = idx - c * UV;
+                const long long e0 = row_e0(b, t0, c < GCG ? c : 0);
+                const long long va = (e0 >> 2) + k;
+                const bool vok = c < GCG && va >= 0 && va < total4;
+                const int sh = (int)(e0 & 3);
+                const float e[4] = {xv[it].x, xv[it].y, xv[it].z, xv[it].w};
 #pragma unroll
-        for (int j = 0; j < GK; ++j) {
-            const float bv = xb[(j & (GS - 1)) * PSP + tt * 16 + (j >> 2)];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bv, acc, 0, 0, 0);
-        }
-        const int t = tbase + (lane & 15);
-        if (t < p.Lout) {
+                for (int i = 0; i < 4; ++i) {
+                    const int u = 4 * k + i - sh, sidx = u0 + u;
+                    const bool ok = vok && sidx >= 0 && sidx < p.Lin;
+                    if (c < GCG && u >= 0 && u < GS * UPS)
+                        xw[c * (GS * UPS) + (u & (GS - 1)) * UPS + (u >> 2)] = ok ? e[i] : 0.f;
+                }
+            }
+        } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mo = (lane >> 4) * 4 + r;
-                if (mo < p.Og) {
-                    const int co = g * p.Og + mo;
-                    const float v = acc[r] + (bias ? bias[co] : 0.f);
-                    y[((size_t)b * p.Cout + co) * p.Lout + t] = ms_apply_act(v, p.act, p.slope);
+            for (int k = 0; k < UK; ++k) {
+                const int u = lane + 64 * k, sidx = u0 + u;
+                const bool ok = u < USPAN && sidx >= 0 && sidx < p.Lin;
+                if (u < GS * UPS) {
+#pragma unroll
+                    for (int c = 0; c < GCG; ++c)
+                        xw[c * (GS * UPS) + (u & (GS - 1)) * UPS + (u >> 2)] = ok ? xr[c * UK + k] : 0.f;
                 }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (unit + wstride < nunits) gload(unit + wstride);
+        const int ntt = min(4, (p.Lout - t0 + 15) >> 4);          // wave-uniform
+        f32x4 acc[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ntt == 4) gfwd_tiles<4>(a, xb, acc);
+        else if (ntt == 3) gfwd_tiles<3>(a, xb, acc);
+        else if (ntt == 2) gfwd_tiles<2>(a, xb, acc);
+        else gfwd_tiles<1>(a, xb, acc);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (VOUT) {
+            // bias + activation, transposed through LDS: D[row = ci*4 + r][col = lane&15] of tile tt
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    xw[(ci * 4 + r) * OPITCH + tt * 16 + (lane & 15)] = ms_apply_act(acc[tt][r] + bq[r], p.act, p.slope);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float4 ov[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = lane + 64 * it;
+                ov[it] = *reinterpret_cast<const float4*>(xw + (idx >> 4) * OPITCH + 4 * (idx & 15));
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = lane + 64 * it;
+                const int row = idx >> 4, t = t0 + 4 * (idx & 15);
+                if (row < p.Og && t < p.Lout)     // Lout % 4 == 0: a vector is all in or all out
+                    *reinterpret_cast<float4*>(y + ((size_t)b * p.Cout + (size_t)g * p.Og + row) * p.Lout + t) = ov[it];
+            }
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int t = t0 + tt * 16 + (lane & 15);
+                if (tt < ntt && t < p.Lout) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int mo = ci * 4 + r;
+                        if (mo < p.Og)
+                            y[((size_t)b * p.Cout + (size_t)g * p.Og + mo) * p.Lout + t] =
+                                ms_apply_act(acc[tt][r] + bq[r], p.act, p.slope);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -296,8 +444,26 @@ const char* msg_fwd_name(const ConvP&) { return "k_gconv_mfma_fwd"; }
 
 int msg_conv1d_fwd(const ConvP& p, const float* x, const float* w, const float* bias, float* y,
                    hipStream_t s) {
-    dim3 grid(ms_ceil_div(p.Lout, WTT), p.groups, p.B);
-    hipLaunchKernelGGL(k_gconv_mfma_fwd, grid, dim3(256), 0, s, p, x, w, bias, y);
+    const int tiles = ms_ceil_div(p.Lout, UT), nunits = p.B * tiles;
+    // 4 wave units per workgroup pass; ~2048 workgroups at most, each wave then loops over units
+    // ~2 waves per SIMD (2048 waves): a wave loops over `upw` units so that its loads, MFMA chains
+    // and stores of consecutive units overlap
+    const char* tw = getenv("MSYNTH_GW");
+    const int target_waves = tw ? atoi(tw) : 2048;
+    const long long total_units = (long long)nunits * p.groups;
+    const int upw = (int)((total_units + target_waves - 1) / target_waves);
+    const int gx = ms_ceil_div(nunits, 4 * (upw > 0 ? upw : 1));
+    // 16-byte loads / stores measured SLOWER here (95 vs 80 us at B=128: the kernel is bound by VALU
+    // + MFMA issue on the SIMD, not by memory instructions); kept behind MSYNTH_GVEC for experiments
+    const char* gv = getenv("MSYNTH_GVEC");
+    const int gvec = gv ? atoi(gv) : 0;
+    const bool vin = (gvec & 1) && (((uintptr_t)x) & 15) == 0 && ((long long)p.B * p.Cin * p.Lin) % 4 == 0;
+    const bool vout = (gvec & 2) && (((uintptr_t)y) & 15) == 0 && p.Lout % 4 == 0;
+    const dim3 grid(gx, p.groups);
+    if (vin && vout) hipLaunchKernelGGL((k_gconv_mfma_fwd<true, true>), grid, dim3(256), 0, s, p, tiles, nunits, x, w, bias, y);
+    else if (vin) hipLaunchKernelGGL((k_gconv_mfma_fwd<true, false>), grid, dim3(256), 0, s, p, tiles, nunits, x, w, bias, y);
+    else if (vout) hipLaunchKernelGGL((k_gconv_mfma_fwd<false, true>), grid, dim3(256), 0, s, p, tiles, nunits, x, w, bias, y);
+    else hipLaunchKernelGGL((k_gconv_mfma_fwd<false, false>), grid, dim3(256), 0, s, p, tiles, nunits, x, w, bias, y);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }

@@ -91,6 +91,9 @@ int msk_reflect_fold_bwd(const ConvP& p, const float* gy, const float* y_act, co
 const char* msk_conv1d_fwd_direct_name(const ConvP& p);
 const char* msk_conv1d_bwd_data_direct_name(const ConvP& p);
 const char* msk_conv1d_bwd_weight_direct_name(const ConvP& p);
+// out = beta*out + sum over nsplit partial slabs (weights, then nbias bias entries per slab)
+int msk_reduce_partials(const float* partial, size_t partial_stride, int nsplit, size_t wsize,
+                        int nbias, float* gw, float* gb, float beta, hipStream_t s);
 size_t msk_channel_sum_ws(int C);
 int msk_channel_sum(const float* g, const float* y_act, int act, float slope, int B, int C, int L,
                     float* out, float beta, void* ws, size_t ws_bytes, hipStream_t s);

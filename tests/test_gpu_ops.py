@@ -214,7 +214,13 @@ HOT_CONVS = [
     ("atom_c32_d9", 2, 32, 1031, 32, 3, 1, 9, 9, 1, 1, False),
     ("g_last_k7_tanh", 2, 32, 1000, 1, 7, 1, 3, 1, 1, 2, False),
     ("d_k15", 2, 1, 2049, 16, 15, 1, 7, 1, 1, 1, False),
+    # one-channel-side stream kernels: 16-byte and scalar paths, chunk (1024) and tile (256) tails
+    ("g_last_k7_tanh_odd", 3, 32, 1301, 1, 7, 1, 3, 1, 1, 2, False),
+    ("g_last_k7_tanh_3chunks", 1, 32, 2308, 1, 7, 1, 3, 1, 1, 2, False),
+    ("d_k15_aligned", 3, 1, 2308, 16, 15, 1, 7, 1, 1, 1, False),
+    ("d_k15_short", 2, 1, 9, 16, 15, 1, 7, 1, 1, 1, False),
     ("d_k41_g4", 2, 16, 2049, 64, 41, 4, 20, 1, 4, 1, False),
+    ("d_k41_g4_long", 3, 16, 3000, 64, 41, 4, 20, 1, 4, 1, False),
     ("d_k41_g16", 2, 64, 513, 256, 41, 4, 20, 1, 16, 1, False),
     ("d_k41_g64", 1, 256, 129, 1024, 41, 4, 20, 1, 64, 1, False),
     ("d_k41_g256", 2, 1024, 33, 1024, 41, 4, 20, 1, 256, 1, False),

@@ -1,0 +1,15 @@
+"""One grouped-conv shape in a loop, for rocprofv3 --pmc runs: python3 tools/pmc_one.py fwd|bwd|wgrad B Cin Lin Cout groups"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
+import torch
+from featuresynth._ops import prims as P
+op = sys.argv[1]; B, Cin, Lin, Cout, groups = map(int, sys.argv[2:7])
+x = torch.randn(B, Cin, Lin, device="cuda"); w = torch.randn(Cout, 4, 41, device="cuda") * 0.05; b = torch.randn(Cout, device="cuda")
+d, lo = P.conv_desc(x.shape, w.shape, stride=4, pad=20, groups=groups, act=1)
+y, _ = P.conv1d_fwd(x, w, b, d, lo); gy = torch.randn_like(y)
+for _ in range(5):
+    if op == "fwd": P.conv1d_fwd(x, w, b, d, lo)
+    elif op == "bwd": P.conv1d_bwd_data(gy, y, w, d)
+    else: P.conv1d_bwd_weight(x, gy, y, d, w.shape)
+torch.cuda.synchronize()
