@@ -38,3 +38,15 @@ int msm_convt1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, co
                          float* gx, void* ws, size_t ws_bytes, hipStream_t s);
 int msm_convt1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act,
                            float* gw, float beta, void* ws, size_t ws_bytes, hipStream_t s);
+
+// deterministic split-K reduce shared by the weight-gradient kernels (conv_mfma.hip)
+int msm_wgrad_reduce(const float* partial, size_t stride_floats, int nsplit, size_t wsize, int nbias,
+                     float* gw, float* gb, float beta, hipStream_t s);
+
+// row-tile weight gradient (wgrad_rows.hip)
+bool msw_bwd_weight_applicable(const ConvP& p);
+size_t msw_bwd_weight_ws(const ConvP& p);
+const char* msw_bwd_weight_name(const ConvP& p);
+int msw_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act,
+                          float* gw, float* gb, float beta, void* ws, size_t ws_bytes,
+                          hipStream_t s);

@@ -1543,3 +1543,12 @@ int msm_convt1d_bwd_weight(const ConvP& p, const float* x, const float* gy, cons
     MS_CHECK_LAUNCH();
     return MS_OK;
 }
+
+int msm_wgrad_reduce(const float* partial, size_t stride_floats, int nsplit, size_t wsize, int nbias,
+                     float* gw, float* gb, float beta, hipStream_t s) {
+    const size_t total = wsize + (size_t)nbias;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, partial,
+                       stride_floats, nsplit, wsize, nbias, gw, gb, beta);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}

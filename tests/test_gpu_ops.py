@@ -231,6 +231,14 @@ HOT_CONVS = [
     ("mfma_m96_k5", 2, 36, 41, 96, 5, 1, 2, 1, 1, 0, False),
     ("mfma_tile128", 4, 128, 12288, 128, 3, 1, 9, 9, 1, 1, False),
     ("mfma_m160_k7_reflect", 2, 24, 50, 160, 7, 1, 3, 1, 1, 2, True),
+    # row-tile weight gradient: short rows packed R per chunk (16-byte and scalar loaders), batch
+    # tail, 1x1, K = 7, M / channel tails
+    ("wrows_k5_l32", 5, 128, 32, 192, 5, 1, 2, 1, 1, 1, False),
+    ("wrows_k3_l16_r3", 7, 64, 16, 64, 3, 1, 1, 1, 1, 1, False),
+    ("wrows_k3_l9_d3", 11, 96, 9, 80, 3, 1, 3, 3, 1, 1, False),
+    ("wrows_k1", 2, 160, 200, 136, 1, 1, 0, 1, 1, 0, False),
+    ("wrows_k7", 3, 48, 132, 72, 7, 1, 3, 1, 1, 1, False),
+    ("wrows_k3_d9_long", 2, 256, 1024, 256, 3, 1, 9, 9, 1, 1, False),
 ]
 
 

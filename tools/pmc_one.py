@@ -4,7 +4,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 from featuresynth._ops import prims as P
-op = sys.argv[1]; B, Cin, Lin, Cout, groups = map(int, sys.argv[2:7])
+op = sys.argv[1]
+if op == "dwgrad":      # dense weight gradient: dwgrad B Cin L Cout K dil
+    B, Cin, Lg, Cout, K, dil = map(int, sys.argv[2:8])
+    x = torch.randn(B, Cin, Lg, device="cuda"); gy = torch.randn(B, Cout, Lg, device="cuda"); ya = torch.randn(B, Cout, Lg, device="cuda")
+    d, lo = P.conv_desc(x.shape, (Cout, Cin, K), pad=dil * (K - 1) // 2, dil=dil, act=1)
+    for _ in range(5): P.conv1d_bwd_weight(x, gy, ya, d, (Cout, Cin, K))
+    torch.cuda.synchronize(); sys.exit(0)
+B, Cin, Lin, Cout, groups = map(int, sys.argv[2:7])
 x = torch.randn(B, Cin, Lin, device="cuda"); w = torch.randn(Cout, 4, 41, device="cuda") * 0.05; b = torch.randn(Cout, device="cuda")
 d, lo = P.conv_desc(x.shape, w.shape, stride=4, pad=20, groups=groups, act=1)
 y, _ = P.conv1d_fwd(x, w, b, d, lo); gy = torch.randn_like(y)
