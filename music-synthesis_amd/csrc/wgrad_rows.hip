@@ -33,21 +33,43 @@ struct WrP {
     float slope;
 };
 
+// Activation handling is a template parameter: a runtime `kind` compiles to scalar branches around
+// every store piece, which cuts the chunk into hundreds of basic blocks and defeats the MFMA /
+// store / load interleaving.  AK 1: LeakyReLU derivative on the gradient (the hot layers);
+// AK 2: LeakyReLU applied to the input (pre-activation blocks); AK 0: runtime kinds (generic).
+template <int AK>
+__device__ __forceinline__ float wr_gact(float g, float ya, int kind, float slope) {
+    if (AK == 1) return ya > 0.f ? g : g * slope;
+    if (AK == 2) return g;
+    return ms_act_grad(g, ya, kind, slope);
+}
+template <int AK>
 __device__ __forceinline__ float wr_xact(float v, int kind, float slope) {
+    if (AK == 1) return v;
+    if (AK == 2) return v > 0.f ? v : v * slope;
     return kind == MS_MOD_LRELU_FWD ? (v > 0.f ? v : v * slope) : v;
 }
 
-template <int K, int TM, bool VEC>
+// Software pipeline (one workgroup per CU, one wave per SIMD, so nothing else hides a stall):
+//   chunk c multiplies out of LDS buffer c&1 in KPI fully unrolled double-steps; between the MFMAs
+//   of double-step `it` the wave stores piece `it` of chunk c+1 (registers -> the other buffer) and
+//   then issues the global load of the same piece of chunk c+2 into the registers just freed.
+//   One barrier per chunk.  All pieces are branch-free (invalid lanes store to a scratch slot,
+//   masked loads read element 0) so that the whole chunk is one basic block the scheduler can
+//   interleave.
+template <int K, int TM, bool VEC, int KPI, int AK>
 __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restrict__ X,
                                                    const float* __restrict__ G,
                                                    const float* __restrict__ Gact,
                                                    float* __restrict__ partial, size_t pstride) {
     constexpr int BM = 2 * TM * 32;
-    constexpr int NGQ = VEC ? TM * 4 : TM * 16;     // G loads per thread and chunk
-    constexpr int NXQ = VEC ? 8 : 32;               // X loads per thread and chunk
+    constexpr int NGQ = VEC ? TM * 4 : TM * 16;     // G pieces (one load per thread each)
+    constexpr int NXQ = VEC ? 8 : 32;               // X pieces
+    constexpr int NP = NGQ + NXQ;
+    constexpr int PPI = (NP + KPI - 1) / KPI;       // pieces per double-step
     extern __shared__ float smem[];
-    float* Gs = smem;                               // [BM][PG]
-    float* Xs = smem + BM * p.PG;                   // [CB][PX]
+    const int tile_floats = BM * p.PG + CB * p.PX;
+    float* scratch = smem + 2 * tile_floats;        // 256 floats: sink for out-of-tile lanes
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
     const int m0 = blockIdx.y * BM, c0 = blockIdx.x * CB;
@@ -66,15 +88,13 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
 #pragma unroll
     for (int i = 0; i < TM; ++i) asum[i] = 0.f;
 
-    // the halo columns of the gradient tile (and the column past the last segment) stay zero
-    for (int i = tid; i < BM * p.PG + CB * p.PX + 8; i += 256) smem[i] = 0.f;
 
     // ---- chunk-invariant loader descriptors
     // VEC: G thread = (vector v = tid&15 of the R*Lt/4 per row, rows (tid>>4) + 16q);
     //      X thread = (aligned vector v = tid&31 of R*NVS per row, rows (tid>>5) + 8q)
     // scalar: G thread = (column tid&63, rows (tid>>6) + 4q); X thread = (column tid&127, rows (tid>>7) + 2q)
     const int sh = (4 - (p.pad & 3)) & 3;           // row start of the X window within its 16-byte vector
-    int g_seg, g_t, x_seg, x_u;                      // segment / position of this thread's column
+    int g_seg, g_t, x_seg, x_u;
     bool g_cv, x_cv;
     if (VEC) {
         const int LV = p.Lt >> 2, v = tid & 15;
@@ -85,139 +105,150 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
         const int k = tid & 63;
         g_seg = k / p.SS; g_t = k - g_seg * p.SS; g_cv = g_seg < p.R && g_t < p.Lt;
         const int c = tid & 127;
-        x_seg = c / p.SS; x_u = c - x_seg * p.SS; x_cv = x_seg < p.R;
+        x_seg = c / p.SS; x_u = c - x_seg * p.SS; x_cv = x_seg < p.R && x_u < p.SS;
     }
-    const int g_row0 = VEC ? tid >> 4 : tid >> 6, g_rstep = VEC ? 16 : 4;
-    const int x_row0 = VEC ? tid >> 5 : tid >> 7, x_rstep = VEC ? 8 : 2;
+    constexpr int g_rstep = VEC ? 16 : 4, x_rstep = VEC ? 8 : 2;
+    const int g_row0 = VEC ? tid >> 4 : tid >> 6;
+    const int x_row0 = VEC ? tid >> 5 : tid >> 7;
+    // element offsets (fit in 31 bits, checked on the host) relative to the chunk origin
+    const int g_off0 = (g_seg * p.M + m0 + g_row0) * p.L + g_t;
+    const int x_off0 = (x_seg * p.CK + c0 + x_row0) * p.L + x_u - p.pad;
+    // LDS offsets inside a buffer; lanes outside the tile write to their scratch slot instead
+    const int g_lds0 = g_row0 * p.PG + g_seg * p.SS + g_t;
+    const int x_lds0 = BM * p.PG + x_row0 * p.PX + x_seg * p.SS + x_u;
+    bool x_ev[4];                                    // VEC: which of the 4 elements fall inside the segment
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x_ev[i] = x_cv && x_u + i >= 0 && x_u + i < p.SS;
 
     float4 gv4[VEC ? NGQ : 1], ga4[VEC ? NGQ : 1], xv4[VEC ? NXQ : 1];
     float gv1[VEC ? 1 : NGQ], ga1[VEC ? 1 : NGQ], xv1[VEC ? 1 : NXQ];
-    auto chunk_origin = [&](int ch, int& b0, int& t0) {
-        if (p.R == 1) { b0 = ch / p.tiles_per_row; t0 = (ch - b0 * p.tiles_per_row) * p.Lt; }
-        else { b0 = ch * p.R; t0 = 0; }
-    };
-    auto gload = [&](int ch) {
+
+    // per-chunk scalars of the chunk whose pieces are being loaded / stored
+    struct Cs { int gbase, xbase; bool gok, xok; };
+    auto chunk_state = [&](int ch, int c_end) {
+        Cs s;
         int b0, t0;
-        chunk_origin(ch, b0, t0);
-        {   // gradient rows
-            const int b = b0 + g_seg, t = t0 + g_t;
-            const bool cok = g_cv && b < p.B && t < p.L;
-#pragma unroll
-            for (int q = 0; q < NGQ; ++q) {
-                const int m = m0 + g_row0 + g_rstep * q;
-                const bool ok = cok && m < p.M;
-                const size_t o = ok ? ((size_t)b * p.M + m) * p.L + t : 0;
-                if (VEC) {
-                    gv4[q] = *reinterpret_cast<const float4*>(G + o);
-                    ga4[q] = *reinterpret_cast<const float4*>(Gq + o);
-                } else {
-                    gv1[q] = G[o];
-                    ga1[q] = Gq[o];
-                }
+        const int bq = ch / p.tiles_per_row;              // (R > 1: tiles_per_row == 1)
+        b0 = bq * p.R;
+        t0 = (ch - bq * p.tiles_per_row) * p.Lt;
+        const bool live = ch < c_end;
+        s.gbase = b0 * p.M * p.L + t0;
+        s.xbase = b0 * p.CK * p.L + t0;
+        const int tg = t0 + g_t, tx = t0 - p.pad + x_u;       // VEC: tx % 4 == 0, vector all in or all out
+        s.gok = live && g_cv && b0 + g_seg < p.B && tg < p.L;
+        s.xok = live && x_cv && b0 + x_seg < p.B && tx >= 0 && tx < p.L;
+        return s;
+    };
+    auto load_piece = [&](int pi, const Cs& s) {
+        if (pi < NGQ) {
+            const int q = pi;
+            const bool ok = s.gok && m0 + g_row0 + g_rstep * q < p.M;
+            const int o = ok ? s.gbase + g_off0 + q * g_rstep * p.L : 0;
+            if (VEC) {
+                gv4[q] = *reinterpret_cast<const float4*>(G + o);
+                if (AK != 2) ga4[q] = *reinterpret_cast<const float4*>(Gq + o);
+            } else {
+                gv1[q] = G[o];
+                if (AK != 2) ga1[q] = Gq[o];
             }
-        }
-        {   // input rows with halo
-            const int b = b0 + x_seg, t = t0 - p.pad + x_u;      // VEC: t % 4 == 0, all in or all out
-            const bool cok = x_cv && b < p.B && t >= 0 && t < p.L && (VEC || x_u < p.SS);
-#pragma unroll
-            for (int q = 0; q < NXQ; ++q) {
-                const int c = c0 + x_row0 + x_rstep * q;
-                const bool ok = cok && c < p.CK;
-                const size_t o = ok ? ((size_t)b * p.CK + c) * p.L + t : 0;
-                if (VEC) xv4[q] = *reinterpret_cast<const float4*>(X + o);
-                else xv1[q] = X[o];
-            }
+        } else {
+            const int q = pi - NGQ;
+            const bool ok = s.xok && c0 + x_row0 + x_rstep * q < p.CK;
+            const int o = ok ? s.xbase + x_off0 + q * x_rstep * p.L : 0;
+            if (VEC) xv4[q] = *reinterpret_cast<const float4*>(X + o);
+            else xv1[q] = X[o];
         }
     };
-    auto lstore = [&](int ch) {
-        int b0, t0;
-        chunk_origin(ch, b0, t0);
-        {
-            const int b = b0 + g_seg, t = t0 + g_t;
-            const bool cok = g_cv && b < p.B && t < p.L;
-            float* d = Gs + g_seg * p.SS + g_t;
-            if (g_cv) {
-#pragma unroll
-                for (int q = 0; q < NGQ; ++q) {
-                    const int row = g_row0 + g_rstep * q;
-                    const bool ok = cok && m0 + row < p.M;
-                    if (VEC) {
-                        d[row * p.PG + 0] = ok ? ms_act_grad(gv4[q].x, ga4[q].x, g_kind, p.slope) : 0.f;
-                        d[row * p.PG + 1] = ok ? ms_act_grad(gv4[q].y, ga4[q].y, g_kind, p.slope) : 0.f;
-                        d[row * p.PG + 2] = ok ? ms_act_grad(gv4[q].z, ga4[q].z, g_kind, p.slope) : 0.f;
-                        d[row * p.PG + 3] = ok ? ms_act_grad(gv4[q].w, ga4[q].w, g_kind, p.slope) : 0.f;
-                    } else {
-                        d[row * p.PG] = ok ? ms_act_grad(gv1[q], ga1[q], g_kind, p.slope) : 0.f;
-                    }
-                }
+    auto store_piece = [&](int pi, const Cs& s, float* buf) {
+        if (pi < NGQ) {
+            const int q = pi;
+            const bool ok = s.gok && m0 + g_row0 + g_rstep * q < p.M;
+            float* d = g_cv ? buf + g_lds0 + q * g_rstep * p.PG : scratch + tid;
+            if (VEC) {
+                const float v0 = ok ? wr_gact<AK>(gv4[q].x, ga4[q].x, g_kind, p.slope) : 0.f;
+                const float v1 = ok ? wr_gact<AK>(gv4[q].y, ga4[q].y, g_kind, p.slope) : 0.f;
+                const float v2 = ok ? wr_gact<AK>(gv4[q].z, ga4[q].z, g_kind, p.slope) : 0.f;
+                const float v3 = ok ? wr_gact<AK>(gv4[q].w, ga4[q].w, g_kind, p.slope) : 0.f;
+                d[0] = v0; d[g_cv ? 1 : 0] = v1; d[g_cv ? 2 : 0] = v2; d[g_cv ? 3 : 0] = v3;
+            } else {
+                d[0] = ok ? wr_gact<AK>(gv1[q], ga1[q], g_kind, p.slope) : 0.f;
             }
-        }
-        {
-            const int b = b0 + x_seg, t = t0 - p.pad + x_u;
-            const bool cok = x_cv && b < p.B && t >= 0 && t < p.L;
-            float* d = Xs + x_seg * p.SS + x_u;
-            if (x_cv) {
+        } else {
+            const int q = pi - NGQ;
+            const bool ok = s.xok && c0 + x_row0 + x_rstep * q < p.CK;
+            float* d = buf + x_lds0 + q * x_rstep * p.PX;
+            if (VEC) {
+                const float e[4] = {xv4[q].x, xv4[q].y, xv4[q].z, xv4[q].w};
 #pragma unroll
-                for (int q = 0; q < NXQ; ++q) {
-                    const int row = x_row0 + x_rstep * q;
-                    const bool ok = cok && c0 + row < p.CK;
-                    if (VEC) {
-                        const float e[4] = {xv4[q].x, xv4[q].y, xv4[q].z, xv4[q].w};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (x_u + i >= 0 && x_u + i < p.SS)
-                                d[row * p.PX + i] = ok ? wr_xact(e[i], p.x_kind, p.slope) : 0.f;
-                    } else if (x_u < p.SS) {
-                        d[row * p.PX] = ok ? wr_xact(xv1[q], p.x_kind, p.slope) : 0.f;
-                    }
+                for (int i = 0; i < 4; ++i) {
+                    float* di = x_ev[i] ? d + i : scratch + tid;
+                    *di = ok ? wr_xact<AK>(e[i], p.x_kind, p.slope) : 0.f;
                 }
+            } else {
+                float* di = x_cv ? d : scratch + tid;
+                *di = ok ? wr_xact<AK>(xv1[q], p.x_kind, p.slope) : 0.f;
             }
         }
     };
 
     const int c_begin = blockIdx.z * p.cps;
     const int c_end = min(c_begin + p.cps, p.nchunks);
-    if (c_begin < c_end) gload(c_begin);
+    // prologue: chunk c_begin -> buffer 0, chunk c_begin + 1 -> registers
+    Cs s_cur = chunk_state(c_begin, c_end);
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi) load_piece(pi, s_cur);
+    // the halo columns of the gradient tiles (and the columns past the last segment) stay zero
+    for (int i = tid; i < 2 * tile_floats + 256; i += 256) smem[i] = 0.f;
     __syncthreads();                                 // zero fill complete
-    if (c_begin < c_end) lstore(c_begin);
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi) store_piece(pi, s_cur, smem);
+    Cs s_next = chunk_state(c_begin + 1, c_end);
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi) load_piece(pi, s_next);
     __syncthreads();
 
-    const float* ap = Gs + (wm * TM * 32 + (lane & 31)) * p.PG + h;
-    const float* bp = Xs + (wn * 32 + (lane & 31)) * p.PX + h;
-    const int KP = p.kcols >> 1;                     // even (kcols % 4 == 0)
-    float a0[TM], b0[K], a1[TM], b1[K];
-    auto frag = [&](int kk, float (&a)[TM], float (&b)[K]) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = ap[i * 32 * p.PG + 2 * kk];
-#pragma unroll
-        for (int j = 0; j < K; ++j) b[j] = bp[2 * kk + j * p.dil];
-    };
-    auto mma = [&](const float (&a)[TM], const float (&b)[K]) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            asum[i] += a[i];
-#pragma unroll
-            for (int j = 0; j < K; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    };
+    const int a_off = (wm * TM * 32 + (lane & 31)) * p.PG + h;
+    const int b_off = BM * p.PG + (wn * 32 + (lane & 31)) * p.PX + h;
     for (int ch = c_begin; ch < c_end; ++ch) {
-        const bool more = ch + 1 < c_end;
-        if (more) gload(ch + 1);
-        // two-stage register pipeline: the fragments of step kk+1 are read while step kk multiplies
-        // (the read past the last step lands in the zeroed pad columns and is not used)
+        const int cur = (ch - c_begin) & 1;
+        const float* ap = smem + cur * tile_floats + a_off;
+        const float* bp = smem + cur * tile_floats + b_off;
+        float* nbuf = smem + (cur ^ 1) * tile_floats;
+        const Cs s_after = chunk_state(ch + 2, c_end);
+        float a0[TM], b0[K], a1[TM], b1[K];
+        auto frag = [&](int kk, float (&a)[TM], float (&b)[K]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = ap[i * 32 * p.PG + 2 * kk];
+#pragma unroll
+            for (int j = 0; j < K; ++j) b[j] = bp[2 * kk + j * p.dil];
+        };
+        auto mma = [&](const float (&a)[TM], const float (&b)[K]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                asum[i] += a[i];
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        };
         frag(0, a0, b0);
-        for (int kk = 0; kk < KP; kk += 2) {
-            frag(kk + 1, a1, b1);
+#pragma unroll
+        for (int it = 0; it < KPI; ++it) {
+            frag(2 * it + 1, a1, b1);
             mma(a0, b0);
-            frag(kk + 2, a0, b0);
+#pragma unroll
+            for (int pp = 0; pp < PPI; ++pp) {
+                const int pi = it * PPI + pp;
+                if (pi < NP) {
+                    store_piece(pi, s_next, nbuf);      // chunk ch+1: registers -> the other buffer
+                    load_piece(pi, s_after);            // chunk ch+2: into the registers just freed
+                }
+            }
+            frag(2 * it + 2, a0, b0);                   // (past the last step: zeroed pad columns, unused)
             mma(a1, b1);
         }
+        s_next = s_after;
         __syncthreads();
-        if (more) {
-            lstore(ch + 1);
-            __syncthreads();
-        }
     }
 
     // D[row][col]: col = lane&31 (input channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (output channel)
@@ -279,15 +310,15 @@ WrPlan plan_wrows(const ConvP& c) {
     }
     p.SS = p.Lt + H;
     p.RSZ = p.R * p.SS;
-    p.kcols = (p.RSZ - H + 3) & ~3;
+    p.kcols = p.RSZ - H <= 32 ? 32 : 64;            // 8 or 16 unrolled double-steps (pad columns are zero)
     q.vec = p.L % 4 == 0 && p.R * (p.Lt / 4) <= 16 && p.R * ((p.SS + 6) / 4) <= 32;
     if (!q.vec && (p.kcols > 64 || p.RSZ > 128)) return q;
     p.PG = (p.kcols + 2) | 1;
     p.PX = (p.kcols + H + 2) | 1;
     q.tm = (K <= 3 && c.Cout >= 128) ? 2 : 1;
     const int BM = 64 * q.tm;
-    q.lds = (size_t)(BM * p.PG + CB * p.PX + 8) * sizeof(float);
-    if (q.lds > 64 * 1024) return q;
+    q.lds = (size_t)(2 * (BM * p.PG + CB * p.PX) + 256) * sizeof(float);   // two buffers + scratch
+    if (q.lds > 150 * 1024) return q;
     const int tiles = ms_ceil_div(p.M, BM) * ms_ceil_div(p.CK, CB);
     q.stride_floats = (size_t)p.M * p.CK * K + p.M;
     int ns = ms_ceil_div(512, tiles);
@@ -304,16 +335,46 @@ WrPlan plan_wrows(const ConvP& c) {
     return q;
 }
 
+template <int K, int TM, bool VEC, int KPI, int AK>
+void launch_wrows_ak(const WrPlan& q, const float* x, const float* gy, const float* y_act,
+                     float* partial, hipStream_t s) {
+    static bool attr_set = false;                    // > 64 KiB of dynamic LDS needs the opt-in once
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_rows<K, TM, VEC, KPI, AK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_wgrad_rows<K, TM, VEC, KPI, AK>), q.grid, dim3(256), q.lds, s, q.p, x, gy, y_act,
+                       partial, q.stride_floats);
+}
+
+template <int K, int TM, bool VEC, int KPI>
+void launch_wrows_inst(const WrPlan& q, const float* x, const float* gy, const float* y_act,
+                       float* partial, hipStream_t s) {
+    const int gk = y_act ? q.p.g_kind : MS_ACT_NONE;
+    if (gk == MS_ACT_LRELU && q.p.x_kind == MS_ACT_NONE) launch_wrows_ak<K, TM, VEC, KPI, 1>(q, x, gy, y_act, partial, s);
+    else if (gk == MS_ACT_NONE && q.p.x_kind == MS_MOD_LRELU_FWD) launch_wrows_ak<K, TM, VEC, KPI, 2>(q, x, gy, y_act, partial, s);
+    else launch_wrows_ak<K, TM, VEC, KPI, 0>(q, x, gy, y_act, partial, s);
+}
+
+template <int K, int TM>
+void launch_wrows_tm(const WrPlan& q, bool vec, const float* x, const float* gy, const float* y_act,
+                     float* partial, hipStream_t s) {
+    const bool k16 = q.p.kcols == 64;
+    if (vec) {
+        if (k16) launch_wrows_inst<K, TM, true, 16>(q, x, gy, y_act, partial, s);
+        else launch_wrows_inst<K, TM, true, 8>(q, x, gy, y_act, partial, s);
+    } else {
+        if (k16) launch_wrows_inst<K, TM, false, 16>(q, x, gy, y_act, partial, s);
+        else launch_wrows_inst<K, TM, false, 8>(q, x, gy, y_act, partial, s);
+    }
+}
+
 template <int K>
 void launch_wrows(const WrPlan& q, bool vec, const float* x, const float* gy, const float* y_act,
                   float* partial, hipStream_t s) {
-    if (q.tm == 2) {
-        if (vec) hipLaunchKernelGGL((k_wgrad_rows<K, 2, true>), q.grid, dim3(256), q.lds, s, q.p, x, gy, y_act, partial, q.stride_floats);
-        else hipLaunchKernelGGL((k_wgrad_rows<K, 2, false>), q.grid, dim3(256), q.lds, s, q.p, x, gy, y_act, partial, q.stride_floats);
-    } else {
-        if (vec) hipLaunchKernelGGL((k_wgrad_rows<K, 1, true>), q.grid, dim3(256), q.lds, s, q.p, x, gy, y_act, partial, q.stride_floats);
-        else hipLaunchKernelGGL((k_wgrad_rows<K, 1, false>), q.grid, dim3(256), q.lds, s, q.p, x, gy, y_act, partial, q.stride_floats);
-    }
+    if (K <= 3 && q.tm == 2) launch_wrows_tm<K, K <= 3 ? 2 : 1>(q, vec, x, gy, y_act, partial, s);
+    else launch_wrows_tm<K, 1>(q, vec, x, gy, y_act, partial, s);
 }
 
 }  // namespace
@@ -332,7 +393,7 @@ size_t msw_bwd_weight_ws(const ConvP& p) {
 const char* msw_bwd_weight_name(const ConvP& p) {
     static thread_local char buf[64];
     const WrPlan q = plan_wrows(p);
-    snprintf(buf, sizeof(buf), "k_wgrad_rows<%d, %d, %s>", p.K, q.tm, q.vec ? "true" : "false");
+    snprintf(buf, sizeof(buf), "k_wgrad_rows<%d, %d, %s, %d>", p.K, q.tm, q.vec ? "true" : "false", q.p.kcols / 4);
     return buf;
 }
 
