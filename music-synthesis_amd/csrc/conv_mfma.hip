@@ -18,6 +18,7 @@
 // in flight while the MFMAs of chunk c run.
 #include <cstdlib>
 #include "conv_mfma.h"
+#include "conv_rows2.h"
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -1055,6 +1056,10 @@ bool rows_applicable(int M, int CK, int K, int L) {
 }
 
 RowCfg pick_row_cfg(int M, int B, int L) {
+    if (const char* e = getenv("MSYNTH_ROWCFG")) {      // tuning switch: force a tile shape
+        const int v = atoi(e);
+        if (v >= 0 && v <= 3 && (M > 32 || v == 3)) return v == 0 ? ROW_128x128 : (v == 1 ? ROW_64x128 : (v == 2 ? ROW_64x64 : ROW_32x256));
+    }
     if (M <= 32) return ROW_32x256;
     if (L < 128) return (M >= 512 && (long long)B * L >= 512) ? ROW_64x128 : ROW_64x64;   // short rows: R = 128 / L rows per tile
     const long long N = (long long)B * L;
@@ -1099,6 +1104,22 @@ int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, 
     row_tile(cfg, &bm, &bn);
     const unsigned gx = p.R == 1 ? (unsigned)(p.B * p.tiles_per_row) : (unsigned)((p.B + p.R - 1) / p.R);
     dim3 grid(gx, (unsigned)((p.M + bm - 1) / bm), (unsigned)((p.CK + p.CKs - 1) / p.CKs));
+    // pipelined second-generation kernel where its requirements hold (conv_rows2.hip)
+    if (IN_S == 1 && p.pad_mode == MS_PAD_ZERO && cfg != ROW_64x256 &&
+        (!HAS_ACT || p.in_act == MS_ACT_LRELU || p.in_act == MS_ACT_NONE) &&
+        ((((uintptr_t)X) | ((uintptr_t)W) | ((uintptr_t)(Xact ? Xact : X)) | ((uintptr_t)Y) |
+          ((uintptr_t)(Yact ? Yact : Y)) | ((uintptr_t)(res ? res : X))) & 15) == 0 &&
+        (long long)p.B * p.CK * p.L < (1LL << 31) && (long long)p.M * p.KG < (1LL << 31)) {
+        Row2P q;
+        q.B = p.B; q.CK = p.CK; q.L = p.L; q.M = p.M; q.dil = p.dil; q.off0 = p.off0; q.act = p.act;
+        q.KG = p.KG; q.Lt = p.Lt; q.R = p.R; q.SS = p.SS; q.RSZ = p.RSZ; q.tiles_per_row = p.tiles_per_row;
+        q.PX = p.RSZ; q.CKs = p.CKs; q.zstride = p.zstride; q.slope = p.slope;
+        const int tile = cfg == ROW_128x128 ? MSR2_128x128 : (cfg == ROW_64x128 ? MSR2_64x128 :
+                         (cfg == ROW_64x64 ? MSR2_64x64 : MSR2_32x256));
+        const int am = (HAS_ACT && p.in_act == MS_ACT_LRELU) ? 1 : 0;
+        if (msr2_supported(tile, K, CC, am, EPI_S, q))
+            return msr2_launch(tile, K, CC, am, EPI_S, q, X, Xact, W, bias, res, Y, Yact, grid.x, grid.y, grid.z, s);
+    }
     const size_t lds = (size_t)(bm * (CC * K + 1) + CC * p.RSZ) * sizeof(float);
     if (lds > 64 * 1024) return MS_ERR_UNSUPPORTED;
     switch (cfg) {

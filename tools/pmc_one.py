@@ -11,6 +11,12 @@ if op == "dwgrad":      # dense weight gradient: dwgrad B Cin L Cout K dil
     d, lo = P.conv_desc(x.shape, (Cout, Cin, K), pad=dil * (K - 1) // 2, dil=dil, act=1)
     for _ in range(5): P.conv1d_bwd_weight(x, gy, ya, d, (Cout, Cin, K))
     torch.cuda.synchronize(); sys.exit(0)
+if op == "dfwd":      # dense forward: dfwd B C L K dil
+    B, C, Lg, K, dil = map(int, sys.argv[2:7])
+    x = torch.randn(B, C, Lg, device="cuda"); w = torch.randn(C, C, K, device="cuda") * 0.02; b = torch.randn(C, device="cuda")
+    d, lo = P.conv_desc(x.shape, w.shape, pad=dil * (K - 1) // 2, dil=dil, act=1)
+    for _ in range(5): P.conv1d_fwd(x, w, b, d, lo)
+    torch.cuda.synchronize(); sys.exit(0)
 B, Cin, Lin, Cout, groups = map(int, sys.argv[2:7])
 x = torch.randn(B, Cin, Lin, device="cuda"); w = torch.randn(Cout, 4, 41, device="cuda") * 0.05; b = torch.randn(Cout, device="cuda")
 d, lo = P.conv_desc(x.shape, w.shape, stride=4, pad=20, groups=groups, act=1)
