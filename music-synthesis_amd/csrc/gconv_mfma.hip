@@ -260,15 +260,30 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_bwd_data(ConvP p, const floa
     const int span = min(WQ + 2 * (JJ - 1), ((qvalid + 15) & ~15) + 2 * (JJ - 1));
     const float* ya = y_act ? y_act : gy;
     const int kind = y_act ? p.act : MS_ACT_NONE;
-    for (int idx = tid; idx < OQ * 4 * span; idx += 256) {
-        const int co = idx / span, tt = idx - co * span;
-        const int t = tlo + tt;
-        const bool ok = t >= 0 && t < p.Lout;
-        const size_t off = ok ? ((size_t)b * p.Cout + (size_t)g * p.Og + co) * p.Lout + t : 0;
-        const float v = gy[off], a = ya[off];
-        gs[co * GRS + tt] = ok ? ms_act_grad(v, a, kind, p.slope) : 0.f;
+    {   // batched staging (all loads issued before the first LDS store)
+        constexpr int SPMAX = WQ + 2 * (JJ - 1);          // 276 columns per co row
+        constexpr int NGI = (OQ * 4 * SPMAX + 255) / 256;
+        float gv[NGI], av[NGI];
+#pragma unroll
+        for (int i = 0; i < NGI; ++i) {
+            const int idx = tid + 256 * i;
+            const int co = idx / SPMAX, tt = idx - co * SPMAX;    // compile-time divisor
+            const int t = tlo + tt;
+            const bool ok = co < OQ * 4 && tt < span && t >= 0 && t < p.Lout;
+            const size_t off = ok ? ((size_t)b * p.Cout + (size_t)g * p.Og + co) * p.Lout + t : 0;
+            gv[i] = gy[off];
+            av[i] = ya[off];
+        }
+#pragma unroll
+        for (int i = 0; i < NGI; ++i) {
+            const int idx = tid + 256 * i;
+            const int co = idx / SPMAX, tt = idx - co * SPMAX;
+            const int t = tlo + tt;
+            const bool ok = tt < span && t >= 0 && t < p.Lout;
+            if (co < OQ * 4 && tt < span) gs[co * GRS + tt] = ok ? ms_act_grad(gv[i], av[i], kind, p.slope) : 0.f;
+        }
     }
-    for (int idx = tid; idx < OQ * 4 * GCG * GK; idx += 256) ws[idx] = w[(size_t)g * p.Og * GCG * GK + idx];
+    stage_weights<(OQ * 4 * GCG * GK + 255) / 256>(w + (size_t)g * p.Og * GCG * GK, ws, OQ * 4 * GCG * GK, tid);
     __syncthreads();
     // weight fragments: lane (m = (ci, r) = lane&15, k = lane>>4): w[g*Og + 4cq + k][ci][r + 4jj]
     const int mrow = lane & 15, ci = mrow >> 2, r = mrow & 3, kq = lane >> 4;
@@ -318,22 +333,30 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_bwd_data(ConvP p, const floa
 // N = (ci, k) = 164 columns in 11 MFMA tiles, MFMA k index = 4 consecutive t.  Every wave sums
 // its own quarter of each 256-output chunk into registers (11 x f32x4) and writes ONE slab per
 // wave at the end; slabs are combined by the deterministic split-K reduce (k_reduce_slabs).
-constexpr int WC = 256;                       // outputs per chunk (4 waves x 64)
-constexpr int RSA = WC + 2;                   // == 2 (mod 32): (co, k) fragment reads conflict-free
-constexpr int XSPAN = WC * GS + GK - 1;       // 1064 inputs per channel and chunk
+// Work unit of a WAVE (as in the forward kernel): 64 consecutive outputs of one batch row.  The wave
+// stages the 16 x 64 gradient values and the 4 x 296 inputs of the unit in its private LDS region,
+// runs 16 k-steps x 11 column tiles, and prefetches the next unit into registers meanwhile.  No
+// workgroup barriers: at the coarse scales (L = 9 .. 65) all four waves work on different batch rows
+// instead of three of them idling behind a 256-output chunk.
+constexpr int WU = 64;                        // outputs per unit
+constexpr int RSA = WU + 2;                   // == 2 (mod 32): (co, k) fragment reads conflict-free
+constexpr int XSPAN = (WU - 1) * GS + GK;     // 293 inputs per channel and unit
+constexpr int XW = 300;                       // LDS pitch of an input row (reads reach 292 + 3)
 constexpr int NT = (GCG * GK + 15) / 16;      // 11 column tiles
+constexpr int WGS = 16 * RSA, WXS = GCG * XW; // floats per wave: gradient / input region
 
 __global__ __launch_bounds__(256) void k_gconv_mfma_wgrad(ConvP p, const float* __restrict__ x,
                                                          const float* __restrict__ gy,
                                                          const float* __restrict__ y_act,
                                                          float* __restrict__ partial,
                                                          size_t partial_stride) {
-    __shared__ float gs[16 * RSA];
-    __shared__ float xs[GCG * XSPAN];
+    __shared__ float lds[4 * (WGS + WXS)];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = blockIdx.y;
     const float* ya = y_act ? y_act : gy;
     const int kind = y_act ? p.act : MS_ACT_NONE;
+    float* gs = lds + wid * (WGS + WXS);
+    float* xs = gs + WGS;
 
     f32x4 acc[NT];
 #pragma unroll
@@ -347,37 +370,62 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_wgrad(ConvP p, const float* 
         int nn = i * 16 + (lane & 15);
         if (nn >= GCG * GK) nn = 0;           // padded columns: computed, never stored
         const int ci = nn / GK, kk = nn - ci * GK;
-        xo[i] = ci * XSPAN + kk + 4 * (lane >> 4) + wid * 64 * GS;
+        xo[i] = ci * XW + kk + 4 * (lane >> 4);
     }
-    const int ao = (lane & 15) * RSA + (lane >> 4) + wid * 64;
+    const int ao = (lane & 15) * RSA + (lane >> 4);
 
-    const int tchunks = (p.Lout + WC - 1) / WC;
-    const int nchunks = p.B * tchunks;
-    for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-        const int b = ch / tchunks, t0 = (ch - b * tchunks) * WC;
-        const int tvalid = min(WC, p.Lout - t0);
-        const int tv4 = (tvalid + 3) & ~3;    // MFMA k-steps cover whole groups of 4 outputs
-        __syncthreads();                      // previous chunk fully consumed
-        for (int idx = tid; idx < 16 * tv4; idx += 256) {
-            const int co = idx / tv4, t = idx - co * tv4;
-            const bool ok = co < p.Og && t0 + t < p.Lout;
-            const size_t off = ok ? ((size_t)b * p.Cout + (size_t)g * p.Og + co) * p.Lout + t0 + t : 0;
-            const float v = gy[off], a = ya[off];
-            gs[co * RSA + t] = ok ? ms_act_grad(v, a, kind, p.slope) : 0.f;
-        }
+    const int tiles = (p.Lout + WU - 1) / WU;
+    const int nunits = p.B * tiles;
+    const int ustride = gridDim.x * 4;
+    constexpr int NXI = (XSPAN + 63) / 64;             // 5 input loads per lane and channel
+    float gv[16], ga[16], xv[GCG][NXI];
+    auto gload = [&](int unit) {
+        const int b = unit / tiles, t0 = (unit - b * tiles) * WU;
         const int u0 = t0 * GS - p.pad;
-        const int xspan = tv4 * GS + GK - 1;
-        for (int idx = tid; idx < GCG * xspan; idx += 256) {
-            const int ci = idx / xspan, u = idx - ci * xspan;
-            const int sidx = u0 + u;
-            const bool ok = sidx >= 0 && sidx < p.Lin;
-            const float v = x[ok ? ((size_t)b * p.Cin + (size_t)g * GCG + ci) * p.Lin + sidx : 0];
-            xs[ci * XSPAN + u] = ok ? v : 0.f;
+        const bool tok = t0 + lane < p.Lout;
+#pragma unroll
+        for (int co = 0; co < 16; ++co) {              // lane = output t, co = row
+            const bool ok = tok && co < p.Og;
+            const size_t off = ok ? ((size_t)b * p.Cout + (size_t)g * p.Og + co) * p.Lout + t0 + lane : 0;
+            gv[co] = gy[off];
+            ga[co] = ya[off];
         }
-        __syncthreads();
-        const int isteps = min(16, max(0, (tv4 - wid * 64) >> 2));   // wave-uniform
+        const float* xrow = x + ((size_t)b * p.Cin + (size_t)g * GCG) * p.Lin;
+#pragma unroll
+        for (int k = 0; k < NXI; ++k) {
+            const int u = lane + 64 * k, sidx = u0 + u;
+            const bool ok = u < XSPAN && sidx >= 0 && sidx < p.Lin;
+            const int so = ok ? sidx : 0;
+#pragma unroll
+            for (int c = 0; c < GCG; ++c) xv[c][k] = xrow[(size_t)c * p.Lin + so];
+        }
+    };
+    int unit = blockIdx.x * 4 + wid;
+    if (unit < nunits) gload(unit);
+    for (; unit < nunits; unit += ustride) {
+        const int b = unit / tiles, t0 = (unit - b * tiles) * WU;
+        (void)b;
+        const int u0 = t0 * GS - p.pad;
+        const bool tok = t0 + lane < p.Lout;
+#pragma unroll
+        for (int co = 0; co < 16; ++co)
+            gs[co * RSA + lane] = (tok && co < p.Og) ? ms_act_grad(gv[co], ga[co], kind, p.slope) : 0.f;
+#pragma unroll
+        for (int k = 0; k < NXI; ++k) {
+            const int u = lane + 64 * k, sidx = u0 + u;
+            const bool ok = u < XSPAN && sidx >= 0 && sidx < p.Lin;
+            if (u < XW) {
+#pragma unroll
+                for (int c = 0; c < GCG; ++c) xs[c * XW + u] = ok ? xv[c][k] : 0.f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (unit + ustride < nunits) gload(unit + ustride);
+        const int tvalid = min(WU, p.Lout - t0);
+        const int isteps = (tvalid + 3) >> 2;          // wave-uniform; outputs past tvalid are zero in gs
 #pragma unroll 4
-        for (int i = 0; i < isteps; ++i) {    // MFMA k-steps of 4 outputs within this wave's 64 outputs
+        for (int i = 0; i < isteps; ++i) {             // MFMA k-steps of 4 outputs
             const float a = gs[ao + 4 * i];
             bsum += a;
 #pragma unroll
@@ -386,6 +434,8 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_wgrad(ConvP p, const float* 
                 acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[n], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 
     float* part = partial + (size_t)(blockIdx.x * 4 + wid) * partial_stride;
@@ -496,8 +546,8 @@ bool msg_bwd_weight_applicable(const ConvP& p) {
 
 static int wgrad_gridx(const ConvP& p) {
     const size_t slab = ((size_t)p.Cout * GCG * GK + p.Cout) * sizeof(float);
-    const int nchunks = p.B * ms_ceil_div(p.Lout, WC);
-    int gx = ms_ceil_div(384, p.groups);                 // ~1.5 workgroups per CU
+    const int nchunks = ms_ceil_div(p.B * ms_ceil_div(p.Lout, WU), 4);   // 4 wave units per workgroup pass
+    int gx = ms_ceil_div(512, p.groups);                 // ~2 workgroups per CU
     const size_t cap = (size_t)16 << 20;                 // slabs (4 per workgroup column) <= 16 MiB
     while (gx > 1 && (size_t)gx * 4 * slab > cap) --gx;
     if (gx > nchunks) gx = nchunks;
