@@ -201,7 +201,16 @@ def main():
         for kk, g_ in sorted(by_geom.items(), key=lambda kv: -kv[1][0])[:200]:
             log("    %-40s %-22s %-44s x%-3d %7.3f ms %7.2f TF/s" % (
                 kk[0], kk[1], str(kk[2]), g_[1], g_[0], g_[2] / g_[0] / 1e9 if g_[0] else 0))
-        k, a = top[0]
+        # dominant kernel = the kernel TEMPLATE with the largest device time (its instantiations differ
+        # only in tile shape / taps / fused epilogue; rocprofv3 lists them separately)
+        fam = {}
+        for k_, a_ in agg.items():
+            f_ = fam.setdefault(k_.split("<")[0], {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0, "inst": {}})
+            for key in ("ms", "n", "flops", "bytes"):
+                f_[key] += a_[key]
+            f_["inst"][k_] = {"launches": a_["n"], "avg_launch_us": 1e3 * a_["ms"] / a_["n"],
+                              "tflops": a_["flops"] / a_["ms"] / 1e9 if a_["ms"] else 0.0}
+        k, a = sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[0]
         avg_s = a["ms"] / a["n"] / 1e3
         fl, by = a["flops"] / a["n"], a["bytes"] / a["n"]
         compute_bound = fl / F32_PEAK >= by / HBM_PEAK
@@ -215,19 +224,23 @@ def main():
         roof["traffic"] = None
         # HBM bytes per launch of that kernel from the TCC counters (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE in separate passes, gfx950 x2 fetch correction: tools/pmc_traffic.sh), collected
-        # on this same workload and committed under profiles/
+        # on this same workload and committed under profiles/ (averaged over the template's dispatches)
         pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as fh:
                 pmc = json.load(fh)
+            tb, nd = 0.0, 0
             for name, rec_ in pmc.items():
-                if (k + "(") in name:
-                    roof["traffic"] = rec_["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/r01_pmc_traffic.json (%d dispatches)" % rec_["dispatches"]
-                    break
+                if ("::" + k + "<") in name or ("::" + k + "(") in name or name.startswith(k):
+                    tb += rec_["hbm_bytes_per_launch"] * rec_["dispatches"]
+                    nd += rec_["dispatches"]
+            if nd:
+                roof["traffic"] = tb / nd
+                roof["traffic_source"] = "profiles/r01_pmc_traffic.json (%d dispatches)" % nd
         roof.update({"kernel": k, "launches_per_DG_pair": a["n"], "avg_launch_us": avg_s * 1e6,
                      "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
-                     "share_of_kernel_time": a["ms"] / tot_ms})
+                     "share_of_kernel_time": a["ms"] / tot_ms,
+                     "instantiations": dict(sorted(a["inst"].items(), key=lambda kv: -kv[1]["launches"] * kv[1]["avg_launch_us"]))})
         result["roofline"] = roof
         launches = W.d_step_launches(B, args.mels, T) + W.g_step_launches(B, args.mels, T)
         ideal = W.roofline_seconds(launches, HBM_PEAK, F32_PEAK)

@@ -226,6 +226,7 @@ struct RowP {
     float slope;
     int CKs;                             // input channels per split-K slice (== CK: no split)
     long long zstride;                   // floats between the partial-output slabs of two slices
+    const float* Wfwd;                   // backward data: the forward-layout weights (pipelined kernel reads them directly)
 };
 
 template <int WGM, int WGN, int TM, int TN, int K, int CC, bool HAS_ACT, int EPI_S, int IN_S>
@@ -1089,12 +1090,35 @@ bool make_rowp(RowP* q, RowCfg cfg, int B, int CK, int L, int M, int K, int dil,
     else { q->Lt = L; q->R = bn / L; q->tiles_per_row = 1; }
     q->SS = q->Lt + H;
     q->RSZ = q->R * q->SS;
-    q->CKs = CK; q->zstride = 0;
+    q->CKs = CK; q->zstride = 0; q->Wfwd = nullptr;
     return q->RSZ <= 512;
 }
 
 // deep contractions (>= 128 input channels) stage two channel chunks per barrier pair
 bool row_deep(int K, int CK) { return K != 7 && K != 1 && CK >= 128 && CK % (2 * row_cc(K)) == 0; }
+
+// Does a row-tile launch go to the pipelined kernel of conv_rows2.hip?  (16-byte aligned operands,
+// zero padding, plain input rows, activation handling it knows; backward data additionally needs
+// the forward-layout weights, which it reads directly.)
+bool rows2_pick(RowCfg cfg, int K, int CC, bool has_act, int epi_s, int in_s, const RowP& p, const float* X,
+                const float* Xact, const float* W, const float* res, const float* Y, const float* Yact,
+                Row2P* q, int* tile, int* am) {
+    if (in_s != 1 || p.pad_mode != MS_PAD_ZERO || cfg == ROW_64x256) return false;
+    if (has_act && p.in_act != MS_ACT_LRELU && p.in_act != MS_ACT_NONE) return false;
+    *am = (has_act && p.in_act == MS_ACT_LRELU) ? 1 : 0;
+    const float* Wuse = *am ? p.Wfwd : W;
+    if (!Wuse || (*am && p.M % 4)) return false;
+    if (((((uintptr_t)X) | ((uintptr_t)Wuse) | ((uintptr_t)(Xact ? Xact : X)) | ((uintptr_t)Y) |
+          ((uintptr_t)(Yact ? Yact : Y)) | ((uintptr_t)(res ? res : X))) & 15) != 0)
+        return false;
+    if ((long long)p.B * p.CK * p.L >= (1LL << 31) || (long long)p.M * p.KG >= (1LL << 31)) return false;
+    q->B = p.B; q->CK = p.CK; q->L = p.L; q->M = p.M; q->dil = p.dil; q->off0 = p.off0; q->act = p.act;
+    q->KG = p.KG; q->Lt = p.Lt; q->R = p.R; q->SS = p.SS; q->RSZ = p.RSZ; q->tiles_per_row = p.tiles_per_row;
+    q->PX = p.RSZ; q->CKs = p.CKs; q->zstride = p.zstride; q->slope = p.slope; q->scratch_off = 0;
+    *tile = cfg == ROW_128x128 ? MSR2_128x128 : (cfg == ROW_64x128 ? MSR2_64x128 :
+            (cfg == ROW_64x64 ? MSR2_64x64 : MSR2_32x256));
+    return msr2_supported(*tile, K, CC, *am, epi_s, *q);
+}
 
 template <int K, bool HAS_ACT, int EPI_S = 0, int IN_S = 1, int CCMUL = 1>
 int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, const float* W,
@@ -1105,20 +1129,12 @@ int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, 
     const unsigned gx = p.R == 1 ? (unsigned)(p.B * p.tiles_per_row) : (unsigned)((p.B + p.R - 1) / p.R);
     dim3 grid(gx, (unsigned)((p.M + bm - 1) / bm), (unsigned)((p.CK + p.CKs - 1) / p.CKs));
     // pipelined second-generation kernel where its requirements hold (conv_rows2.hip)
-    if (IN_S == 1 && p.pad_mode == MS_PAD_ZERO && cfg != ROW_64x256 &&
-        (!HAS_ACT || p.in_act == MS_ACT_LRELU || p.in_act == MS_ACT_NONE) &&
-        ((((uintptr_t)X) | ((uintptr_t)W) | ((uintptr_t)(Xact ? Xact : X)) | ((uintptr_t)Y) |
-          ((uintptr_t)(Yact ? Yact : Y)) | ((uintptr_t)(res ? res : X))) & 15) == 0 &&
-        (long long)p.B * p.CK * p.L < (1LL << 31) && (long long)p.M * p.KG < (1LL << 31)) {
+    {
         Row2P q;
-        q.B = p.B; q.CK = p.CK; q.L = p.L; q.M = p.M; q.dil = p.dil; q.off0 = p.off0; q.act = p.act;
-        q.KG = p.KG; q.Lt = p.Lt; q.R = p.R; q.SS = p.SS; q.RSZ = p.RSZ; q.tiles_per_row = p.tiles_per_row;
-        q.PX = p.RSZ; q.CKs = p.CKs; q.zstride = p.zstride; q.slope = p.slope;
-        const int tile = cfg == ROW_128x128 ? MSR2_128x128 : (cfg == ROW_64x128 ? MSR2_64x128 :
-                         (cfg == ROW_64x64 ? MSR2_64x64 : MSR2_32x256));
-        const int am = (HAS_ACT && p.in_act == MS_ACT_LRELU) ? 1 : 0;
-        if (msr2_supported(tile, K, CC, am, EPI_S, q))
-            return msr2_launch(tile, K, CC, am, EPI_S, q, X, Xact, W, bias, res, Y, Yact, grid.x, grid.y, grid.z, s);
+        int tile, am;
+        if (rows2_pick(cfg, K, CC, HAS_ACT, EPI_S, IN_S, p, X, Xact, W, res, Y, Yact, &q, &tile, &am))
+            return msr2_launch(tile, K, CC, am, EPI_S, q, X, Xact, am ? p.Wfwd : W, bias, res, Y, Yact, grid.x,
+                               grid.y, grid.z, s);
     }
     const size_t lds = (size_t)(bm * (CC * K + 1) + CC * p.RSZ) * sizeof(float);
     if (lds > 64 * 1024) return MS_ERR_UNSUPPORTED;
@@ -1164,11 +1180,25 @@ int launch_rows(int K, RowCfg cfg, const RowP& p, const float* X, const float* X
     return MS_ERR_UNSUPPORTED;
 }
 
-const char* row_kname(RowCfg c, int K, bool act, int CK) {
+// name of the kernel a row-tile launch resolves to (16-byte aligned tensors assumed): the pipelined
+// second generation where its requirements hold (conv_rows2.hip), else the first
+const char* row_kname(RowCfg c, int K, bool act, int CK, int L = 0, int R = 1, int SS = 0, int pad_mode = MS_PAD_ZERO,
+                      int in_act = MS_ACT_LRELU, int epi_s = 0) {
     static thread_local char buf[96];
     const char* tile = row_tile_str(c);
-    snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, %d, %d, %s, 0, 1>", tile, K,
-             row_cc(K) * (row_deep(K, CK) ? 2 : 1), act ? "true" : "false");
+    const int CC = epi_s ? row_cc(K) : row_cc(K) * (row_deep(K, CK) ? 2 : 1);
+    const int am = (act && in_act == MS_ACT_LRELU) ? 1 : 0;
+    if (L > 0 && c != ROW_64x256 && pad_mode == MS_PAD_ZERO && (!act || in_act == MS_ACT_LRELU || in_act == MS_ACT_NONE)) {
+        Row2P q;
+        q.L = L; q.R = R; q.SS = SS;
+        const int t2 = c == ROW_128x128 ? MSR2_128x128 : (c == ROW_64x128 ? MSR2_64x128 : (c == ROW_64x64 ? MSR2_64x64 : MSR2_32x256));
+        if (msr2_supported(t2, K, CC, am, epi_s, q)) {
+            snprintf(buf, sizeof(buf), "k_conv_rows2<%s, %d, %d, %d, %d>", tile, K, CC, am, epi_s);
+            return buf;
+        }
+    }
+    if (epi_s) snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, 3, 8, false, %d, 1>", tile, epi_s);
+    else snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, %d, %d, %s, 0, 1>", tile, K, CC, act ? "true" : "false");
     return buf;
 }
 
@@ -1304,11 +1334,21 @@ size_t msm_convt_fwd_ws(const ConvP& p) {
 }
 
 const char* msm_fwd_name(const ConvP& p) {
-    if (rows_ok(p, false)) return row_kname(pick_row_cfg(p.Cout, p.B, p.Lin), p.K, false, p.Cin);
+    if (rows_ok(p, false)) {
+        RowP r;
+        const RowCfg cfg = pick_row_cfg(p.Cout, p.B, p.Lin);
+        make_rowp(&r, cfg, p.B, p.Cin, p.Lin, p.Cout, p.K, p.dil, -p.pad, p.pad_mode, 0, 0, 0.f);
+        return row_kname(cfg, p.K, p.in_act != 0, p.Cin, p.Lin, r.R, r.SS, p.pad_mode, p.in_act ? MS_MOD_LRELU_FWD : 0);
+    }
     return kname("k_igemm_conv", pick_cfg(p.Cout, (long long)p.B * p.Lin), p.K, ", false");
 }
 const char* msm_bwd_data_name(const ConvP& p) {
-    if (rows_ok(p, true)) return row_kname(pick_row_cfg(p.Cin, p.B, p.Lin), p.K, p.act != MS_ACT_NONE, p.Cout);
+    if (rows_ok(p, true)) {
+        RowP r;
+        const RowCfg cfg = pick_row_cfg(p.Cin, p.B, p.Lin);
+        make_rowp(&r, cfg, p.B, p.Cout, p.Lin, p.Cin, p.K, p.dil, 0, 0, 0, 0, 0.f);
+        return row_kname(cfg, p.K, p.act != MS_ACT_NONE, p.Cout, p.Lin, r.R, r.SS, MS_PAD_ZERO, p.act);
+    }
     return kname("k_igemm_conv", pick_cfg(p.Cin, (long long)p.B * p.Lin), p.K, ", true");
 }
 const char* msm_bwd_weight_name(const ConvP& p) {
@@ -1318,9 +1358,10 @@ const char* msm_bwd_weight_name(const ConvP& p) {
 const char* msm_convt_fwd_name(const ConvP& p) {
     static thread_local char buf[96];
     const RowCfg c = pick_row_cfg(p.Cin * p.stride, p.B, p.Lout);
-    const char* tile = row_tile_str(c);
-    snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, 3, 8, false, %d, 1>", tile, p.stride);
-    return buf;
+    RowP r;
+    make_rowp(&r, c, p.B, p.Cout, p.Lout, p.Cin * p.stride, 3, 1, -1, 0, 0, 0, 0.f);
+    (void)buf;
+    return row_kname(c, 3, p.in_act != 0, p.Cout, p.Lout, r.R, r.SS, MS_PAD_ZERO, p.in_act ? MS_MOD_LRELU_FWD : 0, p.stride);
 }
 
 int msm_conv1d_fwd(const ConvP& p, const float* x, const float* x_act, int x_act_kind,
@@ -1351,14 +1392,23 @@ int msm_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, con
         float* wt = (float*)ws;
         const size_t total = (size_t)p.Cin * p.Cout * p.K;
         const size_t wbytes = align16(total * sizeof(float));
-        unsigned nb = (unsigned)((total + 255) / 256);
-        if (nb > 2048) nb = 2048;
-        hipLaunchKernelGGL(k_transpose_flip_w, dim3(nb), dim3(256), 0, s, w, wt, p.Cout, p.Cin, p.K);
-        MS_CHECK_LAUNCH();
         RowP r;
         const RowCfg cfg = pick_row_cfg(p.Cin, p.B, p.Lin);
         make_rowp(&r, cfg, p.B, p.Cout, p.Lin, p.Cin, p.K, p.dil, p.pad - (p.K - 1) * p.dil,
                   MS_PAD_ZERO, MS_ACT_NONE, p.act, p.slope);
+        r.Wfwd = w;
+        {
+            Row2P q2;
+            int tile2, am2;
+            const bool direct = y_act && rows2_pick(cfg, p.K, rows_cc_eff(p.K, p.Cout), true, 0, 1, r, gy, y_act, wt,
+                                                    gx_add, gx, nullptr, &q2, &tile2, &am2) && am2 == 1;
+            if (!direct) {     // first-generation kernel: weights re-laid-out (transposed + tap-flipped)
+                unsigned nb = (unsigned)((total + 255) / 256);
+                if (nb > 2048) nb = 2048;
+                hipLaunchKernelGGL(k_transpose_flip_w, dim3(nb), dim3(256), 0, s, w, wt, p.Cout, p.Cin, p.K);
+                MS_CHECK_LAUNCH();
+            }
+        }
         const int K = p.K;
         return rows_maybe_split(cfg, r, rows_cc_eff(K, p.Cout), p.Cin, p.Lin, nullptr, gx_add, gx, nullptr,
                                 (char*)ws + wbytes, ws_bytes - wbytes, s,

@@ -51,16 +51,33 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
     const int sh = ((p.off0 % 4) + 4) % 4;           // segment start within its 16-byte vector
     const int NVS = (p.SS + 6) >> 2;                 // aligned vectors covering one segment
     const int NVT = p.R * NVS;                       // ... one channel row of the tile
-    int a_goff[RA4], a_loff[RA4];
+    // AM 0: W is [M][CK][K] (forward weights, or pre-transposed backward weights): a 16-byte piece is 4
+    //       consecutive (c, j) of one output row.
+    // AM 1: backward data straight from the forward layout W[co][ci][j] (no transpose pass): for one
+    //       co of the chunk the BM*K floats of rows ci = m0.. are contiguous; a piece is 4 consecutive
+    //       (ci, j) of one co, scattered to As[ci][co_l*K + (K-1-j)] (taps flipped).
+    int a_goff[RA4], a_loff[RA4][AM ? 4 : 1];
     bool a_ok[RA4];
 #pragma unroll
     for (int i = 0; i < RA4; ++i) {
         const int e = i * 256 + tid;
-        const int row = e / (KK / 4), q4 = e - row * (KK / 4);
         const bool in = e < A4;
-        a_ok[i] = in && m0 + row < p.M;
-        a_goff[i] = a_ok[i] ? (m0 + row) * p.KG + q4 * 4 : 0;
-        a_loff[i] = in ? row * AS + q4 * 4 : -1;
+        if (AM == 0) {
+            const int row = e / (KK / 4), q4 = e - row * (KK / 4);
+            a_ok[i] = in && m0 + row < p.M;
+            a_goff[i] = a_ok[i] ? (m0 + row) * p.KG + q4 * 4 : 0;
+            a_loff[i][0] = in ? row * AS + q4 * 4 : -1;
+        } else {
+            constexpr int PER_CO = BM * K / 4;               // pieces per output channel of the chunk
+            const int co_l = e / PER_CO, f4 = e - co_l * PER_CO;
+            a_ok[i] = in && 4 * f4 < (p.M - m0) * K;          // (M, m0 multiples of 4: all 4 in or out)
+            a_goff[i] = a_ok[i] ? (co_l * p.M + m0) * K + 4 * f4 : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = 4 * f4 + u, ci_l = f / K, j = f - ci_l * K;
+                a_loff[i][u] = in ? ci_l * AS + co_l * K + (K - 1 - j) : -1;
+            }
+        }
     }
     int x_goff[NXQ], x_loff[NXQ];
     bool x_ok[NXQ];
@@ -109,7 +126,7 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
     auto load_piece = [&](int pi, int c0, bool live) {        // c0: first channel of the chunk
         if (pi < RA4) {
             const int i = pi;
-            const int o = (live && a_ok[i]) ? a_goff[i] + c0 * K : 0;
+            const int o = (live && a_ok[i]) ? a_goff[i] + c0 * (AM ? p.M * K : K) : 0;
             ra[i] = *reinterpret_cast<const float4*>(W + o);
         } else {
             const int q = pi - RA4;
@@ -122,12 +139,14 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
         if (pi < RA4) {
             const int i = pi;
             const bool ok = live && a_ok[i];
-            const bool in = a_loff[i] >= 0;
-            float* d = in ? buf + a_loff[i] : scratch + tid;
-            d[0] = ok ? ra[i].x : 0.f;
-            d[in ? 1 : 0] = ok ? ra[i].y : 0.f;
-            d[in ? 2 : 0] = ok ? ra[i].z : 0.f;
-            d[in ? 3 : 0] = ok ? ra[i].w : 0.f;
+            const float e[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int lo = AM ? a_loff[i][u] : a_loff[i][0] + u;
+                const bool in = (AM ? a_loff[i][u] : a_loff[i][0]) >= 0;
+                float* d = in ? buf + lo : scratch + tid;
+                *d = ok ? e[u] : 0.f;
+            }
         } else {
             const int q = pi - RA4;
             const bool ok = live && x_ok[q];

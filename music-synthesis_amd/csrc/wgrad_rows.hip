@@ -231,11 +231,12 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         };
+        const bool wave_live = m0 + wm * TM * 32 < p.M;     // rows of this wave exist (M = 32 under a 64-row tile)
         frag(0, a0, b0);
 #pragma unroll
         for (int it = 0; it < KPI; ++it) {
             frag(2 * it + 1, a1, b1);
-            mma(a0, b0);
+            if (wave_live) mma(a0, b0);
 #pragma unroll
             for (int pp = 0; pp < PPI; ++pp) {
                 const int pi = it * PPI + pp;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
                 }
             }
             frag(2 * it + 2, a0, b0);                   // (past the last step: zeroed pad columns, unused)
-            mma(a1, b1);
+            if (wave_live) mma(a1, b1);
         }
         s_next = s_after;
         __syncthreads();
@@ -293,7 +294,7 @@ WrPlan plan_wrows(const ConvP& c) {
     const int K = c.K;
     if (c.groups != 1 || c.stride != 1 || c.Lout != c.Lin || c.pad_mode != MS_PAD_ZERO) return q;
     if (!(K == 1 || K == 3 || K == 5 || K == 7)) return q;
-    if (c.Cout < 64 || c.Cin < 32) return q;
+    if (c.Cout < 64 || c.Cin < 32) return q;      // (32-channel layers: measured slower than the im2col kernel)
     const int H = (K - 1) * c.dil;
     if (H > 24 || c.pad > H) return q;
     if ((long long)c.B * c.Cout * c.Lin >= (1LL << 31) || (long long)c.B * c.Cin * c.Lin >= (1LL << 31)) return q;

@@ -13,7 +13,7 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n * 1e3, out
 
 torch.manual_seed(0)
-shapes = [(32, 128, 2048, 128, 3, 1), (32, 128, 2048, 128, 3, 9), (32, 256, 256, 256, 3, 1), (32, 256, 256, 256, 3, 9),
+shapes = [(32, 32, 8192, 32, 3, 1), (32, 32, 8192, 32, 3, 9), (32, 128, 2048, 128, 3, 1), (32, 128, 2048, 128, 3, 9), (32, 256, 256, 256, 3, 1), (32, 256, 256, 256, 3, 9),
           (32, 64, 4096, 64, 3, 1), (32, 64, 4096, 64, 3, 3), (64, 1024, 32, 1024, 5, 1), (64, 1024, 17, 1024, 5, 1),
           (64, 1024, 9, 1024, 5, 1), (32, 512, 32, 512, 3, 1)]
 tot = [0.0, 0.0]
