@@ -1052,7 +1052,7 @@ constexpr int row_cc(int K) { return K == 7 ? 4 : (K == 1 ? 32 : 8); }
 bool rows_applicable(int M, int CK, int K, int L) {
     if (!(K == 1 || K == 3 || K == 5 || K == 7)) return false;
     if (CK % row_cc(K)) return false;
-    if (M < 32) return false;
+    if (M < 32 && CK < 256) return false;   // (few outputs, deep contraction: the judge conv 1024 -> 1 with split-K)
     return L >= 1;
 }
 
@@ -1288,7 +1288,7 @@ const char* kname(const char* kernel, Cfg c, int K, const char* tail) {
 }  // namespace
 
 bool msm_fwd_applicable(const ConvP& p) {
-    return dense_same(p) && p.Cout >= 32 && p.Cin * p.K >= 32;
+    return dense_same(p) && (p.Cout >= 32 || p.Cin >= 256) && p.Cin * p.K >= 32;
 }
 bool msm_bwd_data_applicable(const ConvP& p) {
     return dense_same(p) && p.pad_mode == MS_PAD_ZERO && p.Cin >= 32 && p.Cout * p.K >= 32;
@@ -1464,12 +1464,7 @@ int msm_conv1d_bwd_weight(const ConvP& p, const float* x, const float* x_act, in
 #undef MS_WG_K
 #undef MS_WG
     MS_CHECK_LAUNCH();
-    const size_t wsize = (size_t)p.Cout * NG;
-    const size_t total = wsize + p.Cout;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, partial,
-                       pl.stride_floats, pl.nsplit, wsize, p.Cout, gw, gb, beta);
-    MS_CHECK_LAUNCH();
-    return MS_OK;
+    return msm_wgrad_reduce(partial, pl.stride_floats, pl.nsplit, (size_t)p.Cout * NG, p.Cout, gw, gb, beta, s);
 }
 
 int msm_convt1d_fwd(const ConvP& p, const float* x, const float* w, const float* bias, float* y,
@@ -1602,11 +1597,11 @@ int msm_convt1d_bwd_weight(const ConvP& p, const float* x, const float* gy, cons
     else MS_TWG(1, 4, 1, 2);
 #undef MS_TWG
     MS_CHECK_LAUNCH();
-    const size_t wsize = (size_t)CinT * NG;
-    const size_t total = wsize + CinT;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, partial,
-                       pl.w.stride_floats, pl.w.nsplit, wsize, CinT, dwq, (float*)nullptr, 0.f);
-    MS_CHECK_LAUNCH();
+    {
+        const int rc = msm_wgrad_reduce(partial, pl.w.stride_floats, pl.w.nsplit, (size_t)CinT * NG, CinT, dwq,
+                                        (float*)nullptr, 0.f, s);
+        if (rc != MS_OK) return rc;
+    }
     const size_t gtotal = (size_t)CinT * CoutT * p.K;
     unsigned nb = (unsigned)((gtotal + 255) / 256);
     if (nb > 4096) nb = 4096;
@@ -1615,9 +1610,72 @@ int msm_convt1d_bwd_weight(const ConvP& p, const float* x, const float* gy, cons
     return MS_OK;
 }
 
+// 16-byte variant: a lane owns 4 consecutive outputs, 8 slabs in flight per lane (the dword version is
+// latency-bound: 30 dependent-ish rounds of 4 loads for the 121 slabs of a 128-channel layer).
+__global__ __launch_bounds__(256) void k_wgrad_reduce_v4(const float* __restrict__ partial,
+                                                        size_t partial_stride, int nsplit,
+                                                        size_t total, float* __restrict__ out,
+                                                        float beta) {
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t i = ((size_t)blockIdx.x * 64 + lane) * 4;
+    const bool ok = i < total;                       // total % 4 == 0
+    float4 s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+        int z = wv;
+        for (; z + 28 < nsplit; z += 32) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = *reinterpret_cast<const float4*>(partial + (size_t)(z + 4 * u) * partial_stride + i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s[u].x += v[u].x; s[u].y += v[u].y; s[u].z += v[u].z; s[u].w += v[u].w; }
+        }
+        for (; z < nsplit; z += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)z * partial_stride + i);
+            s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+        }
+    }
+    float4 t;
+    t.x = ((s[0].x + s[1].x) + (s[2].x + s[3].x)) + ((s[4].x + s[5].x) + (s[6].x + s[7].x));
+    t.y = ((s[0].y + s[1].y) + (s[2].y + s[3].y)) + ((s[4].y + s[5].y) + (s[6].y + s[7].y));
+    t.z = ((s[0].z + s[1].z) + (s[2].z + s[3].z)) + ((s[4].z + s[5].z) + (s[6].z + s[7].z));
+    t.w = ((s[0].w + s[1].w) + (s[2].w + s[3].w)) + ((s[4].w + s[5].w) + (s[6].w + s[7].w));
+    red[wv][lane] = t;
+    __syncthreads();
+    if (wv == 0 && ok) {
+        float4 r;
+        r.x = (red[0][lane].x + red[1][lane].x) + (red[2][lane].x + red[3][lane].x);
+        r.y = (red[0][lane].y + red[1][lane].y) + (red[2][lane].y + red[3][lane].y);
+        r.z = (red[0][lane].z + red[1][lane].z) + (red[2][lane].z + red[3][lane].z);
+        r.w = (red[0][lane].w + red[1][lane].w) + (red[2][lane].w + red[3][lane].w);
+        float4* o = reinterpret_cast<float4*>(out + i);
+        if (beta != 0.f) {
+            const float4 p = *o;
+            r.x += beta * p.x; r.y += beta * p.y; r.z += beta * p.z; r.w += beta * p.w;
+        }
+        *o = r;
+    }
+}
+
 int msm_wgrad_reduce(const float* partial, size_t stride_floats, int nsplit, size_t wsize, int nbias,
                      float* gw, float* gb, float beta, hipStream_t s) {
     const size_t total = wsize + (size_t)nbias;
+    // weights with 16-byte accesses where the layout allows it, the bias tail with the dword kernel
+    if (wsize % 4 == 0 && stride_floats % 4 == 0 && nsplit >= 8 &&
+        ((((uintptr_t)partial) | ((uintptr_t)gw)) & 15) == 0) {
+        hipLaunchKernelGGL(k_wgrad_reduce_v4, dim3((unsigned)((wsize / 4 + 63) / 64)), dim3(256), 0, s, partial,
+                           stride_floats, nsplit, wsize, gw, beta);
+        MS_CHECK_LAUNCH();
+        if (nbias > 0 && gb) {
+            hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nbias + 63) / 64)), dim3(256), 0, s,
+                               partial + wsize, stride_floats, nsplit, (size_t)0, nbias, gw, gb, beta);
+            MS_CHECK_LAUNCH();
+        }
+        return MS_OK;
+    }
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, partial,
                        stride_floats, nsplit, wsize, nbias, gw, gb, beta);
     MS_CHECK_LAUNCH();

@@ -41,6 +41,32 @@ class GradSink:
         self.acc[i] = self.acc[i + 1] = True
 
 
+class _WgradFork:
+    """Weight gradients of the generator on a side stream (MSYNTH_WGSTREAM=0 disables): each layer's
+    weight-grad only needs the incoming gradient, so it can run beside the backward-data chain.
+    Tensors it reads are kept alive until the join (the caching allocator is per stream)."""
+
+    def __init__(self, device):
+        self.on = os.environ.get("MSYNTH_WGSTREAM", "1") == "1" and _concurrent_scales() and not _on_aux(device)
+        self.keep = []
+        if self.on:
+            self.main = torch.cuda.current_stream(device)
+            self.side = _side_streams(device, 2)[0]
+
+    def run(self, fn, *tensors):
+        if not self.on:
+            return fn()
+        self.keep.extend(t for t in tensors if t is not None)
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            return fn()
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+            self.keep.clear()
+
+
 def atom_forward(h, w0, b0, w1, b1, dil, save):
     d0, lo = P.conv_desc(h.shape, w0.shape, pad=dil, dil=dil, act=L.ACT_LRELU)
     t, _ = P.conv1d_fwd(h, w0, b0, d0, lo)
@@ -49,16 +75,17 @@ def atom_forward(h, w0, b0, w1, b1, dil, save):
     return out, (d0, d1, h, t, u)
 
 
-def atom_backward(rec, w0, w1, g, sink, i, need_wgrad=True, need_gx=True):
+def atom_backward(rec, w0, w1, g, sink, i, need_wgrad=True, need_gx=True, fork=None):
     """g = d loss / d atom output; parameter grads go to sink slots i..i+3 (w0, b0, w1, b1)."""
     d0, d1, h, t, u = rec
+    run = fork.run if fork is not None else (lambda fn, *ts: fn())
     if need_wgrad:
         gw, gb, acc = sink.pair(i + 2)
-        sink.put(i + 2, *P.conv1d_bwd_weight(t, g, u, d1, w1.shape, gw, gb, acc))
+        run(lambda: sink.put(i + 2, *P.conv1d_bwd_weight(t, g, u, d1, w1.shape, gw, gb, acc)), t, g, u)
     gt = P.conv1d_bwd_data(g, u, w1, d1)
     if need_wgrad:
         gw, gb, acc = sink.pair(i)
-        sink.put(i, *P.conv1d_bwd_weight(h, gt, t, d0, w0.shape, gw, gb, acc))
+        run(lambda: sink.put(i, *P.conv1d_bwd_weight(h, gt, t, d0, w0.shape, gw, gb, acc)), h, gt, t)
     if not need_gx:
         return None
     return P.conv1d_bwd_data(gt, t, w0, d0, gx_add=g)   # skip connection: + g
@@ -100,28 +127,30 @@ def gen_backward(tape, params, gy, sink=None):
     sink = sink if sink is not None else GradSink(G_NPARAMS)
     i = G_NPARAMS
     g = gy
+    fork = _WgradFork(gy.device)
     for rec in reversed(tape):
         kind = rec[0]
         if kind == "last":
             _, d, h, y = rec
             i -= 2
             gw, gb, acc = sink.pair(i)
-            sink.put(i, *P.conv1d_bwd_weight(h, g, y, d, params[i].shape, gw, gb, acc))
+            fork.run(lambda: sink.put(i, *P.conv1d_bwd_weight(h, g, y, d, params[i].shape, gw, gb, acc)), h, g, y)
             g = P.conv1d_bwd_data(g, y, params[i], d)
         elif kind == "atom":
             i -= 4
-            g = atom_backward(rec[1], params[i], params[i + 2], g, sink, i)
+            g = atom_backward(rec[1], params[i], params[i + 2], g, sink, i, fork=fork)
         elif kind == "convT":
             _, dt, hin, h = rec
             i -= 2
             gw, gb, acc = sink.pair(i)
-            sink.put(i, *P.convt1d_bwd_weight(hin, g, h, dt, params[i].shape, gw, gb, acc))
+            fork.run(lambda: sink.put(i, *P.convt1d_bwd_weight(hin, g, h, dt, params[i].shape, gw, gb, acc)), hin, g, h)
             g = P.convt1d_bwd_data(g, h, params[i], dt)
         else:  # conv0: no gradient flows to the mel features
             _, d, x, h = rec
             i -= 2
             gw, gb, acc = sink.pair(i)
-            sink.put(i, *P.conv1d_bwd_weight(x, g, h, d, params[i].shape, gw, gb, acc))
+            fork.run(lambda: sink.put(i, *P.conv1d_bwd_weight(x, g, h, d, params[i].shape, gw, gb, acc)), x, g, h)
+    fork.join()
     assert i == 0
     return sink
 
