@@ -41,13 +41,17 @@ class GradSink:
         self.acc[i] = self.acc[i + 1] = True
 
 
+_FORK_DEPTH = 0     # > 0 while work is being issued on a forked stream (forks stay one level deep)
+
+
 class _WgradFork:
     """Weight gradients of the generator on a side stream (MSYNTH_WGSTREAM=0 disables): each layer's
     weight-grad only needs the incoming gradient, so it can run beside the backward-data chain.
     Tensors it reads are kept alive until the join (the caching allocator is per stream)."""
 
     def __init__(self, device):
-        self.on = os.environ.get("MSYNTH_WGSTREAM", "1") == "1" and _concurrent_scales() and not _on_aux(device)
+        self.on = (os.environ.get("MSYNTH_WGSTREAM", "1") == "1" and _concurrent_scales() and
+                   not _on_aux(device) and _FORK_DEPTH == 0)
         self.keep = []
         if self.on:
             self.main = torch.cuda.current_stream(device)
@@ -153,6 +157,7 @@ def gen_backward(tape, params, gy, sink=None):
     fork.join()
     assert i == 0
     return sink
+
 
 
 def disc_forward(x, params):
