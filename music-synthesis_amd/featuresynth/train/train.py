@@ -16,6 +16,7 @@ import os
 import sys
 from datetime import datetime
 
+import numpy as np
 import torch
 
 from .. import _dist
@@ -217,19 +218,67 @@ class DiscriminatorTrainer(_TrainerBase):
         return {'d_loss': loss.item()}
 
 
+class _Prefetcher:
+    """H2D prefetch (replaces the blocking copy of the reference's
+    train.py:85): the next batch is preprocessed, staged in pinned host memory and copied on a side
+    stream while the current step runs; the consumer's stream waits on the copy's event only."""
+
+    def __init__(self, batch_stream, experiment, device):
+        self.it = iter(batch_stream)
+        self.exp = experiment
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.pending = None
+        self._fetch()
+
+    def _to_device(self, x):
+        if isinstance(x, dict):
+            return {k: self._to_device(v) for k, v in x.items()}
+        t = torch.from_numpy(np.ascontiguousarray(x))
+        if not self.cuda:
+            return t.to(self.device).float()
+        t = t.float().pin_memory()
+        return t.to(self.device, non_blocking=True)
+
+    def _fetch(self):
+        try:
+            batch = next(self.it)
+        except StopIteration:
+            self.pending = None
+            return
+        pre = self.exp.preprocess_batch(batch)
+        if self.cuda:
+            with torch.cuda.stream(self.stream):
+                tensors = [self._to_device(x) for x in pre]
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+        else:
+            tensors, ev = [self._to_device(x) for x in pre], None
+        self.pending = (pre, tensors, ev)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.pending is None:
+            raise StopIteration
+        pre, tensors, ev = self.pending
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            for t in tensors:                     # allocated on the copy stream, consumed on this one
+                for u in (t.values() if isinstance(t, dict) else (t,)):
+                    u.record_stream(torch.cuda.current_stream(self.device))
+        self._fetch()                             # the next copy overlaps the step the caller now runs
+        return pre, tensors
+
+
 def training_loop(batch_stream, experiment, device, loggers):
     """Driver with the contract of the reference's train.py:77-106: numpy batch -> float tensors
-    on `device` -> next training step -> loggers; yields (i, elapsed, log_results)."""
+    on `device` -> next training step -> loggers; yields (i, elapsed, log_results).  The host-to-device
+    copy of batch i+1 is prefetched while step i runs."""
     started = datetime.utcnow()
-
-    def to_device(x):
-        if isinstance(x, dict):
-            return {k: torch.from_numpy(v).to(device).float() for k, v in x.items()}
-        return torch.from_numpy(x).to(device).float()
-
-    for i, batch in enumerate(batch_stream):
-        preprocessed = experiment.preprocess_batch(batch)
-        tensors = [to_device(x) for x in preprocessed]
+    for i, (preprocessed, tensors) in enumerate(_Prefetcher(batch_stream, experiment, device)):
         step = next(experiment.training_steps)
         step_result = step(*tensors)
         elapsed = datetime.utcnow() - started
