@@ -75,55 +75,60 @@ __device__ inline void gfwd_tiles(const float (&a)[GK], const float* __restrict_
     }
 }
 
-template <bool VIN, bool VOUT>
-__global__ __launch_bounds__(256) void k_gconv_mfma_fwd(ConvP p, int tiles, int nunits,
+// Lean scalar bookkeeping (PMC: the first version spent 553 vector + 212 scalar instructions per
+// 164 MFMAs of a unit, mostly 64-bit address arithmetic and per-unit divisions, and the matrix pipe
+// sat at 37 %): wave-uniform 64-bit bases + 32-bit lane offsets, unit -> (b, tile) advanced
+// incrementally, LDS / output offsets hoisted out of the unit loop, activation as a template flag.
+template <bool LRELU>
+__global__ __launch_bounds__(256, 3) void k_gconv_mfma_fwd(ConvP p, int tiles, int nunits,
                                                        const float* __restrict__ x,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias,
                                                        float* __restrict__ y) {
-    __shared__ __attribute__((aligned(16))) float xs[4 * UWS];
+    __shared__ float xs[4 * UWS];
     __shared__ float ws[16 * GCG * GK];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = blockIdx.y;
     const int m = lane & 15, ci = lane >> 4;
     float* xw = xs + wid * UWS;
-    const float* xb = xw + ci * (GS * UPS) + (lane & 15);
+    const float* xb = xw + ci * (GS * UPS) + m;
     const int wstride = gridDim.x * 4;
-    const long long total4 = (long long)p.B * p.Cin * p.Lin / 4;
-    constexpr int NLD = VIN ? UVI : GCG * UK;
-    float4 xv[VIN ? UVI : 1];
-    float xr[VIN ? 1 : GCG * UK];
-    // element index (in the flat tensor) of the unit's first input of channel c
-    auto row_e0 = [&](int b, int t0, int c) {
-        return ((long long)b * p.Cin + (long long)g * GCG + c) * p.Lin + (long long)t0 * GS - p.pad;
-    };
-    auto gload = [&](int unit) {
-        const int b = unit / tiles, t0 = (unit - b * tiles) * UT;
-        if (VIN) {
+    const int db = wstride / tiles, dt = wstride - db * tiles;      // unit += wstride, in (b, tile) form
+
+    // loop-invariant lane offsets
+    int lo[UK];                                  // LDS offset of input u = lane + 64k (phase-split)
 #pragma unroll
-            for (int it = 0; it < UVI; ++it) {
-                const int idx = lane + 64 * it;
-                const int c = idx / UV, k = idx - c * UV;
-                const long long va = (row_e0(b, t0, c < GCG ? c : 0) >> 2) + k;
-                const bool ok = c < GCG && va >= 0 && va < total4;
-                xv[it] = reinterpret_cast<const float4*>(x)[ok ? va : 0];
-            }
-        } else {
-            const int u0 = t0 * GS - p.pad;
-            const float* xrow = x + ((size_t)b * p.Cin + (size_t)g * GCG) * p.Lin;
+    for (int k = 0; k < UK; ++k) {
+        const int u = lane + 64 * k;
+        lo[k] = (u & (GS - 1)) * UPS + (u >> 2);
+    }
+    unsigned ro[4];                              // output offset of accumulator row r (relative to the unit)
+    bool rok[4];
+    float bq[4];
 #pragma unroll
-            for (int k = 0; k < UK; ++k) {
-                const int u = lane + 64 * k, sidx = u0 + u;
-                const bool ok = u < USPAN && sidx >= 0 && sidx < p.Lin;
-                const int so = ok ? sidx : 0;
+    for (int r = 0; r < 4; ++r) {
+        const int mo = ci * 4 + r;
+        rok[r] = mo < p.Og;
+        ro[r] = (unsigned)(mo * p.Lout + m);
+        bq[r] = bias ? bias[g * p.Og + (rok[r] ? mo : 0)] : 0.f;
+    }
+
+    float xr[GCG][UK];
+    auto gload = [&](int b, int ti) {
+        const int u0 = ti * (UT * GS) - p.pad;
+        const float* xg = x + ((size_t)b * p.Cin + (size_t)g * GCG) * p.Lin;      // wave-uniform base
 #pragma unroll
-                for (int c = 0; c < GCG; ++c) xr[c * UK + k] = xrow[(size_t)c * p.Lin + so];
-            }
+        for (int k = 0; k < UK; ++k) {
+            const int u = lane + 64 * k, sidx = u0 + u;
+            const bool ok = u < USPAN && sidx >= 0 && sidx < p.Lin;
+            const unsigned so = ok ? (unsigned)sidx : 0u;
+#pragma unroll
+            for (int c = 0; c < GCG; ++c) xr[c][k] = xg[so + (unsigned)(c * p.Lin)];
         }
     };   // (masking happens at the LDS store, so the loads stay in flight across the MFMA loop)
-    (void)NLD;
     int unit = blockIdx.x * 4 + wid;
-    if (unit < nunits) gload(unit);      // in flight while the weights are staged
+    int b = unit / tiles, ti = unit - b * tiles;
+    if (unit < nunits) gload(b, ti);     // in flight while the weights are staged
     const int nwf = p.Og * GCG * GK;
     stage_weights<(16 * GCG * GK + 255) / 256>(w + (size_t)g * nwf, ws, nwf, tid);
     __syncthreads();
@@ -138,49 +143,24 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_fwd(ConvP p, int tiles, int 
             a[j] = ok ? v : 0.f;
         }
     }
-    float bq[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int mo = ci * 4 + r;
-        bq[r] = bias ? bias[g * p.Og + (mo < p.Og ? mo : 0)] : 0.f;
-    }
 
     for (; unit < nunits; unit += wstride) {
-        const int b = unit / tiles, t0 = (unit - b * tiles) * UT;
-        const int u0 = t0 * GS - p.pad;
-        if (VIN) {
+        const int t0 = ti * UT, u0 = t0 * GS - p.pad;
 #pragma unroll
-            for (int it = 0; it < UVI; ++it) {
-                const int idx = lane + 64 * it;
-                const int c = idx / UV, k = idx - c * UV;
-                const long long e0 = row_e0(b, t0, c < GCG ? c : 0);
-                const long long va = (e0 >> 2) + k;
-                const bool vok = c < GCG && va >= 0 && va < total4;
-                const int sh = (int)(e0 & 3);
-                const float e[4] = {xv[it].x, xv[it].y, xv[it].z, xv[it].w};
+        for (int k = 0; k < UK; ++k) {
+            const int u = lane + 64 * k, sidx = u0 + u;
+            const bool ok = u < USPAN && sidx >= 0 && sidx < p.Lin;
+            if (u < GS * UPS) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int u = 4 * k + i - sh, sidx = u0 + u;
-                    const bool ok = vok && sidx >= 0 && sidx < p.Lin;
-                    if (c < GCG && u >= 0 && u < GS * UPS)
-                        xw[c * (GS * UPS) + (u & (GS - 1)) * UPS + (u >> 2)] = ok ? e[i] : 0.f;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < UK; ++k) {
-                const int u = lane + 64 * k, sidx = u0 + u;
-                const bool ok = u < USPAN && sidx >= 0 && sidx < p.Lin;
-                if (u < GS * UPS) {
-#pragma unroll
-                    for (int c = 0; c < GCG; ++c)
-                        xw[c * (GS * UPS) + (u & (GS - 1)) * UPS + (u >> 2)] = ok ? xr[c * UK + k] : 0.f;
-                }
+                for (int c = 0; c < GCG; ++c) xw[c * (GS * UPS) + lo[k]] = ok ? xr[c][k] : 0.f;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (unit + wstride < nunits) gload(unit + wstride);
+        float* yg = y + ((size_t)b * p.Cout + (size_t)g * p.Og) * p.Lout + t0;     // wave-uniform base
+        int nb = b + db, nti = ti + dt;
+        if (nti >= tiles) { nti -= tiles; ++nb; }
+        if (unit + wstride < nunits) gload(nb, nti);
         const int ntt = min(4, (p.Lout - t0 + 15) >> 4);          // wave-uniform
         f32x4 acc[4];
 #pragma unroll
@@ -191,45 +171,19 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_fwd(ConvP p, int tiles, int 
         else gfwd_tiles<1>(a, xb, acc);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (VOUT) {
-            // bias + activation, transposed through LDS: D[row = ci*4 + r][col = lane&15] of tile tt
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
+        for (int tt = 0; tt < 4; ++tt) {
+            if (tt < ntt && t0 + tt * 16 + m < p.Lout) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    xw[(ci * 4 + r) * OPITCH + tt * 16 + (lane & 15)] = ms_apply_act(acc[tt][r] + bq[r], p.act, p.slope);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            float4 ov[4];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int idx = lane + 64 * it;
-                ov[it] = *reinterpret_cast<const float4*>(xw + (idx >> 4) * OPITCH + 4 * (idx & 15));
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int idx = lane + 64 * it;
-                const int row = idx >> 4, t = t0 + 4 * (idx & 15);
-                if (row < p.Og && t < p.Lout)     // Lout % 4 == 0: a vector is all in or all out
-                    *reinterpret_cast<float4*>(y + ((size_t)b * p.Cout + (size_t)g * p.Og + row) * p.Lout + t) = ov[it];
-            }
-        } else {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const int t = t0 + tt * 16 + (lane & 15);
-                if (tt < ntt && t < p.Lout) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int mo = ci * 4 + r;
-                        if (mo < p.Og)
-                            y[((size_t)b * p.Cout + (size_t)g * p.Og + mo) * p.Lout + t] =
-                                ms_apply_act(acc[tt][r] + bq[r], p.act, p.slope);
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[tt][r] + bq[r];
+                    if (LRELU) v = v > 0.f ? v : v * p.slope;
+                    else v = ms_apply_act(v, p.act, p.slope);
+                    if (rok[r]) yg[ro[r] + tt * 16] = v;
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        b = nb; ti = nti;
     }
 }
 
@@ -377,34 +331,37 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_wgrad(ConvP p, const float* 
     const int tiles = (p.Lout + WU - 1) / WU;
     const int nunits = p.B * tiles;
     const int ustride = gridDim.x * 4;
+    const int db = ustride / tiles, dt = ustride - db * tiles;     // unit += ustride, in (b, tile) form
     constexpr int NXI = (XSPAN + 63) / 64;             // 5 input loads per lane and channel
     float gv[16], ga[16], xv[GCG][NXI];
-    auto gload = [&](int unit) {
-        const int b = unit / tiles, t0 = (unit - b * tiles) * WU;
-        const int u0 = t0 * GS - p.pad;
+    // wave-uniform 64-bit bases + 32-bit lane offsets (the address arithmetic was most of this kernel)
+    auto gload = [&](int b, int ti) {
+        const int t0 = ti * WU, u0 = t0 * GS - p.pad;
         const bool tok = t0 + lane < p.Lout;
+        const size_t gbase = ((size_t)b * p.Cout + (size_t)g * p.Og) * p.Lout + t0;
+        const float* gyb = gy + gbase;
+        const float* yab = ya + gbase;
 #pragma unroll
         for (int co = 0; co < 16; ++co) {              // lane = output t, co = row
-            const bool ok = tok && co < p.Og;
-            const size_t off = ok ? ((size_t)b * p.Cout + (size_t)g * p.Og + co) * p.Lout + t0 + lane : 0;
-            gv[co] = gy[off];
-            ga[co] = ya[off];
+            const unsigned off = (tok && co < p.Og) ? (unsigned)(co * p.Lout + lane) : 0u;
+            gv[co] = gyb[off];
+            ga[co] = yab[off];
         }
-        const float* xrow = x + ((size_t)b * p.Cin + (size_t)g * GCG) * p.Lin;
+        const float* xg = x + ((size_t)b * p.Cin + (size_t)g * GCG) * p.Lin;
 #pragma unroll
         for (int k = 0; k < NXI; ++k) {
             const int u = lane + 64 * k, sidx = u0 + u;
             const bool ok = u < XSPAN && sidx >= 0 && sidx < p.Lin;
-            const int so = ok ? sidx : 0;
+            const unsigned so = ok ? (unsigned)sidx : 0u;
 #pragma unroll
-            for (int c = 0; c < GCG; ++c) xv[c][k] = xrow[(size_t)c * p.Lin + so];
+            for (int c = 0; c < GCG; ++c) xv[c][k] = xg[so + (unsigned)(c * p.Lin)];
         }
     };
     int unit = blockIdx.x * 4 + wid;
-    if (unit < nunits) gload(unit);
+    int b = unit / tiles, ti = unit - b * tiles;
+    if (unit < nunits) gload(b, ti);
     for (; unit < nunits; unit += ustride) {
-        const int b = unit / tiles, t0 = (unit - b * tiles) * WU;
-        (void)b;
+        const int t0 = ti * WU;
         const int u0 = t0 * GS - p.pad;
         const bool tok = t0 + lane < p.Lout;
 #pragma unroll
@@ -421,7 +378,9 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_wgrad(ConvP p, const float* 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (unit + ustride < nunits) gload(unit + ustride);
+        int nb = b + db, nti = ti + dt;
+        if (nti >= tiles) { nti -= tiles; ++nb; }
+        if (unit + ustride < nunits) gload(nb, nti);
         const int tvalid = min(WU, p.Lout - t0);
         const int isteps = (tvalid + 3) >> 2;          // wave-uniform; outputs past tvalid are zero in gs
 #pragma unroll 4
@@ -436,6 +395,7 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_wgrad(ConvP p, const float* 
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        b = nb; ti = nti;
     }
 
     float* part = partial + (size_t)(blockIdx.x * 4 + wid) * partial_stride;
@@ -503,17 +463,11 @@ int msg_conv1d_fwd(const ConvP& p, const float* x, const float* w, const float* 
     const long long total_units = (long long)nunits * p.groups;
     const int upw = (int)((total_units + target_waves - 1) / target_waves);
     const int gx = ms_ceil_div(nunits, 4 * (upw > 0 ? upw : 1));
-    // 16-byte loads / stores measured SLOWER here (95 vs 80 us at B=128: the kernel is bound by VALU
-    // + MFMA issue on the SIMD, not by memory instructions); kept behind MSYNTH_GVEC for experiments
-    const char* gv = getenv("MSYNTH_GVEC");
-    const int gvec = gv ? atoi(gv) : 0;
-    const bool vin = (gvec & 1) && (((uintptr_t)x) & 15) == 0 && ((long long)p.B * p.Cin * p.Lin) % 4 == 0;
-    const bool vout = (gvec & 2) && (((uintptr_t)y) & 15) == 0 && p.Lout % 4 == 0;
+    // (16-byte loads / stores were measured SLOWER here -- 95 vs 80 us at B=128: the kernel is bound by
+    // vector-instruction issue beside the matrix pipe, not by memory instructions)
     const dim3 grid(gx, p.groups);
-    if (vin && vout) hipLaunchKernelGGL((k_gconv_mfma_fwd<true, true>), grid, dim3(256), 0, s, p, tiles, nunits, x, w, bias, y);
-    else if (vin) hipLaunchKernelGGL((k_gconv_mfma_fwd<true, false>), grid, dim3(256), 0, s, p, tiles, nunits, x, w, bias, y);
-    else if (vout) hipLaunchKernelGGL((k_gconv_mfma_fwd<false, true>), grid, dim3(256), 0, s, p, tiles, nunits, x, w, bias, y);
-    else hipLaunchKernelGGL((k_gconv_mfma_fwd<false, false>), grid, dim3(256), 0, s, p, tiles, nunits, x, w, bias, y);
+    if (p.act == MS_ACT_LRELU) hipLaunchKernelGGL((k_gconv_mfma_fwd<true>), grid, dim3(256), 0, s, p, tiles, nunits, x, w, bias, y);
+    else hipLaunchKernelGGL((k_gconv_mfma_fwd<false>), grid, dim3(256), 0, s, p, tiles, nunits, x, w, bias, y);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }
