@@ -1228,7 +1228,10 @@ RowSplit plan_rows_split(RowCfg cfg, const RowP& p, int CC) {
     q.ns = 1; q.cks = p.CK; q.out_floats = (size_t)p.B * p.M * p.L;
     const int wgs = rows_wgs(cfg, p);
     const int nchunks = p.CK / CC;
-    if (wgs > split_max_wgs() || nchunks < 8) return q;
+    // (one workgroup per CU is still under-filled when the contraction is long enough to amortise the
+    // slab pass: the 1024 -> 1024 k5 conv at B*L = 2048 has 256 tiles and 64 chunks)
+    const int lim = nchunks >= 32 ? (split_max_wgs() * 4) / 3 : split_max_wgs();
+    if (wgs > lim || nchunks < 8) return q;
     int ns = ms_ceil_div(512, wgs);
     if (ns > nchunks / 4) ns = nchunks / 4;
     if (ns > 16) ns = 16;

@@ -365,7 +365,8 @@ bool msr2_supported(int tile, int K, int CC, int act_mode, int epi_s, const Row2
     if (act_mode != 0 && act_mode != 1) return false;
     if (p.L % 4) return false;
     const bool k3 = K == 3 && (CC == 8 || CC == 16) && (epi_s == 0 || ((epi_s == 2 || epi_s == 8) && CC == 8 && act_mode == 0));
-    const bool k5 = K == 5 && CC == 16 && epi_s == 0;
+    // (k5 forward: the first-generation kernel measured 8 % faster, 194 vs 212 us at B*L = 2048)
+    const bool k5 = K == 5 && CC == 16 && epi_s == 0 && act_mode == 1;
     if (!k3 && !k5) return false;
     int bn = tile == MSR2_32x256 ? 256 : (tile == MSR2_64x64 ? 64 : 128);
     const int nvt = p.R * ((p.SS + 6) / 4);
