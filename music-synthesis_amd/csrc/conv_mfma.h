@@ -50,3 +50,8 @@ const char* msw_bwd_weight_name(const ConvP& p);
 int msw_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act,
                           float* gw, float* gb, float beta, void* ws, size_t ws_bytes,
                           hipStream_t s);
+
+// transposed-conv weight gradient, phase-split row-tile form (wgrad_rows.hip): dWq[Cin_T][(co, r), d]
+size_t msw_convt_ws(const ConvP& p);
+int msw_convt_dwq(const ConvP& p, const float* x, const float* gy, const float* y_act, float* dwq,
+                  void* ws, size_t ws_bytes, hipStream_t s);

@@ -1566,12 +1566,21 @@ static ConvtWgradPlan plan_convt_wgrad(const ConvP& p) {
     return q;
 }
 
+// workspace: [dWq | split-K slabs of whichever kernel takes the launch]
 size_t msm_convt_bwd_weight_ws(const ConvP& p) {
     const ConvtWgradPlan q = plan_convt_wgrad(p);
-    return ((size_t)q.w.nsplit * q.w.stride_floats + q.dwq_floats) * sizeof(float);
+    size_t slabs = (size_t)q.w.nsplit * q.w.stride_floats * sizeof(float);
+    const size_t rows = msw_convt_ws(p);
+    if (rows > slabs) slabs = rows;
+    return align16(q.dwq_floats * sizeof(float)) + slabs;
 }
 
 const char* msm_convt_bwd_weight_name(const ConvP& p) {
+    if (msw_convt_ws(p) > 0 && p.act != MS_ACT_TANH) {
+        static thread_local char buf[64];
+        snprintf(buf, sizeof(buf), "k_wgrad_rows<3, %d, true, %d, 3, %d>", p.Cout >= 128 ? 2 : 1, p.Lout <= 32 ? 8 : 16, p.stride);
+        return buf;
+    }
     return kname("k_igemm_wgrad", plan_convt_wgrad(p).w.cfg, 3, "");
 }
 
@@ -1581,8 +1590,18 @@ int msm_convt1d_bwd_weight(const ConvP& p, const float* x, const float* gy, cons
     const int S = p.stride, CinT = p.Cout, CoutT = p.Cin, LinT = p.Lout;
     const ConvtWgradPlan pl = plan_convt_wgrad(p);
     if (!ws || ws_bytes < msm_convt_bwd_weight_ws(p)) return MS_ERR_WORKSPACE;
-    float* partial = (float*)ws;
-    float* dwq = partial + (size_t)pl.w.nsplit * pl.w.stride_floats;
+    float* dwq = (float*)ws;
+    const size_t dbytes = align16(pl.dwq_floats * sizeof(float));
+    float* partial = (float*)((char*)ws + dbytes);
+    const size_t gtotal0 = (size_t)CinT * CoutT * p.K;
+    // row-tile form (wgrad_rows.hip) where it applies; the im2col form below otherwise
+    if (msw_convt_dwq(p, x, gy, y_act, dwq, partial, ws_bytes - dbytes, s) == MS_OK) {
+        unsigned nb0 = (unsigned)((gtotal0 + 255) / 256);
+        if (nb0 > 4096) nb0 = 4096;
+        hipLaunchKernelGGL(k_unpack_convt_gw, dim3(nb0), dim3(256), 0, s, dwq, gw, CinT, CoutT, p.K, S, p.pad, beta);
+        MS_CHECK_LAUNCH();
+        return MS_OK;
+    }
     IgP q;
     q.B = p.B; q.CK = CoutT * S; q.L = LinT; q.M = CinT; q.dil = 1; q.off0 = -1;
     q.pad_mode = MS_PAD_ZERO; q.act = MS_ACT_NONE; q.in_act = p.act; q.slope = p.slope;

@@ -40,12 +40,12 @@ struct WrP {
 template <int AK>
 __device__ __forceinline__ float wr_gact(float g, float ya, int kind, float slope) {
     if (AK == 1) return ya > 0.f ? g : g * slope;
-    if (AK == 2) return g;
+    if (AK == 2 || AK == 3) return g;
     return ms_act_grad(g, ya, kind, slope);
 }
 template <int AK>
 __device__ __forceinline__ float wr_xact(float v, int kind, float slope) {
-    if (AK == 1) return v;
+    if (AK == 1 || AK == 3) return v;
     if (AK == 2) return v > 0.f ? v : v * slope;
     return kind == MS_MOD_LRELU_FWD ? (v > 0.f ? v : v * slope) : v;
 }
@@ -57,14 +57,18 @@ __device__ __forceinline__ float wr_xact(float v, int kind, float slope) {
 //   One barrier per chunk.  All pieces are branch-free (invalid lanes store to a scratch slot,
 //   masked loads read element 0) so that the whole chunk is one basic block the scheduler can
 //   interleave.
-template <int K, int TM, bool VEC, int KPI, int AK>
+template <int K, int TM, bool VEC, int KPI, int AK, int XS = 1>
 __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restrict__ X,
+                                                   const float* __restrict__ Xact,
                                                    const float* __restrict__ G,
                                                    const float* __restrict__ Gact,
                                                    float* __restrict__ partial, size_t pstride) {
     constexpr int BM = 2 * TM * 32;
     constexpr int NGQ = VEC ? TM * 4 : TM * 16;     // G pieces (one load per thread each)
-    constexpr int NXQ = VEC ? 8 : 32;               // X pieces
+    // XS > 1 (transposed-conv weight grads): the 64 X rows are the XS phases of 64/XS channels of a
+    // stride-XS signal; a piece is a 16-byte vector of the phase-interleaved span of one channel and its
+    // 4 elements scatter to (phase row, column); the activation derivative sits on this operand (AK 3)
+    constexpr int NXQ = XS > 1 ? 5 : (VEC ? 8 : 32); // X pieces
     constexpr int NP = NGQ + NXQ;
     constexpr int PPI = (NP + KPI - 1) / KPI;       // pieces per double-step
     extern __shared__ float smem[];
@@ -120,11 +124,33 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
 #pragma unroll
     for (int i = 0; i < 4; ++i) x_ev[i] = x_cv && x_u + i >= 0 && x_u + i < p.SS;
 
-    float4 gv4[VEC ? NGQ : 1], ga4[VEC ? NGQ : 1], xv4[VEC ? NXQ : 1];
+    int t_off[XS > 1 ? NXQ : 1], t_pos[XS > 1 ? NXQ : 1], t_lds[XS > 1 ? NXQ : 1][4];
+    bool t_in[XS > 1 ? NXQ : 1];
+    if (XS > 1) {
+        const int span = p.SS * XS;                  // phase-interleaved floats of one channel and chunk
+        const int NVco = (span + 6) >> 2;
+        const int shx = (4 - ((p.pad * XS) & 3)) & 3;
+#pragma unroll
+        for (int q = 0; q < NXQ; ++q) {
+            const int idx = tid + 256 * q;
+            const int corow = idx / NVco, v = idx - corow * NVco;
+            t_in[q] = corow < CB / XS && c0 / XS + corow < p.CK / XS;
+            t_pos[q] = 4 * v - shx - p.pad * XS;     // position of the vector relative to t0*XS (multiple of 4)
+            t_off[q] = t_in[q] ? (c0 / XS + corow) * p.L * XS + t_pos[q] : 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int pos = 4 * v + e - shx;
+                const int r = pos % XS, u = pos / XS;
+                t_lds[q][e] = (t_in[q] && pos >= 0 && pos < span) ? BM * p.PG + (corow * XS + r) * p.PX + u : -1;
+            }
+        }
+    }
+
+    float4 gv4[VEC ? NGQ : 1], ga4[VEC ? NGQ : 1], xv4[VEC ? NXQ : 1], xa4[(VEC && XS > 1) ? NXQ : 1];
     float gv1[VEC ? 1 : NGQ], ga1[VEC ? 1 : NGQ], xv1[VEC ? 1 : NXQ];
 
     // per-chunk scalars of the chunk whose pieces are being loaded / stored
-    struct Cs { int gbase, xbase; bool gok, xok; };
+    struct Cs { int gbase, xbase, t0x; bool gok, xok; };
     auto chunk_state = [&](int ch, int c_end) {
         Cs s;
         int b0, t0;
@@ -133,10 +159,11 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
         t0 = (ch - bq * p.tiles_per_row) * p.Lt;
         const bool live = ch < c_end;
         s.gbase = b0 * p.M * p.L + t0;
-        s.xbase = b0 * p.CK * p.L + t0;
+        s.xbase = b0 * p.CK * p.L + t0 * XS;
+        s.t0x = t0 * XS;
         const int tg = t0 + g_t, tx = t0 - p.pad + x_u;       // VEC: tx % 4 == 0, vector all in or all out
         s.gok = live && g_cv && b0 + g_seg < p.B && tg < p.L;
-        s.xok = live && x_cv && b0 + x_seg < p.B && tx >= 0 && tx < p.L;
+        s.xok = XS > 1 ? (live && b0 < p.B) : (live && x_cv && b0 + x_seg < p.B && tx >= 0 && tx < p.L);
         return s;
     };
     auto load_piece = [&](int pi, const Cs& s) {
@@ -146,17 +173,25 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
             const int o = ok ? s.gbase + g_off0 + q * g_rstep * p.L : 0;
             if (VEC) {
                 gv4[q] = *reinterpret_cast<const float4*>(G + o);
-                if (AK != 2) ga4[q] = *reinterpret_cast<const float4*>(Gq + o);
+                if (AK != 2 && AK != 3) ga4[q] = *reinterpret_cast<const float4*>(Gq + o);
             } else {
                 gv1[q] = G[o];
-                if (AK != 2) ga1[q] = Gq[o];
+                if (AK != 2 && AK != 3) ga1[q] = Gq[o];
             }
         } else {
             const int q = pi - NGQ;
-            const bool ok = s.xok && c0 + x_row0 + x_rstep * q < p.CK;
-            const int o = ok ? s.xbase + x_off0 + q * x_rstep * p.L : 0;
-            if (VEC) xv4[q] = *reinterpret_cast<const float4*>(X + o);
-            else xv1[q] = X[o];
+            if (XS > 1) {
+                const int gp = s.t0x + t_pos[q];         // all 4 samples inside [0, L*XS) or none
+                const bool ok = s.xok && t_in[q] && gp >= 0 && gp < p.L * XS;
+                const int o = ok ? s.xbase + t_off[q] : 0;
+                xv4[q] = *reinterpret_cast<const float4*>(X + o);
+                if (AK == 3) xa4[q] = *reinterpret_cast<const float4*>(Xact + o);
+            } else {
+                const bool ok = s.xok && c0 + x_row0 + x_rstep * q < p.CK;
+                const int o = ok ? s.xbase + x_off0 + q * x_rstep * p.L : 0;
+                if (VEC) xv4[q] = *reinterpret_cast<const float4*>(X + o);
+                else xv1[q] = X[o];
+            }
         }
     };
     auto store_piece = [&](int pi, const Cs& s, float* buf) {
@@ -175,6 +210,22 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
             }
         } else {
             const int q = pi - NGQ;
+            if (XS > 1) {
+                const int gp = s.t0x + t_pos[q];
+                const bool ok = s.xok && t_in[q] && gp >= 0 && gp < p.L * XS;
+                float e[4] = {xv4[q].x, xv4[q].y, xv4[q].z, xv4[q].w};
+                if (AK == 3) {
+                    const float a[4] = {xa4[q].x, xa4[q].y, xa4[q].z, xa4[q].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) e[i] = a[i] > 0.f ? e[i] : e[i] * p.slope;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float* di = t_lds[q][i] >= 0 ? buf + t_lds[q][i] : scratch + tid;
+                    *di = ok ? e[i] : 0.f;
+                }
+                return;
+            }
             const bool ok = s.xok && c0 + x_row0 + x_rstep * q < p.CK;
             float* d = buf + x_lds0 + q * x_rstep * p.PX;
             if (VEC) {
@@ -345,8 +396,8 @@ void launch_wrows_ak(const WrPlan& q, const float* x, const float* gy, const flo
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_wgrad_rows<K, TM, VEC, KPI, AK>), q.grid, dim3(256), q.lds, s, q.p, x, gy, y_act,
-                       partial, q.stride_floats);
+    hipLaunchKernelGGL((k_wgrad_rows<K, TM, VEC, KPI, AK>), q.grid, dim3(256), q.lds, s, q.p, x,
+                       (const float*)nullptr, gy, y_act, partial, q.stride_floats);
 }
 
 template <int K, int TM, bool VEC, int KPI>
@@ -396,6 +447,103 @@ const char* msw_bwd_weight_name(const ConvP& p) {
     const WrPlan q = plan_wrows(p);
     snprintf(buf, sizeof(buf), "k_wgrad_rows<%d, %d, %s, %d>", p.K, q.tm, q.vec ? "true" : "false", q.p.kcols / 4);
     return buf;
+}
+
+// ---- transposed-conv weight gradient through the phase-split identity: M = Cin_T (rows of x_T),
+// X rows = the S phases of the Cout_T gradient channels, 3 taps (d = -1, 0, +1), contraction over
+// (b, q).  Produces dWq[Cin_T][(co, r), d] (the caller un-packs it into (Cin_T, Cout_T, K)).
+// c = mirrored conv of the transposed conv: Cin_T = c.Cout, Cout_T = c.Cin, Lin_T = c.Lout.
+namespace {
+
+WrPlan plan_wrows_t(const ConvP& c) {
+    WrPlan q;
+    q.ok = false;
+    const int S = c.stride, CinT = c.Cout, CoutT = c.Cin, LinT = c.Lout;
+    if (!(S == 2 || S == 8) || c.K != 2 * S || 2 * c.pad != S || c.dil != 1 || c.groups != 1 || c.in_act) return q;
+    if (CinT < 64 || (CoutT * S) % CB || LinT % 4) return q;
+    if ((long long)c.B * CinT * LinT >= (1LL << 31) || (long long)c.B * CoutT * S * LinT >= (1LL << 31)) return q;
+    WrP& p = q.p;
+    p.B = c.B; p.CK = CoutT * S; p.L = LinT; p.M = CinT; p.dil = 1; p.pad = 1;
+    p.g_kind = MS_ACT_NONE; p.x_kind = MS_ACT_NONE; p.slope = c.slope;
+    if (p.L >= KMAX) { p.Lt = KMAX; p.R = 1; p.tiles_per_row = ms_ceil_div(p.L, KMAX); }
+    else { p.Lt = p.L; p.R = 1; p.tiles_per_row = 1; }
+    p.nchunks = p.B * p.tiles_per_row;
+    p.SS = p.Lt + 2;
+    p.RSZ = p.SS;
+    p.kcols = p.Lt <= 32 ? 32 : 64;
+    if (p.Lt != 32 && p.Lt != 64) return q;
+    if ((CB / S) * ((p.SS * S + 6) / 4) > 5 * 256) return q;
+    p.PG = (p.kcols + 2) | 1;
+    p.PX = (p.kcols + 2 + 2) | 1;
+    q.vec = true;
+    q.tm = CinT >= 128 ? 2 : 1;
+    const int BM = 64 * q.tm;
+    q.lds = (size_t)(2 * (BM * p.PG + CB * p.PX) + 256) * sizeof(float);
+    const int tiles = ms_ceil_div(p.M, BM) * (p.CK / CB);
+    q.stride_floats = (size_t)p.M * p.CK * 3 + p.M;
+    int ns = ms_ceil_div(512, tiles);
+    const int max_by_work = p.nchunks / 2 > 0 ? p.nchunks / 2 : 1;
+    if (ns > max_by_work) ns = max_by_work;
+    const size_t max_by_bytes = ((size_t)32 << 20) / (q.stride_floats * 4);
+    if ((size_t)ns > max_by_bytes) ns = max_by_bytes > 0 ? (int)max_by_bytes : 1;
+    if (ns < 1) ns = 1;
+    p.cps = ms_ceil_div(p.nchunks, ns);
+    q.nsplit = ms_ceil_div(p.nchunks, p.cps);
+    q.grid = dim3((unsigned)(p.CK / CB), (unsigned)ms_ceil_div(p.M, BM), (unsigned)q.nsplit);
+    q.ok = true;
+    return q;
+}
+
+template <int TM, int KPI, int AK, int XS>
+void launch_wrows_t(const WrPlan& q, const float* gy, const float* y_act, const float* x, float* partial,
+                    hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_rows<3, TM, true, KPI, AK, XS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_wgrad_rows<3, TM, true, KPI, AK, XS>), q.grid, dim3(256), q.lds, s, q.p, gy, y_act, x,
+                       (const float*)nullptr, partial, q.stride_floats);
+}
+
+template <int AK, int XS>
+void launch_wrows_t2(const WrPlan& q, const float* gy, const float* y_act, const float* x, float* partial,
+                     hipStream_t s) {
+    if (q.tm == 2) {
+        if (q.p.kcols == 64) launch_wrows_t<2, 16, AK, XS>(q, gy, y_act, x, partial, s);
+        else launch_wrows_t<2, 8, AK, XS>(q, gy, y_act, x, partial, s);
+    } else {
+        if (q.p.kcols == 64) launch_wrows_t<1, 16, AK, XS>(q, gy, y_act, x, partial, s);
+        else launch_wrows_t<1, 8, AK, XS>(q, gy, y_act, x, partial, s);
+    }
+}
+
+}  // namespace
+
+size_t msw_convt_ws(const ConvP& c) {
+    const char* e = getenv("MSYNTH_WROWS");
+    if (e && atoi(e) == 0) return 0;
+    const WrPlan q = plan_wrows_t(c);
+    return q.ok ? (size_t)q.nsplit * q.stride_floats * sizeof(float) : 0;
+}
+
+int msw_convt_dwq(const ConvP& c, const float* x, const float* gy, const float* y_act, float* dwq,
+                  void* ws, size_t ws_bytes, hipStream_t s) {
+    const char* e = getenv("MSYNTH_WROWS");
+    if (e && atoi(e) == 0) return MS_ERR_UNSUPPORTED;
+    const WrPlan q = plan_wrows_t(c);
+    if (!q.ok) return MS_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < (size_t)q.nsplit * q.stride_floats * sizeof(float)) return MS_ERR_UNSUPPORTED;
+    if (((((uintptr_t)x) | ((uintptr_t)gy) | ((uintptr_t)(y_act ? y_act : gy))) & 15) != 0) return MS_ERR_UNSUPPORTED;
+    if (y_act && c.act != MS_ACT_LRELU) return MS_ERR_UNSUPPORTED;
+    float* partial = (float*)ws;
+    const int S = c.stride;
+    if (y_act) { if (S == 8) launch_wrows_t2<3, 8>(q, gy, y_act, x, partial, s); else launch_wrows_t2<3, 2>(q, gy, y_act, x, partial, s); }
+    else { if (S == 8) launch_wrows_t2<0, 8>(q, gy, y_act, x, partial, s); else launch_wrows_t2<0, 2>(q, gy, y_act, x, partial, s); }
+    MS_CHECK_LAUNCH();
+    return msm_wgrad_reduce(partial, q.stride_floats, q.nsplit, (size_t)q.p.M * q.p.CK * 3, q.p.M, dwq,
+                            (float*)nullptr, 0.f, s);
 }
 
 int msw_conv1d_bwd_weight(const ConvP& c, const float* x, const float* gy, const float* y_act,

@@ -274,7 +274,10 @@ def test_conv_hot_shapes_vs_oracle(case):
 
 
 HOT_CONVT = [("ct_512_256", 2, 512, 9, 256, 16, 8, 4), ("ct_256_128", 1, 256, 70, 128, 16, 8, 4),
-             ("ct_128_64", 2, 128, 130, 64, 4, 2, 1), ("ct_64_32", 1, 64, 1027, 32, 4, 2, 1)]
+             ("ct_128_64", 2, 128, 130, 64, 4, 2, 1), ("ct_64_32", 1, 64, 1027, 32, 4, 2, 1),
+             # lengths the pipelined kernels take (L % 4 == 0): one-chunk rows, chunk tails, batch tails
+             ("ct_512_256_l32", 3, 512, 32, 256, 16, 8, 4), ("ct_256_128_l132", 1, 256, 132, 128, 16, 8, 4),
+             ("ct_128_64_l192", 2, 128, 192, 64, 4, 2, 1), ("ct_64_32_l1028", 1, 64, 1028, 32, 4, 2, 1)]
 
 
 @pytest.mark.parametrize("case", HOT_CONVT, ids=[c[0] for c in HOT_CONVT])
