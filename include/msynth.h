@@ -184,6 +184,28 @@ int ms_ls_d_fwd(const float* r, const float* f, int64_t n, float* out, void* wor
                 size_t workspace_bytes, ms_stream_t stream);
 int ms_ls_d_bwd(const float* r, const float* f, int64_t n, const float* gout, float scale,
                 float* gr, float* gf, ms_stream_t stream);
+/*
+ * Feature-matching loss over up to MS_L1_MULTI_MAX tensor pairs in ONE launch pair
+ * (mel_gan_feature_loss, loss/loss.py:28-65: 18 L1 means per generator step):
+ *   fwd: out[0] = sum_i w[i] * mean(|f_i - r_i|)
+ *   bwd: gf_i = sign(f_i - r_i) * w[i] * scale * (*gout) / n[i]     (gf[i] == NULL: skipped)
+ * The descriptor is passed by value to the kernels: pointers are device pointers, n[i] > 0.
+ */
+#define MS_L1_MULTI_MAX 24
+typedef struct ms_l1_multi_desc {
+    int32_t count;
+    int32_t reserved;
+    const float* r[MS_L1_MULTI_MAX];
+    const float* f[MS_L1_MULTI_MAX];
+    float* gf[MS_L1_MULTI_MAX];
+    int64_t n[MS_L1_MULTI_MAX];
+    float w[MS_L1_MULTI_MAX];
+} ms_l1_multi_desc;
+size_t ms_l1_mean_multi_workspace_bytes(const ms_l1_multi_desc* d);
+int ms_l1_mean_multi_fwd(const ms_l1_multi_desc* d, float* out, void* workspace,
+                         size_t workspace_bytes, ms_stream_t stream);
+int ms_l1_mean_multi_bwd(const ms_l1_multi_desc* d, const float* gout, float scale,
+                         ms_stream_t stream);
 /* out[0] = sum_i coef[i] * (*terms[i]) for n device scalars laid out contiguously in `terms` */
 int ms_weighted_sum(const float* terms, const float* coef, int32_t n, float* out,
                     ms_stream_t stream);

@@ -318,6 +318,101 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 
 }  // namespace
 
+
+// ---------------------------------------------------------------- multi-tensor L1 (feature matching)
+// One launch covers all the feature maps: block -> map through the prefix table in the by-value
+// descriptor.  2048 elements per block in the forward (partial sum per block, folded per map in a
+// fixed order by one block), 2048 per block in the backward.
+namespace {
+struct L1MultiK {
+    ms_l1_multi_desc d;
+    int blk0[MS_L1_MULTI_MAX + 1];       // first block of map i
+};
+
+__device__ __forceinline__ int l1m_map(const L1MultiK& k, int blk) {
+    int m = 0;
+#pragma unroll 1
+    for (int i = 1; i < k.d.count; ++i) m = blk >= k.blk0[i] ? i : m;
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_l1_multi_fwd(L1MultiK k, float* __restrict__ partials) {
+    __shared__ float red[4];
+    const int m = l1m_map(k, blockIdx.x);
+    const float* r = k.d.r[m];
+    const float* f = k.d.f[m];
+    const int64_t n = k.d.n[m];
+    const int64_t base = (int64_t)(blockIdx.x - k.blk0[m]) * 2048;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t e = base + threadIdx.x + 256 * i;
+        const int64_t ec = e < n ? e : 0;
+        const float d = f[ec] - r[ec];
+        v[i] = e < n ? fabsf(d) : 0.f;
+    }
+    const float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    const float tot = ms_block_sum(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_l1_multi_final(L1MultiK k, const float* __restrict__ partials,
+                                                       float* __restrict__ out) {
+    __shared__ float red[4];
+    __shared__ float per_map[MS_L1_MULTI_MAX];
+    // map i is summed by wave-sized strides of thread group i (fixed order: deterministic)
+    for (int m = threadIdx.x >> 3; m < k.d.count; m += 32) {
+        const int sub = threadIdx.x & 7;
+        float s = 0.f;
+        for (int b = k.blk0[m] + sub; b < k.blk0[m + 1]; b += 8) s += partials[b];
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        if (sub == 0) per_map[m] = s * k.d.w[m] / (float)k.d.n[m];
+    }
+    __syncthreads();
+    float t = threadIdx.x < k.d.count ? per_map[threadIdx.x] : 0.f;
+    const float tot = ms_block_sum(t, red);
+    if (threadIdx.x == 0) out[0] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_l1_multi_bwd(L1MultiK k, const float* __restrict__ gout,
+                                                     float scale) {
+    const int m = l1m_map(k, blockIdx.x);
+    float* gf = k.d.gf[m];
+    if (!gf) return;
+    const float* r = k.d.r[m];
+    const float* f = k.d.f[m];
+    const int64_t n = k.d.n[m];
+    const float g = gout[0] * scale * k.d.w[m] / (float)n;
+    const int64_t base = (int64_t)(blockIdx.x - k.blk0[m]) * 2048;
+    float d[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t e = base + threadIdx.x + 256 * i;
+        const int64_t ec = e < n ? e : 0;
+        d[i] = f[ec] - r[ec];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t e = base + threadIdx.x + 256 * i;
+        if (e < n) gf[e] = d[i] > 0.f ? g : (d[i] < 0.f ? -g : 0.f);
+    }
+}
+
+bool l1m_plan(const ms_l1_multi_desc* d, L1MultiK* k) {
+    if (!d || d->count <= 0 || d->count > MS_L1_MULTI_MAX) return false;
+    k->d = *d;
+    long long blk = 0;
+    for (int i = 0; i < d->count; ++i) {
+        if (!d->r[i] || !d->f[i] || d->n[i] <= 0) return false;
+        k->blk0[i] = (int)blk;
+        blk += (d->n[i] + 2047) / 2048;
+        if (blk > (1 << 30)) return false;
+    }
+    for (int i = d->count; i <= MS_L1_MULTI_MAX; ++i) k->blk0[i] = (int)blk;
+    return true;
+}
+}  // namespace
+
 extern "C" {
 
 int ms_avg_pool1d_4_2_2_fwd(const float* x, float* y, int64_t rows, int32_t Lin, ms_stream_t stream) {
@@ -432,6 +527,35 @@ int ms_l1_mean_bwd(const float* r, const float* f, int64_t n, const float* gout,
     if (!r || !f || !gout || !gf || n <= 0) return MS_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_l1_bwd, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, r, f, n, gout,
                        scale, gf, accumulate);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+size_t ms_l1_mean_multi_workspace_bytes(const ms_l1_multi_desc* d) {
+    L1MultiK k;
+    if (!l1m_plan(d, &k)) return 0;
+    return (size_t)k.blk0[MS_L1_MULTI_MAX] * sizeof(float);
+}
+
+int ms_l1_mean_multi_fwd(const ms_l1_multi_desc* d, float* out, void* ws, size_t wsb,
+                         ms_stream_t stream) {
+    L1MultiK k;
+    if (!out || !l1m_plan(d, &k)) return MS_ERR_INVALID_ARG;
+    const int nblk = k.blk0[MS_L1_MULTI_MAX];
+    if (!ws || wsb < (size_t)nblk * sizeof(float)) return MS_ERR_WORKSPACE;
+    hipLaunchKernelGGL(k_l1_multi_fwd, dim3(nblk), dim3(256), 0, (hipStream_t)stream, k, (float*)ws);
+    MS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_l1_multi_final, dim3(1), dim3(256), 0, (hipStream_t)stream, k, (const float*)ws, out);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_l1_mean_multi_bwd(const ms_l1_multi_desc* d, const float* gout, float scale,
+                         ms_stream_t stream) {
+    L1MultiK k;
+    if (!gout || !l1m_plan(d, &k)) return MS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_l1_multi_bwd, dim3(k.blk0[MS_L1_MULTI_MAX]), dim3(256), 0, (hipStream_t)stream, k, gout,
+                       scale);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }

@@ -282,14 +282,20 @@ class MelGanGenLossFn(Function):
         nf = S * Lyr
         rf, ff, fj = ts[:nf], ts[nf:2 * nf], ts[2 * nf:2 * nf + S]
         dev = fj[0].device
+        fscale = float(weight) * (1.0 / S) * (1.0 / Lyr)
+        ctx.cfg = (S, nf, fscale)
+        ctx.ts = ts
+        if nf <= L.L1_MULTI_MAX:     # all feature-matching terms in one launch pair
+            terms = torch.empty((S + 1,), dtype=torch.float32, device=dev)
+            for s in range(S):
+                P.neg_mean_fwd(fj[s], terms[s])
+            P.l1_mean_multi_fwd(rf, ff, [1.0] * nf, terms[S:])
+            return P.weighted_sum(terms, _coef([1.0] * S + [fscale], dev))
         terms = torch.empty((S + nf,), dtype=torch.float32, device=dev)
         for s in range(S):
             P.neg_mean_fwd(fj[s], terms[s])
         for i in range(nf):
             P.l1_mean_fwd(rf[i], ff[i], terms[S + i])
-        fscale = float(weight) * (1.0 / S) * (1.0 / Lyr)
-        ctx.cfg = (S, nf, fscale)
-        ctx.ts = ts
         return P.weighted_sum(terms, _coef([1.0] * S + [fscale] * nf, dev))
 
     @staticmethod
@@ -299,8 +305,13 @@ class MelGanGenLossFn(Function):
         g = _c(g)
         rf, ff, fj = ts[:nf], ts[nf:2 * nf], ts[2 * nf:2 * nf + S]
         need = ctx.needs_input_grad[3:]
-        g_rf = [P.l1_mean_bwd(ff[i], rf[i], g, fscale) if need[i] else None for i in range(nf)]
-        g_ff = [P.l1_mean_bwd(rf[i], ff[i], g, fscale) if need[nf + i] else None for i in range(nf)]
+        if nf <= L.L1_MULTI_MAX:
+            nr, nfk = list(need[:nf]), list(need[nf:2 * nf])
+            g_rf = P.l1_mean_multi_bwd(ff, rf, [1.0] * nf, g, fscale, nr) if any(nr) else [None] * nf
+            g_ff = P.l1_mean_multi_bwd(rf, ff, [1.0] * nf, g, fscale, nfk) if any(nfk) else [None] * nf
+        else:
+            g_rf = [P.l1_mean_bwd(ff[i], rf[i], g, fscale) if need[i] else None for i in range(nf)]
+            g_ff = [P.l1_mean_bwd(rf[i], ff[i], g, fscale) if need[nf + i] else None for i in range(nf)]
         g_fj = [P.neg_mean_bwd(fj[s], g) if need[2 * nf + s] else None for s in range(S)]
         return (None, None, None) + tuple(g_rf) + tuple(g_ff) + tuple(g_fj)
 

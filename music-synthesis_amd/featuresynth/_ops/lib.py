@@ -31,6 +31,15 @@ class ConvTDesc(ctypes.Structure):
                [("slope", _c_f), ("in_act", _c_int)]
 
 
+L1_MULTI_MAX = 24
+
+
+class L1MultiDesc(ctypes.Structure):            # ms_l1_multi_desc
+    _fields_ = [("count", _c_int), ("reserved", _c_int),
+                ("r", _vp * L1_MULTI_MAX), ("f", _vp * L1_MULTI_MAX), ("gf", _vp * L1_MULTI_MAX),
+                ("n", ctypes.c_int64 * L1_MULTI_MAX), ("w", _c_f * L1_MULTI_MAX)]
+
+
 # name -> (restype, argtypes); every symbol include/msynth.h declares
 SIGNATURES = {
     "ms_version": (_c_int, []),
@@ -62,6 +71,9 @@ SIGNATURES = {
     "ms_neg_mean_bwd": (_c_int, [_c_i64, _vp, _c_f, _vp, _vp]),
     "ms_l1_mean_fwd": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _sz, _vp]),
     "ms_l1_mean_bwd": (_c_int, [_vp, _vp, _c_i64, _vp, _c_f, _vp, _c_int, _vp]),
+    "ms_l1_mean_multi_workspace_bytes": (_sz, [ctypes.POINTER(L1MultiDesc)]),
+    "ms_l1_mean_multi_fwd": (_c_int, [ctypes.POINTER(L1MultiDesc), _vp, _vp, _sz, _vp]),
+    "ms_l1_mean_multi_bwd": (_c_int, [ctypes.POINTER(L1MultiDesc), _vp, _c_f, _vp]),
     "ms_ls_g_fwd": (_c_int, [_vp, _c_i64, _vp, _vp, _sz, _vp]),
     "ms_ls_g_bwd": (_c_int, [_vp, _c_i64, _vp, _c_f, _vp, _vp]),
     "ms_ls_d_fwd": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _sz, _vp]),

@@ -301,6 +301,40 @@ def l1_mean_bwd(r, f, gout, scale=1.0, gf=None):
     return gf
 
 
+def _l1_multi_desc(rs, fs, ws, gfs=None):
+    if len(rs) > L.L1_MULTI_MAX or len(rs) != len(fs) or len(rs) != len(ws):
+        raise RuntimeError("l1_mean_multi: at most %d tensor pairs" % L.L1_MULTI_MAX)
+    d = L.L1MultiDesc()
+    d.count = len(rs)
+    for i, (r, f) in enumerate(zip(rs, fs)):
+        L.require(r, "real feature"); L.require(f, "fake feature")
+        if r.shape != f.shape:
+            raise RuntimeError("l1_mean_multi: shape mismatch %s vs %s" % (tuple(r.shape), tuple(f.shape)))
+        d.r[i], d.f[i], d.n[i], d.w[i] = r.data_ptr(), f.data_ptr(), r.numel(), float(ws[i])
+        d.gf[i] = gfs[i].data_ptr() if (gfs is not None and gfs[i] is not None) else None
+    return d
+
+
+def l1_mean_multi_fwd(rs, fs, ws, out):
+    """out[0] = sum_i ws[i] * mean(|fs[i] - rs[i]|) in one launch pair (the 18 feature-matching terms)."""
+    d = _l1_multi_desc(rs, fs, ws)
+    lib = L.load()
+    nws = lib.ms_l1_mean_multi_workspace_bytes(d)
+    wsb = L.workspace(nws, out.device)
+    n = sum(int(r.numel()) for r in rs)
+    L.call("ms_l1_mean_multi_fwd", _scost(n, 2, 0, 2), d, out.data_ptr(), L.ptr(wsb), nws, L.stream())
+    return out
+
+
+def l1_mean_multi_bwd(rs, fs, ws, gout, scale, need):
+    """Gradients w.r.t. fs[i] for the i with need[i] (others None), one launch."""
+    gfs = [torch.empty_like(f) if nd else None for f, nd in zip(fs, need)]
+    d = _l1_multi_desc(rs, fs, ws, gfs)
+    n = sum(int(f.numel()) for f, nd in zip(fs, need) if nd)
+    L.call("ms_l1_mean_multi_bwd", _scost(n, 2, 1, 2), d, gout.data_ptr(), float(scale), L.stream())
+    return gfs
+
+
 def ls_g_bwd(j, gout, scale=1.0):
     gj = torch.empty_like(j)
     L.call("ms_ls_g_bwd", _scost(j.numel(), 1, 1), j.data_ptr(), j.numel(), gout.data_ptr(), scale,

@@ -67,3 +67,4 @@ def test_host_side_queries(lib):
 def test_struct_layout(lib):
     assert ctypes.sizeof(lib.ConvDesc) == 13 * 4
     assert ctypes.sizeof(lib.ConvTDesc) == 10 * 4
+    assert ctypes.sizeof(lib.L1MultiDesc) == 8 + 24 * (8 + 8 + 8 + 8 + 4)     # ms_l1_multi_desc
