@@ -1636,8 +1636,9 @@ int msm_convt1d_bwd_weight(const ConvP& p, const float* x, const float* gy, cons
 // latency-bound: 30 dependent-ish rounds of 4 loads for the 121 slabs of a 128-channel layer).
 __global__ __launch_bounds__(256) void k_wgrad_reduce_v4(const float* __restrict__ partial,
                                                         size_t partial_stride, int nsplit,
-                                                        size_t total, float* __restrict__ out,
-                                                        float beta) {
+                                                        size_t wsize, size_t total,
+                                                        float* __restrict__ out,
+                                                        float* __restrict__ outb, float beta) {
     __shared__ float4 red[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t i = ((size_t)blockIdx.x * 64 + lane) * 4;
@@ -1673,7 +1674,9 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_v4(const float* __restrict
         r.y = (red[0][lane].y + red[1][lane].y) + (red[2][lane].y + red[3][lane].y);
         r.z = (red[0][lane].z + red[1][lane].z) + (red[2][lane].z + red[3][lane].z);
         r.w = (red[0][lane].w + red[1][lane].w) + (red[2][lane].w + red[3][lane].w);
-        float4* o = reinterpret_cast<float4*>(out + i);
+        // (wsize % 4 == 0: a vector is all weights or all bias; the bias entries follow the weights in a slab)
+        if (i >= wsize && !outb) return;
+        float4* o = i < wsize ? reinterpret_cast<float4*>(out + i) : reinterpret_cast<float4*>(outb + (i - wsize));
         if (beta != 0.f) {
             const float4 p = *o;
             r.x += beta * p.x; r.y += beta * p.y; r.z += beta * p.z; r.w += beta * p.w;
@@ -1688,10 +1691,13 @@ int msm_wgrad_reduce(const float* partial, size_t stride_floats, int nsplit, siz
     // weights with 16-byte accesses where the layout allows it, the bias tail with the dword kernel
     if (wsize % 4 == 0 && stride_floats % 4 == 0 && nsplit >= 8 &&
         ((((uintptr_t)partial) | ((uintptr_t)gw)) & 15) == 0) {
-        hipLaunchKernelGGL(k_wgrad_reduce_v4, dim3((unsigned)((wsize / 4 + 63) / 64)), dim3(256), 0, s, partial,
-                           stride_floats, nsplit, wsize, gw, beta);
+        // the bias tail rides along when it is 16-byte sized and aligned too (one launch instead of two)
+        const bool with_bias = nbias > 0 && gb && nbias % 4 == 0 && (((uintptr_t)gb) & 15) == 0;
+        const size_t tot4 = with_bias ? wsize + (size_t)nbias : wsize;
+        hipLaunchKernelGGL(k_wgrad_reduce_v4, dim3((unsigned)((tot4 / 4 + 63) / 64)), dim3(256), 0, s, partial,
+                           stride_floats, nsplit, wsize, tot4, gw, with_bias ? gb : (float*)nullptr, beta);
         MS_CHECK_LAUNCH();
-        if (nbias > 0 && gb) {
+        if (nbias > 0 && gb && !with_bias) {
             hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((nbias + 63) / 64)), dim3(256), 0, s,
                                partial + wsize, stride_floats, nsplit, (size_t)0, nbias, gw, gb, beta);
             MS_CHECK_LAUNCH();
