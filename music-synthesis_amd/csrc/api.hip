@@ -123,6 +123,10 @@ int ms_conv1d_bwd_weight(const ms_conv1d_desc* d, const float* x, const float* g
     const int xk = p.in_act ? MS_MOD_LRELU_FWD : 0;
     if (mst_bwd_weight_applicable(p))   // one-channel side: HBM-bound stream kernels
         return mst_conv1d_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
+    if (msw32_applicable(p)) {          // 32 -> 32 k3 atoms: HBM-bound, per-wave units
+        const int rc = msw32_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
+        if (rc != MS_ERR_UNSUPPORTED) return rc;
+    }
     if (msw_bwd_weight_applicable(p))   // dense stride-1 convs: row-tile MFMA form
         return msw_conv1d_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
     if (msm_bwd_weight_applicable(p))
@@ -141,6 +145,11 @@ size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which) {
     if (which == 1) return msm_bwd_data_applicable(p) ? msm_bwd_data_ws(p) : 0;
     if (which == 2) {
         if (mst_bwd_weight_applicable(p)) return mst_bwd_weight_ws(p);
+        if (msw32_applicable(p)) {
+            const size_t a32 = msw32_ws(p);
+            const size_t rest = msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p);
+            return a32 > rest ? a32 : rest;
+        }
         if (msw_bwd_weight_applicable(p)) return msw_bwd_weight_ws(p);
         return msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p)
                : (msg_bwd_weight_applicable(p) ? msg_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p));
@@ -161,6 +170,7 @@ const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which) {
                   : (mst_bwd_data_applicable(p) && p.pad_mode == MS_PAD_ZERO ? mst_bwd_data_name(p)
                                                                               : msk_conv1d_bwd_data_direct_name(p)));
     if (which == 2 && mst_bwd_weight_applicable(p)) return mst_bwd_weight_name(p);
+    if (which == 2 && msw32_applicable(p)) return p.act == MS_ACT_LRELU ? "k_wgrad32<1>" : "k_wgrad32<0>";
     if (which == 2 && msw_bwd_weight_applicable(p)) return msw_bwd_weight_name(p);
     if (which == 2)
         return msm_bwd_weight_applicable(p) ? msm_bwd_weight_name(p)

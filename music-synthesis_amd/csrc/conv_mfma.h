@@ -55,3 +55,9 @@ int msw_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const
 size_t msw_convt_ws(const ConvP& p);
 int msw_convt_dwq(const ConvP& p, const float* x, const float* gy, const float* y_act, float* dwq,
                   void* ws, size_t ws_bytes, hipStream_t s);
+
+// 32 -> 32 k3 weight gradient, per-wave units (wgrad_rows.hip)
+bool msw32_applicable(const ConvP& p);
+size_t msw32_ws(const ConvP& p);
+int msw32_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act, float* gw,
+                     float* gb, float beta, void* ws, size_t ws_bytes, hipStream_t s);

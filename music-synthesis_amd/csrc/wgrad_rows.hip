@@ -563,3 +563,199 @@ int msw_conv1d_bwd_weight(const ConvP& c, const float* x, const float* gy, const
     return msm_wgrad_reduce(partial, q.stride_floats, q.nsplit, (size_t)c.Cout * c.Cin * c.K, c.Cout, gw,
                             gb, beta, s);
 }
+
+// ------------------------------------------------------------------ 32-channel layers
+// The 32 -> 32 k3 atoms at L = 8192 move 100 MB for 1.6 GFLOP: the weight gradient is bound by HBM,
+// and the whole 32 x (32 x 3) result is ONE MFMA tile row.  Work unit of a WAVE (as in the grouped
+// convs): 64 time steps of one batch row -- the wave stages the 32 x 64 gradient tile (activation
+// derivative applied) and the 32 x (64 + halo) input tile in its private LDS region with 16-byte loads,
+// multiplies 32 k-pair steps x 3 taps, and prefetches the next unit meanwhile.  No workgroup barrier
+// until the end, where the 4 waves' accumulators are summed through LDS into one slab per workgroup.
+namespace {
+
+constexpr int W32_PG = 65;                 // gradient tile pitch (odd)
+constexpr int W32_PX = 89;                 // input tile pitch (odd, >= 64 + 18 + 3 + 3)
+constexpr int W32_WF = 32 * W32_PG + 32 * W32_PX;   // floats per wave region (4928)
+
+struct W32P {
+    int B, L, dil, pad, tiles, nunits;
+    float slope;
+};
+
+template <int AK>   // 1: LeakyReLU derivative on the gradient (y_act given); 0: plain gradient
+__global__ __launch_bounds__(256, 2) void k_wgrad32(W32P p, const float* __restrict__ X,
+                                                   const float* __restrict__ G,
+                                                   const float* __restrict__ Gact,
+                                                   float* __restrict__ partial, size_t pstride) {
+    constexpr int K = 3, NGQ = 8, NXQ = 11;
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // 4 * W32_WF floats
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5;
+    float* Gs = lds + wid * W32_WF;
+    float* Xs = Gs + 32 * W32_PG;
+    const int H = 2 * p.dil;
+    const int SS = 64 + H;
+    const int NVS = (SS + 6) >> 2;                         // aligned vectors covering one input row
+    const int sh = (4 - (p.pad & 3)) & 3;
+
+    // lane-invariant piece descriptors
+    int g_off[NGQ], g_lds[NGQ];
+#pragma unroll
+    for (int q = 0; q < NGQ; ++q) {
+        const int idx = lane + 64 * q, row = idx >> 4, v = idx & 15;
+        g_off[q] = row * p.L + 4 * v;
+        g_lds[q] = row * W32_PG + 4 * v;
+    }
+    int x_off[NXQ], x_lds[NXQ], x_u[NXQ];
+    bool x_in[NXQ];
+#pragma unroll
+    for (int q = 0; q < NXQ; ++q) {
+        const int idx = lane + 64 * q, row = idx / NVS, sv = idx - row * NVS;
+        x_in[q] = row < 32;
+        x_u[q] = 4 * sv - sh;                              // column of the vector's first element
+        x_off[q] = (x_in[q] ? row : 0) * p.L + x_u[q] - p.pad;
+        x_lds[q] = (x_in[q] ? row : 0) * W32_PX + x_u[q];
+    }
+
+    f32x16 acc[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float asum = 0.f;
+
+    float4 gv[NGQ], ga[AK ? NGQ : 1], xv[NXQ];
+    auto gload = [&](int b, int ti) {
+        const int t0 = ti * 64;
+        const float* gb = G + (size_t)b * 32 * p.L + t0;
+        const float* ab = Gact + (size_t)b * 32 * p.L + t0;
+        const float* xb = X + (size_t)b * 32 * p.L + t0;
+#pragma unroll
+        for (int q = 0; q < NGQ; ++q) {
+            const bool ok = t0 + 4 * ((lane + 64 * q) & 15) < p.L;       // L % 4 == 0: all in or all out
+            const int o = ok ? g_off[q] : 0;
+            gv[q] = *reinterpret_cast<const float4*>(gb + o);
+            if (AK) ga[q] = *reinterpret_cast<const float4*>(ab + o);
+        }
+#pragma unroll
+        for (int q = 0; q < NXQ; ++q) {
+            const int t = t0 - p.pad + x_u[q];                            // multiple of 4
+            const bool ok = x_in[q] && t >= 0 && t < p.L;
+            xv[q] = *reinterpret_cast<const float4*>(ok ? xb + x_off[q] : X);
+        }
+    };
+
+    const int wstride = gridDim.x * 4;
+    const int db = wstride / p.tiles, dt = wstride - db * p.tiles;
+    int unit = blockIdx.x * 4 + wid;
+    int b = unit / p.tiles, ti = unit - b * p.tiles;
+    if (unit < p.nunits) gload(b, ti);
+    const float* ap = Gs + (lane & 31) * W32_PG + h;
+    const float* bp = Xs + (lane & 31) * W32_PX + h;
+    for (; unit < p.nunits; unit += wstride) {
+        const int t0 = ti * 64;
+#pragma unroll
+        for (int q = 0; q < NGQ; ++q) {
+            const bool ok = t0 + 4 * ((lane + 64 * q) & 15) < p.L;
+            float e[4] = {gv[q].x, gv[q].y, gv[q].z, gv[q].w};
+            if (AK) {
+                const float a[4] = {ga[q].x, ga[q].y, ga[q].z, ga[q].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = a[i] > 0.f ? e[i] : e[i] * p.slope;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Gs[g_lds[q] + i] = ok ? e[i] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < NXQ; ++q) {
+            const int t = t0 - p.pad + x_u[q];
+            const bool ok = x_in[q] && t >= 0 && t < p.L;
+            const float e[4] = {xv[q].x, xv[q].y, xv[q].z, xv[q].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (x_in[q] && x_u[q] + i >= 0 && x_u[q] + i < SS) Xs[x_lds[q] + i] = ok ? e[i] : 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int nb = b + db, nti = ti + dt;
+        if (nti >= p.tiles) { nti -= p.tiles; ++nb; }
+        if (unit + wstride < p.nunits) gload(nb, nti);
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            const float a = ap[2 * kk];
+            asum += a;
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[2 * kk + j * p.dil], acc[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        b = nb; ti = nti;
+    }
+
+    // workgroup reduction of the 4 waves' tiles through LDS, then one slab per workgroup
+    __syncthreads();
+    float* mine = lds + wid * W32_WF;                     // [j][reg][lane]: 3 * 16 * 64 floats
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[(j * 16 + r) * 64 + lane] = acc[j][r];
+    const float bsum = asum + __shfl_xor(asum, 32, 64);
+    if (lane < 32) mine[K * 16 * 64 + lane] = bsum;
+    __syncthreads();
+    float* part = partial + (size_t)blockIdx.x * pstride;
+    for (int e = tid; e < K * 16 * 64 + 32; e += 256) {
+        const float v = (lds[e] + lds[W32_WF + e]) + (lds[2 * W32_WF + e] + lds[3 * W32_WF + e]);
+        if (e < K * 16 * 64) {
+            // D[row][col]: col = lane&31 (input channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+            const int l = e & 63, rr = (e >> 6) & 15, j = e >> 10;
+            const int m = (rr & 3) + 8 * (rr >> 2) + 4 * (l >> 5), c = l & 31;
+            part[(size_t)m * (32 * K) + c * K + j] = v;
+        } else {
+            part[(size_t)32 * 32 * K + (e - K * 16 * 64)] = v;
+        }
+    }
+}
+
+}  // namespace
+
+bool msw32_applicable(const ConvP& c) {
+    const char* e = getenv("MSYNTH_WROWS");
+    if (e && atoi(e) == 0) return false;
+    return c.groups == 1 && c.stride == 1 && c.Lout == c.Lin && c.pad_mode == MS_PAD_ZERO && c.K == 3 &&
+           c.Cout == 32 && c.Cin == 32 && c.dil >= 1 && c.dil <= 9 && c.pad == c.dil && !c.in_act &&
+           c.Lin % 4 == 0 && c.Lin >= 64 && (c.act == MS_ACT_LRELU || c.act == MS_ACT_NONE) &&
+           (long long)c.B * 32 * c.Lin < (1LL << 31);
+}
+
+static int w32_grid(const ConvP& c) {
+    const int units = c.B * ms_ceil_div(c.Lin, 64);
+    int g = ms_ceil_div(units, 4);
+    return g > 512 ? 512 : g;
+}
+
+size_t msw32_ws(const ConvP& c) { return (size_t)w32_grid(c) * (32 * 32 * 3 + 32) * sizeof(float); }
+
+int msw32_bwd_weight(const ConvP& c, const float* x, const float* gy, const float* y_act, float* gw,
+                     float* gb, float beta, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!ws || ws_bytes < msw32_ws(c)) return MS_ERR_WORKSPACE;
+    if (((((uintptr_t)x) | ((uintptr_t)gy) | ((uintptr_t)(y_act ? y_act : gy))) & 15) != 0) return MS_ERR_UNSUPPORTED;
+    W32P p;
+    p.B = c.B; p.L = c.Lin; p.dil = c.dil; p.pad = c.pad; p.slope = c.slope;
+    p.tiles = ms_ceil_div(c.Lin, 64); p.nunits = c.B * p.tiles;
+    const int g = w32_grid(c);
+    const size_t stride = 32 * 32 * 3 + 32;
+    float* partial = (float*)ws;
+    const size_t lds = (size_t)4 * W32_WF * sizeof(float);
+    static bool attr_set = false;                    // > 64 KiB of dynamic LDS needs the opt-in once
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad32<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        attr_set = true;
+    }
+    if (y_act && c.act == MS_ACT_LRELU)
+        hipLaunchKernelGGL(k_wgrad32<1>, dim3(g), dim3(256), lds, s, p, x, gy, y_act, partial, stride);
+    else
+        hipLaunchKernelGGL(k_wgrad32<0>, dim3(g), dim3(256), lds, s, p, x, gy, gy, partial, stride);
+    MS_CHECK_LAUNCH();
+    return msm_wgrad_reduce(partial, stride, g, (size_t)32 * 32 * 3, 32, gw, gb, beta, s);
+}

@@ -235,6 +235,9 @@ HOT_CONVS = [
     ("mfma_m160_k7_reflect", 2, 24, 50, 160, 7, 1, 3, 1, 1, 2, True),
     # row-tile weight gradient: short rows packed R per chunk (16-byte and scalar loaders), batch
     # tail, 1x1, K = 7, M / channel tails
+    ("w32_d1", 3, 32, 2052, 32, 3, 1, 1, 1, 1, 1, False),
+    ("w32_d9_noact", 2, 32, 1024, 32, 3, 1, 9, 9, 1, 0, False),
+    ("w32_d3_short", 5, 32, 64, 32, 3, 1, 3, 3, 1, 1, False),
     ("wrows_k5_l32", 5, 128, 32, 192, 5, 1, 2, 1, 1, 1, False),
     ("wrows_k3_l16_r3", 7, 64, 16, 64, 3, 1, 1, 1, 1, 1, False),
     ("wrows_k3_l9_d3", 11, 96, 9, 80, 3, 1, 3, 3, 1, 1, False),

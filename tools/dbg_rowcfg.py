@@ -9,7 +9,7 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for (B, C, Lg, K, dil) in ((32, 128, 2048, 3, 1), (32, 256, 256, 3, 1), (32, 64, 4096, 3, 3), (64, 1024, 32, 5, 1)):
+for (B, C, Lg, K, dil) in ((64, 1024, 32, 5, 1), (32, 1024, 32, 5, 1), (64, 1024, 17, 5, 1), (32, 1024, 17, 5, 1), (64, 1024, 9, 5, 1), (32, 1024, 9, 5, 1)):
     x = torch.randn(B, C, Lg, device="cuda"); w = torch.randn(C, C, K, device="cuda") * 0.02; b = torch.randn(C, device="cuda")
     res = torch.randn(B, C, Lg, device="cuda"); gy = torch.randn(B, C, Lg, device="cuda"); ya = torch.randn(B, C, Lg, device="cuda")
     d, lo = P.conv_desc(x.shape, w.shape, pad=dil * (K - 1) // 2, dil=dil, act=1)
