@@ -1103,11 +1103,12 @@ bool row_deep(int K, int CK) { return K != 7 && K != 1 && CK >= 128 && CK % (2 *
 bool rows2_pick(RowCfg cfg, int K, int CC, bool has_act, int epi_s, int in_s, const RowP& p, const float* X,
                 const float* Xact, const float* W, const float* res, const float* Y, const float* Yact,
                 Row2P* q, int* tile, int* am) {
-    if (in_s != 1 || p.pad_mode != MS_PAD_ZERO || cfg == ROW_64x256) return false;
+    if (p.pad_mode != MS_PAD_ZERO || cfg == ROW_64x256) return false;
     if (has_act && p.in_act != MS_ACT_LRELU && p.in_act != MS_ACT_NONE) return false;
-    *am = (has_act && p.in_act == MS_ACT_LRELU) ? 1 : 0;
-    const float* Wuse = *am ? p.Wfwd : W;
-    if (!Wuse || (*am && p.M % 4)) return false;
+    *am = (has_act && p.in_act == MS_ACT_LRELU) ? (in_s == 1 ? 1 : 2) : 0;
+    if (in_s != 1 && *am != 2) return false;
+    const float* Wuse = *am == 1 ? p.Wfwd : W;
+    if (!Wuse || (*am == 1 && p.M % 4)) return false;
     if (((((uintptr_t)X) | ((uintptr_t)Wuse) | ((uintptr_t)(Xact ? Xact : X)) | ((uintptr_t)Y) |
           ((uintptr_t)(Yact ? Yact : Y)) | ((uintptr_t)(res ? res : X))) & 15) != 0)
         return false;
@@ -1117,7 +1118,7 @@ bool rows2_pick(RowCfg cfg, int K, int CC, bool has_act, int epi_s, int in_s, co
     q->PX = p.RSZ; q->CKs = p.CKs; q->zstride = p.zstride; q->slope = p.slope; q->scratch_off = 0;
     *tile = cfg == ROW_128x128 ? MSR2_128x128 : (cfg == ROW_64x128 ? MSR2_64x128 :
             (cfg == ROW_64x64 ? MSR2_64x64 : MSR2_32x256));
-    return msr2_supported(*tile, K, CC, *am, epi_s, *q);
+    return msr2_supported(*tile, K, CC, *am, epi_s, *q, in_s);
 }
 
 template <int K, bool HAS_ACT, int EPI_S = 0, int IN_S = 1, int CCMUL = 1>
@@ -1133,8 +1134,8 @@ int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, 
         Row2P q;
         int tile, am;
         if (rows2_pick(cfg, K, CC, HAS_ACT, EPI_S, IN_S, p, X, Xact, W, res, Y, Yact, &q, &tile, &am))
-            return msr2_launch(tile, K, CC, am, EPI_S, q, X, Xact, am ? p.Wfwd : W, bias, res, Y, Yact, grid.x,
-                               grid.y, grid.z, s);
+            return msr2_launch(tile, K, CC, am, EPI_S, q, X, Xact, am == 1 ? p.Wfwd : W, bias, res, Y, Yact, grid.x,
+                               grid.y, grid.z, s, IN_S);
     }
     const size_t lds = (size_t)(bm * (CC * K + 1) + CC * p.RSZ) * sizeof(float);
     if (lds > 64 * 1024) return MS_ERR_UNSUPPORTED;
@@ -1519,7 +1520,15 @@ const char* msm_convt_bwd_data_name(const ConvP& p) {
     static thread_local char buf[96];
     const RowCfg c = pick_row_cfg(p.Cout, p.B, p.Lout);
     const char* tile = row_tile_str(c);
-    snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, 3, 8, true, 0, %d>", tile, p.stride);
+    RowP r;
+    make_rowp(&r, c, p.B, p.Cin * p.stride, p.Lout, p.Cout, 3, 1, -1, 0, 0, 0, 0.f);
+    Row2P q;
+    q.L = p.Lout; q.R = r.R; q.SS = r.SS;
+    const int t2 = c == ROW_128x128 ? MSR2_128x128 : (c == ROW_64x128 ? MSR2_64x128 : (c == ROW_64x64 ? MSR2_64x64 : MSR2_32x256));
+    if (c != ROW_64x256 && p.act == MS_ACT_LRELU && msr2_supported(t2, 3, 8, 2, 0, q, p.stride))
+        snprintf(buf, sizeof(buf), "k_conv_rows2<%s, 3, 8, 2, 0, %d>", tile, p.stride);
+    else
+        snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, 3, 8, true, 0, %d>", tile, p.stride);
     return buf;
 }
 

@@ -16,8 +16,9 @@ enum { MSR2_128x128 = 0, MSR2_64x128 = 1, MSR2_64x64 = 2, MSR2_32x256 = 3 };
 // activation pieces (16-byte loads per thread and chunk) a tile of BN columns and CC channels needs
 constexpr int msr2_nxq(int CC, int BN) { return (CC * (BN / 4 + 12) + 255) / 256; }
 
-// act_mode 0: no activation operand; 1: LeakyReLU derivative from Xact
-bool msr2_supported(int tile, int K, int CC, int act_mode, int epi_s, const Row2P& p);
+// act_mode 0: no activation operand; 1: LeakyReLU derivative from Xact, W in the forward layout;
+// 2: the derivative with pre-packed W and in_s > 1 (transposed-conv backward data)
+bool msr2_supported(int tile, int K, int CC, int act_mode, int epi_s, const Row2P& p, int in_s = 1);
 int msr2_launch(int tile, int K, int CC, int act_mode, int epi_s, const Row2P& p, const float* X,
                 const float* Xact, const float* W, const float* bias, const float* res, float* Y,
-                float* Yact, unsigned gx, unsigned gy, unsigned gz, hipStream_t s);
+                float* Yact, unsigned gx, unsigned gy, unsigned gz, hipStream_t s, int in_s = 1);

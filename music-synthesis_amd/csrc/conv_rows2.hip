@@ -11,14 +11,17 @@
 //    shadow (one wave per SIMD: nothing else would hide them).
 // Requirements (the caller falls back to k_conv_mfma_rows otherwise): zero padding, L % 4 == 0,
 // 16-byte aligned tensors, plain stride-1 input (IN_S == 1), activation handling one of
-//   AM 0: none (forward);  AM 1: LeakyReLU derivative from the saved output (backward data).
+//   AM 0: none (forward);  AM 1: LeakyReLU derivative from the saved output, weights read in the forward
+//   layout (backward data);  AM 2: the same derivative with pre-packed weights and IN_S > 1: the CC
+//   rows of a chunk are the IN_S phases of CC/IN_S channels of a stride-IN_S signal (transposed-conv
+//   backward data), staged from contiguous 16-byte loads of the phase-interleaved spans.
 #include "conv_rows2.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int WGM, int WGN, int TM, int TN, int K, int CC, int AM, int EPI_S>
+template <int WGM, int WGN, int TM, int TN, int K, int CC, int AM, int EPI_S, int IN_S = 1>
 __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __restrict__ X,
                                                    const float* __restrict__ Xact,
                                                    const float* __restrict__ W,
@@ -56,13 +59,13 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
     // AM 1: backward data straight from the forward layout W[co][ci][j] (no transpose pass): for one
     //       co of the chunk the BM*K floats of rows ci = m0.. are contiguous; a piece is 4 consecutive
     //       (ci, j) of one co, scattered to As[ci][co_l*K + (K-1-j)] (taps flipped).
-    int a_goff[RA4], a_loff[RA4][AM ? 4 : 1];
+    int a_goff[RA4], a_loff[RA4][AM == 1 ? 4 : 1];
     bool a_ok[RA4];
 #pragma unroll
     for (int i = 0; i < RA4; ++i) {
         const int e = i * 256 + tid;
         const bool in = e < A4;
-        if (AM == 0) {
+        if (AM != 1) {
             const int row = e / (KK / 4), q4 = e - row * (KK / 4);
             a_ok[i] = in && m0 + row < p.M;
             a_goff[i] = a_ok[i] ? (m0 + row) * p.KG + q4 * 4 : 0;
@@ -82,22 +85,47 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
     int x_goff[NXQ], x_loff[NXQ];
     bool x_ok[NXQ];
     unsigned x_em[NXQ];                              // which of the 4 elements fall inside the segment
+    int x_loff4[IN_S > 1 ? NXQ : 1][4];              // IN_S > 1: LDS offset of each element (-1: none)
+    if (IN_S == 1) {
 #pragma unroll
-    for (int q = 0; q < NXQ; ++q) {
-        const int i = tid + 256 * q;
-        const int c = i / NVT, v = i - c * NVT;
-        const int r = v / NVS, sv = v - r * NVS;
-        const int u0 = 4 * sv - sh;
-        const int t = t0 + p.off0 + u0;                // multiple of 4: the vector is all in or all out
-        const bool in = c < CC;
-        x_ok[q] = in && b0 + r < p.B && t >= 0 && t < p.L;
-        x_goff[q] = x_ok[q] ? ((b0 + r) * p.CK + c) * p.L + t : 0;
-        x_loff[q] = BM * AS + c * p.PX + r * p.SS + u0;
-        unsigned em = 0;
+        for (int q = 0; q < NXQ; ++q) {
+            const int i = tid + 256 * q;
+            const int c = i / NVT, v = i - c * NVT;
+            const int r = v / NVS, sv = v - r * NVS;
+            const int u0 = 4 * sv - sh;
+            const int t = t0 + p.off0 + u0;                // multiple of 4: the vector is all in or all out
+            const bool in = c < CC;
+            x_ok[q] = in && b0 + r < p.B && t >= 0 && t < p.L;
+            x_goff[q] = x_ok[q] ? ((b0 + r) * p.CK + c) * p.L + t : 0;
+            x_loff[q] = BM * AS + c * p.PX + r * p.SS + u0;
+            unsigned em = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (in && u0 + e >= 0 && u0 + e < p.SS) em |= 1u << e;
-        x_em[q] = em;
+            for (int e = 0; e < 4; ++e)
+                if (in && u0 + e >= 0 && u0 + e < p.SS) em |= 1u << e;
+            x_em[q] = em;
+        }
+    } else {
+        // a piece = 16-byte vector v of the SS*IN_S phase-interleaved floats of (segment r, channel co_l)
+        const int span = p.SS * IN_S;
+        const int NVco = (span + 6) >> 2;
+        const int shx = ((((p.off0 * IN_S) % 4) + 4) % 4);  // span start within its 16-byte vector
+#pragma unroll
+        for (int q = 0; q < NXQ; ++q) {
+            const int i = tid + 256 * q;
+            const int sc = i / NVco, v = i - sc * NVco;     // sc = (segment, channel) pair
+            const int r = sc / (CC / IN_S), co_l = sc - r * (CC / IN_S);
+            const bool in = r < p.R;
+            const int gp = (t0 + p.off0) * IN_S - shx + 4 * v;   // multiple of 4: all in or all out of the row
+            x_ok[q] = in && b0 + r < p.B && gp >= 0 && gp < p.L * IN_S;
+            x_goff[q] = x_ok[q] ? ((b0 + r) * p.CK + co_l * IN_S) * p.L + gp : 0;
+            x_loff[q] = 0; x_em[q] = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int pos = 4 * v + e - shx;
+                const int rr = pos % IN_S, u = pos / IN_S;
+                x_loff4[q][e] = (in && pos >= 0 && pos < span) ? BM * AS + (co_l * IN_S + rr) * p.PX + r * p.SS + u : -1;
+            }
+        }
     }
 
     f32x16 acc[TM][TN];
@@ -126,7 +154,7 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
     auto load_piece = [&](int pi, int c0, bool live) {        // c0: first channel of the chunk
         if (pi < RA4) {
             const int i = pi;
-            const int o = (live && a_ok[i]) ? a_goff[i] + c0 * (AM ? p.M * K : K) : 0;
+            const int o = (live && a_ok[i]) ? a_goff[i] + c0 * (AM == 1 ? p.M * K : K) : 0;
             ra[i] = *reinterpret_cast<const float4*>(W + o);
         } else {
             const int q = pi - RA4;
@@ -142,8 +170,8 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
             const float e[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int lo = AM ? a_loff[i][u] : a_loff[i][0] + u;
-                const bool in = (AM ? a_loff[i][u] : a_loff[i][0]) >= 0;
+                const int lo = AM == 1 ? a_loff[i][u] : a_loff[i][0] + u;
+                const bool in = (AM == 1 ? a_loff[i][u] : a_loff[i][0]) >= 0;
                 float* d = in ? buf + lo : scratch + tid;
                 *d = ok ? e[u] : 0.f;
             }
@@ -158,7 +186,9 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float* d = (x_em[q] >> i) & 1u ? buf + x_loff[q] + i : scratch + tid;
+                float* d;
+                if (IN_S > 1) d = x_loff4[q][i] >= 0 ? buf + x_loff4[q][i] : scratch + tid;
+                else d = (x_em[q] >> i) & 1u ? buf + x_loff[q] + i : scratch + tid;
                 *d = ok ? e[i] : 0.f;
             }
         }
@@ -322,7 +352,7 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
     }
 }
 
-template <int WGM, int WGN, int TM, int TN, int K, int CC, int AM, int EPI_S>
+template <int WGM, int WGN, int TM, int TN, int K, int CC, int AM, int EPI_S, int IN_S = 1>
 int launch_inst(const Row2P& p, const float* X, const float* Xact, const float* W, const float* bias,
                 const float* res, float* Y, float* Yact, dim3 grid, hipStream_t s) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
@@ -332,38 +362,44 @@ int launch_inst(const Row2P& p, const float* X, const float* Xact, const float* 
     if (lds > 150 * 1024) return MS_ERR_UNSUPPORTED;
     static bool attr_set = false;                    // > 64 KiB of dynamic LDS needs the opt-in once
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rows2<WGM, WGN, TM, TN, K, CC, AM, EPI_S>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rows2<WGM, WGN, TM, TN, K, CC, AM, EPI_S, IN_S>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
     Row2P pp = p;
     pp.scratch_off = (int)fl;
-    hipLaunchKernelGGL((k_conv_rows2<WGM, WGN, TM, TN, K, CC, AM, EPI_S>), grid, dim3(256), lds, s, pp, X, Xact,
+    hipLaunchKernelGGL((k_conv_rows2<WGM, WGN, TM, TN, K, CC, AM, EPI_S, IN_S>), grid, dim3(256), lds, s, pp, X, Xact,
                        W, bias, res, Y, Yact);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }
 
-template <int K, int CC, int AM, int EPI_S>
+template <int K, int CC, int AM, int EPI_S, int IN_S = 1>
 int launch_tile(int tile, const Row2P& p, const float* X, const float* Xact, const float* W,
                 const float* bias, const float* res, float* Y, float* Yact, dim3 grid, hipStream_t s) {
     switch (tile) {
-        case MSR2_128x128: return launch_inst<2, 2, 2, 2, K, CC, AM, EPI_S>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
-        case MSR2_64x128: return launch_inst<2, 2, 1, 2, K, CC, AM, EPI_S>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
-        case MSR2_64x64: return launch_inst<2, 2, 1, 1, K, CC, AM, EPI_S>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
-        case MSR2_32x256: return launch_inst<1, 4, 1, 2, K, CC, AM, EPI_S>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+        case MSR2_128x128: return launch_inst<2, 2, 2, 2, K, CC, AM, EPI_S, IN_S>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+        case MSR2_64x128: return launch_inst<2, 2, 1, 2, K, CC, AM, EPI_S, IN_S>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+        case MSR2_64x64: return launch_inst<2, 2, 1, 1, K, CC, AM, EPI_S, IN_S>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+        case MSR2_32x256: return launch_inst<1, 4, 1, 2, K, CC, AM, EPI_S, IN_S>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
         default: return MS_ERR_UNSUPPORTED;
     }
 }
 
 }  // namespace
 
-bool msr2_supported(int tile, int K, int CC, int act_mode, int epi_s, const Row2P& p) {
+bool msr2_supported(int tile, int K, int CC, int act_mode, int epi_s, const Row2P& p, int in_s) {
     const char* e = getenv("MSYNTH_ROWS2");            // tuning / test switch (0 disables)
     if (e && atoi(e) == 0) return false;
     if (tile < 0 || tile > MSR2_32x256) return false;
-    if (act_mode != 0 && act_mode != 1) return false;
+    if (act_mode < 0 || act_mode > 2) return false;
     if (p.L % 4) return false;
+    if (in_s != 1) {      // transposed-conv backward data: phase-split input rows, pre-packed weights
+        if (!(in_s == 2 || in_s == 8) || act_mode != 2 || K != 3 || CC != 8 || epi_s != 0) return false;
+        const int bnI = tile == MSR2_32x256 ? 256 : (tile == MSR2_64x64 ? 64 : 128);
+        return p.R * (CC / in_s) * ((p.SS * in_s + 6) / 4) <= 256 * msr2_nxq(CC, bnI);
+    }
+    if (act_mode == 2) return false;
     const bool k3 = K == 3 && (CC == 8 || CC == 16) && (epi_s == 0 || ((epi_s == 2 || epi_s == 8) && CC == 8 && act_mode == 0));
     // (k5 forward: the first-generation kernel measured 8 % faster, 194 vs 212 us at B*L = 2048)
     const bool k5 = K == 5 && CC == 16 && epi_s == 0 && act_mode == 1;
@@ -375,8 +411,10 @@ bool msr2_supported(int tile, int K, int CC, int act_mode, int epi_s, const Row2
 
 int msr2_launch(int tile, int K, int CC, int act_mode, int epi_s, const Row2P& p, const float* X,
                 const float* Xact, const float* W, const float* bias, const float* res, float* Y,
-                float* Yact, unsigned gx, unsigned gy, unsigned gz, hipStream_t s) {
+                float* Yact, unsigned gx, unsigned gy, unsigned gz, hipStream_t s, int in_s) {
     const dim3 grid(gx, gy, gz);
+    if (in_s == 8) return launch_tile<3, 8, 2, 0, 8>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    if (in_s == 2) return launch_tile<3, 8, 2, 0, 2>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
 #define MSR2_GO(KK, C, A, E) return launch_tile<KK, C, A, E>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s)
     if (K == 3 && epi_s == 0) {
         if (CC == 8) { if (act_mode) MSR2_GO(3, 8, 1, 0); else MSR2_GO(3, 8, 0, 0); }

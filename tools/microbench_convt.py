@@ -24,5 +24,14 @@ for (Cin, Lin, Cout, K, S) in ((512, 32, 256, 16, 8), (256, 256, 128, 16, 8), (1
         us, out = timeit(lambda: P.convt1d_bwd_weight(x, gy, ya, d, w.shape))
         res.append((us, out[0] if isinstance(out, tuple) else out))
     e = float((res[1][1] - res[0][1]).norm() / res[0][1].norm())
-    print("%-28s im2col %7.1f us %5.1f TF/s | rows %7.1f us %5.1f TF/s  rel diff %.1e" % (
+    print("%-28s wgrad: im2col %7.1f us %5.1f TF/s | rows %7.1f us %5.1f TF/s  rel diff %.1e" % (
         (Cin, Lin, Cout, K, S), res[0][0], fl / res[0][0] / 1e6, res[1][0], fl / res[1][0] / 1e6, e), flush=True)
+    res = []
+    for mode in ("0", None):
+        if mode is None: os.environ.pop("MSYNTH_ROWS2", None)
+        else: os.environ["MSYNTH_ROWS2"] = mode
+        us, out = timeit(lambda: P.convt1d_bwd_data(gy, ya, w, d))
+        res.append((us, out))
+    e = float((res[1][1] - res[0][1]).abs().max() / res[0][1].abs().max())
+    print("%-28s bwd_data: gen1 %7.1f us %5.1f TF/s | gen2 %7.1f us %5.1f TF/s  rel maxdiff %.1e" % (
+        "", res[0][0], fl / res[0][0] / 1e6, res[1][0], fl / res[1][0] / 1e6, e), flush=True)
