@@ -1233,9 +1233,17 @@ RowSplit plan_rows_split(RowCfg cfg, const RowP& p, int CC) {
     // slab pass: the 1024 -> 1024 k5 conv at B*L = 2048 has 256 tiles and 64 chunks)
     const int lim = nchunks >= 32 ? (split_max_wgs() * 4) / 3 : split_max_wgs();
     if (wgs > lim || nchunks < 8) return q;
-    int ns = ms_ceil_div(512, wgs);
-    if (ns > nchunks / 4) ns = nchunks / 4;
-    if (ns > 16) ns = 16;
+    // slices so that tiles * slices fills the 512 resident workgroup slots (2 per CU) without spilling
+    // into a mostly empty second round: 160 tiles x 4 slices = 640 workgroups ran 63 % longer than
+    // 128 x 4 = 512 (k5 conv at L = 17 vs 16); 160 x 3 = 480 fits
+    int ns = 1;
+    double best = 0.0;
+    const int ns_max = nchunks / 4 < 16 ? nchunks / 4 : 16;
+    for (int c = 1; c <= ns_max; ++c) {
+        const int tot = wgs * c, rounds = ms_ceil_div(tot, 512);
+        const double eff = (double)tot / (rounds * 512.0);
+        if (eff > best + 1e-9) { best = eff; ns = c; }
+    }
     while (ns > 1 && (size_t)ns * q.out_floats * sizeof(float) > ((size_t)64 << 20)) --ns;
     if (ns <= 1) return q;
     q.cks = ms_ceil_div(nchunks, ns) * CC;
@@ -1698,7 +1706,7 @@ int msm_wgrad_reduce(const float* partial, size_t stride_floats, int nsplit, siz
                      float* gw, float* gb, float beta, hipStream_t s) {
     const size_t total = wsize + (size_t)nbias;
     // weights with 16-byte accesses where the layout allows it, the bias tail with the dword kernel
-    if (wsize % 4 == 0 && stride_floats % 4 == 0 && nsplit >= 8 &&
+    if (wsize % 4 == 0 && stride_floats % 4 == 0 &&
         ((((uintptr_t)partial) | ((uintptr_t)gw)) & 15) == 0) {
         // the bias tail rides along when it is 16-byte sized and aligned too (one launch instead of two)
         const bool with_bias = nbias > 0 && gb && nbias % 4 == 0 && (((uintptr_t)gb) & 15) == 0;

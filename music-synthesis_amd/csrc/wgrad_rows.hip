@@ -330,6 +330,21 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
     }
 }
 
+// Split-K slice count: fill the resident workgroup slots without a mostly empty extra round
+// (160 tiles x 4 slices = 640 workgroups on 512 slots ran 63 % longer than 128 x 4).
+int pick_slices(int tiles, int slots, int ns_max) {
+    int ns = 1;
+    double best = 0.0;
+    if (ns_max > 2 * slots) ns_max = 2 * slots;
+    for (int c = 1; c <= ns_max; ++c) {
+        const int tot = tiles * c, rounds = ms_ceil_div(tot, slots);
+        if (rounds > 2) break;
+        const double eff = (double)tot / (rounds * (double)slots);
+        if (eff > best + 1e-9) { best = eff; ns = c; }
+    }
+    return ns;
+}
+
 struct WrPlan {
     bool ok;
     WrP p;
@@ -373,13 +388,14 @@ WrPlan plan_wrows(const ConvP& c) {
     if (q.lds > 150 * 1024) return q;
     const int tiles = ms_ceil_div(p.M, BM) * ms_ceil_div(p.CK, CB);
     q.stride_floats = (size_t)p.M * p.CK * K + p.M;
-    int ns = ms_ceil_div(512, tiles);
+    // split-K slices: fill the resident workgroup slots (1 per CU above 80 KiB of LDS, else 2) without a
+    // mostly empty extra round; >= 4 chunks per slice; slabs <= 48 MiB
+    const int slots = 256 * (q.lds > 80 * 1024 ? 1 : 2);
     const int max_by_work = p.nchunks / 4 > 0 ? p.nchunks / 4 : 1;
-    if (ns > max_by_work) ns = max_by_work;
-    const size_t cap = (size_t)24 << 20;
-    const size_t max_by_bytes = cap / (q.stride_floats * 4);
-    if ((size_t)ns > max_by_bytes) ns = max_by_bytes > 0 ? (int)max_by_bytes : 1;
-    if (ns < 1) ns = 1;
+    const size_t max_by_bytes = ((size_t)48 << 20) / (q.stride_floats * 4);
+    int ns_max = max_by_work;
+    if ((size_t)ns_max > max_by_bytes) ns_max = max_by_bytes > 0 ? (int)max_by_bytes : 1;
+    const int ns = pick_slices(tiles, slots, ns_max);
     p.cps = ms_ceil_div(p.nchunks, ns);
     q.nsplit = ms_ceil_div(p.nchunks, p.cps);
     q.grid = dim3((unsigned)ms_ceil_div(p.CK, CB), (unsigned)ms_ceil_div(p.M, BM), (unsigned)q.nsplit);
@@ -481,12 +497,11 @@ WrPlan plan_wrows_t(const ConvP& c) {
     q.lds = (size_t)(2 * (BM * p.PG + CB * p.PX) + 256) * sizeof(float);
     const int tiles = ms_ceil_div(p.M, BM) * (p.CK / CB);
     q.stride_floats = (size_t)p.M * p.CK * 3 + p.M;
-    int ns = ms_ceil_div(512, tiles);
-    const int max_by_work = p.nchunks / 2 > 0 ? p.nchunks / 2 : 1;
-    if (ns > max_by_work) ns = max_by_work;
-    const size_t max_by_bytes = ((size_t)32 << 20) / (q.stride_floats * 4);
-    if ((size_t)ns > max_by_bytes) ns = max_by_bytes > 0 ? (int)max_by_bytes : 1;
-    if (ns < 1) ns = 1;
+    const int slots = 256 * (q.lds > 80 * 1024 ? 1 : 2);
+    int ns_max = p.nchunks / 2 > 0 ? p.nchunks / 2 : 1;
+    const size_t max_by_bytes = ((size_t)48 << 20) / (q.stride_floats * 4);
+    if ((size_t)ns_max > max_by_bytes) ns_max = max_by_bytes > 0 ? (int)max_by_bytes : 1;
+    const int ns = pick_slices(tiles, slots, ns_max);
     p.cps = ms_ceil_div(p.nchunks, ns);
     q.nsplit = ms_ceil_div(p.nchunks, p.cps);
     q.grid = dim3((unsigned)(p.CK / CB), (unsigned)ms_ceil_div(p.M, BM), (unsigned)q.nsplit);

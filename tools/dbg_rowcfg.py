@@ -17,7 +17,7 @@ for (B, C, Lg, K, dil) in ((64, 1024, 32, 5, 1), (32, 1024, 32, 5, 1), (64, 1024
     for gen in ("0", "1"):
         os.environ["MSYNTH_ROWS2"] = gen
         msg = "%s gen%s:" % ((B, C, Lg, K, dil), "2" if gen == "1" else "1")
-        for cfg in ("0", "1", "2"):
+        for cfg in ("9",):
             os.environ["MSYNTH_ROWCFG"] = cfg
             a = timeit(lambda: P.conv1d_fwd(x, w, b, d, lo, residual=res, want_y_act=True))
             a2 = timeit(lambda: P.conv1d_fwd(x, w, b, d, lo))
