@@ -318,3 +318,21 @@ def test_bad_arguments_raise():
     with pytest.raises(RuntimeError):                  # non-contiguous
         F_.Conv1dFn.apply(torch.zeros(1, 16, 4, device="cuda").transpose(1, 2),
                           torch.zeros(4, 4, 3, device="cuda"), None, 1, 1, 1, 1, 0, 0)
+
+
+def test_audio2mel_dataset_scale():
+    """the reference runs Audio2Mel over 30-second chunks
+    (feature/feature.py:80-85); a batch of such chunks on the device vs the oracle, plus frame
+    independence (a chunk's frames do not depend on the batch it sits in)."""
+    from featuresynth.feature import Audio2Mel
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    n = 22050 * 30
+    x = (rng.standard_normal((3, 1, n)) * 0.1).astype(np.float32)
+    a2m = Audio2Mel().cuda()
+    y = a2m(dev(x))
+    ref = O.audio2mel(x[1, 0], n_mel=80)
+    assert tuple(y.shape) == (3,) + tuple(ref.shape[1:]) and ref.shape[2] > 2500
+    assert rel_l2(host(y[1:2]), ref) < 1e-4
+    y1 = a2m(dev(x[1:2]))
+    assert torch.equal(y1, y[1:2])
