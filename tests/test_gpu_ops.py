@@ -336,3 +336,31 @@ def test_audio2mel_dataset_scale():
     assert rel_l2(host(y[1:2]), ref) < 1e-4
     y1 = a2m(dev(x[1:2]))
     assert torch.equal(y1, y[1:2])
+
+
+@pytest.mark.parametrize("shape", [(4, 128, 512, 3, 3), (3, 256, 64, 3, 9), (5, 1024, 32, 5, 1), (2, 64, 1028, 3, 1)],
+                         ids=["c128", "c256_d9", "k5_l32", "c64_tail"])
+def test_kernel_generations_agree(shape, monkeypatch):
+    """The pipelined kernels (conv_rows2.hip, wgrad_rows.hip) against the first-generation ones they
+    replace (MSYNTH_ROWS2=0 / MSYNTH_WROWS=0): forward and backward-data accumulate in the same order
+    (bit-identical), the weight gradient differs only in split-K grouping."""
+    from featuresynth._ops import prims as P
+    B, C, Lg, K, dil = shape
+    rng = np.random.default_rng(11)
+    x = dev(rng.standard_normal((B, C, Lg)).astype(np.float32))
+    w = dev((rng.standard_normal((C, C, K)) * 0.05).astype(np.float32))
+    b = dev(rng.standard_normal((C,)).astype(np.float32))
+    res = dev(rng.standard_normal((B, C, Lg)).astype(np.float32))
+    gy = dev(rng.standard_normal((B, C, Lg)).astype(np.float32))
+    d, lo = P.conv_desc(x.shape, w.shape, pad=dil * (K - 1) // 2, dil=dil, act=1)
+    out = {}
+    for gen in ("0", "1"):
+        monkeypatch.setenv("MSYNTH_ROWS2", gen)
+        monkeypatch.setenv("MSYNTH_WROWS", gen)
+        y, ya = P.conv1d_fwd(x, w, b, d, lo, residual=res, want_y_act=True)
+        gx = P.conv1d_bwd_data(gy, ya, w, d, gx_add=res)
+        gw, gb = P.conv1d_bwd_weight(x, gy, ya, d, w.shape)
+        out[gen] = [host(t) for t in (y, ya, gx, gw, gb)]
+    for i in range(3):
+        assert np.array_equal(out["0"][i], out["1"][i])
+    assert rel_l2(out["1"][3], out["0"][3]) < 2e-6 and rel_l2(out["1"][4], out["0"][4]) < 2e-6
