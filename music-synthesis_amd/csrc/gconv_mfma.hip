@@ -45,22 +45,14 @@ __device__ inline void stage_weights(const float* __restrict__ w, float* __restr
 // the matrix cores work.  No workgroup barrier after the weight fill: short rows (L = 9 .. 65 at
 // the coarse scales) keep all four waves busy on different batch rows.
 //
-// Memory instructions are 16 bytes per lane wherever the tensors allow it (dword loads / stores
-// are issue-bound at ~7 B/cycle/CU, MI355X_MICROARCH.md "store tail"):
-//  * inputs: 16-byte-ALIGNED vectors of the flat tensor; a row that starts off a 16-byte boundary
-//    (the odd lengths 4097 / 1025 / .. of the pooled scales) just shifts where each of the four
-//    elements lands in LDS (sh = element offset of the row start within its vector);
-//  * outputs: bias + activation, then a transpose through the wave's LDS region so that a lane
-//    stores 4 consecutive samples of one channel (rows of 256 contiguous bytes per 16 lanes).
+// (16-byte loads / an LDS-transposed 16-byte store path were built and measured SLOWER -- 95 vs 80 us
+// at B = 128: the kernel is bound by vector-instruction issue beside the matrix pipe, not by memory
+// instructions -- and removed.)
 constexpr int UT = 64;                               // outputs per unit
 constexpr int USPAN = (UT - 1) * GS + GK;            // 293 inputs per channel
 constexpr int UK = (USPAN + 63) / 64;                // 5 dword loads per lane and channel
-constexpr int UV = (USPAN + 3 + 3) / 4;              // 75 aligned vectors cover a shifted row
-constexpr int UVI = (GCG * UV + 63) / 64;            // 5 vector loads per lane
 constexpr int UPS = 76;                              // phase-row pitch: >= 74, == 4 (mod 8)
 constexpr int UWS = GCG * GS * UPS;                  // floats per wave region
-constexpr int OPITCH = 68;                           // output-transpose pitch: == 4 (mod 8), 16 B rows
-static_assert(16 * OPITCH <= UWS, "output transpose reuses the input region");
 
 template <int NTT>
 __device__ inline void gfwd_tiles(const float (&a)[GK], const float* __restrict__ xb, f32x4 (&acc)[4]) {

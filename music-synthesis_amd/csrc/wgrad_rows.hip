@@ -383,6 +383,7 @@ WrPlan plan_wrows(const ConvP& c) {
     p.PG = (p.kcols + 2) | 1;
     p.PX = (p.kcols + H + 2) | 1;
     q.tm = (K <= 3 && c.Cout >= 128) ? 2 : 1;
+    if (const char* e = getenv("MSYNTH_WTM")) q.tm = atoi(e) == 1 ? 1 : q.tm;   // tuning switch
     const int BM = 64 * q.tm;
     q.lds = (size_t)(2 * (BM * p.PG + CB * p.PX) + 256) * sizeof(float);   // two buffers + scratch
     if (q.lds > 150 * 1024) return q;
