@@ -277,9 +277,12 @@ def ls_d_fwd(r, f, out=None):
     return _reduce("ms_ls_d_fwd", L.require(r, "real judgement"), L.require(f, "fake judgement"), out)
 
 
-def hinge_d_bwd(r, f, gout, scale=1.0, want_r=True, want_f=True):
-    gr = torch.empty_like(r) if want_r else None
-    gf = torch.empty_like(f) if want_f else None
+def hinge_d_bwd(r, f, gout, scale=1.0, want_r=True, want_f=True, gr=None, gf=None):
+    """gr / gf may be preallocated (e.g. the two halves of one [fake; real] gradient tensor)."""
+    if gr is None:
+        gr = torch.empty_like(r) if want_r else None
+    if gf is None:
+        gf = torch.empty_like(f) if want_f else None
     L.call("ms_hinge_d_bwd", _scost(r.numel(), 2, 2), r.data_ptr(), f.data_ptr(), r.numel(),
            gout.data_ptr(), scale, L.ptr(gr), L.ptr(gf), L.stream())
     return gr, gf

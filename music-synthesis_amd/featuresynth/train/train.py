@@ -21,7 +21,9 @@ import torch
 
 from .. import _dist
 from .._ops import graph as _graph
+from .._ops import functional as _F
 from ..loss import hinge_discriminator_loss, hinge_generator_loss
+from ..loss import mel_gan_disc_loss as _mel_gan_disc_loss
 from ..optim import FlatAdam
 from ..util.modules import zero_grad
 
@@ -197,9 +199,12 @@ class DiscriminatorTrainer(_TrainerBase):
         B = fake.shape[0]
         both = torch.cat([fake, samples], 0)
         _, scores = self.discriminator(both, features)
-        f_score = [j[:B] for j in scores]
-        r_score = [j[B:] for j in scores]
-        loss = self.loss(r_score, f_score, gan_loss=self.sub_loss)
+        if self.loss is _mel_gan_disc_loss and self.sub_loss is hinge_discriminator_loss:
+            loss = _F.MelGanDiscLossCatFn.apply(len(scores), B, *scores)   # no per-slice autograd nodes
+        else:
+            f_score = [j[:B] for j in scores]
+            r_score = [j[B:] for j in scores]
+            loss = self.loss(r_score, f_score, gan_loss=self.sub_loss)
         loss.backward()
         return {"loss": loss.detach()}
 
