@@ -186,50 +186,77 @@ __global__ __launch_bounds__(256, 3) void k_gconv_mfma_fwd(ConvP p, int tiles, i
 // M = (ci, r) = 16 rows, N = 16 consecutive q, K = co (4 per MFMA) x jj (11).  A lane's 4
 // accumulator rows are the 4 phases r of one (ci, q): 4 consecutive samples of gx.
 constexpr int JJ = (GK + GS - 1) / GS;        // 11 taps per phase
-constexpr int TQ = 64;                        // q's per wave
-constexpr int WQ = 4 * TQ;                    // q's per workgroup
-constexpr int GRS = ((WQ + 2 * (JJ - 1) + 31) / 32) * 32 + 16;   // == 16 (mod 32)
+constexpr int TQ = 64;                        // q's per unit (4 MFMA column tiles)
+constexpr int BSP = TQ + 2 * (JJ - 1);        // 84 gradient columns a unit reads per output channel
+constexpr int BGR = 112;                      // LDS row pitch: >= 84, == 16 (mod 32)
 
-template <int OQ>   // OQ = Og / 4 co-quads (4 for Og = 16, 1 for Og = 4)
-__global__ __launch_bounds__(256) void k_gconv_mfma_bwd_data(ConvP p, const float* __restrict__ gy,
-                                                            const float* __restrict__ y_act,
-                                                            const float* __restrict__ w,
-                                                            const float* __restrict__ gx_add,
-                                                            float* __restrict__ gx) {
-    __shared__ float gs[OQ * 4 * GRS];
-    __shared__ float ws[OQ * 4 * GCG * GK];
+template <int OQ, int NTQ>
+__device__ inline void gbwd_tiles(const float (&a)[OQ * JJ], const float* __restrict__ gb, f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int cq = 0; cq < OQ; ++cq)
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) {
+            float bv[NTQ];
+#pragma unroll
+            for (int tq = 0; tq < NTQ; ++tq) bv[tq] = gb[cq * 4 * BGR + tq * 16 - jj];
+#pragma unroll
+            for (int tq = 0; tq < NTQ; ++tq)
+                acc[tq] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cq * JJ + jj], bv[tq], acc[tq], 0, 0, 0);
+        }
+}
+
+// Work unit of a WAVE: 64 consecutive q (256 samples of the 4 input-channel rows) of one (batch row,
+// group): private LDS tile of the Og x 84 gradient values it needs (activation derivative applied),
+// 4 independent MFMA chains, next unit prefetched into registers, 16-byte stores where the rows allow.
+template <int OQ, bool VOUT>   // OQ = Og / 4 co-quads (4 for Og = 16, 1 for Og = 4)
+__global__ __launch_bounds__(256, 2) void k_gconv_mfma_bwd_data(ConvP p, int tiles, int nunits,
+                                                               const float* __restrict__ gy,
+                                                               const float* __restrict__ y_act,
+                                                               const float* __restrict__ w,
+                                                               const float* __restrict__ gx_add,
+                                                               float* __restrict__ gx) {
+    constexpr int ROWS = OQ * 4;
+    constexpr int NLD = (ROWS * BSP + 63) / 64;       // 21 (Og = 16) / 6 (Og = 4) loads per lane and tensor
+    __shared__ float gsm[4 * ROWS * BGR];
+    __shared__ float ws[ROWS * GCG * GK];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int g = blockIdx.y, b = blockIdx.z;
-    const int Q0 = blockIdx.x * WQ;
-    const int tlo = Q0 + 5 - (JJ - 1);               // first gp index staged (may be < 0)
-    const int qvalid = min(WQ, (p.Lin + GS - 1) / GS - Q0);
-    const int span = min(WQ + 2 * (JJ - 1), ((qvalid + 15) & ~15) + 2 * (JJ - 1));
+    const int g = blockIdx.y;
+    float* gsw = gsm + wid * ROWS * BGR;
     const float* ya = y_act ? y_act : gy;
     const int kind = y_act ? p.act : MS_ACT_NONE;
-    {   // batched staging (all loads issued before the first LDS store)
-        constexpr int SPMAX = WQ + 2 * (JJ - 1);          // 276 columns per co row
-        constexpr int NGI = (OQ * 4 * SPMAX + 255) / 256;
-        float gv[NGI], av[NGI];
+    const int wstride = gridDim.x * 4;
+    const int db = wstride / tiles, dt = wstride - db * tiles;
+
+    // lane-invariant: element idx = lane + 64 i -> (row co, column tt) of the tile
+    unsigned loff[NLD];                                // global offset relative to (b, g, q0 - 5): co*Lout + tt
+    int lds_o[NLD], ltt[NLD];
 #pragma unroll
-        for (int i = 0; i < NGI; ++i) {
-            const int idx = tid + 256 * i;
-            const int co = idx / SPMAX, tt = idx - co * SPMAX;    // compile-time divisor
-            const int t = tlo + tt;
-            const bool ok = co < OQ * 4 && tt < span && t >= 0 && t < p.Lout;
-            const size_t off = ok ? ((size_t)b * p.Cout + (size_t)g * p.Og + co) * p.Lout + t : 0;
-            gv[i] = gy[off];
-            av[i] = ya[off];
-        }
-#pragma unroll
-        for (int i = 0; i < NGI; ++i) {
-            const int idx = tid + 256 * i;
-            const int co = idx / SPMAX, tt = idx - co * SPMAX;
-            const int t = tlo + tt;
-            const bool ok = tt < span && t >= 0 && t < p.Lout;
-            if (co < OQ * 4 && tt < span) gs[co * GRS + tt] = ok ? ms_act_grad(gv[i], av[i], kind, p.slope) : 0.f;
-        }
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = lane + 64 * i;
+        const int co = idx / BSP, tt = idx - co * BSP;    // compile-time divisor
+        ltt[i] = co < ROWS ? tt : -1000000;
+        loff[i] = (unsigned)((co < ROWS ? co : 0) * p.Lout);
+        lds_o[i] = (co < ROWS ? co : 0) * BGR + tt;
     }
-    stage_weights<(OQ * 4 * GCG * GK + 255) / 256>(w + (size_t)g * p.Og * GCG * GK, ws, OQ * 4 * GCG * GK, tid);
+    float gv[NLD], av[NLD];
+    auto gload = [&](int b, int ti) {
+        const int tlo = ti * TQ + 5 - (JJ - 1);            // first gradient index of the unit (may be < 0)
+        const size_t base = ((size_t)b * p.Cout + (size_t)g * p.Og) * p.Lout;
+        const float* gb_ = gy + base;
+        const float* ab_ = ya + base;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int t = tlo + ltt[i];
+            const bool ok = t >= 0 && t < p.Lout;         // (ltt = -1e6 for lanes past the tile)
+            const unsigned o = ok ? loff[i] + (unsigned)t : 0u;
+            gv[i] = gb_[o];
+            av[i] = ab_[o];
+        }
+    };
+    int unit = blockIdx.x * 4 + wid;
+    int b = unit / tiles, ti = unit - b * tiles;
+    if (unit < nunits) gload(b, ti);
+    stage_weights<(ROWS * GCG * GK + 255) / 256>(w + (size_t)g * p.Og * GCG * GK, ws, ROWS * GCG * GK, tid);
     __syncthreads();
     // weight fragments: lane (m = (ci, r) = lane&15, k = lane>>4): w[g*Og + 4cq + k][ci][r + 4jj]
     const int mrow = lane & 15, ci = mrow >> 2, r = mrow & 3, kq = lane >> 4;
@@ -243,33 +270,64 @@ __global__ __launch_bounds__(256) void k_gconv_mfma_bwd_data(ConvP p, const floa
             const float v = ws[((cq * 4 + kq) * GCG + ci) * GK + (ok ? k : 0)];
             a[cq * JJ + jj] = ok ? v : 0.f;
         }
+    // gp index for (q, jj): q + 5 - jj  ->  LDS column (q - q0) + (JJ-1) - jj
+    const float* gb = gsw + kq * BGR + (lane & 15) + (JJ - 1);
+    const int Lq = (p.Lin + GS - 1) / GS;
 
+    for (; unit < nunits; unit += wstride) {
+        const int q0 = ti * TQ;
+        const int tlo = q0 + 5 - (JJ - 1);
 #pragma unroll
-    for (int tq = 0; tq < TQ / 16; ++tq) {
-        const int qbase = Q0 + wid * TQ + tq * 16;
-        if (qbase * GS >= p.Lin) break;              // wave-uniform
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        // gp index for (q, jj): q + 5 - jj  ->  LDS column (q - Q0) + (JJ-1) - jj
-        const float* gb = gs + kq * GRS + wid * TQ + tq * 16 + (lane & 15) + (JJ - 1);
-#pragma unroll
-        for (int cq = 0; cq < OQ; ++cq)
-#pragma unroll
-            for (int jj = 0; jj < JJ; ++jj) {
-                const float bv = gb[cq * 4 * GRS - jj];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cq * JJ + jj], bv, acc, 0, 0, 0);
-            }
+        for (int i = 0; i < NLD; ++i) {
+            const int t = tlo + ltt[i];
+            const bool ok = t >= 0 && t < p.Lout;
+            if (ltt[i] >= 0) gsw[lds_o[i]] = ok ? ms_act_grad(gv[i], av[i], kind, p.slope) : 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         // D[row][col]: col = lane&15 = q, row = (lane>>4)*4 + reg = ci*4 + r  ->  ci = lane>>4, r = reg
-        const int q = qbase + (lane & 15);
         const size_t rowoff = ((size_t)b * p.Cin + (size_t)g * GCG + (lane >> 4)) * p.Lin;
+        const int ntq = min(4, (Lq - q0 + 15) >> 4);       // wave-uniform
+        float4 addv[4];
+        if (VOUT && gx_add) {                              // residual gradient: 16-byte loads, batched
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int sidx = q * GS + rr;
-            if (sidx < p.Lin) {
-                float v = acc[rr];
-                if (gx_add) v += gx_add[rowoff + sidx];
-                gx[rowoff + sidx] = v;
+            for (int tq = 0; tq < 4; ++tq) {
+                const int sidx = (q0 + tq * 16 + (lane & 15)) * GS;
+                addv[tq] = *reinterpret_cast<const float4*>(gx_add + (sidx < p.Lin ? rowoff + sidx : 0));
             }
         }
+        int nb = b + db, nti = ti + dt;
+        if (nti >= tiles) { nti -= tiles; ++nb; }
+        if (unit + wstride < nunits) gload(nb, nti);
+        f32x4 acc[4];
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) acc[tq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ntq == 4) gbwd_tiles<OQ, 4>(a, gb, acc);
+        else if (ntq == 3) gbwd_tiles<OQ, 3>(a, gb, acc);
+        else if (ntq == 2) gbwd_tiles<OQ, 2>(a, gb, acc);
+        else gbwd_tiles<OQ, 1>(a, gb, acc);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+            const int sidx = (q0 + tq * 16 + (lane & 15)) * GS;
+            if (tq >= ntq || sidx >= p.Lin) continue;
+            if (VOUT) {                                    // Lin % 4 == 0: the 4 samples exist together
+                float4 v = make_float4(acc[tq][0], acc[tq][1], acc[tq][2], acc[tq][3]);
+                if (gx_add) { v.x += addv[tq].x; v.y += addv[tq].y; v.z += addv[tq].z; v.w += addv[tq].w; }
+                *reinterpret_cast<float4*>(gx + rowoff + sidx) = v;
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    if (sidx + rr < p.Lin) {
+                        float v = acc[tq][rr];
+                        if (gx_add) v += gx_add[rowoff + sidx + rr];
+                        gx[rowoff + sidx + rr] = v;
+                    }
+                }
+            }
+        }
+        b = nb; ti = nti;
     }
 }
 
@@ -476,11 +534,23 @@ const char* msg_bwd_data_name(const ConvP& p) {
 int msg_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, const float* w,
                         const float* gx_add, float* gx, hipStream_t s) {
     const int Lq = ms_ceil_div(p.Lin, GS);
-    dim3 grid(ms_ceil_div(Lq, WQ), p.groups, p.B);
-    if (p.Og == 16)
-        hipLaunchKernelGGL(k_gconv_mfma_bwd_data<4>, grid, dim3(256), 0, s, p, gy, y_act, w, gx_add, gx);
-    else
-        hipLaunchKernelGGL(k_gconv_mfma_bwd_data<1>, grid, dim3(256), 0, s, p, gy, y_act, w, gx_add, gx);
+    const int tiles = ms_ceil_div(Lq, TQ), nunits = p.B * tiles;
+    // ~2 waves per SIMD; a wave loops over `upw` units (loads / MFMAs / stores of consecutive units overlap)
+    const long long total_units = (long long)nunits * p.groups;
+    const int upw = (int)((total_units + 2047) / 2048);
+    const int gxn = ms_ceil_div(nunits, 4 * (upw > 0 ? upw : 1));
+    const dim3 grid(gxn, p.groups);
+    const bool vout = p.Lin % 4 == 0 && (((uintptr_t)gx) & 15) == 0 && (!gx_add || (((uintptr_t)gx_add) & 15) == 0);
+#define MS_GBWD(OQV)                                                                                         \
+    do {                                                                                                     \
+        if (vout) hipLaunchKernelGGL((k_gconv_mfma_bwd_data<OQV, true>), grid, dim3(256), 0, s, p, tiles,    \
+                                     nunits, gy, y_act, w, gx_add, gx);                                      \
+        else hipLaunchKernelGGL((k_gconv_mfma_bwd_data<OQV, false>), grid, dim3(256), 0, s, p, tiles,        \
+                                nunits, gy, y_act, w, gx_add, gx);                                           \
+    } while (0)
+    if (p.Og == 16) MS_GBWD(4);
+    else MS_GBWD(1);
+#undef MS_GBWD
     MS_CHECK_LAUNCH();
     return MS_OK;
 }
