@@ -344,6 +344,58 @@ def test_train_step_mel128_odd_batch_vs_torch_graph():
             assert rel_l2(host(p.grad), r) < 2e-3 or np.linalg.norm(r) < 1e-12, (kind, k)
 
 
+def test_full_size_train_step_vs_torch_graph():
+    """BASELINE config 3 sizes (B=32, 8192-sample windows, 80 mels): one D-step and one G-step
+    against the torch-functional oracle's autograd -- the kernels, tile shapes and split-K plans
+    the benchmark actually runs.  fp32 torch is the comparison here (the float64 C oracle would
+    take minutes at this size), so the bounds are those of two fp32 summation orders: loss 1e-4,
+    typical layer gradient 1e-3, every layer 5e-2 (LeakyReLU mask flips)."""
+    import torch as th
+    import featuresynth as fs
+    from featuresynth import loss as LS
+    from featuresynth._synthetic import synthetic_features, synthetic_samples
+    from featuresynth.train import DiscriminatorTrainer, GeneratorTrainer
+    from oracle import torch_graph as TG
+    B, T = 32, 32
+    samples, feats = synthetic_samples(B, T * 256, rank=2), synthetic_features(B, 80, T, rank=2)
+    th.set_num_threads(16)
+    for kind in ("d", "g"):
+        g, d, gsd, dsd = make_nets(dict(seed=7, bias_scale=0.02), dict(seed=8, bias_scale=0.02))
+        go = fs.FlatAdam(g.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        do = fs.FlatAdam(d.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        gp, dp = TG.to_params(gsd), TG.to_params(dsd)
+        fake = TG.generator(gp, th.from_numpy(feats))
+        ff, fj = TG.discriminator(dp, fake)
+        rf, rj = TG.discriminator(dp, th.from_numpy(samples))
+        if kind == "d":
+            ref = TG.disc_loss(rj, fj); ref.backward()
+            loss = DiscriminatorTrainer(g, go, d, do, LS.mel_gan_disc_loss).train(dev(samples), dev(feats))["d_loss"]
+            net, refp = d, dp
+        else:
+            ref = TG.gen_loss(rf, ff, fj); ref.backward()
+            res = GeneratorTrainer(g, go, d, do, LS.mel_gan_gen_loss).train(dev(samples), dev(feats))
+            loss, net, refp = res["g_loss"], g, gp
+            assert rel_l2(res["fake"], fake.detach().numpy()) < 1e-4
+        assert abs(loss - ref.item()) <= 1e-4 * abs(ref.item()), (kind, loss, ref.item())
+        # (the hinge gradient of the judge bias is sum(+1/n over fake) - sum(1/n over real) = 0 up to
+        # rounding at this init: a relative error is meaningless for such fully cancelling entries,
+        # they are held to an absolute bound instead)
+        refs = {k: refp[k].grad.numpy() for k, _ in net.named_parameters()}
+        gmax = max(float(np.linalg.norm(r)) for r in refs.values())
+        errs = {}
+        for k, p in net.named_parameters():
+            r = refs[k]
+            if np.linalg.norm(r) > 1e-4 * gmax:
+                errs[k] = rel_l2(host(p.grad), r)
+            else:      # e.g. judge bias: exactly 0 here, -2^-22 (rounding residue) in fp32 torch
+                assert float(np.abs(host(p.grad) - r).max()) < 1e-4 * gmax, (kind, k)
+        wk = max(errs, key=errs.get)
+        assert max(errs.values()) < 5e-2, (kind, sorted(errs.items(), key=lambda kv: -kv[1])[:4], wk, host(dict(net.named_parameters())[wk].grad).ravel()[:4], refs[wk].ravel()[:4], gmax)
+        assert float(np.median(list(errs.values()))) < 1e-3, (kind, sorted(errs.items(), key=lambda kv: -kv[1])[:4])
+        print("%s-step full size: loss %.6f (oracle %.6f), grad rel-L2 median %.1e max %.1e" % (
+            kind, loss, ref.item(), float(np.median(list(errs.values()))), max(errs.values())))
+
+
 def test_training_loop_checkpoint_resume(tmp_path, monkeypatch):
     """featuresynth.train.training_loop over an Experiment: alternating D/G
     steps, logger plumbing, checkpoint + resume including the optimizer state."""
