@@ -99,6 +99,33 @@ class _TrainerBase(object):
     def _fwd_bwd(self, samples, features):
         raise NotImplementedError
 
+    def _result(self, out, device, loss_key, with_fake):
+        if out["loss"].is_cuda:                 # torch-optimizer path: plain device tensors
+            res = {loss_key: out["loss"].item()}
+            if with_fake:
+                res['fake'] = out["fake"].cpu().numpy()
+            return res
+        torch.cuda.current_stream(device).synchronize()
+        res = {loss_key: float(out["loss"])}
+        if with_fake:
+            res['fake'] = out["fake"].numpy().copy()   # (the pinned buffer is reused by the next step)
+        return res
+
+    def _to_host(self, out):
+        """Device results -> pinned host buffers with asynchronous copies issued on the step's stream
+        (inside the captured graph they become memcpy nodes): the caller then needs ONE stream
+        synchronisation instead of a blocking .item() plus a blocking pageable copy of `fake`."""
+        if not hasattr(self, "_pins"):
+            self._pins = {}
+        host = {}
+        for k, v in out.items():
+            key = (k, tuple(v.shape))
+            if key not in self._pins:
+                self._pins[key] = torch.empty(tuple(v.shape), dtype=v.dtype, pin_memory=True)
+            self._pins[key].copy_(v, non_blocking=True)
+            host[k] = self._pins[key]
+        return host
+
     def _native_step(self, samples, features):
         """fwd+bwd graph -> (RCCL all-reduce of the stepped bucket) -> Adam graph."""
         opt = self._stepped_optim()
@@ -120,11 +147,11 @@ class _TrainerBase(object):
                 def body(s, f):
                     out = self._fwd_bwd(s, f)
                     opt.step()
-                    return out
+                    return self._to_host(out)
                 self._runner = _GraphedStep(body)
             return self._runner(samples, features)
         if self._runner is None:
-            self._runner = _GraphedStep(self._fwd_bwd)
+            self._runner = _GraphedStep(lambda s, f: self._to_host(self._fwd_bwd(s, f)))
             self._tail = _GraphedStep(lambda s, f: (opt.step(), {})[1])
         out = self._runner(samples, features)
         _dist.allreduce_sum_(opt.flat_grads)
@@ -166,7 +193,7 @@ class GeneratorTrainer(_TrainerBase):
     def train(self, samples, features):
         if self._native_ok(samples, features):
             out = self._native_step(samples, features)
-            return {'g_loss': out["loss"].item(), 'fake': out["fake"].cpu().numpy()}
+            return self._result(out, samples.device, 'g_loss', True)
         # reference order of operations (train.py:26-42)
         zero_grad(self.g_optim, self.d_optim)
         fake = self.generator(features)
@@ -211,7 +238,7 @@ class DiscriminatorTrainer(_TrainerBase):
     def train(self, samples, features):
         if self._native_ok(samples, features):
             out = self._native_step(samples, features)
-            return {'d_loss': out["loss"].item()}
+            return self._result(out, samples.device, 'd_loss', False)
         # reference order of operations (train.py:63-74)
         zero_grad(self.g_optim, self.d_optim)
         fake = self.generator(features)
