@@ -1065,7 +1065,8 @@ RowCfg pick_row_cfg(int M, int B, int L) {
     if (L < 128) return (M >= 512 && (long long)B * L >= 512) ? ROW_64x128 : ROW_64x64;   // short rows: R = 128 / L rows per tile
     const long long N = (long long)B * L;
     if (M >= 128 && (N / 128) * (M / 128) >= 384) return ROW_128x128;
-    if ((N / 128) * (M / 64) < 192) return ROW_64x64;   // small batches: more, smaller workgroups
+    static const int t64 = getenv("MSYNTH_T64") ? atoi(getenv("MSYNTH_T64")) : 192;   // tuning switch
+    if ((N / 128) * (M / 64) < t64) return ROW_64x64;   // small batches: more, smaller workgroups
     return ROW_64x128;
 }
 
