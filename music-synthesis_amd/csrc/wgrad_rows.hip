@@ -81,11 +81,17 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
     const float* Gq = Gact ? Gact : G;
     const int g_kind = Gact ? p.g_kind : MS_ACT_NONE;
 
-    f32x16 acc[TM][K];
+    // XS > 1: a transposed conv with K = 2*XS, pad = XS/2 has exactly two live taps per phase (d in {0,+1}
+    // for the low phases, {-1,0} for the high ones).  The LDS rows are ordered [low phases | high phases]
+    // so a wave's 32 rows share their tap pair, and only those two taps are multiplied and written.
+    constexpr int KT = XS > 1 ? 2 : K;
+    constexpr int XH = XS > 1 ? XS / 2 : 1;       // phases per half
+    const int jlo = XS > 1 ? 1 - wn : 0;
+    f32x16 acc[TM][KT];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < K; ++j)
+        for (int j = 0; j < KT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float asum[TM];
@@ -141,7 +147,8 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
             for (int e = 0; e < 4; ++e) {
                 const int pos = 4 * v + e - shx;
                 const int r = pos % XS, u = pos / XS;
-                t_lds[q][e] = (t_in[q] && pos >= 0 && pos < span) ? BM * p.PG + (corow * XS + r) * p.PX + u : -1;
+                const int xrow = (r / XH) * 32 + corow * XH + r % XH;
+                t_lds[q][e] = (t_in[q] && pos >= 0 && pos < span) ? BM * p.PG + xrow * p.PX + u : -1;
             }
         }
     }
@@ -266,19 +273,19 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
         const float* bp = smem + cur * tile_floats + b_off;
         float* nbuf = smem + (cur ^ 1) * tile_floats;
         const Cs s_after = chunk_state(ch + 2, c_end);
-        float a0[TM], b0[K], a1[TM], b1[K];
-        auto frag = [&](int kk, float (&a)[TM], float (&b)[K]) {
+        float a0[TM], b0[KT], a1[TM], b1[KT];
+        auto frag = [&](int kk, float (&a)[TM], float (&b)[KT]) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = ap[i * 32 * p.PG + 2 * kk];
 #pragma unroll
-            for (int j = 0; j < K; ++j) b[j] = bp[2 * kk + j * p.dil];
+            for (int j = 0; j < KT; ++j) b[j] = bp[2 * kk + (jlo + j) * p.dil];
         };
-        auto mma = [&](const float (&a)[TM], const float (&b)[K]) {
+        auto mma = [&](const float (&a)[TM], const float (&b)[KT]) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 asum[i] += a[i];
 #pragma unroll
-                for (int j = 0; j < K; ++j)
+                for (int j = 0; j < KT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         };
@@ -305,7 +312,11 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
 
     // D[row][col]: col = lane&31 (input channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (output channel)
     float* part = partial + (size_t)blockIdx.z * pstride;
-    const int c = c0 + wn * 32 + (lane & 31);
+    int c = c0 + wn * 32 + (lane & 31);
+    if (XS > 1) {       // undo the [low | high] phase ordering of the LDS rows
+        const int l = lane & 31;
+        c = c0 + (l / XH) * XS + wn * XH + l % XH;
+    }
     if (c < p.CK) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -314,7 +325,7 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
                 const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m < p.M) {
 #pragma unroll
-                    for (int j = 0; j < K; ++j) part[(size_t)m * NG + (size_t)c * K + j] = acc[i][j][r];
+                    for (int j = 0; j < KT; ++j) part[(size_t)m * NG + (size_t)c * K + jlo + j] = acc[i][j][r];
                 }
             }
         }
