@@ -548,6 +548,25 @@ __global__ __launch_bounds__(256) void k_pack_convt_bwd_w(const float* __restric
     }
 }
 
+// The same weights with only the two live taps of each phase (K = 2S, pad = S/2: d in {0,+1} for
+// r < S/2, {-1,0} above):  Wq2[ci][(co*S + r)*2 + jj] = W[ci, co, r + pad + (jb(r) + jj - 1)*S]
+__global__ __launch_bounds__(256) void k_pack_convt_bwd_w2(const float* __restrict__ W,
+                                                          float* __restrict__ Wq, int Cin, int Cout,
+                                                          int K, int S, int pad) {
+    const size_t total = (size_t)Cin * Cout * S * 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int jj = (int)(i % 2);
+        size_t r0 = i / 2;
+        const int r = (int)(r0 % S);
+        r0 /= S;
+        const int co = (int)(r0 % Cout);
+        const int ci = (int)(r0 / Cout);
+        const int d = (r < S / 2 ? 1 : 0) + jj - 1;
+        const int k = r + pad + d * S;
+        Wq[i] = (k >= 0 && k < K) ? W[((size_t)ci * Cout + co) * K + k] : 0.f;
+    }
+}
+
 // gw[ci, co, k] = beta*gw + dWq[ci][(co*S + r)*3 + (d+1)] with k = r + pad + d*S
 __global__ __launch_bounds__(256) void k_unpack_convt_gw(const float* __restrict__ dWq,
                                                         float* __restrict__ gw, int Cin, int Cout,
@@ -1534,8 +1553,8 @@ const char* msm_convt_bwd_data_name(const ConvP& p) {
     Row2P q;
     q.L = p.Lout; q.R = r.R; q.SS = r.SS;
     const int t2 = c == ROW_128x128 ? MSR2_128x128 : (c == ROW_64x128 ? MSR2_64x128 : (c == ROW_64x64 ? MSR2_64x64 : MSR2_32x256));
-    if (c != ROW_64x256 && p.act == MS_ACT_LRELU && msr2_supported(t2, 3, 8, 2, 0, q, p.stride))
-        snprintf(buf, sizeof(buf), "k_conv_rows2<%s, 3, 8, 2, 0, %d>", tile, p.stride);
+    if (c != ROW_64x256 && p.act == MS_ACT_LRELU && msr2_supported(t2, 2, 8, 2, 0, q, p.stride))
+        snprintf(buf, sizeof(buf), "k_conv_rows2<%s, 2, 8, 2, 0, %d>", tile, p.stride);
     else
         snprintf(buf, sizeof(buf), "k_conv_mfma_rows<%s, 3, 8, true, 0, %d>", tile, p.stride);
     return buf;
@@ -1550,8 +1569,6 @@ int msm_convt1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, co
     const size_t total = (size_t)CinT * CoutT * S * 3;
     unsigned nb = (unsigned)((total + 255) / 256);
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(k_pack_convt_bwd_w, dim3(nb), dim3(256), 0, s, w, wq, CinT, CoutT, p.K, S, p.pad);
-    MS_CHECK_LAUNCH();
     RowP r;
     const RowCfg cfg = pick_row_cfg(CinT, p.B, LinT);
     make_rowp(&r, cfg, p.B, CoutT * S, LinT, CinT, 3, 1, -1, MS_PAD_ZERO, MS_ACT_NONE, p.act, p.slope);
@@ -1559,9 +1576,31 @@ int msm_convt1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, co
     const float* ya = y_act ? y_act : gy;
     if (!y_act) r.in_act = MS_ACT_NONE;
     const size_t wbytes = align16(total * sizeof(float));
+    // pipelined kernel: the 3-tap window stays, but only the two live taps of each phase are multiplied
+    Row2P q2;
+    int tile2 = 0, am2 = 0;
+    const bool two = rows2_pick(cfg, 2, 8, true, 0, S, r, gy, ya, wq, nullptr, gx, nullptr, &q2, &tile2, &am2);
+    if (two)
+        hipLaunchKernelGGL(k_pack_convt_bwd_w2, dim3(nb), dim3(256), 0, s, w, wq, CinT, CoutT, p.K, S, p.pad);
+    else
+        hipLaunchKernelGGL(k_pack_convt_bwd_w, dim3(nb), dim3(256), 0, s, w, wq, CinT, CoutT, p.K, S, p.pad);
+    MS_CHECK_LAUNCH();
     return rows_maybe_split(cfg, r, row_cc(3), CinT, LinT, nullptr, nullptr, gx, nullptr,
                             (char*)ws + wbytes, ws_bytes - wbytes, s,
                             [&](const RowP& rp, const float* b_, const float* r_, float* y_, float* ya_) {
+                                if (two) {
+                                    Row2P q;
+                                    int tile, am, bm, bn;
+                                    if (!rows2_pick(cfg, 2, 8, true, 0, S, rp, gy, ya, wq, r_, y_, ya_, &q, &tile, &am))
+                                        return (int)MS_ERR_UNSUPPORTED;
+                                    q.KG = rp.CK * 2;
+                                    row_tile(cfg, &bm, &bn);
+                                    const unsigned gx_ = rp.R == 1 ? (unsigned)(rp.B * rp.tiles_per_row)
+                                                                   : (unsigned)((rp.B + rp.R - 1) / rp.R);
+                                    return msr2_launch(tile, 2, 8, am, 0, q, gy, ya, wq, b_, r_, y_, ya_, gx_,
+                                                       (unsigned)((rp.M + bm - 1) / bm),
+                                                       (unsigned)((rp.CK + rp.CKs - 1) / rp.CKs), s, S);
+                                }
                                 if (S == 8) return launch_rows_k<3, true, 0, 8>(cfg, rp, gy, ya, wq, b_, r_, y_, ya_, s);
                                 return launch_rows_k<3, true, 0, 2>(cfg, rp, gy, ya, wq, b_, r_, y_, ya_, s);
                             });

@@ -218,9 +218,14 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
         float a0[TM], b0f[TN], a1[TM], b1f[TN];
         auto frag = [&](int q, float (&a)[TM], float (&b)[TN]) {
             // k-pair q: lane half h takes GEMM-k element 2q + h = (channel, tap) of the chunk
+            // IN_S > 1 with K = 2 (transposed conv, kernel 2*IN_S, padding IN_S/2): of the 3-tap window a
+            // phase channel has two live taps -- {0,+1} for the low phases, {-1,0} for the high ones
             const int kk0 = 2 * q, kk1 = 2 * q + 1;
-            const int off_lo = (kk0 / K) * p.PX + (kk0 % K) * p.dil;
-            const int off_hi = (kk1 / K) * p.PX + (kk1 % K) * p.dil;
+            constexpr bool TWO = IN_S > 1 && K == 2;
+            const int jb0 = TWO && ((kk0 / K) % IN_S) < IN_S / 2 ? 1 : 0;
+            const int jb1 = TWO && ((kk1 / K) % IN_S) < IN_S / 2 ? 1 : 0;
+            const int off_lo = (kk0 / K) * p.PX + (kk0 % K + jb0) * p.dil;
+            const int off_hi = (kk1 / K) * p.PX + (kk1 % K + jb1) * p.dil;
             const int off = h ? off_hi : off_lo;
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = As[arow + i * 32 * AS + 2 * q];
@@ -395,7 +400,7 @@ bool msr2_supported(int tile, int K, int CC, int act_mode, int epi_s, const Row2
     if (act_mode < 0 || act_mode > 2) return false;
     if (p.L % 4) return false;
     if (in_s != 1) {      // transposed-conv backward data: phase-split input rows, pre-packed weights
-        if (!(in_s == 2 || in_s == 8) || act_mode != 2 || K != 3 || CC != 8 || epi_s != 0) return false;
+        if (!(in_s == 2 || in_s == 8) || act_mode != 2 || K != 2 || CC != 8 || epi_s != 0) return false;
         const int bnI = tile == MSR2_32x256 ? 256 : (tile == MSR2_64x64 ? 64 : 128);
         return p.R * (CC / in_s) * ((p.SS * in_s + 6) / 4) <= 256 * msr2_nxq(CC, bnI);
     }
@@ -413,8 +418,8 @@ int msr2_launch(int tile, int K, int CC, int act_mode, int epi_s, const Row2P& p
                 const float* Xact, const float* W, const float* bias, const float* res, float* Y,
                 float* Yact, unsigned gx, unsigned gy, unsigned gz, hipStream_t s, int in_s) {
     const dim3 grid(gx, gy, gz);
-    if (in_s == 8) return launch_tile<3, 8, 2, 0, 8>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
-    if (in_s == 2) return launch_tile<3, 8, 2, 0, 2>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    if (in_s == 8) return launch_tile<2, 8, 2, 0, 8>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    if (in_s == 2) return launch_tile<2, 8, 2, 0, 2>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
 #define MSR2_GO(KK, C, A, E) return launch_tile<KK, C, A, E>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s)
     if (K == 3 && epi_s == 0) {
         if (CC == 8) { if (act_mode) MSR2_GO(3, 8, 1, 0); else MSR2_GO(3, 8, 0, 0); }
