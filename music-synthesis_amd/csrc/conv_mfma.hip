@@ -515,6 +515,27 @@ __global__ __launch_bounds__(256) void k_pack_convt_w(const float* __restrict__ 
     }
 }
 
+// Two-live-tap form of the same weights (K = 2S, pad = S/2: d in {-1,0} for r < S/2, {0,+1} above), rows
+// in groups of 64 = [32 low-phase | 32 high-phase] rows of the same 64/S output channels:
+//   Wp2[g*64 + half*32 + co_l*(S/2) + rh][ci*2 + jj] = W[ci, co, r + pad - (half + jj - 1)*S]
+//   with co = g*(64/S) + co_l, r = half*(S/2) + rh
+__global__ __launch_bounds__(256) void k_pack_convt_w2(const float* __restrict__ W,
+                                                      float* __restrict__ Wp, int Cin, int Cout,
+                                                      int K, int S, int pad) {
+    const size_t total = (size_t)Cout * S * Cin * 2;
+    const int SH = S / 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int jj = (int)(i % 2);
+        size_t r0 = i / 2;
+        const int ci = (int)(r0 % Cin);
+        const int m = (int)(r0 / Cin);
+        const int g = m / 64, half = (m % 64) / 32, l = m % 32;
+        const int co = g * (64 / S) + l / SH, r = half * SH + l % SH;
+        const int k = r + pad - (half + jj - 1) * S;
+        Wp[i] = (k >= 0 && k < K) ? W[((size_t)ci * Cout + co) * K + k] : 0.f;
+    }
+}
+
 // Wt[ci][co*K + j'] = W[co][ci][K-1-j']  (weights of the conv that computes backward-data)
 __global__ __launch_bounds__(256) void k_transpose_flip_w(const float* __restrict__ W,
                                                          float* __restrict__ Wt, int Co, int Ci,
@@ -1392,7 +1413,14 @@ const char* msm_convt_fwd_name(const ConvP& p) {
     const RowCfg c = pick_row_cfg(p.Cin * p.stride, p.B, p.Lout);
     RowP r;
     make_rowp(&r, c, p.B, p.Cout, p.Lout, p.Cin * p.stride, 3, 1, -1, 0, 0, 0, 0.f);
-    (void)buf;
+    if (!p.in_act && (c == ROW_128x128 || c == ROW_64x128)) {
+        Row2P q;
+        q.L = p.Lout; q.R = r.R; q.SS = r.SS; q.M = p.Cin * p.stride;
+        if (msr2_supported(c == ROW_128x128 ? MSR2_128x128 : MSR2_64x128, 2, 8, 0, p.stride, q)) {
+            snprintf(buf, sizeof(buf), "k_conv_rows2<%s, 2, 8, 0, %d>", c == ROW_128x128 ? "2, 2, 2, 2" : "1, 4, 2, 1", p.stride);
+            return buf;
+        }
+    }
     return row_kname(c, 3, p.in_act != 0, p.Cout, p.Lout, r.R, r.SS, MS_PAD_ZERO, p.in_act ? MS_MOD_LRELU_FWD : 0, p.stride);
 }
 
@@ -1507,17 +1535,37 @@ int msm_convt1d_fwd(const ConvP& p, const float* x, const float* w, const float*
     const size_t total = (size_t)CoutT * S * CinT * 3;
     unsigned nb = (unsigned)((total + 255) / 256);
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(k_pack_convt_w, dim3(nb), dim3(256), 0, s, w, wp, CinT, CoutT, p.K, S, p.pad);
-    MS_CHECK_LAUNCH();
     RowP r;
     const RowCfg cfg = pick_row_cfg(CoutT * S, p.B, LinT);
     make_rowp(&r, cfg, p.B, CinT, LinT, CoutT * S, 3, 1, -1, MS_PAD_ZERO, p.act, MS_ACT_NONE, p.slope);
     const size_t wbytes = align16(total * sizeof(float));
     const bool ia = p.in_act != 0;   // LeakyReLU in front of the transposed conv: applied to x on load
     if (ia) r.in_act = MS_MOD_LRELU_FWD;
+    // pipelined kernel: the 3-tap window stays, but only the two live taps of each phase are multiplied
+    Row2P q2;
+    int tile2 = 0, am2 = 0;
+    const bool two = !ia && rows2_pick(cfg, 2, 8, false, S, 1, r, x, nullptr, wp, nullptr, y, nullptr, &q2, &tile2, &am2);
+    if (two)
+        hipLaunchKernelGGL(k_pack_convt_w2, dim3(nb), dim3(256), 0, s, w, wp, CinT, CoutT, p.K, S, p.pad);
+    else
+        hipLaunchKernelGGL(k_pack_convt_w, dim3(nb), dim3(256), 0, s, w, wp, CinT, CoutT, p.K, S, p.pad);
+    MS_CHECK_LAUNCH();
     return rows_maybe_split(cfg, r, row_cc(3), CoutT, LinT * S, bias, nullptr, y, nullptr,
                             (char*)ws + wbytes, ws_bytes - wbytes, s,
                             [&](const RowP& rp, const float* b_, const float* r_, float* y_, float* ya_) {
+                                if (two) {
+                                    Row2P q;
+                                    int tile, am, bm, bn;
+                                    if (!rows2_pick(cfg, 2, 8, false, S, 1, rp, x, nullptr, wp, r_, y_, ya_, &q, &tile, &am))
+                                        return (int)MS_ERR_UNSUPPORTED;
+                                    q.KG = rp.CK * 2;
+                                    row_tile(cfg, &bm, &bn);
+                                    const unsigned gx_ = rp.R == 1 ? (unsigned)(rp.B * rp.tiles_per_row)
+                                                                   : (unsigned)((rp.B + rp.R - 1) / rp.R);
+                                    return msr2_launch(tile, 2, 8, am, S, q, x, nullptr, wp, b_, r_, y_, ya_, gx_,
+                                                       (unsigned)((rp.M + bm - 1) / bm),
+                                                       (unsigned)((rp.CK + rp.CKs - 1) / rp.CKs), s, 1);
+                                }
                                 if (ia) {
                                     if (S == 8) return launch_rows_k<3, true, 8>(cfg, rp, x, x, wp, b_, r_, y_, ya_, s);
                                     return launch_rows_k<3, true, 2>(cfg, rp, x, x, wp, b_, r_, y_, ya_, s);

@@ -38,6 +38,13 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
     constexpr int NP = RA4 + NXQ;
     constexpr int NSTEP = KK / 2;            // MFMA k-pair steps per chunk
     constexpr int PPS = (NP + NSTEP - 1) / NSTEP;
+    // HALF (transposed-conv forward, kernel 2S, padding S/2): every output phase has two live taps of the
+    // 3-tap window -- {-1,0} for the low phases, {0,+1} for the high ones.  GEMM rows come packed in groups
+    // of 64 = [32 low-phase rows | 32 high-phase rows] of the same output channels, so a wave's two M
+    // sub-tiles differ only in the window offset of their B fragments.
+    constexpr bool HALF = K == 2 && EPI_S > 0 && IN_S == 1;
+    constexpr int NBH = HALF ? 2 : 1;
+    static_assert(!HALF || TM == 2, "HALF needs two M sub-tiles per wave");
     static_assert(WGM * WGN == 4, "4 waves");
     static_assert(KK % 4 == 0, "chunk must be float4-sized");
     extern __shared__ float smem[];
@@ -215,8 +222,8 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
         float* nbuf = smem + ((ch & 1) ^ 1) * tile_floats;
         const bool live1 = ch + 1 < nchunks, live2 = ch + 2 < nchunks;
         const int c2 = cbeg + (ch + 2) * CC;
-        float a0[TM], b0f[TN], a1[TM], b1f[TN];
-        auto frag = [&](int q, float (&a)[TM], float (&b)[TN]) {
+        float a0[TM], b0f[NBH][TN], a1[TM], b1f[NBH][TN];
+        auto frag = [&](int q, float (&a)[TM], float (&b)[NBH][TN]) {
             // k-pair q: lane half h takes GEMM-k element 2q + h = (channel, tap) of the chunk
             // IN_S > 1 with K = 2 (transposed conv, kernel 2*IN_S, padding IN_S/2): of the 3-tap window a
             // phase channel has two live taps -- {0,+1} for the low phases, {-1,0} for the high ones
@@ -230,14 +237,18 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = As[arow + i * 32 * AS + 2 * q];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Xs[off + bbase[j]];
+            for (int j = 0; j < TN; ++j) b[0][j] = Xs[off + bbase[j]];
+            if (HALF) {         // the high-phase rows (M sub-tile 1) read the window one tap later
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[NBH - 1][j] = Xs[off + p.dil + bbase[j]];
+            }
         };
-        auto mma = [&](const float (&a)[TM], const float (&b)[TN]) {
+        auto mma = [&](const float (&a)[TM], const float (&b)[NBH][TN]) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[HALF ? i : 0][j], acc[i][j], 0, 0, 0);
         };
         frag(0, a0, b0f);
 #pragma unroll
@@ -314,6 +325,43 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
         constexpr int ES = EPI_S > 0 ? EPI_S : 1;
         const int Cout = p.M / ES;
         const size_t Lo = (size_t)p.L * ES;
+        if (HALF) {
+            const int mg = m0 + wm * 64;                     // this wave's 64-row group
+            if (mg < p.M) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (!nvalid[j]) continue;
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        if (EPI_S >= 4) {       // row-in-half 8rg+4h+u = (channel 2rg+h, phase u) for S = 8
+                            const int co = mg / ES + (8 * rg + 4 * h) / (ES / 2);
+                            const float bv = bias ? bias[co] : 0.f;
+                            float* yp = Y + ((size_t)ob[j] * Cout + co) * Lo + (size_t)ot[j] * ES;
+#pragma unroll
+                            for (int i = 0; i < TM; ++i) {
+                                float4 v;
+                                v.x = ms_apply_act(acc[i][j][4 * rg + 0] + bv, p.act, p.slope);
+                                v.y = ms_apply_act(acc[i][j][4 * rg + 1] + bv, p.act, p.slope);
+                                v.z = ms_apply_act(acc[i][j][4 * rg + 2] + bv, p.act, p.slope);
+                                v.w = ms_apply_act(acc[i][j][4 * rg + 3] + bv, p.act, p.slope);
+                                *reinterpret_cast<float4*>(yp + (i % 2) * (ES / 2)) = v;
+                            }
+                        } else {                // S = 2: row-in-half = channel, sub-tile = phase
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int co = mg / 2 + 8 * rg + 4 * h + u;
+                                const float bv = bias ? bias[co] : 0.f;
+                                float2 v;
+                                v.x = ms_apply_act(acc[0][j][4 * rg + u] + bv, p.act, p.slope);
+                                v.y = ms_apply_act(acc[TM - 1][j][4 * rg + u] + bv, p.act, p.slope);
+                                *reinterpret_cast<float2*>(Y + ((size_t)ob[j] * Cout + co) * Lo + (size_t)ot[j] * 2) = v;
+                            }
+                        }
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             if (!nvalid[j]) continue;
@@ -405,6 +453,10 @@ bool msr2_supported(int tile, int K, int CC, int act_mode, int epi_s, const Row2
         return p.R * (CC / in_s) * ((p.SS * in_s + 6) / 4) <= 256 * msr2_nxq(CC, bnI);
     }
     if (act_mode == 2) return false;
+    // transposed-conv forward with the two live taps per phase: 128x128 tile, whole 64-row groups
+    if (K == 2) return CC == 8 && act_mode == 0 && (epi_s == 2 || epi_s == 8) &&
+                       (tile == MSR2_128x128 || tile == MSR2_64x128) && p.M % 64 == 0 &&
+                       CC * (p.R * ((p.SS + 6) / 4)) <= 256 * msr2_nxq(CC, 128);
     const bool k3 = K == 3 && (CC == 8 || CC == 16) && (epi_s == 0 || ((epi_s == 2 || epi_s == 8) && CC == 8 && act_mode == 0));
     // (k5 forward: the first-generation kernel measured 8 % faster, 194 vs 212 us at B*L = 2048)
     const bool k5 = K == 5 && CC == 16 && epi_s == 0 && act_mode == 1;
@@ -420,6 +472,14 @@ int msr2_launch(int tile, int K, int CC, int act_mode, int epi_s, const Row2P& p
     const dim3 grid(gx, gy, gz);
     if (in_s == 8) return launch_tile<2, 8, 2, 0, 8>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
     if (in_s == 2) return launch_tile<2, 8, 2, 0, 2>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    if (K == 2 && CC == 8 && act_mode == 0 && tile == MSR2_128x128) {
+        if (epi_s == 8) return launch_inst<2, 2, 2, 2, 2, 8, 0, 8>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+        if (epi_s == 2) return launch_inst<2, 2, 2, 2, 2, 8, 0, 2>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    }
+    if (K == 2 && CC == 8 && act_mode == 0 && tile == MSR2_64x128) {   // 64 x 128 as 1 x 4 waves of 64 x 32
+        if (epi_s == 8) return launch_inst<1, 4, 2, 1, 2, 8, 0, 8>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+        if (epi_s == 2) return launch_inst<1, 4, 2, 1, 2, 8, 0, 2>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    }
 #define MSR2_GO(KK, C, A, E) return launch_tile<KK, C, A, E>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s)
     if (K == 3 && epi_s == 0) {
         if (CC == 8) { if (act_mode) MSR2_GO(3, 8, 1, 0); else MSR2_GO(3, 8, 0, 0); }

@@ -35,3 +35,13 @@ for (Cin, Lin, Cout, K, S) in ((512, 32, 256, 16, 8), (256, 256, 128, 16, 8), (1
     e = float((res[1][1] - res[0][1]).abs().max() / res[0][1].abs().max())
     print("%-28s bwd_data: gen1 %7.1f us %5.1f TF/s | gen2 %7.1f us %5.1f TF/s  rel maxdiff %.1e" % (
         "", res[0][0], fl / res[0][0] / 1e6, res[1][0], fl / res[1][0] / 1e6, e), flush=True)
+    res = []
+    bias = torch.randn(Cout, device="cuda")
+    for mode in ("0", None):
+        if mode is None: os.environ.pop("MSYNTH_ROWS2", None)
+        else: os.environ["MSYNTH_ROWS2"] = mode
+        us, out = timeit(lambda: P.convt1d_fwd(x, w, bias, d, lo))
+        res.append((us, out[0] if isinstance(out, tuple) else out))
+    e = float((res[1][1] - res[0][1]).abs().max() / res[0][1].abs().max())
+    print("%-28s fwd:      gen1 %7.1f us %5.1f TF/s | gen2 %7.1f us %5.1f TF/s  rel maxdiff %.1e" % (
+        "", res[0][0], fl / res[0][0] / 1e6, res[1][0], fl / res[1][0] / 1e6, e), flush=True)
