@@ -93,9 +93,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # MSYNTH_BENCH_SHARE_GPU=1: rehearsal of the N > 1 control flow on a one-GPU box (every rank on
+    # cuda:0, gloo instead of RCCL); the line it prints is marked and is not a measurement
+    share = os.environ.get("MSYNTH_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    _dist.init_from_env("nccl")
+    _dist.init_from_env("gloo" if share else "nccl")
     rank = _dist.rank()
     L.load()
 
@@ -168,6 +173,8 @@ def main():
                    "parallelism": "dp%d" % world, "hipgraph": graphs},
     }
 
+    if share:
+        result["rehearsal"] = "ranks share cuda:0 over gloo: control-flow check only, not a measurement"
     if rank == 0 and not args.no_roofline:
         # instrumented eager pass: HIP events around every C-ABI launch on the launch stream
         s, f = batches[0]
