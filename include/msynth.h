@@ -147,6 +147,27 @@ int ms_weight_norm_fwd(const float* v, const float* g, float* w, int32_t rows, i
 int ms_weight_norm_bwd(const float* v, const float* g, const float* gw, float* gv, float* gg,
                        int32_t rows, int32_t cols, float beta, ms_stream_t stream);
 
+/*
+ * The same for every weight-normed layer of a network in ONE launch (the reference re-derives all
+ * weights on each forward through the weight_norm pre-hooks, realmelgan.py:24-29: 63 tiny launches
+ * per forward otherwise).  Tensor i is a (rows[i], cols[i]) view; the descriptor is passed by value.
+ * Forward writes out[i]; backward reads out[i] as gw and writes gv[i], gg[i] (beta as above).
+ */
+#define MS_WN_MULTI_MAX 64
+typedef struct ms_wn_multi_desc {
+    int32_t count;
+    int32_t reserved;
+    const float* v[MS_WN_MULTI_MAX];
+    const float* g[MS_WN_MULTI_MAX];
+    float* out[MS_WN_MULTI_MAX];       /* fwd: w (written);  bwd: gw (read) */
+    float* gv[MS_WN_MULTI_MAX];        /* bwd only */
+    float* gg[MS_WN_MULTI_MAX];        /* bwd only */
+    int32_t rows[MS_WN_MULTI_MAX];
+    int32_t cols[MS_WN_MULTI_MAX];
+} ms_wn_multi_desc;
+int ms_weight_norm_multi_fwd(const ms_wn_multi_desc* d, ms_stream_t stream);
+int ms_weight_norm_multi_bwd(const ms_wn_multi_desc* d, float beta, ms_stream_t stream);
+
 /* gpre = gy * act'(y_act), elementwise (stand-alone form of the fused modifier above) */
 int ms_act_bwd(const float* y_act, const float* gy, float* gpre, int64_t n, int32_t act,
                float slope, ms_stream_t stream);

@@ -156,6 +156,59 @@ __global__ __launch_bounds__(256) void k_weight_norm_bwd(const float* __restrict
     }
 }
 
+// multi-tensor forms: workgroup b owns row b of the concatenated row list
+__device__ __forceinline__ int wn_find(const ms_wn_multi_desc& d, int b, int* row) {
+    int t = 0;
+    while (t + 1 < d.count && b >= d.rows[t]) { b -= d.rows[t]; ++t; }
+    *row = b;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void k_weight_norm_multi_fwd(ms_wn_multi_desc d) {
+    __shared__ float red[4];
+    __shared__ float scale;
+    int r;
+    const int t = wn_find(d, blockIdx.x, &r);
+    const int cols = d.cols[t];
+    const float* vr = d.v[t] + (size_t)r * cols;
+    float* wr = d.out[t] + (size_t)r * cols;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) s += vr[c] * vr[c];
+    const float tot = ms_block_sum(s, red);
+    if (threadIdx.x == 0) scale = d.g[t][r] / sqrtf(tot);
+    __syncthreads();
+    const float sc = scale;
+    for (int c = threadIdx.x; c < cols; c += 256) wr[c] = vr[c] * sc;
+}
+
+__global__ __launch_bounds__(256) void k_weight_norm_multi_bwd(ms_wn_multi_desc d, float beta) {
+    __shared__ float red[4];
+    __shared__ float sh[2];
+    int r;
+    const int t = wn_find(d, blockIdx.x, &r);
+    const int cols = d.cols[t];
+    const float* vr = d.v[t] + (size_t)r * cols;
+    const float* gr = d.out[t] + (size_t)r * cols;
+    float* gvr = d.gv[t] + (size_t)r * cols;
+    float s2 = 0.f, dot = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        s2 += vr[c] * vr[c];
+        dot += gr[c] * vr[c];
+    }
+    const float t2 = ms_block_sum(s2, red);
+    const float td = ms_block_sum(dot, red);
+    if (threadIdx.x == 0) { sh[0] = t2; sh[1] = td; }
+    __syncthreads();
+    const float nrm = sqrtf(sh[0]);
+    const float gdot = sh[1] / nrm;
+    const float gs = d.g[t][r] / nrm;
+    if (threadIdx.x == 0) d.gg[t][r] = (beta != 0.f ? beta * d.gg[t][r] : 0.f) + gdot;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float val = gs * (gr[c] - gdot * vr[c] / nrm);
+        gvr[c] = (beta != 0.f ? beta * gvr[c] : 0.f) + val;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ ya,
                                                 const float* __restrict__ gy,
                                                 float* __restrict__ out, int64_t n, int act,
@@ -467,6 +520,33 @@ int ms_weight_norm_bwd(const float* v, const float* g, const float* gw, float* g
     if (beta != 0.f && beta != 1.f) return MS_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_weight_norm_bwd, dim3(rows), dim3(256), 0, (hipStream_t)stream, v, g, gw, gv,
                        gg, cols, beta);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+static int wn_multi_rows(const ms_wn_multi_desc* d, bool bwd) {
+    if (!d || d->count <= 0 || d->count > MS_WN_MULTI_MAX) return -1;
+    long long rows = 0;
+    for (int i = 0; i < d->count; ++i) {
+        if (!d->v[i] || !d->g[i] || !d->out[i] || d->rows[i] <= 0 || d->cols[i] <= 0) return -1;
+        if (bwd && (!d->gv[i] || !d->gg[i])) return -1;
+        rows += d->rows[i];
+    }
+    return rows < (1LL << 31) ? (int)rows : -1;
+}
+
+int ms_weight_norm_multi_fwd(const ms_wn_multi_desc* d, ms_stream_t stream) {
+    const int rows = wn_multi_rows(d, false);
+    if (rows <= 0) return MS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_weight_norm_multi_fwd, dim3(rows), dim3(256), 0, (hipStream_t)stream, *d);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_weight_norm_multi_bwd(const ms_wn_multi_desc* d, float beta, ms_stream_t stream) {
+    const int rows = wn_multi_rows(d, true);
+    if (rows <= 0 || (beta != 0.f && beta != 1.f)) return MS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_weight_norm_multi_bwd, dim3(rows), dim3(256), 0, (hipStream_t)stream, *d, beta);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }

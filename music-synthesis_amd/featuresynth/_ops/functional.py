@@ -365,6 +365,29 @@ class WeightNormFn(Function):
         return gv, gg
 
 
+class WeightNormMultiFn(Function):
+    """(v0, g0, v1, g1, ...) -> (w0, w1, ...): all weight-normed layers of a network at once."""
+
+    @staticmethod
+    def forward(ctx, *vg):
+        vs, gs = list(vg[0::2]), list(vg[1::2])
+        ctx.save_for_backward(*vg)
+        return tuple(P.weight_norm_multi_fwd(vs, gs))
+
+    @staticmethod
+    def backward(ctx, *gws):
+        vg = ctx.saved_tensors
+        vs, gs = list(vg[0::2]), list(vg[1::2])
+        live = [i for i, gw in enumerate(gws) if gw is not None]
+        out = [None] * len(vg)
+        if live:
+            gvs, ggs = P.weight_norm_multi_bwd([vs[i] for i in live], [gs[i] for i in live],
+                                               [_c(gws[i]) for i in live])
+            for k, i in enumerate(live):
+                out[2 * i], out[2 * i + 1] = gvs[k], ggs[k]
+        return tuple(out)
+
+
 class Conv1dExFn(Function):
     """conv1d with an optional activation IN FRONT (in_act, applied on load), reflection padding,
     a fused activation behind and a fused residual add:  y = residual + act(conv(in_act(x)))."""

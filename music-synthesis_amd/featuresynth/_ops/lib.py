@@ -40,6 +40,16 @@ class L1MultiDesc(ctypes.Structure):            # ms_l1_multi_desc
                 ("n", ctypes.c_int64 * L1_MULTI_MAX), ("w", _c_f * L1_MULTI_MAX)]
 
 
+WN_MULTI_MAX = 64
+
+
+class WnMultiDesc(ctypes.Structure):            # ms_wn_multi_desc
+    _fields_ = [("count", _c_int), ("reserved", _c_int),
+                ("v", _vp * WN_MULTI_MAX), ("g", _vp * WN_MULTI_MAX), ("out", _vp * WN_MULTI_MAX),
+                ("gv", _vp * WN_MULTI_MAX), ("gg", _vp * WN_MULTI_MAX),
+                ("rows", _c_int * WN_MULTI_MAX), ("cols", _c_int * WN_MULTI_MAX)]
+
+
 # name -> (restype, argtypes); every symbol include/msynth.h declares
 SIGNATURES = {
     "ms_version": (_c_int, []),
@@ -62,6 +72,8 @@ SIGNATURES = {
     "ms_avg_pool1d_4_2_1_bwd": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _vp]),
     "ms_weight_norm_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _vp]),
     "ms_weight_norm_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_f, _vp]),
+    "ms_weight_norm_multi_fwd": (_c_int, [ctypes.POINTER(WnMultiDesc), _vp]),
+    "ms_weight_norm_multi_bwd": (_c_int, [ctypes.POINTER(WnMultiDesc), _c_f, _vp]),
     "ms_act_bwd": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _c_f, _vp]),
     "ms_add": (_c_int, [_vp, _vp, _vp, _c_i64, _vp]),
     "ms_reduce_workspace_bytes": (_sz, [_c_i64]),

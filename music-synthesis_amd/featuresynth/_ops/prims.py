@@ -217,6 +217,46 @@ def weight_norm_bwd(v, g, gw, gv=None, gg=None):
     return gv, gg
 
 
+def _wn_chunks(n):
+    return [(i, min(i + L.WN_MULTI_MAX, n)) for i in range(0, n, L.WN_MULTI_MAX)]
+
+
+def weight_norm_multi_fwd(vs, gs):
+    """Effective weights of every weight-normed layer of a network in one launch per 64 tensors."""
+    ws = [torch.empty_like(v) for v in vs]
+    for lo, hi in _wn_chunks(len(vs)):
+        d = L.WnMultiDesc()
+        d.count = hi - lo
+        n = 0
+        for i in range(lo, hi):
+            v, g = vs[i], gs[i]
+            L.require(v, "weight_v"); L.require(g, "weight_g")
+            k = i - lo
+            d.v[k], d.g[k], d.out[k] = v.data_ptr(), g.data_ptr(), ws[i].data_ptr()
+            d.rows[k], d.cols[k] = v.shape[0], v.numel() // v.shape[0]
+            n += v.numel()
+        L.call("ms_weight_norm_multi_fwd", _scost(n, 2, 1, 3), d, L.stream())
+    return ws
+
+
+def weight_norm_multi_bwd(vs, gs, gws):
+    gvs = [torch.empty_like(v) for v in vs]
+    ggs = [torch.empty_like(g) for g in gs]
+    for lo, hi in _wn_chunks(len(vs)):
+        d = L.WnMultiDesc()
+        d.count = hi - lo
+        n = 0
+        for i in range(lo, hi):
+            L.require(gws[i], "weight grad")
+            k = i - lo
+            d.v[k], d.g[k], d.out[k] = vs[i].data_ptr(), gs[i].data_ptr(), gws[i].data_ptr()
+            d.gv[k], d.gg[k] = gvs[i].data_ptr(), ggs[i].data_ptr()
+            d.rows[k], d.cols[k] = vs[i].shape[0], vs[i].numel() // vs[i].shape[0]
+            n += vs[i].numel()
+        L.call("ms_weight_norm_multi_bwd", _scost(n, 3, 1, 6), d, 0.0, L.stream())
+    return gvs, ggs
+
+
 def act_bwd(y_act, gy, act):
     """gy * act'(.) evaluated from y_act (for LeakyReLU: the sign of y_act)."""
     L.require(y_act, "activation"); L.require(gy, "grad")

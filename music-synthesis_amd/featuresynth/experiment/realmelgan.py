@@ -53,7 +53,25 @@ class _WNConvBase(nn.Module):
         self.weight_v = nn.Parameter(ref)
 
     def effective_weight(self):
+        w = getattr(self, "_w", None)
+        if w is not None:                   # derived for the whole network by _derive_weights()
+            self._w = None
+            return w
         return F_.WeightNormFn.apply(self.weight_v, self.weight_g)
+
+
+def _derive_weights(root):
+    """w = g * v / ||v|| for every weight-normed layer under `root` in one launch (the reference's
+    weight_norm pre-hooks do it layer by layer, realmelgan.py:24-29); each layer's forward consumes
+    its entry once."""
+    mods = [m for m in root.modules() if isinstance(m, _WNConvBase)]
+    if not mods or not mods[0].weight_v.is_cuda:
+        return
+    vg = []
+    for m in mods:
+        vg += [m.weight_v, m.weight_g]
+    for m, w in zip(mods, F_.WeightNormMultiFn.apply(*vg)):
+        m._w = w
 
 
 class WNConv1d(_WNConvBase):
@@ -136,6 +154,7 @@ class Generator(nn.Module):
         self.model = nn.Sequential(*model)
 
     def forward(self, x):
+        _derive_weights(self)
         return self.model(x)
 
 
@@ -189,6 +208,7 @@ class Discriminator(nn.Module):
         return F_.AvgPool421Fn.apply(x)
 
     def forward(self, x, feat=None):
+        _derive_weights(self)
         features, judgements = [], []
         for key, disc in self.model.items():
             z = disc(x, feat)
@@ -212,6 +232,20 @@ def real_mel_gan_feature_loss(real_features, fake_features):
 def mel_gan_gen_loss(real_features, fake_features, real_judgements, fake_judgements,
                      gan_loss=hinge_generator_loss, feature_loss_weight=10):
     """realmelgan.py:206-218."""
+    real_features = [list(g) for g in real_features]
+    fake_features = [list(g) for g in fake_features]
+    fake_judgements = list(fake_judgements)
+    S = len(fake_features)
+    if gan_loss is hinge_generator_loss and S and len(fake_judgements) == S and \
+            all(len(g) == len(fake_features[0]) for g in real_features + fake_features) and \
+            fake_judgements[0].is_cuda:
+        # fused form (all l1 terms in one launch pair): per-term scale weight * (1/3)(4/5)
+        Lyr = len(fake_features[0])
+        wt = (1 / 3) * (4.0 / (4 + 1))
+        flat_r = [t for g in real_features for t in g]
+        flat_f = [t for g in fake_features for t in g]
+        return F_.MelGanGenLossFn.apply(S, Lyr, float(feature_loss_weight) * wt * S * Lyr, *flat_r, *flat_f,
+                                        *fake_judgements)
     j_loss = None
     for _, f in zip(real_judgements, fake_judgements):
         term = gan_loss(f)

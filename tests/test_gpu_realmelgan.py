@@ -105,6 +105,30 @@ def test_weight_norm(shape):
     assert rel_l2(host(gt.grad), gc.grad.numpy()) < 1e-5
 
 
+def test_weight_norm_multi():
+    """All layers of a network in one launch (70 tensors: two descriptor chunks) vs float64 torch."""
+    from featuresynth._ops import functional as F_
+    rng = np.random.default_rng(5)
+    shapes = [(16, 1, 15), (64, 4, 41), (256, 256, 3), (512, 256, 16), (1, 32, 7), (1024, 4, 41), (3, 5, 1)] * 10
+    vs = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    gs = [(0.5 + rng.random((s[0], 1, 1))).astype(np.float32) for s in shapes]
+    gws = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    vt = [dev(v).requires_grad_(True) for v in vs]
+    gt = [dev(g).requires_grad_(True) for g in gs]
+    args = []
+    for a, b in zip(vt, gt):
+        args += [a, b]
+    ws = F_.WeightNormMultiFn.apply(*args)
+    torch.autograd.backward(list(ws), [dev(g) for g in gws])
+    for i, s in enumerate(shapes):
+        vc, gc = torch.from_numpy(vs[i]).double().requires_grad_(True), torch.from_numpy(gs[i]).double().requires_grad_(True)
+        wc = gc * vc / vc.reshape(s[0], -1).norm(dim=1).reshape(-1, 1, 1)
+        wc.backward(torch.from_numpy(gws[i]).double())
+        assert rel_l2(host(ws[i]), wc.detach().numpy()) < 1e-6, i
+        assert rel_l2(host(vt[i].grad), vc.grad.numpy()) < 1e-5, i
+        assert rel_l2(host(gt[i].grad), gc.grad.numpy()) < 1e-5, i
+
+
 def _nets():
     from featuresynth._synthetic import module_param_shapes, synthetic_state_dict
     from featuresynth.experiment import realmelgan as R
