@@ -460,7 +460,10 @@ bool msr2_supported(int tile, int K, int CC, int act_mode, int epi_s, const Row2
     const bool k3 = K == 3 && (CC == 8 || CC == 16) && (epi_s == 0 || ((epi_s == 2 || epi_s == 8) && CC == 8 && act_mode == 0));
     // (k5 forward: the first-generation kernel measured 8 % faster, 194 vs 212 us at B*L = 2048)
     const bool k5 = K == 5 && CC == 16 && epi_s == 0 && act_mode == 1;
-    if (!k3 && !k5) return false;
+    // pointwise convs (shortcuts): measured 44 vs 60 us on the 128-channel layer, but no better than the
+    // first generation on the smaller tiles (4 chunks of 32 channels: the prologue dominates)
+    const bool k1 = K == 1 && CC == 32 && epi_s == 0 && act_mode == 0 && tile == MSR2_128x128;
+    if (!k3 && !k5 && !k1) return false;
     int bn = tile == MSR2_32x256 ? 256 : (tile == MSR2_64x64 ? 64 : 128);
     const int nvt = p.R * ((p.SS + 6) / 4);
     return CC * nvt <= 256 * msr2_nxq(CC, bn);
@@ -489,6 +492,7 @@ int msr2_launch(int tile, int K, int CC, int act_mode, int epi_s, const Row2P& p
         if (epi_s == 2) MSR2_GO(3, 8, 0, 2);
         if (epi_s == 8) MSR2_GO(3, 8, 0, 8);
     }
+    if (K == 1 && CC == 32 && epi_s == 0 && act_mode == 0) MSR2_GO(1, 32, 0, 0);
     if (K == 5 && CC == 16 && epi_s == 0) { if (act_mode) MSR2_GO(5, 16, 1, 0); else MSR2_GO(5, 16, 0, 0); }
 #undef MSR2_GO
     return MS_ERR_UNSUPPORTED;

@@ -38,6 +38,11 @@ CASES = [  # name, B, Cin, L, Cout, K, pad, dil, in_act, act, reflect, residual
     ("res_conv3_c256_d9", 2, 256, 70, 256, 3, 9, 9, 1, 1, True, False),
     ("res_conv1x1_c128", 2, 128, 257, 128, 1, 0, 1, 0, 0, False, True),
     ("shortcut_1x1_c32", 3, 32, 1031, 32, 1, 0, 1, 0, 0, False, False),
+    # pointwise convs on the pipelined row kernel (16-byte aligned rows), incl. packed short rows
+    ("res_conv1x1_c128_l256", 2, 128, 256, 128, 1, 0, 1, 0, 0, False, True),
+    ("shortcut_1x1_c32_l1024", 3, 32, 1024, 32, 1, 0, 1, 0, 0, False, False),
+    ("shortcut_1x1_c256_l64", 5, 256, 64, 256, 1, 0, 1, 0, 0, False, True),
+    ("shortcut_1x1_c64_l2048", 2, 64, 2048, 64, 1, 0, 1, 0, 0, False, False),
     ("first_k7_reflect", 2, 128, 9, 512, 7, 3, 1, 0, 0, True, False),
     ("last_k7_reflect_tanh", 2, 32, 515, 1, 7, 3, 1, 1, 2, True, False),
     ("d_first_k15_reflect", 2, 1, 1025, 16, 15, 7, 1, 0, 1, True, False),

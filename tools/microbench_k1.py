@@ -1,0 +1,22 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
+import torch
+from featuresynth._ops import prims as P
+def timeit(fn, n=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize(); e0 = torch.cuda.Event(True); e1 = torch.cuda.Event(True); e0.record()
+    for _ in range(n): out = fn()
+    e1.record(); torch.cuda.synchronize()
+    if isinstance(out, tuple): out = out[0]
+    return e0.elapsed_time(e1) / n * 1e3, out
+for (B, C, Lg) in ((32, 256, 256), (32, 128, 2048), (32, 64, 4096), (32, 32, 8192)):
+    x = torch.randn(B, C, Lg, device="cuda"); w = torch.randn(C, C, 1, device="cuda") * 0.05; b = torch.randn(C, device="cuda")
+    res = torch.randn(B, C, Lg, device="cuda")
+    d, lo = P.conv_desc(x.shape, w.shape, pad=0, dil=1, act=0)
+    r = []
+    for mode in ("0", None):
+        if mode is None: os.environ.pop("MSYNTH_ROWS2", None)
+        else: os.environ["MSYNTH_ROWS2"] = mode
+        r.append(timeit(lambda: P.conv1d_fwd(x, w, b, d, lo, residual=res)))
+    print((B, C, Lg), "k1 fwd gen1 %.1f us gen2 %.1f us diff %.1e" % (r[0][0], r[1][0], float((r[0][1]-r[1][1]).abs().max())), flush=True)
