@@ -127,8 +127,10 @@ int ms_conv1d_bwd_weight(const ms_conv1d_desc* d, const float* x, const float* g
         const int rc = msw32_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
         if (rc != MS_ERR_UNSUPPORTED) return rc;
     }
-    if (msw_bwd_weight_applicable(p))   // dense stride-1 convs: row-tile MFMA form
-        return msw_conv1d_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
+    if (msw_bwd_weight_applicable(p)) { // dense stride-1 convs: row-tile MFMA form
+        const int rc = msw_conv1d_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
+        if (rc != MS_ERR_UNSUPPORTED) return rc;     // (unaligned operands: the im2col form below)
+    }
     if (msm_bwd_weight_applicable(p))
         return msm_conv1d_bwd_weight(p, x, xa, xk, gy, y_act, p.act, gw, gb, beta, workspace,
                                      workspace_bytes, s);
@@ -150,7 +152,12 @@ size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which) {
             const size_t rest = msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p);
             return a32 > rest ? a32 : rest;
         }
-        if (msw_bwd_weight_applicable(p)) return msw_bwd_weight_ws(p);
+        if (msw_bwd_weight_applicable(p)) {
+            const size_t a = msw_bwd_weight_ws(p);
+            const size_t rest = msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p)
+                                : (msg_bwd_weight_applicable(p) ? msg_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p));
+            return a > rest ? a : rest;
+        }
         return msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p)
                : (msg_bwd_weight_applicable(p) ? msg_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p));
     }

@@ -36,17 +36,20 @@ struct WrP {
 // Activation handling is a template parameter: a runtime `kind` compiles to scalar branches around
 // every store piece, which cuts the chunk into hundreds of basic blocks and defeats the MFMA /
 // store / load interleaving.  AK 1: LeakyReLU derivative on the gradient (the hot layers);
-// AK 2: LeakyReLU applied to the input (pre-activation blocks); AK 0: runtime kinds (generic).
+// AK 2: LeakyReLU applied to the input (pre-activation blocks); AK 0: runtime kinds (generic);
+// AK 4: both of those AND reflection padding (the dilated conv of a weight-normed ResnetBlock): an
+// aligned input vector that lies wholly in the padding is loaded from its mirror image (4 consecutive
+// samples, generally not 16-byte aligned) and stored in reverse order.
 template <int AK>
 __device__ __forceinline__ float wr_gact(float g, float ya, int kind, float slope) {
-    if (AK == 1) return ya > 0.f ? g : g * slope;
+    if (AK == 1 || AK == 4) return ya > 0.f ? g : g * slope;
     if (AK == 2 || AK == 3) return g;
     return ms_act_grad(g, ya, kind, slope);
 }
 template <int AK>
 __device__ __forceinline__ float wr_xact(float v, int kind, float slope) {
     if (AK == 1 || AK == 3) return v;
-    if (AK == 2) return v > 0.f ? v : v * slope;
+    if (AK == 2 || AK == 4) return v > 0.f ? v : v * slope;
     return kind == MS_MOD_LRELU_FWD ? (v > 0.f ? v : v * slope) : v;
 }
 
@@ -127,8 +130,12 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
     const int g_lds0 = g_row0 * p.PG + g_seg * p.SS + g_t;
     const int x_lds0 = BM * p.PG + x_row0 * p.PX + x_seg * p.SS + x_u;
     bool x_ev[4];                                    // VEC: which of the 4 elements fall inside the segment
+    unsigned x_evm = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x_ev[i] = x_cv && x_u + i >= 0 && x_u + i < p.SS;
+    for (int i = 0; i < 4; ++i) {
+        x_ev[i] = x_cv && x_u + i >= 0 && x_u + i < p.SS;
+        x_evm |= x_ev[i] ? 1u << i : 0u;
+    }
 
     int t_off[XS > 1 ? NXQ : 1], t_pos[XS > 1 ? NXQ : 1], t_lds[XS > 1 ? NXQ : 1][4];
     bool t_in[XS > 1 ? NXQ : 1];
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
     float gv1[VEC ? 1 : NGQ], ga1[VEC ? 1 : NGQ], xv1[VEC ? 1 : NXQ];
 
     // per-chunk scalars of the chunk whose pieces are being loaded / stored
-    struct Cs { int gbase, xbase, t0x; bool gok, xok; };
+    struct Cs { int gbase, xbase, t0x, xdelta; bool gok, xok, xrev; };
     auto chunk_state = [&](int ch, int c_end) {
         Cs s;
         int b0, t0;
@@ -171,6 +178,14 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
         const int tg = t0 + g_t, tx = t0 - p.pad + x_u;       // VEC: tx % 4 == 0, vector all in or all out
         s.gok = live && g_cv && b0 + g_seg < p.B && tg < p.L;
         s.xok = XS > 1 ? (live && b0 < p.B) : (live && x_cv && b0 + x_seg < p.B && tx >= 0 && tx < p.L);
+        s.xdelta = 0; s.xrev = false;
+        if (AK == 4) {                                    // mirror image of a vector in the padding
+            int src = tx;
+            if (tx < 0) { src = -tx - 3; s.xrev = true; }
+            else if (tx >= p.L) { src = 2 * p.L - 5 - tx; s.xrev = true; }
+            s.xdelta = src - tx;
+            s.xok = live && x_cv && b0 + x_seg < p.B && src >= 0 && src + 3 < p.L;
+        }
         return s;
     };
     auto load_piece = [&](int pi, const Cs& s) {
@@ -195,7 +210,7 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
                 if (AK == 3) xa4[q] = *reinterpret_cast<const float4*>(Xact + o);
             } else {
                 const bool ok = s.xok && c0 + x_row0 + x_rstep * q < p.CK;
-                const int o = ok ? s.xbase + x_off0 + q * x_rstep * p.L : 0;
+                const int o = ok ? s.xbase + x_off0 + q * x_rstep * p.L + (AK == 4 ? s.xdelta : 0) : 0;
                 if (VEC) xv4[q] = *reinterpret_cast<const float4*>(X + o);
                 else xv1[q] = X[o];
             }
@@ -239,7 +254,13 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
                 const float e[4] = {xv4[q].x, xv4[q].y, xv4[q].z, xv4[q].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float* di = x_ev[i] ? d + i : scratch + tid;
+                    float* di;
+                    if (AK == 4) {
+                        const int j = s.xrev ? 3 - i : i;
+                        di = (x_evm >> j) & 1u ? d + j : scratch + tid;
+                    } else {
+                        di = x_ev[i] ? d + i : scratch + tid;
+                    }
                     *di = ok ? wr_xact<AK>(e[i], p.x_kind, p.slope) : 0.f;
                 }
             } else {
@@ -360,7 +381,7 @@ struct WrPlan {
     bool ok;
     WrP p;
     int tm, nsplit;
-    bool vec;
+    bool vec, refl = false;
     dim3 grid;
     size_t lds, stride_floats;
 };
@@ -369,7 +390,11 @@ WrPlan plan_wrows(const ConvP& c) {
     WrPlan q;
     q.ok = false;
     const int K = c.K;
-    if (c.groups != 1 || c.stride != 1 || c.Lout != c.Lin || c.pad_mode != MS_PAD_ZERO) return q;
+    if (c.groups != 1 || c.stride != 1 || c.Lout != c.Lin) return q;
+    // reflection padding: only the pre-activation dilated k3 conv of the weight-normed ResnetBlock
+    // (LeakyReLU in front and behind), on the 16-byte path with one row per chunk
+    const bool refl = c.pad_mode == MS_PAD_REFLECT;
+    if (refl && !(c.K == 3 && c.in_act && c.act == MS_ACT_LRELU && c.Lin % 4 == 0 && c.Lin >= KMAX && c.pad + 4 < c.Lin)) return q;
     if (!(K == 1 || K == 3 || K == 5 || K == 7)) return q;
     if (c.Cout < 64 || c.Cin < 32) return q;      // (32-channel layers: measured slower than the im2col kernel)
     const int H = (K - 1) * c.dil;
@@ -390,6 +415,8 @@ WrPlan plan_wrows(const ConvP& c) {
     p.RSZ = p.R * p.SS;
     p.kcols = p.RSZ - H <= 32 ? 32 : 64;            // 8 or 16 unrolled double-steps (pad columns are zero)
     q.vec = p.L % 4 == 0 && p.R * (p.Lt / 4) <= 16 && p.R * ((p.SS + 6) / 4) <= 32;
+    q.refl = refl;
+    if (refl && !q.vec) return q;
     if (!q.vec && (p.kcols > 64 || p.RSZ > 128)) return q;
     p.PG = (p.kcols + 2) | 1;
     p.PX = (p.kcols + H + 2) | 1;
@@ -432,6 +459,10 @@ template <int K, int TM, bool VEC, int KPI>
 void launch_wrows_inst(const WrPlan& q, const float* x, const float* gy, const float* y_act,
                        float* partial, hipStream_t s) {
     const int gk = y_act ? q.p.g_kind : MS_ACT_NONE;
+    if (q.refl) {
+        if constexpr (VEC && K == 3) launch_wrows_ak<3, TM, true, KPI, 4>(q, x, gy, y_act, partial, s);
+        return;
+    }
     if (gk == MS_ACT_LRELU && q.p.x_kind == MS_ACT_NONE) launch_wrows_ak<K, TM, VEC, KPI, 1>(q, x, gy, y_act, partial, s);
     else if (gk == MS_ACT_NONE && q.p.x_kind == MS_MOD_LRELU_FWD) launch_wrows_ak<K, TM, VEC, KPI, 2>(q, x, gy, y_act, partial, s);
     else launch_wrows_ak<K, TM, VEC, KPI, 0>(q, x, gy, y_act, partial, s);
@@ -582,6 +613,7 @@ int msw_conv1d_bwd_weight(const ConvP& c, const float* x, const float* gy, const
     float* partial = (float*)ws;
     const bool vec = q.vec && ((((uintptr_t)x) | ((uintptr_t)gy) | ((uintptr_t)(y_act ? y_act : gy))) & 15) == 0;
     if (!vec && (q.p.kcols > 64 || q.p.RSZ > 128)) return MS_ERR_UNSUPPORTED;
+    if (q.refl && (!vec || !y_act)) return MS_ERR_UNSUPPORTED;
     if (c.K == 1) launch_wrows<1>(q, vec, x, gy, y_act, partial, s);
     else if (c.K == 3) launch_wrows<3>(q, vec, x, gy, y_act, partial, s);
     else if (c.K == 5) launch_wrows<5>(q, vec, x, gy, y_act, partial, s);

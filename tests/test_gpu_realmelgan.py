@@ -36,6 +36,11 @@ def _ref_conv(x, w, b, pad, dil, in_act, act, reflect, residual=None):
 CASES = [  # name, B, Cin, L, Cout, K, pad, dil, in_act, act, reflect, residual
     ("res_conv3_c64", 2, 64, 300, 64, 3, 3, 3, 1, 1, True, False),
     ("res_conv3_c256_d9", 2, 256, 70, 256, 3, 9, 9, 1, 1, True, False),
+    # reflect-padded dilated convs at 16-byte aligned lengths (row-tile weight-gradient kernel, mirrored vectors)
+    ("res_conv3_c128_d9_l2048", 1, 128, 2048, 128, 3, 9, 9, 1, 1, True, False),
+    ("res_conv3_c256_d1_l256", 2, 256, 256, 256, 3, 1, 1, 1, 1, True, False),
+    ("res_conv3_c64_d9_l64", 3, 64, 64, 64, 3, 9, 9, 1, 1, True, False),
+    ("res_conv3_c64_d3_l132", 2, 64, 132, 64, 3, 3, 3, 1, 1, True, False),
     ("res_conv1x1_c128", 2, 128, 257, 128, 1, 0, 1, 0, 0, False, True),
     ("shortcut_1x1_c32", 3, 32, 1031, 32, 1, 0, 1, 0, 0, False, False),
     # pointwise convs on the pipelined row kernel (16-byte aligned rows), incl. packed short rows
