@@ -144,7 +144,11 @@ size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which) {
     ConvP p;
     if (!make_conv(d, &p)) return 0;
     if (which == 0) return msm_fwd_applicable(p) ? msm_fwd_ws(p) : 0;
-    if (which == 1) return msm_bwd_data_applicable(p) ? msm_bwd_data_ws(p) : 0;
+    if (which == 1) {
+        // (reflection padding runs the zero-padded backward + the edge fold, see ms_conv1d_bwd_data)
+        if (p.pad_mode == MS_PAD_REFLECT && p.stride == 1 && p.groups == 1) p.pad_mode = MS_PAD_ZERO;
+        return msm_bwd_data_applicable(p) ? msm_bwd_data_ws(p) : 0;
+    }
     if (which == 2) {
         if (mst_bwd_weight_applicable(p)) return mst_bwd_weight_ws(p);
         if (msw32_applicable(p)) {
@@ -171,6 +175,11 @@ const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which) {
         return msm_fwd_applicable(p) ? msm_fwd_name(p)
                : (msg_fwd_applicable(p) ? msg_fwd_name(p)
                   : (mst_fwd_applicable(p) ? mst_fwd_name(p) : msk_conv1d_fwd_direct_name(p)));
+    if (which == 1 && p.pad_mode == MS_PAD_REFLECT && p.stride == 1 && p.groups == 1) {
+        ConvP z = p;
+        z.pad_mode = MS_PAD_ZERO;       // zero-padded backward + edge fold
+        if (msm_bwd_data_applicable(z)) return msm_bwd_data_name(z);
+    }
     if (which == 1)
         return msm_bwd_data_applicable(p) ? msm_bwd_data_name(p)
                : (msg_bwd_data_applicable(p) ? msg_bwd_data_name(p)
