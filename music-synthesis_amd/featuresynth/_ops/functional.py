@@ -372,6 +372,10 @@ class WeightNormMultiFn(Function):
     def forward(ctx, *vg):
         vs, gs = list(vg[0::2]), list(vg[1::2])
         ctx.save_for_backward(*vg)
+        # parameters bound to a FlatAdam bucket: gradients accumulate straight into their slots
+        # (see _sink_for) instead of going through one AccumulateGrad add kernel per tensor
+        slots = [getattr(t, "_ms_slot", None) for t in vg]
+        ctx.slots = slots if all(s is not None for s in slots) else None
         return tuple(P.weight_norm_multi_fwd(vs, gs))
 
     @staticmethod
@@ -380,9 +384,13 @@ class WeightNormMultiFn(Function):
         vs, gs = list(vg[0::2]), list(vg[1::2])
         live = [i for i, gw in enumerate(gws) if gw is not None]
         out = [None] * len(vg)
-        if live:
-            gvs, ggs = P.weight_norm_multi_bwd([vs[i] for i in live], [gs[i] for i in live],
-                                               [_c(gws[i]) for i in live])
+        if not live:
+            return tuple(out)
+        direct = ctx.slots is not None and all(ctx.needs_input_grad)
+        into = ([ctx.slots[2 * i] for i in live], [ctx.slots[2 * i + 1] for i in live]) if direct else None
+        gvs, ggs = P.weight_norm_multi_bwd([vs[i] for i in live], [gs[i] for i in live],
+                                           [_c(gws[i]) for i in live], into=into)
+        if not direct:
             for k, i in enumerate(live):
                 out[2 * i], out[2 * i + 1] = gvs[k], ggs[k]
         return tuple(out)

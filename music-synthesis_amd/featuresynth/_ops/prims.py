@@ -239,9 +239,15 @@ def weight_norm_multi_fwd(vs, gs):
     return ws
 
 
-def weight_norm_multi_bwd(vs, gs, gws):
-    gvs = [torch.empty_like(v) for v in vs]
-    ggs = [torch.empty_like(g) for g in gs]
+def weight_norm_multi_bwd(vs, gs, gws, into=None):
+    """`into` = (gv tensors, gg tensors) to ACCUMULATE into (flat-bucket slots); else fresh outputs."""
+    if into is not None:
+        gvs, ggs = into
+        for t in list(gvs) + list(ggs):
+            L.require(t, "gradient slot")
+    else:
+        gvs = [torch.empty_like(v) for v in vs]
+        ggs = [torch.empty_like(g) for g in gs]
     for lo, hi in _wn_chunks(len(vs)):
         d = L.WnMultiDesc()
         d.count = hi - lo
@@ -253,7 +259,7 @@ def weight_norm_multi_bwd(vs, gs, gws):
             d.gv[k], d.gg[k] = gvs[i].data_ptr(), ggs[i].data_ptr()
             d.rows[k], d.cols[k] = vs[i].shape[0], vs[i].numel() // vs[i].shape[0]
             n += vs[i].numel()
-        L.call("ms_weight_norm_multi_bwd", _scost(n, 3, 1, 6), d, 0.0, L.stream())
+        L.call("ms_weight_norm_multi_bwd", _scost(n, 3, 1, 6), d, 1.0 if into is not None else 0.0, L.stream())
     return gvs, ggs
 
 
