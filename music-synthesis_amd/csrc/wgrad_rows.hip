@@ -44,11 +44,12 @@ template <int AK>
 __device__ __forceinline__ float wr_gact(float g, float ya, int kind, float slope) {
     if (AK == 1 || AK == 4) return ya > 0.f ? g : g * slope;
     if (AK == 2 || AK == 3) return g;
+    if (AK == 5) return g > 0.f ? g : g * slope;   // transposed conv with LeakyReLU in front: G is its INPUT
     return ms_act_grad(g, ya, kind, slope);
 }
 template <int AK>
 __device__ __forceinline__ float wr_xact(float v, int kind, float slope) {
-    if (AK == 1 || AK == 3) return v;
+    if (AK == 1 || AK == 3 || AK == 5) return v;
     if (AK == 2 || AK == 4) return v > 0.f ? v : v * slope;
     return kind == MS_MOD_LRELU_FWD ? (v > 0.f ? v : v * slope) : v;
 }
@@ -195,10 +196,10 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
             const int o = ok ? s.gbase + g_off0 + q * g_rstep * p.L : 0;
             if (VEC) {
                 gv4[q] = *reinterpret_cast<const float4*>(G + o);
-                if (AK != 2 && AK != 3) ga4[q] = *reinterpret_cast<const float4*>(Gq + o);
+                if (AK != 2 && AK != 3 && AK != 5) ga4[q] = *reinterpret_cast<const float4*>(Gq + o);
             } else {
                 gv1[q] = G[o];
-                if (AK != 2 && AK != 3) ga1[q] = Gq[o];
+                if (AK != 2 && AK != 3 && AK != 5) ga1[q] = Gq[o];
             }
         } else {
             const int q = pi - NGQ;
@@ -518,7 +519,7 @@ WrPlan plan_wrows_t(const ConvP& c) {
     WrPlan q;
     q.ok = false;
     const int S = c.stride, CinT = c.Cout, CoutT = c.Cin, LinT = c.Lout;
-    if (!(S == 2 || S == 8) || c.K != 2 * S || 2 * c.pad != S || c.dil != 1 || c.groups != 1 || c.in_act) return q;
+    if (!(S == 2 || S == 8) || c.K != 2 * S || 2 * c.pad != S || c.dil != 1 || c.groups != 1) return q;
     if (CinT < 64 || (CoutT * S) % CB || LinT % 4) return q;
     if ((long long)c.B * CinT * LinT >= (1LL << 31) || (long long)c.B * CoutT * S * LinT >= (1LL << 31)) return q;
     WrP& p = q.p;
@@ -595,9 +596,11 @@ int msw_convt_dwq(const ConvP& c, const float* x, const float* gy, const float* 
     if (!ws || ws_bytes < (size_t)q.nsplit * q.stride_floats * sizeof(float)) return MS_ERR_UNSUPPORTED;
     if (((((uintptr_t)x) | ((uintptr_t)gy) | ((uintptr_t)(y_act ? y_act : gy))) & 15) != 0) return MS_ERR_UNSUPPORTED;
     if (y_act && c.act != MS_ACT_LRELU) return MS_ERR_UNSUPPORTED;
+    if (c.in_act && y_act) return MS_ERR_UNSUPPORTED;
     float* partial = (float*)ws;
     const int S = c.stride;
-    if (y_act) { if (S == 8) launch_wrows_t2<3, 8>(q, gy, y_act, x, partial, s); else launch_wrows_t2<3, 2>(q, gy, y_act, x, partial, s); }
+    if (c.in_act) { if (S == 8) launch_wrows_t2<5, 8>(q, gy, y_act, x, partial, s); else launch_wrows_t2<5, 2>(q, gy, y_act, x, partial, s); }
+    else if (y_act) { if (S == 8) launch_wrows_t2<3, 8>(q, gy, y_act, x, partial, s); else launch_wrows_t2<3, 2>(q, gy, y_act, x, partial, s); }
     else { if (S == 8) launch_wrows_t2<0, 8>(q, gy, y_act, x, partial, s); else launch_wrows_t2<0, 2>(q, gy, y_act, x, partial, s); }
     MS_CHECK_LAUNCH();
     return msm_wgrad_reduce(partial, q.stride_floats, q.nsplit, (size_t)q.p.M * q.p.CK * 3, q.p.M, dwq,

@@ -81,6 +81,37 @@ def test_conv_ex_vs_torch_cpu(case):
         assert rel_l2(host(rt.grad), rc.grad.numpy()) < 1e-6
 
 
+CONVT_CASES = [  # name, B, Cin, L, Cout, K, S  (LeakyReLU in front, none behind: realmelgan.py:62-70)
+    ("up8_c512_l32", 2, 512, 32, 256, 16, 8),
+    ("up8_c256_l64", 2, 256, 64, 128, 16, 8),
+    ("up2_c128_l128", 2, 128, 128, 64, 4, 2),
+    ("up2_c64_l96", 3, 64, 96, 32, 4, 2),
+    ("up8_c64_l7", 2, 64, 7, 32, 16, 8),
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES, ids=[c[0] for c in CONVT_CASES])
+def test_convt_ex_vs_torch_cpu(case):
+    import torch.nn.functional as F
+    from featuresynth._ops import functional as F_
+    name, B, Cin, L, Cout, K, S = case
+    rng = np.random.default_rng(abs(hash(name)) % (2 ** 31))
+    x = rng.standard_normal((B, Cin, L)).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout, K)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal((Cout,)) * 0.1).astype(np.float32)
+    xt, wt, bt = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    y = F_.ConvTranspose1dExFn.apply(xt, wt, bt, S, S // 2, 0, 1)
+    gy = rng.standard_normal(y.shape).astype(np.float32)
+    y.backward(dev(gy))
+    xc, wc, bc = [torch.from_numpy(a).double().requires_grad_(True) for a in (x, w, b)]
+    yc = F.conv_transpose1d(F.leaky_relu(xc, 0.2), wc, bc, stride=S, padding=S // 2)
+    yc.backward(torch.from_numpy(gy).double())
+    assert rel_l2(host(y), yc.detach().numpy()) < 1e-5
+    assert rel_l2(host(xt.grad), xc.grad.numpy()) < 1e-5, "gx"
+    assert rel_l2(host(wt.grad), wc.grad.numpy()) < 1e-5, "gw"
+    assert rel_l2(host(bt.grad), bc.grad.numpy()) < 1e-5, "gb"
+
+
 @pytest.mark.parametrize("L", [64, 67, 5])
 def test_avg_pool_421(L):
     import torch.nn.functional as F
