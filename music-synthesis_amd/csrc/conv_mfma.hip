@@ -1145,9 +1145,10 @@ bool rows2_pick(RowCfg cfg, int K, int CC, bool has_act, int epi_s, int in_s, co
                 const float* Xact, const float* W, const float* res, const float* Y, const float* Yact,
                 Row2P* q, int* tile, int* am) {
     if (p.pad_mode != MS_PAD_ZERO || cfg == ROW_64x256) return false;
-    if (has_act && p.in_act != MS_ACT_LRELU && p.in_act != MS_ACT_NONE) return false;
+    if (has_act && p.in_act != MS_ACT_LRELU && p.in_act != MS_ACT_NONE && p.in_act != MS_MOD_LRELU_FWD) return false;
     *am = (has_act && p.in_act == MS_ACT_LRELU) ? (in_s == 1 ? 1 : 2) : 0;
-    if (in_s != 1 && *am != 2) return false;
+    if (has_act && p.in_act == MS_MOD_LRELU_FWD) *am = 3;      // LeakyReLU in front of the conv, on load
+    if (in_s != 1 && *am != 2 && *am != 0) return false;
     const float* Wuse = *am == 1 ? p.Wfwd : W;
     if (!Wuse || (*am == 1 && p.M % 4)) return false;
     if (((((uintptr_t)X) | ((uintptr_t)Wuse) | ((uintptr_t)(Xact ? Xact : X)) | ((uintptr_t)Y) |
@@ -1413,11 +1414,12 @@ const char* msm_convt_fwd_name(const ConvP& p) {
     const RowCfg c = pick_row_cfg(p.Cin * p.stride, p.B, p.Lout);
     RowP r;
     make_rowp(&r, c, p.B, p.Cout, p.Lout, p.Cin * p.stride, 3, 1, -1, 0, 0, 0, 0.f);
-    if (!p.in_act && (c == ROW_128x128 || c == ROW_64x128)) {
+    if (c == ROW_128x128 || c == ROW_64x128) {
         Row2P q;
         q.L = p.Lout; q.R = r.R; q.SS = r.SS; q.M = p.Cin * p.stride;
-        if (msr2_supported(c == ROW_128x128 ? MSR2_128x128 : MSR2_64x128, 2, 8, 0, p.stride, q)) {
-            snprintf(buf, sizeof(buf), "k_conv_rows2<%s, 2, 8, 0, %d>", c == ROW_128x128 ? "2, 2, 2, 2" : "1, 4, 2, 1", p.stride);
+        const int am = p.in_act ? 3 : 0;
+        if (msr2_supported(c == ROW_128x128 ? MSR2_128x128 : MSR2_64x128, 2, 8, am, p.stride, q)) {
+            snprintf(buf, sizeof(buf), "k_conv_rows2<%s, 2, 8, %d, %d>", c == ROW_128x128 ? "2, 2, 2, 2" : "1, 4, 2, 1", am, p.stride);
             return buf;
         }
     }
@@ -1544,7 +1546,7 @@ int msm_convt1d_fwd(const ConvP& p, const float* x, const float* w, const float*
     // pipelined kernel: the 3-tap window stays, but only the two live taps of each phase are multiplied
     Row2P q2;
     int tile2 = 0, am2 = 0;
-    const bool two = !ia && rows2_pick(cfg, 2, 8, false, S, 1, r, x, nullptr, wp, nullptr, y, nullptr, &q2, &tile2, &am2);
+    const bool two = rows2_pick(cfg, 2, 8, ia, S, 1, r, x, ia ? x : nullptr, wp, nullptr, y, nullptr, &q2, &tile2, &am2);
     if (two)
         hipLaunchKernelGGL(k_pack_convt_w2, dim3(nb), dim3(256), 0, s, w, wp, CinT, CoutT, p.K, S, p.pad);
     else
@@ -1556,7 +1558,7 @@ int msm_convt1d_fwd(const ConvP& p, const float* x, const float* w, const float*
                                 if (two) {
                                     Row2P q;
                                     int tile, am, bm, bn;
-                                    if (!rows2_pick(cfg, 2, 8, false, S, 1, rp, x, nullptr, wp, r_, y_, ya_, &q, &tile, &am))
+                                    if (!rows2_pick(cfg, 2, 8, ia, S, 1, rp, x, ia ? x : nullptr, wp, r_, y_, ya_, &q, &tile, &am))
                                         return (int)MS_ERR_UNSUPPORTED;
                                     q.KG = rp.CK * 2;
                                     row_tile(cfg, &bm, &bn);

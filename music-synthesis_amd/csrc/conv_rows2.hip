@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
         ot[j] = t0 + tc;
     }
 
-    float4 ra[RA4], rx[NXQ], rxa[AM ? NXQ : 1];
+    constexpr bool ACTOP = AM == 1 || AM == 2;       // a second operand carries the activation derivative
+    float4 ra[RA4], rx[NXQ], rxa[ACTOP ? NXQ : 1];
     auto load_piece = [&](int pi, int c0, bool live) {        // c0: first channel of the chunk
         if (pi < RA4) {
             const int i = pi;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
             const int q = pi - RA4;
             const int o = (live && x_ok[q]) ? x_goff[q] + c0 * p.L : 0;
             rx[q] = *reinterpret_cast<const float4*>(X + o);
-            if (AM) rxa[q] = *reinterpret_cast<const float4*>(Xact + o);
+            if (ACTOP) rxa[q] = *reinterpret_cast<const float4*>(Xact + o);
         }
     };
     auto store_piece = [&](int pi, bool live, float* buf) {
@@ -186,10 +187,13 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
             const int q = pi - RA4;
             const bool ok = live && x_ok[q];
             float e[4] = {rx[q].x, rx[q].y, rx[q].z, rx[q].w};
-            if (AM) {
+            if (ACTOP) {
                 const float a[4] = {rxa[q].x, rxa[q].y, rxa[q].z, rxa[q].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) e[i] = a[i] > 0.f ? e[i] : e[i] * p.slope;
+            } else if (AM == 3) {                    // LeakyReLU in front of the conv, applied on load
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = e[i] > 0.f ? e[i] : e[i] * p.slope;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -445,16 +449,17 @@ bool msr2_supported(int tile, int K, int CC, int act_mode, int epi_s, const Row2
     const char* e = getenv("MSYNTH_ROWS2");            // tuning / test switch (0 disables)
     if (e && atoi(e) == 0) return false;
     if (tile < 0 || tile > MSR2_32x256) return false;
-    if (act_mode < 0 || act_mode > 2) return false;
+    if (act_mode < 0 || act_mode > 3) return false;
     if (p.L % 4) return false;
     if (in_s != 1) {      // transposed-conv backward data: phase-split input rows, pre-packed weights
-        if (!(in_s == 2 || in_s == 8) || act_mode != 2 || K != 2 || CC != 8 || epi_s != 0) return false;
+        if (!(in_s == 2 || in_s == 8) || (act_mode != 2 && act_mode != 0) || K != 2 || CC != 8 || epi_s != 0) return false;
         const int bnI = tile == MSR2_32x256 ? 256 : (tile == MSR2_64x64 ? 64 : 128);
         return p.R * (CC / in_s) * ((p.SS * in_s + 6) / 4) <= 256 * msr2_nxq(CC, bnI);
     }
-    if (act_mode == 2) return false;
-    // transposed-conv forward with the two live taps per phase: 128x128 tile, whole 64-row groups
-    if (K == 2) return CC == 8 && act_mode == 0 && (epi_s == 2 || epi_s == 8) &&
+    if (act_mode == 2 || (act_mode == 3 && K != 2)) return false;
+    // transposed-conv forward with the two live taps per phase (act_mode 3: LeakyReLU in front, on load):
+    // 128x128 tile or 64x128 as 1x4 waves, whole 64-row groups
+    if (K == 2) return CC == 8 && (act_mode == 0 || act_mode == 3) && (epi_s == 2 || epi_s == 8) &&
                        (tile == MSR2_128x128 || tile == MSR2_64x128) && p.M % 64 == 0 &&
                        CC * (p.R * ((p.SS + 6) / 4)) <= 256 * msr2_nxq(CC, 128);
     const bool k3 = K == 3 && (CC == 8 || CC == 16) && (epi_s == 0 || ((epi_s == 2 || epi_s == 8) && CC == 8 && act_mode == 0));
@@ -473,16 +478,22 @@ int msr2_launch(int tile, int K, int CC, int act_mode, int epi_s, const Row2P& p
                 const float* Xact, const float* W, const float* bias, const float* res, float* Y,
                 float* Yact, unsigned gx, unsigned gy, unsigned gz, hipStream_t s, int in_s) {
     const dim3 grid(gx, gy, gz);
-    if (in_s == 8) return launch_tile<2, 8, 2, 0, 8>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
-    if (in_s == 2) return launch_tile<2, 8, 2, 0, 2>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
-    if (K == 2 && CC == 8 && act_mode == 0 && tile == MSR2_128x128) {
-        if (epi_s == 8) return launch_inst<2, 2, 2, 2, 2, 8, 0, 8>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
-        if (epi_s == 2) return launch_inst<2, 2, 2, 2, 2, 8, 0, 2>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    if (in_s == 8 && act_mode == 2) return launch_tile<2, 8, 2, 0, 8>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    if (in_s == 2 && act_mode == 2) return launch_tile<2, 8, 2, 0, 2>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    if (in_s == 8) return launch_tile<2, 8, 0, 0, 8>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    if (in_s == 2) return launch_tile<2, 8, 0, 0, 2>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
+#define MSR2_HALF(A)                                                                                              \
+    if (K == 2 && CC == 8 && act_mode == A && tile == MSR2_128x128) {                                            \
+        if (epi_s == 8) return launch_inst<2, 2, 2, 2, 2, 8, A, 8>(p, X, Xact, W, bias, res, Y, Yact, grid, s);  \
+        if (epi_s == 2) return launch_inst<2, 2, 2, 2, 2, 8, A, 2>(p, X, Xact, W, bias, res, Y, Yact, grid, s);  \
+    }                                                                                                            \
+    if (K == 2 && CC == 8 && act_mode == A && tile == MSR2_64x128) {   /* 64 x 128 as 1 x 4 waves of 64 x 32 */  \
+        if (epi_s == 8) return launch_inst<1, 4, 2, 1, 2, 8, A, 8>(p, X, Xact, W, bias, res, Y, Yact, grid, s);  \
+        if (epi_s == 2) return launch_inst<1, 4, 2, 1, 2, 8, A, 2>(p, X, Xact, W, bias, res, Y, Yact, grid, s);  \
     }
-    if (K == 2 && CC == 8 && act_mode == 0 && tile == MSR2_64x128) {   // 64 x 128 as 1 x 4 waves of 64 x 32
-        if (epi_s == 8) return launch_inst<1, 4, 2, 1, 2, 8, 0, 8>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
-        if (epi_s == 2) return launch_inst<1, 4, 2, 1, 2, 8, 0, 2>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
-    }
+    MSR2_HALF(0)
+    MSR2_HALF(3)
+#undef MSR2_HALF
 #define MSR2_GO(KK, C, A, E) return launch_tile<KK, C, A, E>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s)
     if (K == 3 && epi_s == 0) {
         if (CC == 8) { if (act_mode) MSR2_GO(3, 8, 1, 0); else MSR2_GO(3, 8, 0, 0); }
