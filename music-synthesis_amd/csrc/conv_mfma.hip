@@ -1143,7 +1143,8 @@ bool row_deep(int K, int CK) { return K != 7 && K != 1 && CK >= 128 && CK % (2 *
 // the forward-layout weights, which it reads directly.)
 bool rows2_pick(RowCfg cfg, int K, int CC, bool has_act, int epi_s, int in_s, const RowP& p, const float* X,
                 const float* Xact, const float* W, const float* res, const float* Y, const float* Yact,
-                Row2P* q, int* tile, int* am) {
+                Row2P* q, int* tile, int* am, int* in_s_out = nullptr) {
+    if (in_s_out) *in_s_out = in_s;
     if (p.pad_mode != MS_PAD_ZERO || cfg == ROW_64x256) return false;
     if (has_act && p.in_act != MS_ACT_LRELU && p.in_act != MS_ACT_NONE && p.in_act != MS_MOD_LRELU_FWD) return false;
     *am = (has_act && p.in_act == MS_ACT_LRELU) ? (in_s == 1 ? 1 : 2) : 0;
@@ -1160,6 +1161,17 @@ bool rows2_pick(RowCfg cfg, int K, int CC, bool has_act, int epi_s, int in_s, co
     q->PX = p.RSZ; q->CKs = p.CKs; q->zstride = p.zstride; q->slope = p.slope; q->scratch_off = 0;
     *tile = cfg == ROW_128x128 ? MSR2_128x128 : (cfg == ROW_64x128 ? MSR2_64x128 :
             (cfg == ROW_64x64 ? MSR2_64x64 : MSR2_32x256));
+    // short rows of a length that is not a multiple of 4 (k5 conv at L = 17 / 9): whole-row staging
+    // (MSYNTH_SR=1 also sends the aligned short rows there: tuning switch)
+    if (in_s == 1 && in_s_out && K == 5 && p.tiles_per_row == 1 && p.Lt == p.L) {
+        static const int sr_all = getenv("MSYNTH_SR") ? atoi(getenv("MSYNTH_SR")) : 0;
+        int bm, bn;
+        row_tile(cfg, &bm, &bn);
+        if (p.L < bn && (p.L % 4 != 0 || sr_all == 1) && sr_all != 2 && msr2_supported(*tile, K, CC, *am, epi_s, *q, 0)) {
+            *in_s_out = 0;
+            return true;
+        }
+    }
     return msr2_supported(*tile, K, CC, *am, epi_s, *q, in_s);
 }
 
@@ -1174,10 +1186,10 @@ int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, 
     // pipelined second-generation kernel where its requirements hold (conv_rows2.hip)
     {
         Row2P q;
-        int tile, am;
-        if (rows2_pick(cfg, K, CC, HAS_ACT, EPI_S, IN_S, p, X, Xact, W, res, Y, Yact, &q, &tile, &am))
+        int tile, am, in_s_eff;
+        if (rows2_pick(cfg, K, CC, HAS_ACT, EPI_S, IN_S, p, X, Xact, W, res, Y, Yact, &q, &tile, &am, &in_s_eff))
             return msr2_launch(tile, K, CC, am, EPI_S, q, X, Xact, am == 1 ? p.Wfwd : W, bias, res, Y, Yact, grid.x,
-                               grid.y, grid.z, s, IN_S);
+                               grid.y, grid.z, s, in_s_eff);
     }
     const size_t lds = (size_t)(bm * (CC * K + 1) + CC * p.RSZ) * sizeof(float);
     if (lds > 64 * 1024) return MS_ERR_UNSUPPORTED;
@@ -1235,6 +1247,12 @@ const char* row_kname(RowCfg c, int K, bool act, int CK, int L = 0, int R = 1, i
         Row2P q;
         q.L = L; q.R = R; q.SS = SS;
         const int t2 = c == ROW_128x128 ? MSR2_128x128 : (c == ROW_64x128 ? MSR2_64x128 : (c == ROW_64x64 ? MSR2_64x64 : MSR2_32x256));
+        int bm, bn;
+        row_tile(c, &bm, &bn);
+        if (K == 5 && CC == 16 && epi_s == 0 && am == 1 && L < bn && L % 4 != 0 && c != ROW_32x256) {   // short-row mode
+            snprintf(buf, sizeof(buf), "k_conv_rows2<%s, 5, 16, %d, 0, 0>", tile, am);
+            return buf;
+        }
         if (msr2_supported(t2, K, CC, am, epi_s, q)) {
             snprintf(buf, sizeof(buf), "k_conv_rows2<%s, %d, %d, %d, %d>", tile, K, CC, am, epi_s);
             return buf;
@@ -1462,8 +1480,9 @@ int msm_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, con
         {
             Row2P q2;
             int tile2, am2;
+            int ins2;
             const bool direct = y_act && rows2_pick(cfg, p.K, rows_cc_eff(p.K, p.Cout), true, 0, 1, r, gy, y_act, wt,
-                                                    gx_add, gx, nullptr, &q2, &tile2, &am2) && am2 == 1;
+                                                    gx_add, gx, nullptr, &q2, &tile2, &am2, &ins2) && am2 == 1;
             if (!direct) {     // first-generation kernel: weights re-laid-out (transposed + tap-flipped)
                 unsigned nb = (unsigned)((total + 255) / 256);
                 if (nb > 2048) nb = 2048;

@@ -34,7 +34,13 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
     constexpr int AS = KK + 1;               // odd LDS stride of the weight tile
     constexpr int A4 = BM * (KK / 4);        // 16-byte loads per weight tile
     constexpr int RA4 = (A4 + 255) / 256;    // weight pieces per thread
-    constexpr int NXQ = msr2_nxq(CC, BN);    // activation pieces per thread
+    // IN_S == 0: SHORT-ROW mode.  A tile packs R whole rows of length L < BN (any L, also odd): the CC*L
+    // floats of one (batch row, channel chunk) are contiguous and start 16-byte aligned, so they are staged
+    // as aligned vectors whose 4 elements scatter to (channel, column) -- no halo loads (the halo is zero
+    // padding: LDS is cleared once), no alignment requirement on L.  The epilogue writes the BM*L
+    // contiguous outputs of a segment the same way.
+    constexpr bool SR = IN_S == 0;
+    constexpr int NXQ = SR ? (CC * BN / 4 + 255) / 256 : msr2_nxq(CC, BN);    // activation pieces per thread
     constexpr int NP = RA4 + NXQ;
     constexpr int NSTEP = KK / 2;            // MFMA k-pair steps per chunk
     constexpr int PPS = (NP + NSTEP - 1) / NSTEP;
@@ -92,8 +98,25 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
     int x_goff[NXQ], x_loff[NXQ];
     bool x_ok[NXQ];
     unsigned x_em[NXQ];                              // which of the 4 elements fall inside the segment
-    int x_loff4[IN_S > 1 ? NXQ : 1][4];              // IN_S > 1: LDS offset of each element (-1: none)
-    if (IN_S == 1) {
+    int x_loff4[IN_S != 1 ? NXQ : 1][4];             // IN_S != 1: LDS offset of each element (-1: none)
+    if (SR) {
+        const int NV = (CC * p.L) >> 2;              // vectors of one (segment, chunk) span
+#pragma unroll
+        for (int q = 0; q < NXQ; ++q) {
+            const int i = tid + 256 * q;
+            const int r = i / NV, v = i - r * NV;
+            const bool in = r < p.R;
+            x_ok[q] = in && b0 + r < p.B;
+            x_goff[q] = x_ok[q] ? (b0 + r) * p.CK * p.L + 4 * v : 0;
+            x_loff[q] = 0; x_em[q] = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int pos = 4 * v + e;
+                const int c = pos / p.L, t = pos - c * p.L;
+                x_loff4[q][e] = in ? BM * AS + c * p.PX + r * p.SS + t - p.off0 : -1;
+            }
+        }
+    } else if (IN_S == 1) {
 #pragma unroll
         for (int q = 0; q < NXQ; ++q) {
             const int i = tid + 256 * q;
@@ -198,7 +221,7 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float* d;
-                if (IN_S > 1) d = x_loff4[q][i] >= 0 ? buf + x_loff4[q][i] : scratch + tid;
+                if (IN_S != 1) d = x_loff4[q][i] >= 0 ? buf + x_loff4[q][i] : scratch + tid;
                 else d = (x_em[q] >> i) & 1u ? buf + x_loff[q] + i : scratch + tid;
                 *d = ok ? e[i] : 0.f;
             }
@@ -213,6 +236,10 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
     // prologue: chunk 0 -> buffer 0, chunk 1 -> registers
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi) load_piece(pi, cbeg, true);
+    if (SR) {                                        // the halo columns are never written: clear both buffers
+        for (int i = tid; i < 2 * tile_floats; i += 256) smem[i] = 0.f;
+        __syncthreads();
+    }
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi) store_piece(pi, true, smem);
 #pragma unroll
@@ -307,12 +334,29 @@ __global__ __launch_bounds__(256) void k_conv_rows2(Row2P p, const float* __rest
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int idx = tid + 256 * q;
-            const int row = idx / V4, c4 = idx - row * V4;
-            const int nl = 4 * c4;                       // tile column of the vector's first sample
-            const int r = nl / p.Lt, tc = nl - r * p.Lt; // Lt % 4 == 0: the 4 samples share a row
-            ok[q] = m0 + row < p.M && r < p.R && b0 + r < p.B && t0 + tc < p.L;
-            go[q] = ok[q] ? ((size_t)(b0 + r) * p.M + m0 + row) * p.L + t0 + tc : 0;
-            tv[q] = *reinterpret_cast<const float4*>(Ts + row * TP + nl);
+            if (SR) {
+                // vector v of the BM*L contiguous outputs of segment r (rows m0.., all L samples each)
+                const int NVo = (BM * p.L) >> 2;
+                const int r = idx / NVo, v = idx - r * NVo;
+                const int rows_left = p.M - m0;              // (M % 4 == 0: a vector never straddles row M)
+                ok[q] = r < p.R && b0 + r < p.B && (4 * v) / p.L < rows_left;
+                go[q] = ok[q] ? ((size_t)(b0 + r) * p.M + m0) * p.L + 4 * v : 0;
+                float e4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int pos = ok[q] ? 4 * v + e : 0;
+                    const int row = pos / p.L, t = pos - row * p.L;
+                    e4[e] = Ts[row * TP + (ok[q] ? r : 0) * p.Lt + t];
+                }
+                tv[q] = make_float4(e4[0], e4[1], e4[2], e4[3]);
+            } else {
+                const int row = idx / V4, c4 = idx - row * V4;
+                const int nl = 4 * c4;                       // tile column of the vector's first sample
+                const int r = nl / p.Lt, tc = nl - r * p.Lt; // Lt % 4 == 0: the 4 samples share a row
+                ok[q] = m0 + row < p.M && r < p.R && b0 + r < p.B && t0 + tc < p.L;
+                go[q] = ok[q] ? ((size_t)(b0 + r) * p.M + m0 + row) * p.L + t0 + tc : 0;
+                tv[q] = *reinterpret_cast<const float4*>(Ts + row * TP + nl);
+            }
             if (res) rv[q] = *reinterpret_cast<const float4*>(res + go[q]);
         }
 #pragma unroll
@@ -450,6 +494,13 @@ bool msr2_supported(int tile, int K, int CC, int act_mode, int epi_s, const Row2
     if (e && atoi(e) == 0) return false;
     if (tile < 0 || tile > MSR2_32x256) return false;
     if (act_mode < 0 || act_mode > 3) return false;
+    if (in_s == 0) {      // short-row mode: R whole rows of any length per tile (the 1024 -> 1024 k5 conv at L = 17 / 9)
+        const int bnS = tile == MSR2_32x256 ? 256 : (tile == MSR2_64x64 ? 64 : 128);
+        // (backward data only: 92 vs 110 us at L = 17, 56 vs 76 us at L = 9; the forward measured 5-8 % slower
+        //  than the first-generation kernel, as at L = 32)
+        return K == 5 && CC == 16 && epi_s == 0 && act_mode == 1 && p.tiles_per_row == 1 &&
+               p.R * p.L <= bnS && (tile == MSR2_64x128 || tile == MSR2_64x64 || tile == MSR2_128x128) && p.M % 4 == 0;
+    }
     if (p.L % 4) return false;
     if (in_s != 1) {      // transposed-conv backward data: phase-split input rows, pre-packed weights
         if (!(in_s == 2 || in_s == 8) || (act_mode != 2 && act_mode != 0) || K != 2 || CC != 8 || epi_s != 0) return false;
@@ -478,6 +529,7 @@ int msr2_launch(int tile, int K, int CC, int act_mode, int epi_s, const Row2P& p
                 const float* Xact, const float* W, const float* bias, const float* res, float* Y,
                 float* Yact, unsigned gx, unsigned gy, unsigned gz, hipStream_t s, int in_s) {
     const dim3 grid(gx, gy, gz);
+    if (in_s == 0) return launch_tile<5, 16, 1, 0, 0>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
     if (in_s == 8 && act_mode == 2) return launch_tile<2, 8, 2, 0, 8>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
     if (in_s == 2 && act_mode == 2) return launch_tile<2, 8, 2, 0, 2>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
     if (in_s == 8) return launch_tile<2, 8, 0, 0, 8>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);

@@ -225,6 +225,12 @@ HOT_CONVS = [
     ("d_k41_g64", 1, 256, 129, 1024, 41, 4, 20, 1, 64, 1, False),
     ("d_k41_g256", 2, 1024, 33, 1024, 41, 4, 20, 1, 256, 1, False),
     ("d_k5", 2, 1024, 17, 1024, 5, 1, 2, 1, 1, 1, False),
+    # short-row mode of the pipelined kernel (rows of a length that is not a multiple of 4): partial
+    # last tile, partial M tile, 1 / 3 / 14 rows per tile
+    ("d_k5_l9_ragged", 17, 256, 9, 328, 5, 1, 2, 1, 1, 1, False),
+    ("d_k5_l17_b9", 9, 128, 17, 64, 5, 1, 2, 1, 1, 1, False),
+    ("d_k5_l33", 5, 128, 33, 128, 5, 1, 2, 1, 1, 1, False),
+    ("d_k5_l101", 3, 128, 101, 64, 5, 1, 2, 1, 1, 1, False),
     ("d_judge", 2, 1024, 9, 1, 3, 1, 1, 1, 1, 0, False),
     ("d_judge_l32", 5, 1024, 32, 1, 3, 1, 1, 1, 1, 0, False),
     ("d_judge_l17", 3, 1024, 17, 1, 3, 1, 1, 1, 1, 0, False),
