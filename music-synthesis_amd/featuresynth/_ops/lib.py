@@ -163,12 +163,26 @@ def profile_begin():
     PROFILE = []
 
 
-def profile_end():
-    """-> list of (symbol, cost, milliseconds); synchronises the device."""
+def profile_end(calibrate=False):
+    """-> list of (symbol, cost, milliseconds); synchronises the device.
+
+    calibrate=True also returns the instrument's own reading: the median time between two event records
+    with NOTHING between them on the same stream (the records are stream commands themselves), which the
+    caller may subtract from every measurement."""
     global PROFILE
     rec, PROFILE = PROFILE, None
+    empty = []
+    if calibrate:
+        for _ in range(64):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); e1.record()
+            empty.append((e0, e1))
     torch.cuda.synchronize()
-    return [(name, cost, e0.elapsed_time(e1)) for name, cost, e0, e1 in rec]
+    out = [(name, cost, e0.elapsed_time(e1)) for name, cost, e0, e1 in rec]
+    if not calibrate:
+        return out
+    gaps = sorted(e0.elapsed_time(e1) for e0, e1 in empty)
+    return out, gaps[len(gaps) // 2]
 
 
 def call(name, cost_fn, *args):
