@@ -90,6 +90,29 @@ int ms_conv1d_bwd_weight(const ms_conv1d_desc* d, const float* x, const float* g
                          const float* y_act, float* gw, float* gb, float beta, void* workspace,
                          size_t workspace_bytes, ms_stream_t stream);
 
+/*
+ * `count` independent ms_conv1d_bwd_weight calls in one entry.  The six k3 convs of a ResidualStack
+ * (util/modules.py:391-405: same channels and length, dilations 1/3/9) are issued as ONE launch pair when
+ * their geometry agrees -- a single layer's weight gradient leaves every workgroup a contraction too short
+ * to amortise its prologue, slab write and reduce launch.  Any other combination runs entry by entry.
+ * Results are identical to the single calls up to fp32 summation order of the split-K slices.
+ */
+#define MS_WGRAD_MULTI_MAX 8
+typedef struct ms_wgrad_multi_desc {
+    int32_t count;
+    int32_t reserved;
+    ms_conv1d_desc conv[MS_WGRAD_MULTI_MAX];
+    const float* x[MS_WGRAD_MULTI_MAX];
+    const float* gy[MS_WGRAD_MULTI_MAX];
+    const float* y_act[MS_WGRAD_MULTI_MAX];     /* may be NULL per entry */
+    float* gw[MS_WGRAD_MULTI_MAX];
+    float* gb[MS_WGRAD_MULTI_MAX];              /* may be NULL per entry */
+    float beta[MS_WGRAD_MULTI_MAX];             /* 0 or 1 per entry */
+} ms_wgrad_multi_desc;
+size_t ms_conv1d_bwd_weight_multi_workspace_bytes(const ms_wgrad_multi_desc* d);
+int ms_conv1d_bwd_weight_multi(const ms_wgrad_multi_desc* d, void* workspace, size_t workspace_bytes,
+                               ms_stream_t stream);
+
 /* which: 0 fwd, 1 bwd_data, 2 bwd_weight */
 size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which);
 

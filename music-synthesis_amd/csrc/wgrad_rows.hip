@@ -33,6 +33,20 @@ struct WrP {
     float slope;
 };
 
+// Several weight gradients of identical geometry (the six k3 convs of a ResidualStack: same channels and
+// length, dilations 1/3/9) in ONE launch: grid.y = problem x M-tile.  A single layer leaves each workgroup
+// only 4-8 chunks of contraction (prologue, slab write and the reduce launch cost as much as the MFMAs);
+// batched, the same 256/512 workgroup slots get 6x longer K loops and 6x fewer slab bytes.
+constexpr int WR_MULTI_MAX = 8;
+struct WrMulti {
+    int n, tiles_m;
+    size_t slab_stride;                 // floats between the problems' regions inside one slice
+    const float* x[WR_MULTI_MAX];
+    const float* g[WR_MULTI_MAX];
+    const float* gact[WR_MULTI_MAX];
+    int dil[WR_MULTI_MAX], pad[WR_MULTI_MAX];
+};
+
 // Activation handling is a template parameter: a runtime `kind` compiles to scalar branches around
 // every store piece, which cuts the chunk into hundreds of basic blocks and defeats the MFMA /
 // store / load interleaving.  AK 1: LeakyReLU derivative on the gradient (the hot layers);
@@ -62,11 +76,25 @@ __device__ __forceinline__ float wr_xact(float v, int kind, float slope) {
 //   masked loads read element 0) so that the whole chunk is one basic block the scheduler can
 //   interleave.
 template <int K, int TM, bool VEC, int KPI, int AK, int XS = 1>
-__global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restrict__ X,
-                                                   const float* __restrict__ Xact,
-                                                   const float* __restrict__ G,
-                                                   const float* __restrict__ Gact,
-                                                   float* __restrict__ partial, size_t pstride) {
+__global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restrict__ X_,
+                                                   const float* __restrict__ Xact_,
+                                                   const float* __restrict__ G_,
+                                                   const float* __restrict__ Gact_,
+                                                   float* __restrict__ partial, size_t pstride, WrMulti mp) {
+    const float* __restrict__ X = X_;
+    const float* __restrict__ Xact = Xact_;
+    const float* __restrict__ G = G_;
+    const float* __restrict__ Gact = Gact_;
+    int by = blockIdx.y;
+    if (mp.n > 0) {                                  // batched launch: this workgroup's problem
+        const int prob = by / mp.tiles_m;
+        by -= prob * mp.tiles_m;
+        X = mp.x[prob]; G = mp.g[prob]; Gact = mp.gact[prob]; Xact = nullptr;
+        p.dil = mp.dil[prob]; p.pad = mp.pad[prob];
+        p.SS = p.Lt + (K - 1) * p.dil;
+        p.RSZ = p.R * p.SS;
+        partial += (size_t)prob * mp.slab_stride;
+    }
     constexpr int BM = 2 * TM * 32;
     constexpr int NGQ = VEC ? TM * 4 : TM * 16;     // G pieces (one load per thread each)
     // XS > 1 (transposed-conv weight grads): the 64 X rows are the XS phases of 64/XS channels of a
@@ -80,7 +108,7 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
     float* scratch = smem + 2 * tile_floats;        // 256 floats: sink for out-of-tile lanes
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
-    const int m0 = blockIdx.y * BM, c0 = blockIdx.x * CB;
+    const int m0 = by * BM, c0 = blockIdx.x * CB;
     const int NG = p.CK * K;
     const float* Gq = Gact ? Gact : G;
     const int g_kind = Gact ? p.g_kind : MS_ACT_NONE;
@@ -385,6 +413,7 @@ struct WrPlan {
     bool vec, refl = false;
     dim3 grid;
     size_t lds, stride_floats;
+    WrMulti mp = {};                    // n == 0: single problem
 };
 
 WrPlan plan_wrows(const ConvP& c) {
@@ -453,7 +482,7 @@ void launch_wrows_ak(const WrPlan& q, const float* x, const float* gy, const flo
         attr_set = true;
     }
     hipLaunchKernelGGL((k_wgrad_rows<K, TM, VEC, KPI, AK>), q.grid, dim3(256), q.lds, s, q.p, x,
-                       (const float*)nullptr, gy, y_act, partial, q.stride_floats);
+                       (const float*)nullptr, gy, y_act, partial, q.stride_floats, q.mp);
 }
 
 template <int K, int TM, bool VEC, int KPI>
@@ -563,7 +592,7 @@ void launch_wrows_t(const WrPlan& q, const float* gy, const float* y_act, const 
         attr_set = true;
     }
     hipLaunchKernelGGL((k_wgrad_rows<3, TM, true, KPI, AK, XS>), q.grid, dim3(256), q.lds, s, q.p, gy, y_act, x,
-                       (const float*)nullptr, partial, q.stride_floats);
+                       (const float*)nullptr, partial, q.stride_floats, q.mp);
 }
 
 template <int AK, int XS>
@@ -624,6 +653,130 @@ int msw_conv1d_bwd_weight(const ConvP& c, const float* x, const float* gy, const
     MS_CHECK_LAUNCH();
     return msm_wgrad_reduce(partial, q.stride_floats, q.nsplit, (size_t)c.Cout * c.Cin * c.K, c.Cout, gw,
                             gb, beta, s);
+}
+
+// ------------------------------------------------------------------ batched launch (see WrMulti)
+namespace {
+
+struct WrReduceMulti {
+    float* gw[WR_MULTI_MAX];
+    float* gb[WR_MULTI_MAX];
+    float beta[WR_MULTI_MAX];
+};
+
+// out[prob] = beta*out + sum over the slices' slabs of problem blockIdx.y (16-byte form of k_wgrad_reduce_v4)
+__global__ __launch_bounds__(256) void k_wgrad_reduce_multi(const float* __restrict__ partial,
+                                                           size_t slice_stride, size_t prob_stride,
+                                                           int nsplit, size_t wsize, size_t total,
+                                                           WrReduceMulti o) {
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int prob = blockIdx.y;
+    partial += (size_t)prob * prob_stride;
+    const size_t i = ((size_t)blockIdx.x * 64 + lane) * 4;
+    const bool ok = i < total;                       // total % 4 == 0
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (ok) {
+        int z = wv;
+        for (; z + 4 < nsplit; z += 8) {
+            const float4 a = *reinterpret_cast<const float4*>(partial + (size_t)z * slice_stride + i);
+            const float4 b = *reinterpret_cast<const float4*>(partial + (size_t)(z + 4) * slice_stride + i);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        for (; z < nsplit; z += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(partial + (size_t)z * slice_stride + i);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+    }
+    red[wv][lane] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (wv == 0 && ok) {
+        float4 r;
+        r.x = (red[0][lane].x + red[1][lane].x) + (red[2][lane].x + red[3][lane].x);
+        r.y = (red[0][lane].y + red[1][lane].y) + (red[2][lane].y + red[3][lane].y);
+        r.z = (red[0][lane].z + red[1][lane].z) + (red[2][lane].z + red[3][lane].z);
+        r.w = (red[0][lane].w + red[1][lane].w) + (red[2][lane].w + red[3][lane].w);
+        float* outb = o.gb[prob];
+        if (i >= wsize && !outb) return;
+        float4* dst = i < wsize ? reinterpret_cast<float4*>(o.gw[prob] + i) : reinterpret_cast<float4*>(outb + (i - wsize));
+        const float beta = o.beta[prob];
+        if (beta != 0.f) {
+            const float4 pv = *dst;
+            r.x += beta * pv.x; r.y += beta * pv.y; r.z += beta * pv.z; r.w += beta * pv.w;
+        }
+        *dst = r;
+    }
+}
+
+// plan of the batched launch; ok only for n identical k3 LeakyReLU convs (dilation / padding may differ)
+WrPlan plan_wrows_multi(const ConvP* cs, int n) {
+    WrPlan q;
+    q.ok = false;
+    if (n < 2 || n > WR_MULTI_MAX) return q;
+    int imax = 0;
+    for (int i = 0; i < n; ++i) {
+        const ConvP& c = cs[i];
+        if (c.B != cs[0].B || c.Cin != cs[0].Cin || c.Lin != cs[0].Lin || c.Cout != cs[0].Cout || c.K != 3 ||
+            c.act != MS_ACT_LRELU || c.in_act || c.pad_mode != MS_PAD_ZERO || c.pad != c.dil || c.slope != cs[0].slope)
+            return q;
+        if (c.dil > cs[imax].dil) imax = i;
+    }
+    q = plan_wrows(cs[imax]);                        // LDS pitches sized for the widest halo
+    if (!q.ok || !q.vec || q.refl || q.p.R != 1 || (q.p.M % 4)) { q.ok = false; return q; }
+    WrP& p = q.p;
+    const int BM = 64 * q.tm;
+    const int tiles_m = ms_ceil_div(p.M, BM), tiles_c = ms_ceil_div(p.CK, CB);
+    const size_t stride_one = (size_t)p.M * p.CK * 3 + p.M;
+    const int tiles = n * tiles_m * tiles_c;
+    const int slots = 256 * (q.lds > 80 * 1024 ? 1 : 2);
+    int ns_max = p.nchunks / 4 > 0 ? p.nchunks / 4 : 1;
+    const size_t max_by_bytes = ((size_t)48 << 20) / (stride_one * n * 4);
+    if ((size_t)ns_max > max_by_bytes) ns_max = max_by_bytes > 0 ? (int)max_by_bytes : 1;
+    const int ns = pick_slices(tiles, slots, ns_max);
+    p.cps = ms_ceil_div(p.nchunks, ns);
+    q.nsplit = ms_ceil_div(p.nchunks, p.cps);
+    q.grid = dim3((unsigned)tiles_c, (unsigned)(n * tiles_m), (unsigned)q.nsplit);
+    q.stride_floats = stride_one * n;                // slice stride
+    q.mp.n = n;
+    q.mp.tiles_m = tiles_m;
+    q.mp.slab_stride = stride_one;
+    for (int i = 0; i < n; ++i) { q.mp.dil[i] = cs[i].dil; q.mp.pad[i] = cs[i].pad; }
+    return q;
+}
+
+}  // namespace
+
+size_t msw_multi_ws(const ConvP* cs, int n) {
+    const char* e = getenv("MSYNTH_WMULTI");         // tuning / test switch (0 disables the batched launch)
+    if (e && atoi(e) == 0) return 0;
+    const WrPlan q = plan_wrows_multi(cs, n);
+    return q.ok ? (size_t)q.nsplit * q.stride_floats * sizeof(float) : 0;
+}
+
+int msw_conv1d_bwd_weight_multi(const ConvP* cs, int n, const float* const* x, const float* const* gy,
+                                const float* const* y_act, float* const* gw, float* const* gb,
+                                const float* beta, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (msw_multi_ws(cs, n) == 0) return MS_ERR_UNSUPPORTED;
+    WrPlan q = plan_wrows_multi(cs, n);
+    if (!ws || ws_bytes < (size_t)q.nsplit * q.stride_floats * sizeof(float) || (((uintptr_t)ws) & 15)) return MS_ERR_UNSUPPORTED;
+    WrReduceMulti o;
+    for (int i = 0; i < n; ++i) {
+        if (!x[i] || !gy[i] || !y_act[i] || !gw[i] || !gb[i]) return MS_ERR_UNSUPPORTED;
+        if (((((uintptr_t)x[i]) | ((uintptr_t)gy[i]) | ((uintptr_t)y_act[i]) | ((uintptr_t)gw[i]) | ((uintptr_t)gb[i])) & 15) != 0)
+            return MS_ERR_UNSUPPORTED;
+        if (beta[i] != 0.f && beta[i] != 1.f) return MS_ERR_INVALID_ARG;
+        q.mp.x[i] = x[i]; q.mp.g[i] = gy[i]; q.mp.gact[i] = y_act[i];
+        o.gw[i] = gw[i]; o.gb[i] = gb[i]; o.beta[i] = beta[i];
+    }
+    float* partial = (float*)ws;
+    launch_wrows<3>(q, true, x[0], gy[0], y_act[0], partial, s);
+    MS_CHECK_LAUNCH();
+    const size_t wsize = (size_t)q.p.M * q.p.CK * 3, total = wsize + (size_t)q.p.M;
+    hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3((unsigned)((total / 4 + 63) / 64), (unsigned)n), dim3(256), 0, s,
+                       partial, q.stride_floats, q.mp.slab_stride, q.nsplit, wsize, total, o);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
 }
 
 // ------------------------------------------------------------------ 32-channel layers

@@ -79,20 +79,44 @@ def atom_forward(h, w0, b0, w1, b1, dil, save):
     return out, (d0, d1, h, t, u)
 
 
-def atom_backward(rec, w0, w1, g, sink, i, need_wgrad=True, need_gx=True, fork=None):
-    """g = d loss / d atom output; parameter grads go to sink slots i..i+3 (w0, b0, w1, b1)."""
+def atom_backward(rec, w0, w1, g, sink, i, need_wgrad=True, need_gx=True, fork=None, batch=None):
+    """g = d loss / d atom output; parameter grads go to sink slots i..i+3 (w0, b0, w1, b1).
+    batch: list collecting the weight-grad jobs (slot, x, gy, y_act, desc, w_shape) instead of running them
+    (the caller issues a stack's six jobs as one launch, flush_wgrad_batch)."""
     d0, d1, h, t, u = rec
     run = fork.run if fork is not None else (lambda fn, *ts: fn())
-    if need_wgrad:
+    if need_wgrad and batch is not None:
+        batch.append((i + 2, t, g, u, d1, w1.shape))
+    elif need_wgrad:
         gw, gb, acc = sink.pair(i + 2)
         run(lambda: sink.put(i + 2, *P.conv1d_bwd_weight(t, g, u, d1, w1.shape, gw, gb, acc)), t, g, u)
     gt = P.conv1d_bwd_data(g, u, w1, d1)
-    if need_wgrad:
+    if need_wgrad and batch is not None:
+        batch.append((i, h, gt, t, d0, w0.shape))
+    elif need_wgrad:
         gw, gb, acc = sink.pair(i)
         run(lambda: sink.put(i, *P.conv1d_bwd_weight(h, gt, t, d0, w0.shape, gw, gb, acc)), h, gt, t)
     if not need_gx:
         return None
     return P.conv1d_bwd_data(gt, t, w0, d0, gx_add=g)   # skip connection: + g
+
+
+def flush_wgrad_batch(batch, sink, fork):
+    """Issues the collected weight-grad jobs of one ResidualStack through the batched C-ABI entry."""
+    if not batch:
+        return
+    jobs, slots, keep = [], [], []
+    for (slot, x, gy, ya, d, w_shape) in batch:
+        gw, gb, acc = sink.pair(slot)
+        jobs.append((x, gy, ya, d, w_shape, gw, gb, acc))
+        slots.append(slot)
+        keep += [x, gy, ya]
+
+    def go():
+        for slot, (gw, gb) in zip(slots, P.conv1d_bwd_weight_multi(jobs)):
+            sink.put(slot, gw, gb)
+    fork.run(go, *keep)
+    batch.clear()
 
 
 def gen_forward(x, params, save):
@@ -132,8 +156,11 @@ def gen_backward(tape, params, gy, sink=None):
     i = G_NPARAMS
     g = gy
     fork = _WgradFork(gy.device)
+    batch = [] if os.environ.get("MSYNTH_WMULTI", "1") == "1" else None
     for rec in reversed(tape):
         kind = rec[0]
+        if kind != "atom" and batch:
+            flush_wgrad_batch(batch, sink, fork)     # the stack's six weight gradients: one launch
         if kind == "last":
             _, d, h, y = rec
             i -= 2
@@ -142,7 +169,7 @@ def gen_backward(tape, params, gy, sink=None):
             g = P.conv1d_bwd_data(g, y, params[i], d)
         elif kind == "atom":
             i -= 4
-            g = atom_backward(rec[1], params[i], params[i + 2], g, sink, i, fork=fork)
+            g = atom_backward(rec[1], params[i], params[i + 2], g, sink, i, fork=fork, batch=batch)
         elif kind == "convT":
             _, dt, hin, h = rec
             i -= 2
@@ -154,6 +181,8 @@ def gen_backward(tape, params, gy, sink=None):
             i -= 2
             gw, gb, acc = sink.pair(i)
             fork.run(lambda: sink.put(i, *P.conv1d_bwd_weight(x, g, h, d, params[i].shape, gw, gb, acc)), x, g, h)
+    if batch:
+        flush_wgrad_batch(batch, sink, fork)
     fork.join()
     assert i == 0
     return sink

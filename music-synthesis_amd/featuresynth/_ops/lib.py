@@ -40,6 +40,17 @@ class L1MultiDesc(ctypes.Structure):            # ms_l1_multi_desc
                 ("n", ctypes.c_int64 * L1_MULTI_MAX), ("w", _c_f * L1_MULTI_MAX)]
 
 
+WGRAD_MULTI_MAX = 8
+
+
+class WgradMultiDesc(ctypes.Structure):         # ms_wgrad_multi_desc
+    _fields_ = [("count", _c_int), ("reserved", _c_int),
+                ("conv", ConvDesc * WGRAD_MULTI_MAX),
+                ("x", _vp * WGRAD_MULTI_MAX), ("gy", _vp * WGRAD_MULTI_MAX), ("y_act", _vp * WGRAD_MULTI_MAX),
+                ("gw", _vp * WGRAD_MULTI_MAX), ("gb", _vp * WGRAD_MULTI_MAX),
+                ("beta", _c_f * WGRAD_MULTI_MAX)]
+
+
 WN_MULTI_MAX = 64
 
 
@@ -58,6 +69,8 @@ SIGNATURES = {
     "ms_conv1d_fwd": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ms_conv1d_bwd_data": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ms_conv1d_bwd_weight": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _c_f, _vp, _sz, _vp]),
+    "ms_conv1d_bwd_weight_multi_workspace_bytes": (_sz, [ctypes.POINTER(WgradMultiDesc)]),
+    "ms_conv1d_bwd_weight_multi": (_c_int, [ctypes.POINTER(WgradMultiDesc), _vp, _sz, _vp]),
     "ms_conv1d_workspace_bytes": (_sz, [ctypes.POINTER(ConvDesc), _c_int]),
     "ms_conv1d_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvDesc), _c_int]),
     "ms_convt1d_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvTDesc), _c_int]),

@@ -99,6 +99,47 @@ def conv1d_bwd_weight(x, gy, y_act, d, w_shape, gw=None, gb=None, accumulate=Fal
     return gw, gb
 
 
+def conv1d_bwd_weight_multi(jobs):
+    """jobs: list of (x, gy, y_act, desc, w_shape, gw, gb, accumulate) -- as many conv1d_bwd_weight calls,
+    issued through ONE C-ABI entry (one launch pair when the geometries agree: the six k3 convs of a
+    ResidualStack).  Returns [(gw, gb)] in job order."""
+    out = []
+    lib = L.load()
+    for lo in range(0, len(jobs), L.WGRAD_MULTI_MAX):
+        chunk = jobs[lo:lo + L.WGRAD_MULTI_MAX]
+        if len(chunk) == 1:
+            x, gy, ya, d, ws_, gw, gb, acc = chunk[0]
+            out.append(conv1d_bwd_weight(x, gy, ya, d, ws_, gw, gb, acc))
+            continue
+        md = L.WgradMultiDesc()
+        md.count = len(chunk)
+        costs = []
+        for k, (x, gy, ya, d, w_shape, gw, gb, acc) in enumerate(chunk):
+            L.require(gy, "conv1d grad_output"); L.require(x, "conv1d input")
+            if gw is None:
+                gw = torch.empty(tuple(w_shape), dtype=torch.float32, device=gy.device)
+                acc = False
+            if gb is None:
+                gb = (torch.zeros if acc else torch.empty)((d.Cout,), dtype=torch.float32, device=gy.device)
+            md.conv[k] = d
+            md.x[k], md.gy[k], md.y_act[k] = x.data_ptr(), gy.data_ptr(), L.ptr(ya)
+            md.gw[k], md.gb[k], md.beta[k] = gw.data_ptr(), gb.data_ptr(), 1.0 if acc else 0.0
+            costs.append(_ccost(d, "bwd_weight", act_read=ya is not None))
+            out.append((gw, gb))
+        nws = lib.ms_conv1d_bwd_weight_multi_workspace_bytes(md)
+        ws = L.workspace(nws, chunk[0][1].device)
+
+        def cost(costs=costs):
+            cs = [c() for c in costs]
+            tot = dict(cs[0])
+            tot["flops"] = sum(c["flops"] for c in cs)
+            tot["bytes"] = sum(c["bytes"] for c in cs)
+            tot["batched"] = len(cs)
+            return tot
+        L.call("ms_conv1d_bwd_weight_multi", cost, md, L.ptr(ws), nws, L.stream())
+    return out
+
+
 def convt_desc(x_shape, w_shape, stride, pad, act=L.ACT_NONE, in_act=L.ACT_NONE):
     B, Cin, Lin = x_shape
     Cin2, Cout, K = w_shape

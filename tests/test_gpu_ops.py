@@ -370,3 +370,37 @@ def test_kernel_generations_agree(shape, monkeypatch):
     for i in range(3):
         assert np.array_equal(out["0"][i], out["1"][i])
     assert rel_l2(out["1"][3], out["0"][3]) < 2e-6 and rel_l2(out["1"][4], out["0"][4]) < 2e-6
+
+
+@pytest.mark.parametrize("case", [
+    # name, B, C, L, dilations (one job per entry), accumulate pattern
+    ("stack_c128", 3, 128, 512, (1, 9, 1, 3, 1, 1), (False, True, False, False, True, False)),
+    ("stack_c64", 2, 64, 1024, (1, 9, 1, 3, 1, 1), (False,) * 6),
+    ("stack_c256_short", 5, 256, 64, (9, 1, 3), (True, False, True)),
+    ("pair_c192_ragged_m", 2, 192, 256, (3, 1), (False, False)),
+    ("fallback_c32", 2, 32, 512, (1, 3, 9, 1), (False, True, False, False)),       # per-wave kernel, entry by entry
+    ("fallback_odd_len", 2, 128, 130, (1, 3), (False, False)),                     # unaligned rows
+], ids=lambda c: c[0])
+def test_wgrad_multi_matches_single_calls(case):
+    """ms_conv1d_bwd_weight_multi == the same jobs through ms_conv1d_bwd_weight one by one (the batched
+    launch only regroups the split-K slices), including accumulation into existing gradients."""
+    from featuresynth._ops import prims as P
+    name, B, C, Lg, dils, accs = case
+    rng = np.random.default_rng(len(name) + C)
+    jobs, ref = [], []
+    for dil, acc in zip(dils, accs):
+        x = dev(rng.standard_normal((B, C, Lg)).astype(np.float32))
+        gy = dev(rng.standard_normal((B, C, Lg)).astype(np.float32))
+        ya = dev(rng.standard_normal((B, C, Lg)).astype(np.float32))
+        d, _ = P.conv_desc(x.shape, (C, C, 3), pad=dil, dil=dil, act=1)
+        gw0 = rng.standard_normal((C, C, 3)).astype(np.float32)
+        gb0 = rng.standard_normal((C,)).astype(np.float32)
+        gw_a, gb_a = (dev(gw0), dev(gb0)) if acc else (None, None)
+        gw_b, gb_b = (dev(gw0), dev(gb0)) if acc else (None, None)
+        jobs.append((x, gy, ya, d, (C, C, 3), gw_a, gb_a, acc))
+        ref.append(P.conv1d_bwd_weight(x, gy, ya, d, (C, C, 3), gw_b, gb_b, acc))
+    got = P.conv1d_bwd_weight_multi(jobs)
+    assert len(got) == len(ref)
+    for (gw, gb), (rw, rb) in zip(got, ref):
+        assert rel_l2(host(gw), host(rw)) < 2e-6
+        assert rel_l2(host(gb), host(rb)) < 2e-6
