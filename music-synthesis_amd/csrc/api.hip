@@ -151,6 +151,7 @@ size_t ms_conv1d_bwd_weight_multi_workspace_bytes(const ms_wgrad_multi_desc* d) 
     ConvP cs[MS_WGRAD_MULTI_MAX];
     const int n = multi_convs(d, cs);
     size_t need = n ? msw_multi_ws(cs, n) : 0;
+    if (n && msw32_multi_ws(cs, n) > need) need = msw32_multi_ws(cs, n);
     for (int i = 0; i < n; ++i) {
         const size_t one = ms_conv1d_workspace_bytes(&d->conv[i], 2);
         if (one > need) need = one;
@@ -165,8 +166,11 @@ int ms_conv1d_bwd_weight_multi(const ms_wgrad_multi_desc* d, void* workspace, si
     if (!n) return MS_ERR_INVALID_ARG;
     for (int i = 0; i < n; ++i)
         if (!d->x[i] || !d->gy[i] || !d->gw[i] || (d->beta[i] != 0.f && d->beta[i] != 1.f)) return MS_ERR_INVALID_ARG;
-    const int rc = msw_conv1d_bwd_weight_multi(cs, n, d->x, d->gy, d->y_act, d->gw, d->gb, d->beta, workspace,
-                                               workspace_bytes, (hipStream_t)stream);
+    int rc = msw_conv1d_bwd_weight_multi(cs, n, d->x, d->gy, d->y_act, d->gw, d->gb, d->beta, workspace,
+                                         workspace_bytes, (hipStream_t)stream);
+    if (rc != MS_ERR_UNSUPPORTED) return rc;
+    rc = msw32_bwd_weight_multi(cs, n, d->x, d->gy, d->y_act, d->gw, d->gb, d->beta, workspace, workspace_bytes,
+                                (hipStream_t)stream);
     if (rc != MS_ERR_UNSUPPORTED) return rc;
     for (int i = 0; i < n; ++i) {       // geometry differs / unaligned operands: entry by entry
         const int r1 = ms_conv1d_bwd_weight(&d->conv[i], d->x[i], d->gy[i], d->y_act[i], d->gw[i], d->gb[i],

@@ -46,6 +46,10 @@ int msm_wgrad_reduce(const float* partial, size_t stride_floats, int nsplit, siz
 // row-tile weight gradient (wgrad_rows.hip)
 bool msw_bwd_weight_applicable(const ConvP& p);
 size_t msw_bwd_weight_ws(const ConvP& p);
+size_t msw32_multi_ws(const ConvP* cs, int n);
+int msw32_bwd_weight_multi(const ConvP* cs, int n, const float* const* x, const float* const* gy,
+                           const float* const* y_act, float* const* gw, float* const* gb, const float* beta,
+                           void* ws, size_t ws_bytes, hipStream_t s);
 // n weight gradients of identical geometry in one launch (0 / UNSUPPORTED: the caller loops over single calls)
 size_t msw_multi_ws(const ConvP* cs, int n);
 int msw_conv1d_bwd_weight_multi(const ConvP* cs, int n, const float* const* x, const float* const* gy,

@@ -797,11 +797,31 @@ struct W32P {
     float slope;
 };
 
+// several 32-channel weight gradients in one launch: workgroups [prob*g_per, (prob+1)*g_per) own problem prob
+struct W32Multi {
+    int n, g_per;
+    const float* x[WR_MULTI_MAX];
+    const float* g[WR_MULTI_MAX];
+    const float* gact[WR_MULTI_MAX];
+    int dil[WR_MULTI_MAX], pad[WR_MULTI_MAX];
+};
+
 template <int AK>   // 1: LeakyReLU derivative on the gradient (y_act given); 0: plain gradient
-__global__ __launch_bounds__(256, 2) void k_wgrad32(W32P p, const float* __restrict__ X,
-                                                   const float* __restrict__ G,
-                                                   const float* __restrict__ Gact,
-                                                   float* __restrict__ partial, size_t pstride) {
+__global__ __launch_bounds__(256, 2) void k_wgrad32(W32P p, const float* __restrict__ X_,
+                                                   const float* __restrict__ G_,
+                                                   const float* __restrict__ Gact_,
+                                                   float* __restrict__ partial, size_t pstride, W32Multi mp) {
+    const float* __restrict__ X = X_;
+    const float* __restrict__ G = G_;
+    const float* __restrict__ Gact = Gact_;
+    int bx = blockIdx.x, gx = gridDim.x;
+    if (mp.n > 0) {
+        const int prob = bx / mp.g_per;
+        bx -= prob * mp.g_per;
+        gx = mp.g_per;
+        X = mp.x[prob]; G = mp.g[prob]; Gact = mp.gact[prob];
+        p.dil = mp.dil[prob]; p.pad = mp.pad[prob];
+    }
     constexpr int K = 3, NGQ = 8, NXQ = 11;
     extern __shared__ __attribute__((aligned(16))) float lds[];       // 4 * W32_WF floats
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5;
@@ -859,9 +879,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad32(W32P p, const float* __restr
         }
     };
 
-    const int wstride = gridDim.x * 4;
+    const int wstride = gx * 4;
     const int db = wstride / p.tiles, dt = wstride - db * p.tiles;
-    int unit = blockIdx.x * 4 + wid;
+    int unit = bx * 4 + wid;
     int b = unit / p.tiles, ti = unit - b * p.tiles;
     if (unit < p.nunits) gload(b, ti);
     const float* ap = Gs + (lane & 31) * W32_PG + h;
@@ -968,9 +988,71 @@ int msw32_bwd_weight(const ConvP& c, const float* x, const float* gy, const floa
         attr_set = true;
     }
     if (y_act && c.act == MS_ACT_LRELU)
-        hipLaunchKernelGGL(k_wgrad32<1>, dim3(g), dim3(256), lds, s, p, x, gy, y_act, partial, stride);
+        hipLaunchKernelGGL(k_wgrad32<1>, dim3(g), dim3(256), lds, s, p, x, gy, y_act, partial, stride, W32Multi{});
     else
-        hipLaunchKernelGGL(k_wgrad32<0>, dim3(g), dim3(256), lds, s, p, x, gy, gy, partial, stride);
+        hipLaunchKernelGGL(k_wgrad32<0>, dim3(g), dim3(256), lds, s, p, x, gy, gy, partial, stride, W32Multi{});
     MS_CHECK_LAUNCH();
     return msm_wgrad_reduce(partial, stride, g, (size_t)32 * 32 * 3, 32, gw, gb, beta, s);
+}
+
+// n 32 -> 32 k3 LeakyReLU weight gradients of one length (a ResidualStack's six) in one launch pair:
+// each problem gets 512/n workgroups, i.e. n times more units per wave and the same slab bytes in total
+static bool w32_multi_ok(const ConvP* cs, int n) {
+    const char* e = getenv("MSYNTH_WMULTI");
+    if (e && atoi(e) == 0) return false;
+    if (n < 2 || n > WR_MULTI_MAX) return false;
+    for (int i = 0; i < n; ++i) {
+        if (!msw32_applicable(cs[i]) || cs[i].B != cs[0].B || cs[i].Lin != cs[0].Lin || cs[i].act != MS_ACT_LRELU ||
+            cs[i].slope != cs[0].slope)
+            return false;
+    }
+    return true;
+}
+
+size_t msw32_multi_ws(const ConvP* cs, int n) {
+    if (!w32_multi_ok(cs, n)) return 0;
+    return (size_t)n * (512 / n) * (32 * 32 * 3 + 32) * sizeof(float);
+}
+
+int msw32_bwd_weight_multi(const ConvP* cs, int n, const float* const* x, const float* const* gy,
+                           const float* const* y_act, float* const* gw, float* const* gb, const float* beta,
+                           void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!w32_multi_ok(cs, n)) return MS_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < msw32_multi_ws(cs, n) || (((uintptr_t)ws) & 15)) return MS_ERR_UNSUPPORTED;
+    W32Multi mp;
+    WrReduceMulti o;
+    mp.n = n;
+    const ConvP& c = cs[0];
+    const int units = c.B * ms_ceil_div(c.Lin, 64);
+    int g_per = 512 / n;
+    if (g_per > ms_ceil_div(units, 4)) g_per = ms_ceil_div(units, 4);
+    mp.g_per = g_per;
+    for (int i = 0; i < n; ++i) {
+        if (!x[i] || !gy[i] || !y_act[i] || !gw[i] || !gb[i]) return MS_ERR_UNSUPPORTED;
+        if (((((uintptr_t)x[i]) | ((uintptr_t)gy[i]) | ((uintptr_t)y_act[i]) | ((uintptr_t)gw[i]) | ((uintptr_t)gb[i])) & 15) != 0)
+            return MS_ERR_UNSUPPORTED;
+        if (beta[i] != 0.f && beta[i] != 1.f) return MS_ERR_INVALID_ARG;
+        mp.x[i] = x[i]; mp.g[i] = gy[i]; mp.gact[i] = y_act[i];
+        mp.dil[i] = cs[i].dil; mp.pad[i] = cs[i].pad;
+        o.gw[i] = gw[i]; o.gb[i] = gb[i]; o.beta[i] = beta[i];
+    }
+    W32P p;
+    p.B = c.B; p.L = c.Lin; p.dil = c.dil; p.pad = c.pad; p.slope = c.slope;
+    p.tiles = ms_ceil_div(c.Lin, 64); p.nunits = c.B * p.tiles;
+    const size_t stride = 32 * 32 * 3 + 32;
+    float* partial = (float*)ws;
+    const size_t lds = (size_t)4 * W32_WF * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_wgrad32<1>, dim3(n * g_per), dim3(256), lds, s, p, x[0], gy[0], y_act[0], partial, stride, mp);
+    MS_CHECK_LAUNCH();
+    // slabs of problem i: workgroups [i*g_per, (i+1)*g_per) -> slice stride = one slab, problem stride = g_per slabs
+    const size_t wsize = 32 * 32 * 3, total = wsize + 32;
+    hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3((unsigned)((total / 4 + 63) / 64), (unsigned)n), dim3(256), 0, s,
+                       partial, stride, (size_t)g_per * stride, g_per, wsize, total, o);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
 }

@@ -378,7 +378,9 @@ def test_kernel_generations_agree(shape, monkeypatch):
     ("stack_c64", 2, 64, 1024, (1, 9, 1, 3, 1, 1), (False,) * 6),
     ("stack_c256_short", 5, 256, 64, (9, 1, 3), (True, False, True)),
     ("pair_c192_ragged_m", 2, 192, 256, (3, 1), (False, False)),
-    ("fallback_c32", 2, 32, 512, (1, 3, 9, 1), (False, True, False, False)),       # per-wave kernel, entry by entry
+    ("stack_c32", 2, 32, 512, (1, 3, 9, 1), (False, True, False, False)),          # batched per-wave kernel
+    ("stack_c32_full", 3, 32, 2048, (1, 9, 1, 3, 1, 1), (False,) * 6),
+    ("fallback_c32_odd", 2, 32, 130, (1, 3), (False, False)),                      # entry by entry
     ("fallback_odd_len", 2, 128, 130, (1, 3), (False, False)),                     # unaligned rows
 ], ids=lambda c: c[0])
 def test_wgrad_multi_matches_single_calls(case):
