@@ -433,7 +433,9 @@ WrPlan plan_wrows(const ConvP& c) {
     WrP& p = q.p;
     p.B = c.B; p.CK = c.Cin; p.L = c.Lin; p.M = c.Cout; p.dil = c.dil; p.pad = c.pad;
     p.g_kind = c.act; p.x_kind = c.in_act ? MS_MOD_LRELU_FWD : MS_ACT_NONE; p.slope = c.slope;
-    if (p.L >= KMAX) { p.Lt = KMAX; p.R = 1; p.tiles_per_row = ms_ceil_div(p.L, KMAX); p.nchunks = p.B * p.tiles_per_row; }
+    static const int lt_env = getenv("MSYNTH_WLT") ? atoi(getenv("MSYNTH_WLT")) : 0;   // tuning switch: 32-column chunks
+    const int LT = (lt_env == 32 && p.L % 32 == 0) ? 32 : KMAX;
+    if (p.L >= KMAX) { p.Lt = LT; p.R = 1; p.tiles_per_row = ms_ceil_div(p.L, LT); p.nchunks = p.B * p.tiles_per_row; }
     else {
         p.Lt = p.L;
         p.R = (KMAX + H) / (p.L + H);
