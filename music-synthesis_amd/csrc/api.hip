@@ -81,6 +81,8 @@ int ms_conv1d_fwd(const ms_conv1d_desc* d, const float* x, const float* w, const
     // activation in front of the conv: applied to x on load (operand modifier "LeakyReLU of the value")
     const float* xa = p.in_act ? x : nullptr;
     const int xk = p.in_act ? MS_MOD_LRELU_FWD : 0;
+    if (mst_fwd_short_applicable(p) && !y_act && !residual)   // judge conv: a 12-MFLOP reduction, not a GEMM
+        return mst_conv1d_fwd(p, x, w, bias, residual, y, s);
     if (msm_fwd_applicable(p))
         return msm_conv1d_fwd(p, x, xa, xk, w, bias, residual, y, y_act, workspace, workspace_bytes, s);
     if (msg_fwd_applicable(p) && !residual && !y_act && !p.in_act) return msg_conv1d_fwd(p, x, w, bias, y, s);
@@ -211,6 +213,7 @@ size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which) {
 const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which) {
     ConvP p;
     if (!make_conv(d, &p)) return "";
+    if (which == 0 && mst_fwd_short_applicable(p)) return mst_fwd_name(p);
     if (which == 0)
         return msm_fwd_applicable(p) ? msm_fwd_name(p)
                : (msg_fwd_applicable(p) ? msg_fwd_name(p)

@@ -2,6 +2,7 @@
 #pragma once
 #include "ms_common.h"
 
+bool mst_fwd_short_applicable(const ConvP& p);   // deep one-output conv on short rows (judge conv): ahead of the GEMM kernels
 bool mst_fwd_applicable(const ConvP& p);
 bool mst_bwd_data_applicable(const ConvP& p);
 bool mst_bwd_weight_applicable(const ConvP& p);

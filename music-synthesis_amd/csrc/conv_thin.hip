@@ -300,6 +300,44 @@ __global__ __launch_bounds__(256) void k_thin_wgrad(int B, int C, int L, int pad
     }
 }
 
+// ------------------------------------------------------------------ deep one-output conv on short rows
+// The judge conv (1024 -> 1, k3, L = 32 / 17 / 9; discriminator/full.py:22): 12 MFLOP per launch -- as a
+// row-tile GEMM with split-K it cost 31 us + a finish launch.  Here a workgroup owns one batch row: thread
+// i walks channels i, i+256, ... over the whole (short) row keeping L accumulators, then the block sums.
+template <int LT>
+__global__ __launch_bounds__(256) void k_thin_short_fwd(int C, int L, int act, float slope,
+                                                       const float* __restrict__ x,
+                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ bias,
+                                                       float* __restrict__ y) {
+    __shared__ float red[4][LT];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, b = blockIdx.x;
+    float acc[LT];
+#pragma unroll
+    for (int t = 0; t < LT; ++t) acc[t] = 0.f;
+    for (int c = tid; c < C; c += 256) {
+        const float w0 = w[c * 3], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2];
+        const float* row = x + ((size_t)b * C + c) * L;
+        float v[LT + 2];
+        v[0] = 0.f;
+#pragma unroll
+        for (int t = 0; t < LT; ++t) v[t + 1] = t < L ? row[t < L ? t : 0] : 0.f;
+        v[LT + 1] = 0.f;
+#pragma unroll
+        for (int t = 0; t < LT; ++t) acc[t] += w0 * v[t] + w1 * v[t + 1] + w2 * v[t + 2];
+    }
+#pragma unroll
+    for (int t = 0; t < LT; ++t) {
+        const float sred = ms_wave_sum(acc[t]);
+        if (lane == 0) red[wid][t] = sred;
+    }
+    __syncthreads();
+    if (tid < L) {
+        const float tot = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]) + (bias ? bias[0] : 0.f);
+        y[(size_t)b * L + tid] = ms_apply_act(tot, act, slope);
+    }
+}
+
 bool thin_common(const ConvP& p) {
     return p.groups == 1 && p.stride == 1 && p.dil == 1 && p.pad_mode == MS_PAD_ZERO &&
            p.Lout == p.Lin && !p.in_act && 2 * p.pad == p.K - 1 && p.B <= 65535;
@@ -307,14 +345,19 @@ bool thin_common(const ConvP& p) {
 bool role0(const ConvP& p) { return thin_common(p) && p.Cout == 1 && p.K == 7 && p.Cin <= 32 && p.Cin >= 4; }
 bool role1(const ConvP& p) { return thin_common(p) && p.Cin == 1 && p.K == 15 && p.Cout <= 16 && p.Cout >= 4; }
 bool aligned16(const void* a) { return (((uintptr_t)a) & 15) == 0; }
+// deep contraction, one output channel, short rows (the judge conv)
+bool role_short(const ConvP& p) {
+    return thin_common(p) && p.Cout == 1 && p.K == 3 && p.Cin >= 256 && p.Lin <= 64;
+}
 
 }  // namespace
 
-bool mst_fwd_applicable(const ConvP& p) { return role0(p); }
+bool mst_fwd_applicable(const ConvP& p) { return role0(p) || role_short(p); }
+bool mst_fwd_short_applicable(const ConvP& p) { return role_short(p); }
 bool mst_bwd_data_applicable(const ConvP& p) { return role0(p) || role1(p); }
 bool mst_bwd_weight_applicable(const ConvP& p) { return role0(p) || role1(p); }
 
-const char* mst_fwd_name(const ConvP&) { return "k_thin_reduce<7, false>"; }
+const char* mst_fwd_name(const ConvP& p) { return role_short(p) ? "k_thin_short_fwd" : "k_thin_reduce<7, false>"; }
 const char* mst_bwd_data_name(const ConvP& p) { return role0(p) ? "k_thin_expand<7, true>" : "k_thin_reduce<15, true>"; }
 const char* mst_bwd_weight_name(const ConvP& p) { return role0(p) ? "k_thin_wgrad<7, 0, 8>" : "k_thin_wgrad<15, 1, 4>"; }
 
@@ -322,6 +365,18 @@ static unsigned thin_grid(const ConvP& p) { return (unsigned)(p.B * ms_ceil_div(
 
 int mst_conv1d_fwd(const ConvP& p, const float* x, const float* w, const float* bias,
                    const float* residual, float* y, hipStream_t s) {
+    if (role_short(p)) {
+        if (residual) return MS_ERR_UNSUPPORTED;
+        const dim3 g((unsigned)p.B);
+        if (p.Lin <= 16)
+            hipLaunchKernelGGL(k_thin_short_fwd<16>, g, dim3(256), 0, s, p.Cin, p.Lin, p.act, p.slope, x, w, bias, y);
+        else if (p.Lin <= 32)
+            hipLaunchKernelGGL(k_thin_short_fwd<32>, g, dim3(256), 0, s, p.Cin, p.Lin, p.act, p.slope, x, w, bias, y);
+        else
+            hipLaunchKernelGGL(k_thin_short_fwd<64>, g, dim3(256), 0, s, p.Cin, p.Lin, p.act, p.slope, x, w, bias, y);
+        MS_CHECK_LAUNCH();
+        return MS_OK;
+    }
     const bool vec = p.Lin % 4 == 0 && aligned16(x);
     const dim3 grid(thin_grid(p));
     if (vec)

@@ -234,6 +234,9 @@ HOT_CONVS = [
     ("d_judge", 2, 1024, 9, 1, 3, 1, 1, 1, 1, 0, False),
     ("d_judge_l32", 5, 1024, 32, 1, 3, 1, 1, 1, 1, 0, False),
     ("d_judge_l17", 3, 1024, 17, 1, 3, 1, 1, 1, 1, 0, False),
+    ("d_judge_l64_c320", 2, 320, 64, 1, 3, 1, 1, 1, 1, 0, False),
+    ("d_judge_l33", 2, 256, 33, 1, 3, 1, 1, 1, 1, 0, False),
+    ("d_judge_l1", 4, 512, 1, 1, 3, 1, 1, 1, 1, 0, False),
     # MFMA implicit-GEMM edge cases: M / N / K-dimension tails, the 128x128 tile, no activation
     ("mfma_m48_k120", 3, 40, 77, 48, 3, 1, 3, 3, 1, 1, False),
     ("mfma_m96_k5", 2, 36, 41, 96, 5, 1, 2, 1, 1, 0, False),
