@@ -309,6 +309,26 @@ def _scale_has_grad(g_feats, g_judges, s):
     return gj is not None or (gf is not None and any(t is not None for t in gf)), gf, gj
 
 
+def _flat_view(sink, params):
+    """(flat tensor spanning the sink's destination slots, per-parameter offsets, length) when the slots
+    are consecutive 16-byte aligned views of one buffer (a FlatAdam gradient bucket) that already hold
+    values to accumulate into; else (None, None, 0)."""
+    if len(sink.t) != len(params) or any(t is None for t in sink.t) or not all(sink.acc):
+        return None, None, 0
+    offs, total = [], 0
+    base = sink.t[0]
+    for t, p in zip(sink.t, params):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != p.shape or \
+                t.untyped_storage().data_ptr() != base.untyped_storage().data_ptr() or \
+                t.storage_offset() - base.storage_offset() != total:
+            return None, None, 0
+        offs.append(total)
+        total += (p.numel() + 3) // 4 * 4
+    if base.storage_offset() + total > base.untyped_storage().nbytes() // 4:
+        return None, None, 0
+    return base.as_strided((total,), (1,)), offs, total
+
+
 def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, need_wgrad=True):
     tapes, xs = ctx
     n = len(tapes)
@@ -319,6 +339,10 @@ def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, nee
         main = torch.cuda.current_stream(dev)
         side = _side_streams(dev, n - 1)
         tmp = [None] * n
+        flat_tmp = [None] * n
+        # when the destination slots are one flat bucket (FlatAdam), every side scale writes into a private
+        # bucket of the same layout, folded in afterwards with ONE add instead of one per parameter
+        flat_main, offs, total = (_flat_view(sink, params) if need_wgrad else (None, None, 0))
         for s in range(1, n):
             has, gf, gj = _scale_has_grad(g_feats, g_judges, s)
             if not has:
@@ -326,7 +350,12 @@ def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, nee
             st = side[s - 1]
             st.wait_stream(main)
             with torch.cuda.stream(st):
-                tmp[s] = GradSink(D_NPARAMS)          # own slabs: no cross-stream accumulation
+                if flat_main is not None:
+                    flat_tmp[s] = torch.zeros_like(flat_main)
+                    views = [flat_tmp[s][o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
+                    tmp[s] = GradSink(D_NPARAMS, views, [False] * D_NPARAMS)
+                else:
+                    tmp[s] = GradSink(D_NPARAMS)      # own slabs: no cross-stream accumulation
                 gxs[s] = disc_backward(tapes[s], params, gf, gj, tmp[s], need_gx=need_gx,
                                        need_wgrad=need_wgrad)
         has, gf, gj = _scale_has_grad(g_feats, g_judges, 0)
@@ -337,6 +366,11 @@ def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, nee
             main.wait_stream(st)
         for s in range(1, n):                          # fold the side-stream weight grads in
             if tmp[s] is None:
+                continue
+            if flat_tmp[s] is not None:
+                P.add_(flat_main, flat_tmp[s])
+                for i in range(D_NPARAMS):
+                    sink.acc[i] = True
                 continue
             for i in range(D_NPARAMS):
                 if tmp[s].t[i] is None:
