@@ -377,6 +377,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 // descriptor.  2048 elements per block in the forward (partial sum per block, folded per map in a
 // fixed order by one block), 2048 per block in the backward.
 namespace {
+constexpr int L1M_FWD_EPB = 16384;       // elements per forward block (the backward keeps 2048)
 struct L1MultiK {
     ms_l1_multi_desc d;
     int blk0[MS_L1_MULTI_MAX + 1];       // first block of map i
@@ -395,16 +396,23 @@ __global__ __launch_bounds__(256) void k_l1_multi_fwd(L1MultiK k, float* __restr
     const float* r = k.d.r[m];
     const float* f = k.d.f[m];
     const int64_t n = k.d.n[m];
-    const int64_t base = (int64_t)(blockIdx.x - k.blk0[m]) * 2048;
-    float v[8];
+    // L1M_FWD_EPB elements per block in 2048-element rounds: 8x fewer partials for the single-block fold
+    const int64_t base0 = (int64_t)(blockIdx.x - k.blk0[m]) * L1M_FWD_EPB;
+    float s = 0.f;
+#pragma unroll 1
+    for (int rnd = 0; rnd < L1M_FWD_EPB / 2048; ++rnd) {
+        const int64_t base = base0 + (int64_t)rnd * 2048;
+        if (base >= n) break;
+        float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int64_t e = base + threadIdx.x + 256 * i;
-        const int64_t ec = e < n ? e : 0;
-        const float d = f[ec] - r[ec];
-        v[i] = e < n ? fabsf(d) : 0.f;
+        for (int i = 0; i < 8; ++i) {
+            const int64_t e = base + threadIdx.x + 256 * i;
+            const int64_t ec = e < n ? e : 0;
+            const float d = f[ec] - r[ec];
+            v[i] = e < n ? fabsf(d) : 0.f;
+        }
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
-    const float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     const float tot = ms_block_sum(s, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
 }
@@ -451,14 +459,14 @@ __global__ __launch_bounds__(256) void k_l1_multi_bwd(L1MultiK k, const float* _
     }
 }
 
-bool l1m_plan(const ms_l1_multi_desc* d, L1MultiK* k) {
+bool l1m_plan(const ms_l1_multi_desc* d, L1MultiK* k, int epb = 2048) {
     if (!d || d->count <= 0 || d->count > MS_L1_MULTI_MAX) return false;
     k->d = *d;
     long long blk = 0;
     for (int i = 0; i < d->count; ++i) {
         if (!d->r[i] || !d->f[i] || d->n[i] <= 0) return false;
         k->blk0[i] = (int)blk;
-        blk += (d->n[i] + 2047) / 2048;
+        blk += (d->n[i] + epb - 1) / epb;
         if (blk > (1 << 30)) return false;
     }
     for (int i = d->count; i <= MS_L1_MULTI_MAX; ++i) k->blk0[i] = (int)blk;
@@ -613,14 +621,14 @@ int ms_l1_mean_bwd(const float* r, const float* f, int64_t n, const float* gout,
 
 size_t ms_l1_mean_multi_workspace_bytes(const ms_l1_multi_desc* d) {
     L1MultiK k;
-    if (!l1m_plan(d, &k)) return 0;
+    if (!l1m_plan(d, &k, L1M_FWD_EPB)) return 0;
     return (size_t)k.blk0[MS_L1_MULTI_MAX] * sizeof(float);
 }
 
 int ms_l1_mean_multi_fwd(const ms_l1_multi_desc* d, float* out, void* ws, size_t wsb,
                          ms_stream_t stream) {
     L1MultiK k;
-    if (!out || !l1m_plan(d, &k)) return MS_ERR_INVALID_ARG;
+    if (!out || !l1m_plan(d, &k, L1M_FWD_EPB)) return MS_ERR_INVALID_ARG;
     const int nblk = k.blk0[MS_L1_MULTI_MAX];
     if (!ws || wsb < (size_t)nblk * sizeof(float)) return MS_ERR_WORKSPACE;
     hipLaunchKernelGGL(k_l1_multi_fwd, dim3(nblk), dim3(256), 0, (hipStream_t)stream, k, (float*)ws);
