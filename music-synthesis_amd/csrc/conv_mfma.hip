@@ -1187,9 +1187,13 @@ int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, 
     {
         Row2P q;
         int tile, am, in_s_eff;
-        if (rows2_pick(cfg, K, CC, HAS_ACT, EPI_S, IN_S, p, X, Xact, W, res, Y, Yact, &q, &tile, &am, &in_s_eff))
+        if (rows2_pick(cfg, K, CC, HAS_ACT, EPI_S, IN_S, p, X, Xact, W, res, Y, Yact, &q, &tile, &am, &in_s_eff)) {
+            if (EPI_S == 0 && IN_S == 1 && in_s_eff == 1 && (cfg == ROW_128x128 || cfg == ROW_64x128) &&
+                msr2h_supported(K, CC, am, q, res != nullptr, Yact != nullptr))
+                return msr2h_launch(K, CC, am, q, X, Xact, am == 1 ? p.Wfwd : W, bias, res, Y, Yact, s);
             return msr2_launch(tile, K, CC, am, EPI_S, q, X, Xact, am == 1 ? p.Wfwd : W, bias, res, Y, Yact, grid.x,
                                grid.y, grid.z, s, in_s_eff);
+        }
     }
     const size_t lds = (size_t)(bm * (CC * K + 1) + CC * p.RSZ) * sizeof(float);
     if (lds > 64 * 1024) return MS_ERR_UNSUPPORTED;
@@ -1238,7 +1242,7 @@ int launch_rows(int K, RowCfg cfg, const RowP& p, const float* X, const float* X
 // name of the kernel a row-tile launch resolves to (16-byte aligned tensors assumed): the pipelined
 // second generation where its requirements hold (conv_rows2.hip), else the first
 const char* row_kname(RowCfg c, int K, bool act, int CK, int L = 0, int R = 1, int SS = 0, int pad_mode = MS_PAD_ZERO,
-                      int in_act = MS_ACT_LRELU, int epi_s = 0) {
+                      int in_act = MS_ACT_LRELU, int epi_s = 0, int B = 0, int M = 0) {
     static thread_local char buf[96];
     const char* tile = row_tile_str(c);
     const int CC = epi_s ? row_cc(K) : row_cc(K) * (row_deep(K, CK) ? 2 : 1);
@@ -1254,6 +1258,14 @@ const char* row_kname(RowCfg c, int K, bool act, int CK, int L = 0, int R = 1, i
             return buf;
         }
         if (msr2_supported(t2, K, CC, am, epi_s, q)) {
+            if (epi_s == 0 && (c == ROW_128x128 || c == ROW_64x128) && B > 0 && M > 0) {
+                Row2P h = q;
+                h.B = B; h.M = M; h.CK = CK; h.CKs = CK; h.PX = SS;
+                if (msr2h_supported(K, CC, am, h, false, false)) {
+                    snprintf(buf, sizeof(buf), "k_conv_rows2h<%d, %d, %d>", K, CC, am);
+                    return buf;
+                }
+            }
             snprintf(buf, sizeof(buf), "k_conv_rows2<%s, %d, %d, %d, %d>", tile, K, CC, am, epi_s);
             return buf;
         }
@@ -1410,7 +1422,8 @@ const char* msm_fwd_name(const ConvP& p) {
         RowP r;
         const RowCfg cfg = pick_row_cfg(p.Cout, p.B, p.Lin);
         make_rowp(&r, cfg, p.B, p.Cin, p.Lin, p.Cout, p.K, p.dil, -p.pad, p.pad_mode, 0, 0, 0.f);
-        return row_kname(cfg, p.K, p.in_act != 0, p.Cin, p.Lin, r.R, r.SS, p.pad_mode, p.in_act ? MS_MOD_LRELU_FWD : 0);
+        return row_kname(cfg, p.K, p.in_act != 0, p.Cin, p.Lin, r.R, r.SS, p.pad_mode, p.in_act ? MS_MOD_LRELU_FWD : 0, 0,
+                         p.B, p.Cout);
     }
     return kname("k_igemm_conv", pick_cfg(p.Cout, (long long)p.B * p.Lin), p.K, ", false");
 }
@@ -1419,7 +1432,7 @@ const char* msm_bwd_data_name(const ConvP& p) {
         RowP r;
         const RowCfg cfg = pick_row_cfg(p.Cin, p.B, p.Lin);
         make_rowp(&r, cfg, p.B, p.Cout, p.Lin, p.Cin, p.K, p.dil, 0, 0, 0, 0, 0.f);
-        return row_kname(cfg, p.K, p.act != MS_ACT_NONE, p.Cout, p.Lin, r.R, r.SS, MS_PAD_ZERO, p.act);
+        return row_kname(cfg, p.K, p.act != MS_ACT_NONE, p.Cout, p.Lin, r.R, r.SS, MS_PAD_ZERO, p.act, 0, p.B, p.Cin);
     }
     return kname("k_igemm_conv", pick_cfg(p.Cin, (long long)p.B * p.Lin), p.K, ", true");
 }
