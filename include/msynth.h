@@ -250,6 +250,29 @@ int ms_l1_mean_multi_fwd(const ms_l1_multi_desc* d, float* out, void* workspace,
                          size_t workspace_bytes, ms_stream_t stream);
 int ms_l1_mean_multi_bwd(const ms_l1_multi_desc* d, const float* gout, float scale,
                          ms_stream_t stream);
+/*
+ * The GAN terms over the (small) judgement tensors of all discriminator scales in ONE launch each way:
+ *   kind MS_JUDGE_HINGE_D:  out[0] = sum_i mean(relu(1 - r_i) + relu(1 + f_i))      (loss/loss.py:17-25)
+ *   kind MS_JUDGE_NEG_MEAN: out[0] = sum_i mean(-f_i)                                (loss/loss.py:9, 68-78)
+ * n[i] <= MS_JUDGE_MULTI_NMAX (one workgroup folds every tensor in a fixed order: deterministic).
+ * Backward writes gr[i] / gf[i] (either may be NULL) = d(out)/d r_i, f_i * gout[0] * scale.
+ */
+#define MS_JUDGE_MULTI_MAX 8
+#define MS_JUDGE_MULTI_NMAX (1 << 20)
+#define MS_JUDGE_HINGE_D 0
+#define MS_JUDGE_NEG_MEAN 1
+typedef struct ms_judge_multi_desc {
+    int32_t count;
+    int32_t kind;
+    const float* r[MS_JUDGE_MULTI_MAX];        /* unused for NEG_MEAN */
+    const float* f[MS_JUDGE_MULTI_MAX];
+    float* gr[MS_JUDGE_MULTI_MAX];
+    float* gf[MS_JUDGE_MULTI_MAX];
+    int64_t n[MS_JUDGE_MULTI_MAX];
+} ms_judge_multi_desc;
+int ms_judge_loss_multi_fwd(const ms_judge_multi_desc* d, float* out, ms_stream_t stream);
+int ms_judge_loss_multi_bwd(const ms_judge_multi_desc* d, const float* gout, float scale,
+                            ms_stream_t stream);
 /* out[0] = sum_i coef[i] * (*terms[i]) for n device scalars laid out contiguously in `terms` */
 int ms_weighted_sum(const float* terms, const float* coef, int32_t n, float* out,
                     ms_stream_t stream);

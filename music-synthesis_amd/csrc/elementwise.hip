@@ -284,6 +284,42 @@ __global__ __launch_bounds__(256) void k_hinge_d_bwd(const float* __restrict__ r
     }
 }
 
+// all judgement tensors of a loss in one launch (ms_judge_multi_desc by value)
+__global__ __launch_bounds__(256) void k_judge_multi_fwd(ms_judge_multi_desc d, float* __restrict__ out) {
+    __shared__ float red[4];
+    float total = 0.f;
+    for (int i = 0; i < d.count; ++i) {
+        const float* r = d.r[i];
+        const float* f = d.f[i];
+        const int64_t n = d.n[i];
+        float s = 0.f;
+        for (int64_t e = threadIdx.x; e < n; e += 256)
+            s += d.kind == MS_JUDGE_HINGE_D ? fmaxf(1.f - r[e], 0.f) + fmaxf(1.f + f[e], 0.f) : -f[e];
+        const float t = ms_block_sum(s, red);
+        if (threadIdx.x == 0) total += t / (float)n;
+    }
+    if (threadIdx.x == 0) out[0] = total;
+}
+
+__global__ __launch_bounds__(256) void k_judge_multi_bwd(ms_judge_multi_desc d, const float* __restrict__ gout,
+                                                        float scale) {
+    const int i = blockIdx.y;
+    const int64_t n = d.n[i];
+    const float g = gout[0] * scale / (float)n;
+    const float* r = d.r[i];
+    const float* f = d.f[i];
+    float* gr = d.gr[i];
+    float* gf = d.gf[i];
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        if (d.kind == MS_JUDGE_HINGE_D) {
+            if (gr) gr[e] = (1.f - r[e] > 0.f) ? -g : 0.f;
+            if (gf) gf[e] = (1.f + f[e] > 0.f) ? g : 0.f;
+        } else if (gf) {
+            gf[e] = -g;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_fill_scaled(int64_t n, const float* __restrict__ gout,
                                                     float scale, float* __restrict__ out) {
     const float g = gout[0] * scale / (float)n;
@@ -588,6 +624,37 @@ int ms_hinge_d_bwd(const float* r, const float* f, int64_t n, const float* gout,
     if (!r || !f || !gout || n <= 0) return MS_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_hinge_d_bwd, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, r, f, n,
                        gout, scale, gr, gf);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+static bool judge_multi_ok(const ms_judge_multi_desc* d, int64_t* nmax) {
+    if (!d || d->count <= 0 || d->count > MS_JUDGE_MULTI_MAX) return false;
+    if (d->kind != MS_JUDGE_HINGE_D && d->kind != MS_JUDGE_NEG_MEAN) return false;
+    *nmax = 0;
+    for (int i = 0; i < d->count; ++i) {
+        if (!d->f[i] || (d->kind == MS_JUDGE_HINGE_D && !d->r[i])) return false;
+        if (d->n[i] <= 0 || d->n[i] > MS_JUDGE_MULTI_NMAX) return false;
+        if (d->n[i] > *nmax) *nmax = d->n[i];
+    }
+    return true;
+}
+
+int ms_judge_loss_multi_fwd(const ms_judge_multi_desc* d, float* out, ms_stream_t stream) {
+    int64_t nmax;
+    if (!out || !judge_multi_ok(d, &nmax)) return MS_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_judge_multi_fwd, dim3(1), dim3(256), 0, (hipStream_t)stream, *d, out);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_judge_loss_multi_bwd(const ms_judge_multi_desc* d, const float* gout, float scale, ms_stream_t stream) {
+    int64_t nmax;
+    if (!gout || !judge_multi_ok(d, &nmax)) return MS_ERR_INVALID_ARG;
+    unsigned gx = (unsigned)((nmax + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_judge_multi_bwd, dim3(gx, (unsigned)d->count), dim3(256), 0, (hipStream_t)stream, *d, gout,
+                       scale);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }

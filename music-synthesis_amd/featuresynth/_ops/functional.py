@@ -279,21 +279,30 @@ class MelGanDiscLossCatFn(Function):
 
     @staticmethod
     def forward(ctx, n, B, *js):
+        ctx.cfg = (n, B)
+        ctx.js = js
+        if P.judge_multi_ok(js):                 # all scales in one launch
+            out = torch.empty((), dtype=torch.float32, device=js[0].device)
+            return P.judge_loss_multi_fwd(L.JUDGE_HINGE_D, [j[B:] for j in js], [j[:B] for j in js], out)
         terms = torch.empty((n,), dtype=torch.float32, device=js[0].device)
         for s in range(n):
             P.hinge_d_fwd(js[s][B:], js[s][:B], terms[s])
-        ctx.cfg = (n, B)
-        ctx.js = js
         return P.weighted_sum(terms, _coef([1.0] * n, terms.device))
 
     @staticmethod
     def backward(ctx, g):
         n, B = ctx.cfg
         g = _c(g)
+        need = [ctx.needs_input_grad[2 + s] for s in range(n)]
+        if P.judge_multi_ok(ctx.js) and all(need):
+            gjs = [torch.empty_like(j) for j in ctx.js]
+            P.judge_loss_multi_bwd(L.JUDGE_HINGE_D, [j[B:] for j in ctx.js], [j[:B] for j in ctx.js], g, 1.0,
+                                   [gj[B:] for gj in gjs], [gj[:B] for gj in gjs])
+            return (None, None) + tuple(gjs)
         outs = []
         for s in range(n):
             j = ctx.js[s]
-            if not ctx.needs_input_grad[2 + s]:
+            if not need[s]:
                 outs.append(None)
                 continue
             gj = torch.empty_like(j)
@@ -316,6 +325,11 @@ class MelGanGenLossFn(Function):
         ctx.cfg = (S, nf, fscale)
         ctx.ts = ts
         if nf <= L.L1_MULTI_MAX:     # all feature-matching terms in one launch pair
+            if P.judge_multi_ok(fj):  # ... and the S adversarial terms in one launch
+                terms = torch.empty((2,), dtype=torch.float32, device=dev)
+                P.judge_loss_multi_fwd(L.JUDGE_NEG_MEAN, None, list(fj), terms[0:])
+                P.l1_mean_multi_fwd(rf, ff, [1.0] * nf, terms[1:])
+                return P.weighted_sum(terms, _coef([1.0, fscale], dev))
             terms = torch.empty((S + 1,), dtype=torch.float32, device=dev)
             for s in range(S):
                 P.neg_mean_fwd(fj[s], terms[s])
@@ -342,7 +356,11 @@ class MelGanGenLossFn(Function):
         else:
             g_rf = [P.l1_mean_bwd(ff[i], rf[i], g, fscale) if need[i] else None for i in range(nf)]
             g_ff = [P.l1_mean_bwd(rf[i], ff[i], g, fscale) if need[nf + i] else None for i in range(nf)]
-        g_fj = [P.neg_mean_bwd(fj[s], g) if need[2 * nf + s] else None for s in range(S)]
+        if P.judge_multi_ok(fj) and all(need[2 * nf + s] for s in range(S)):
+            g_fj = [torch.empty_like(t) for t in fj]
+            P.judge_loss_multi_bwd(L.JUDGE_NEG_MEAN, None, list(fj), g, 1.0, None, g_fj)
+        else:
+            g_fj = [P.neg_mean_bwd(fj[s], g) if need[2 * nf + s] else None for s in range(S)]
         return (None, None, None) + tuple(g_rf) + tuple(g_ff) + tuple(g_fj)
 
 

@@ -40,6 +40,18 @@ class L1MultiDesc(ctypes.Structure):            # ms_l1_multi_desc
                 ("n", ctypes.c_int64 * L1_MULTI_MAX), ("w", _c_f * L1_MULTI_MAX)]
 
 
+JUDGE_MULTI_MAX = 8
+JUDGE_MULTI_NMAX = 1 << 20
+JUDGE_HINGE_D, JUDGE_NEG_MEAN = 0, 1
+
+
+class JudgeMultiDesc(ctypes.Structure):         # ms_judge_multi_desc
+    _fields_ = [("count", _c_int), ("kind", _c_int),
+                ("r", _vp * JUDGE_MULTI_MAX), ("f", _vp * JUDGE_MULTI_MAX),
+                ("gr", _vp * JUDGE_MULTI_MAX), ("gf", _vp * JUDGE_MULTI_MAX),
+                ("n", ctypes.c_int64 * JUDGE_MULTI_MAX)]
+
+
 WGRAD_MULTI_MAX = 8
 
 
@@ -85,6 +97,8 @@ SIGNATURES = {
     "ms_avg_pool1d_4_2_1_bwd": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _vp]),
     "ms_weight_norm_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _vp]),
     "ms_weight_norm_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_f, _vp]),
+    "ms_judge_loss_multi_fwd": (_c_int, [ctypes.POINTER(JudgeMultiDesc), _vp, _vp]),
+    "ms_judge_loss_multi_bwd": (_c_int, [ctypes.POINTER(JudgeMultiDesc), _vp, _c_f, _vp]),
     "ms_weight_norm_multi_fwd": (_c_int, [ctypes.POINTER(WnMultiDesc), _vp]),
     "ms_weight_norm_multi_bwd": (_c_int, [ctypes.POINTER(WnMultiDesc), _c_f, _vp]),
     "ms_act_bwd": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _c_f, _vp]),

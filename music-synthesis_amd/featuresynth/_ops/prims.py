@@ -439,6 +439,41 @@ def ls_d_bwd(r, f, gout, scale=1.0):
     return gr, gf
 
 
+def judge_multi_ok(ts):
+    return 0 < len(ts) <= L.JUDGE_MULTI_MAX and all(t is not None and t.numel() <= L.JUDGE_MULTI_NMAX for t in ts)
+
+
+def _judge_desc(kind, rs, fs, grs=None, gfs=None):
+    d = L.JudgeMultiDesc()
+    d.count, d.kind = len(fs), kind
+    for i, f in enumerate(fs):
+        L.require(f, "judgement")
+        d.f[i], d.n[i] = f.data_ptr(), f.numel()
+        if rs is not None:
+            L.require(rs[i], "real judgement")
+            if rs[i].numel() != f.numel():
+                raise RuntimeError("judge loss: real / fake judgement sizes differ")
+            d.r[i] = rs[i].data_ptr()
+        d.gr[i] = grs[i].data_ptr() if (grs is not None and grs[i] is not None) else None
+        d.gf[i] = gfs[i].data_ptr() if (gfs is not None and gfs[i] is not None) else None
+    return d
+
+
+def judge_loss_multi_fwd(kind, rs, fs, out):
+    """out[0] = sum over the scales of the hinge-D / negative-mean term, one launch."""
+    d = _judge_desc(kind, rs, fs)
+    n = sum(int(f.numel()) for f in fs)
+    L.call("ms_judge_loss_multi_fwd", _scost(n, 2 if rs is not None else 1, 0, 3), d, out.data_ptr(), L.stream())
+    return out
+
+
+def judge_loss_multi_bwd(kind, rs, fs, gout, scale, grs, gfs):
+    d = _judge_desc(kind, rs, fs, grs, gfs)
+    n = sum(int(f.numel()) for f in fs)
+    L.call("ms_judge_loss_multi_bwd", _scost(n, 2 if rs is not None else 0, 2), d, gout.data_ptr(), float(scale),
+           L.stream())
+
+
 def weighted_sum(terms, coef):
     """terms, coef: 1-D fp32 device tensors of equal length -> 0-d tensor sum(coef*terms)."""
     out = torch.empty((), dtype=torch.float32, device=terms.device)

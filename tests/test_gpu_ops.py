@@ -441,3 +441,27 @@ def test_two_half_row_kernel_matches(shape, monkeypatch):
         out[mode] = [host(t) for t in (y1, y2, ya2, y3, g1, g2)]
     for a, c in zip(out["0"], out["2"]):
         assert np.array_equal(a, c)
+
+
+def test_judge_loss_multi_matches_single_terms():
+    """The hinge-D / negative-mean terms of all scales in one launch == the sum of the per-scale kernels,
+    forward value and gradients (loss/loss.py:9-25 on judgements of 32 / 17 / 9 frames)."""
+    from featuresynth._ops import lib as L_, prims as P
+    rng = np.random.default_rng(3)
+    rs = [dev(rng.standard_normal((8, 1, n)).astype(np.float32) * 2) for n in (32, 17, 9)]
+    fs = [dev(rng.standard_normal((8, 1, n)).astype(np.float32) * 2) for n in (32, 17, 9)]
+    g = dev(np.array(0.7, dtype=np.float32))
+    for kind, use_r in ((L_.JUDGE_HINGE_D, True), (L_.JUDGE_NEG_MEAN, False)):
+        out = torch.empty((), dtype=torch.float32, device="cuda")
+        P.judge_loss_multi_fwd(kind, rs if use_r else None, fs, out)
+        ref = sum(float(P.hinge_d_fwd(r, f)) if use_r else float(P.neg_mean_fwd(f)) for r, f in zip(rs, fs))
+        assert abs(float(out) - ref) <= 1e-6 * max(1.0, abs(ref))
+        grs = [torch.empty_like(r) for r in rs] if use_r else None
+        gfs = [torch.empty_like(f) for f in fs]
+        P.judge_loss_multi_bwd(kind, rs if use_r else None, fs, g, 1.0, grs, gfs)
+        for i in range(3):
+            if use_r:
+                er, ef = P.hinge_d_bwd(rs[i], fs[i], g)
+                assert np.array_equal(host(grs[i]), host(er)) and np.array_equal(host(gfs[i]), host(ef))
+            else:
+                assert np.array_equal(host(gfs[i]), host(P.neg_mean_bwd(fs[i], g)))
