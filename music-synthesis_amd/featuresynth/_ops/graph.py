@@ -157,6 +157,7 @@ def gen_backward(tape, params, gy, sink=None):
     g = gy
     fork = _WgradFork(gy.device)
     batch = [] if os.environ.get("MSYNTH_WMULTI", "1") == "1" else None
+    deferred = []
     for rec in reversed(tape):
         kind = rec[0]
         if kind != "atom" and batch:
@@ -174,7 +175,15 @@ def gen_backward(tape, params, gy, sink=None):
             _, dt, hin, h = rec
             i -= 2
             gw, gb, acc = sink.pair(i)
-            fork.run(lambda: sink.put(i, *P.convt1d_bwd_weight(hin, g, h, dt, params[i].shape, gw, gb, acc)), hin, g, h)
+            if i == 2 and fork.on:
+                # the FIRST transposed conv is processed last: by then the side stream still holds the last
+                # stack's batched weight gradients while the main stream runs dry, so this one's weight
+                # gradient goes to the main stream, issued after conv0's (which forks off first, below)
+                def late(i=i, dt=dt, hin=hin, h=h, g=g, gw=gw, gb=gb, acc=acc):
+                    sink.put(i, *P.convt1d_bwd_weight(hin, g, h, dt, params[i].shape, gw, gb, acc))
+                deferred.append(late)
+            else:
+                fork.run(lambda: sink.put(i, *P.convt1d_bwd_weight(hin, g, h, dt, params[i].shape, gw, gb, acc)), hin, g, h)
             g = P.convt1d_bwd_data(g, h, params[i], dt)
         else:  # conv0: no gradient flows to the mel features
             _, d, x, h = rec
@@ -183,6 +192,8 @@ def gen_backward(tape, params, gy, sink=None):
             fork.run(lambda: sink.put(i, *P.conv1d_bwd_weight(x, g, h, d, params[i].shape, gw, gb, acc)), x, g, h)
     if batch:
         flush_wgrad_batch(batch, sink, fork)
+    for fn in deferred:
+        fn()
     fork.join()
     assert i == 0
     return sink
