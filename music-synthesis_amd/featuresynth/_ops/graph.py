@@ -354,12 +354,22 @@ def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, nee
         # when the destination slots are one flat bucket (FlatAdam), every side scale writes into a private
         # bucket of the same layout, folded in afterwards with ONE add instead of one per parameter
         flat_main, offs, total = (_flat_view(sink, params) if need_wgrad else (None, None, 0))
+        # the full-rate scale has the most work: it is issued FIRST (longest job first), the side scales
+        # fork off the point before it through an event instead of waiting for the main stream's tail
+        fork_ev = torch.cuda.Event()
+        fork_ev.record(main)
+        first = os.environ.get("MSYNTH_SCALE0_FIRST", "1") == "1"
+        if first:
+            has, gf, gj = _scale_has_grad(g_feats, g_judges, 0)
+            if has:
+                gxs[0] = disc_backward(tapes[0], params, gf, gj, sink, need_gx=need_gx,
+                                       need_wgrad=need_wgrad)
         for s in range(1, n):
             has, gf, gj = _scale_has_grad(g_feats, g_judges, s)
             if not has:
                 continue
             st = side[s - 1]
-            st.wait_stream(main)
+            st.wait_event(fork_ev)
             with torch.cuda.stream(st):
                 if flat_main is not None:
                     flat_tmp[s] = torch.zeros_like(flat_main)
@@ -369,10 +379,11 @@ def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, nee
                     tmp[s] = GradSink(D_NPARAMS)      # own slabs: no cross-stream accumulation
                 gxs[s] = disc_backward(tapes[s], params, gf, gj, tmp[s], need_gx=need_gx,
                                        need_wgrad=need_wgrad)
-        has, gf, gj = _scale_has_grad(g_feats, g_judges, 0)
-        if has:
-            gxs[0] = disc_backward(tapes[0], params, gf, gj, sink, need_gx=need_gx,
-                                   need_wgrad=need_wgrad)
+        if not first:
+            has, gf, gj = _scale_has_grad(g_feats, g_judges, 0)
+            if has:
+                gxs[0] = disc_backward(tapes[0], params, gf, gj, sink, need_gx=need_gx,
+                                       need_wgrad=need_wgrad)
         for st in side:
             main.wait_stream(st)
         for s in range(1, n):                          # fold the side-stream weight grads in
