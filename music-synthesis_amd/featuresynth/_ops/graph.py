@@ -297,12 +297,20 @@ def melgan_forward(x, params, scales=2):
     if scales > 0 and _concurrent_scales() and not _on_aux(x.device):   # forks are kept one level deep
         main = torch.cuda.current_stream(x.device)
         side = _side_streams(x.device, scales)
+        # longest job first: the full-rate pass is issued before the pooled ones, which fork off an event
+        # recorded ahead of it (see melgan_backward)
+        first = os.environ.get("MSYNTH_SCALE0_FIRST", "1") == "1"
+        fork_ev = torch.cuda.Event()
+        fork_ev.record(main)
+        if first:
+            res[0] = disc_forward(xs[0], params)
         for s in range(1, scales + 1):
             st = side[s - 1]
-            st.wait_stream(main)
+            st.wait_event(fork_ev)
             with torch.cuda.stream(st):
                 res[s] = disc_forward(xs[s], params)
-        res[0] = disc_forward(xs[0], params)
+        if not first:
+            res[0] = disc_forward(xs[0], params)
         for st in side:
             main.wait_stream(st)
     else:
