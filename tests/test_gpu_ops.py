@@ -7,7 +7,7 @@ gradients within 1e-3 rel-L2 per tensor."""
 import numpy as np
 import pytest
 
-from conftest import rel_l2
+from conftest import grad_close, rel_l2, stable_seed
 
 pytestmark = pytest.mark.gpu
 
@@ -261,7 +261,7 @@ def test_conv_hot_shapes_vs_oracle(case):
     from featuresynth._ops import functional as F_
     from oracle import oracle as O
     name, B, Cin, L, Cout, K, stride, pad, dil, groups, act, reflect = case
-    rng = np.random.default_rng(abs(hash(name)) % (2 ** 31))
+    rng = np.random.default_rng(stable_seed(name))
     x = rng.standard_normal((B, Cin, L)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin // groups, K)) * 0.1).astype(np.float32)
     b = (rng.standard_normal((Cout,)) * 0.1).astype(np.float32)
@@ -297,7 +297,7 @@ def test_convt_hot_shapes_vs_oracle(case):
     from featuresynth._ops import functional as F_
     from oracle import oracle as O
     name, B, Cin, L, Cout, K, stride, pad = case
-    rng = np.random.default_rng(abs(hash(name)) % (2 ** 31))
+    rng = np.random.default_rng(stable_seed(name))
     x = rng.standard_normal((B, Cin, L)).astype(np.float32)
     w = (rng.standard_normal((Cin, Cout, K)) * 0.1).astype(np.float32)
     b = (rng.standard_normal((Cout,)) * 0.1).astype(np.float32)

@@ -4,7 +4,7 @@ AvgPool1d(4,2,1,count_include_pad=False), weight norm."""
 import numpy as np
 import pytest
 
-from conftest import rel_l2
+from conftest import grad_close, rel_l2, stable_seed
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -58,7 +58,7 @@ CASES = [  # name, B, Cin, L, Cout, K, pad, dil, in_act, act, reflect, residual
 def test_conv_ex_vs_torch_cpu(case):
     from featuresynth._ops import functional as F_
     name, B, Cin, L, Cout, K, pad, dil, in_act, act, reflect, with_res = case
-    rng = np.random.default_rng(abs(hash(name)) % (2 ** 31))
+    rng = np.random.default_rng(stable_seed(name))
     x = rng.standard_normal((B, Cin, L)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, K)) * 0.1).astype(np.float32)
     b = (rng.standard_normal((Cout,)) * 0.1).astype(np.float32)
@@ -74,9 +74,11 @@ def test_conv_ex_vs_torch_cpu(case):
     yc = _ref_conv(xc, wc, bc, pad, dil, in_act, act, reflect, rc)
     yc.backward(torch.from_numpy(gy).double())
     assert rel_l2(host(y), yc.detach().numpy()) < 1e-5
-    assert rel_l2(host(xt.grad), xc.grad.numpy()) < 1e-3, "gx"
-    assert rel_l2(host(wt.grad), wc.grad.numpy()) < 1e-3, "gw"
-    assert rel_l2(host(bt.grad), bc.grad.numpy()) < 1e-3, "gb"
+    # (grad_close: an output within fp32 rounding of zero may sit on the other LeakyReLU branch than in the
+    #  float64 reference; that flips the gradient of its small neighbourhood and nothing else)
+    assert grad_close(host(xt.grad), xc.grad.numpy(), 1e-3), "gx"
+    assert grad_close(host(wt.grad), wc.grad.numpy(), 1e-3), "gw"
+    assert grad_close(host(bt.grad), bc.grad.numpy(), 1e-3), "gb"
     if with_res:
         assert rel_l2(host(rt.grad), rc.grad.numpy()) < 1e-6
 
@@ -95,7 +97,7 @@ def test_convt_ex_vs_torch_cpu(case):
     import torch.nn.functional as F
     from featuresynth._ops import functional as F_
     name, B, Cin, L, Cout, K, S = case
-    rng = np.random.default_rng(abs(hash(name)) % (2 ** 31))
+    rng = np.random.default_rng(stable_seed(name))
     x = rng.standard_normal((B, Cin, L)).astype(np.float32)
     w = (rng.standard_normal((Cin, Cout, K)) * 0.1).astype(np.float32)
     b = (rng.standard_normal((Cout,)) * 0.1).astype(np.float32)
