@@ -59,6 +59,25 @@ def host_cpu_share(cap=16):
     return max(1, min(n, cap))
 
 
+def launch_workers(args):
+    """`python bench.py --gpus N` outside torchrun: this process never touches the GPU (no torch import);
+    it starts N fresh worker processes, one per GPU, through torch.distributed.run and relays rank 0's
+    JSON line (the workers inherit stdout) and their exit status."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] launching %d workers: %s" % (args.gpus, " ".join(cmd)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,7 +90,14 @@ def main():
     ap.add_argument("--model", default="melgan", choices=["melgan", "realmelgan"],
                     help="melgan = the north-star variant (headline); realmelgan = the weight-normed "
                          "variant of experiment/realmelgan.py (SURVEY.md 8(f) row 1, 128 mels)")
+    ap.add_argument("--no-gforward", action="store_true",
+                    help="skip the BASELINE config-2 leg (generator forward, B=1): keeps its B=1 dispatches out "
+                         "of a rocprofv3 trace of the train step")
     args = ap.parse_args()
+
+    # decided before torch is imported: a multi-GPU run not started by torchrun launches its own workers
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_workers(args))
 
     import numpy as np
     import torch
@@ -86,9 +112,6 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
-                             "--nproc-per-node %d (one process per GPU)" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d != WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
@@ -103,6 +126,10 @@ def main():
     _dist.init_from_env("gloo" if share else "nccl")
     rank = _dist.rank()
     L.load()
+    if world > 1:
+        log("[bench] rank %d/%d on %s: process group backend %s (%s), gradient transport %s" % (
+            rank, _dist.world_size(), torch.cuda.get_device_name(device), torch.distributed.get_backend(),
+            "RCCL over xGMI" if not share else "rehearsal", os.environ.get("MSYNTH_COMM", "torch")))
 
     B, T = args.batch, WINDOW // 256
     gen_loss = LS.mel_gan_gen_loss
@@ -175,7 +202,13 @@ def main():
                                "weight-normed MelGAN of experiment/realmelgan.py (SURVEY.md 8(f) row 1), same step",
                    "per_gpu_batch": B, "global_batch": world * B, "window": WINDOW,
                    "mels": args.mels, "optimizer": "FlatAdam(1e-4,(0.5,0.9))",
-                   "parallelism": "dp%d" % world, "hipgraph": graphs},
+                   "parallelism": "dp%d" % world, "hipgraph": graphs,
+                   "graph_segments": [len(e[0]) for e in dt._runner.graphs.values()] if graphs else [],
+                   "gradient_exchange": None if world == 1 else
+                   "%s all-reduce of the stepped net's flat bucket in two slices (early slice overlapped with "
+                   "the rest of the backward), transport=%s" % ("gloo" if share else "RCCL",
+                                                                os.environ.get("MSYNTH_COMM", "torch")),
+                   "switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MSYNTH_")}},
     }
 
     if share:
@@ -273,7 +306,7 @@ def main():
             "algorithmic_mb_per_DG_pair": W.totals(launches)["bytes"] / 1e6,
             "kernel_ms_per_DG_pair_eager": tot_ms}
 
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not args.no_gforward:
         # BASELINE config 2: generator forward only, B=1, 80-bin mel x 32 frames -> 8192 samples
         feat1 = torch.from_numpy(np.random.default_rng(1).standard_normal((1, args.mels, T)).astype(np.float32)).to(device)
         with torch.no_grad():

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MSYNTH_VERSION 100 /* 0.1.0 */
+#define MSYNTH_VERSION 200 /* 0.2.0 */
 
 typedef void* ms_stream_t; /* hipStream_t */
 
@@ -38,7 +38,8 @@ enum ms_status {
     MS_ERR_INVALID_ARG = -1, /* null pointer, non-positive size, inconsistent shapes */
     MS_ERR_UNSUPPORTED = -2, /* shape/mode outside what the kernels implement */
     MS_ERR_WORKSPACE = -3,   /* workspace missing or too small */
-    MS_ERR_LAUNCH = -4       /* HIP launch failure (hipGetLastError) */
+    MS_ERR_LAUNCH = -4,      /* HIP launch failure (hipGetLastError) */
+    MS_ERR_COMM = -5         /* RCCL missing, or an RCCL call failed (see ms_comm_last_error) */
 };
 
 enum ms_act { MS_ACT_NONE = 0, MS_ACT_LRELU = 1, MS_ACT_TANH = 2 };
@@ -296,6 +297,32 @@ int ms_audio2mel_frames(int32_t N, int32_t n_fft, int32_t hop);
 int ms_audio2mel_fwd(const float* audio, int32_t B, int32_t N, const float* window, int32_t n_fft,
                      int32_t hop, const float* mel_basis, int32_t n_mel, float* out,
                      ms_stream_t stream);
+
+/*
+ * Data-parallel gradient exchange (the reference is single-process, so these
+ * replace nothing in it: they are what its training loop would call between loss.backward() and
+ * optim.step(), train/train.py:37-38,72-73, once the batch is sharded over ranks).
+ *
+ * One RCCL communicator per process (one process per GPU).  The library binds the RCCL that is already
+ * loaded into the process (torch's "nccl" backend IS RCCL on ROCm), else librccl.so.1 from the loader
+ * path, at the first ms_comm_* call; nothing links against it at build time.
+ *   ms_comm_unique_id   rank 0 fills a MS_COMM_ID_BYTES buffer; the caller ships it to the other ranks
+ *                       (file, TCP store, torch.distributed broadcast ... -- bootstrap is the host's job)
+ *   ms_comm_init        collective over all ranks; the current HIP device is the rank's GPU
+ *   ms_allreduce_f32    in-place SUM over ranks of n floats, enqueued on `stream` (no host sync; the
+ *                       flat FlatAdam gradient bucket or a 16-byte aligned slice of it)
+ *   ms_comm_destroy     releases the communicator
+ * The only global state is the bound RCCL entry points and the text of the last RCCL error.
+ */
+#define MS_COMM_ID_BYTES 128
+typedef struct ms_comm* ms_comm_t;
+int ms_comm_unique_id(void* id_out /* MS_COMM_ID_BYTES, host */);
+int ms_comm_init(const void* id /* MS_COMM_ID_BYTES, host */, int32_t world, int32_t rank, ms_comm_t* out);
+int ms_comm_world(ms_comm_t comm);
+int ms_comm_rank(ms_comm_t comm);
+int ms_allreduce_f32(ms_comm_t comm, float* buf, int64_t n, ms_stream_t stream);
+int ms_comm_destroy(ms_comm_t comm);
+const char* ms_comm_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,7 @@ const char* ms_status_string(int status) {
         case MS_ERR_UNSUPPORTED: return "configuration not supported by the MI355X kernels";
         case MS_ERR_WORKSPACE: return "workspace missing or too small";
         case MS_ERR_LAUNCH: return "HIP kernel launch failed";
+        case MS_ERR_COMM: return "RCCL unavailable or an RCCL call failed (ms_comm_last_error)";
         default: return "unknown status";
     }
 }

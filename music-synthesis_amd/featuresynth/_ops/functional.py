@@ -19,6 +19,16 @@ def _c(g):
     return None if g is None else (g if g.is_contiguous() else g.contiguous())
 
 
+def _bound_slot(p):
+    """p's view of its FlatAdam gradient bucket, but only while p.grad IS that view: after a plain
+    `net.zero_grad()` (torch sets .grad = None) the bucket is no longer where autograd's consumers look,
+    so the gradient must travel through autograd like any other (optim.FlatAdam gathers it in step())."""
+    slot = getattr(p, "_ms_slot", None)
+    if slot is None or p.grad is None or p.grad.data_ptr() != slot.data_ptr():
+        return None
+    return slot
+
+
 def _sink_for(params, needs):
     """GradSink for `params`.  A parameter bound to a FlatAdam bucket (optim.py) carries
     `_ms_slot`, its view of the flat gradient bucket: the weight-grad kernels accumulate straight
@@ -26,7 +36,7 @@ def _sink_for(params, needs):
     to autograd, so no AccumulateGrad add kernels run."""
     dests, acc, direct = [], [], []
     for p, need in zip(params, needs):
-        slot = getattr(p, "_ms_slot", None) if need else None
+        slot = _bound_slot(p) if need else None
         dests.append(slot)
         acc.append(slot is not None)
         direct.append(slot is not None)
@@ -121,7 +131,7 @@ class GeneratorFn(Function):
 
     @staticmethod
     def forward(ctx, x, *params):
-        save = any(ctx.needs_input_grad[1:])
+        save = any(ctx.needs_input_grad)
         y, tape = G.gen_forward(x, params, save)
         ctx.tape = tape
         ctx.params = params
@@ -133,9 +143,9 @@ class GeneratorFn(Function):
             return (None,) * (1 + len(ctx.params))
         needs = ctx.needs_input_grad[1:]
         sink, direct = _sink_for(ctx.params, needs)
-        G.gen_backward(ctx.tape, ctx.params, _c(gy), sink)
+        _, gx = G.gen_backward(ctx.tape, ctx.params, _c(gy), sink, need_gx=ctx.needs_input_grad[0])
         ctx.tape = None
-        return (None,) + _grads_out(sink, direct, needs)
+        return (gx,) + _grads_out(sink, direct, needs)
 
 
 class MelGanDiscFn(Function):
@@ -272,6 +282,39 @@ class MelGanDiscLossFn(Function):
         return (None,) + tuple(grs) + tuple(gfs)
 
 
+def disc_loss_cat_fwd(js, B):
+    """sum_s hinge_discriminator_loss(real = j_s[B:], fake = j_s[:B]) -> 0-d device tensor."""
+    n = len(js)
+    if P.judge_multi_ok(js):                 # all scales in one launch
+        out = torch.empty((), dtype=torch.float32, device=js[0].device)
+        return P.judge_loss_multi_fwd(L.JUDGE_HINGE_D, [j[B:] for j in js], [j[:B] for j in js], out)
+    terms = torch.empty((n,), dtype=torch.float32, device=js[0].device)
+    for s in range(n):
+        P.hinge_d_fwd(js[s][B:], js[s][:B], terms[s])
+    return P.weighted_sum(terms, _coef([1.0] * n, terms.device))
+
+
+def disc_loss_cat_bwd(js, B, g, need=None):
+    """Gradients of the loss above w.r.t. each j_s (both halves written into one tensor)."""
+    n = len(js)
+    need = [True] * n if need is None else need
+    if P.judge_multi_ok(js) and all(need):
+        gjs = [torch.empty_like(j) for j in js]
+        P.judge_loss_multi_bwd(L.JUDGE_HINGE_D, [j[B:] for j in js], [j[:B] for j in js], g, 1.0,
+                               [gj[B:] for gj in gjs], [gj[:B] for gj in gjs])
+        return gjs
+    outs = []
+    for s in range(n):
+        j = js[s]
+        if not need[s]:
+            outs.append(None)
+            continue
+        gj = torch.empty_like(j)
+        P.hinge_d_bwd(j[B:], j[:B], g, 1.0, gr=gj[B:], gf=gj[:B])
+        outs.append(gj)
+    return outs
+
+
 class MelGanDiscLossCatFn(Function):
     """The same loss on judgements of ONE discriminator pass over [fake; real] (batch 2B): fake =
     j[:B], real = j[B:].  The gradient is written into the two halves of one tensor -- slicing the
@@ -281,34 +324,54 @@ class MelGanDiscLossCatFn(Function):
     def forward(ctx, n, B, *js):
         ctx.cfg = (n, B)
         ctx.js = js
-        if P.judge_multi_ok(js):                 # all scales in one launch
-            out = torch.empty((), dtype=torch.float32, device=js[0].device)
-            return P.judge_loss_multi_fwd(L.JUDGE_HINGE_D, [j[B:] for j in js], [j[:B] for j in js], out)
-        terms = torch.empty((n,), dtype=torch.float32, device=js[0].device)
-        for s in range(n):
-            P.hinge_d_fwd(js[s][B:], js[s][:B], terms[s])
-        return P.weighted_sum(terms, _coef([1.0] * n, terms.device))
+        return disc_loss_cat_fwd(js, B)
 
     @staticmethod
     def backward(ctx, g):
         n, B = ctx.cfg
-        g = _c(g)
         need = [ctx.needs_input_grad[2 + s] for s in range(n)]
-        if P.judge_multi_ok(ctx.js) and all(need):
-            gjs = [torch.empty_like(j) for j in ctx.js]
-            P.judge_loss_multi_bwd(L.JUDGE_HINGE_D, [j[B:] for j in ctx.js], [j[:B] for j in ctx.js], g, 1.0,
-                                   [gj[B:] for gj in gjs], [gj[:B] for gj in gjs])
-            return (None, None) + tuple(gjs)
-        outs = []
-        for s in range(n):
-            j = ctx.js[s]
-            if not need[s]:
-                outs.append(None)
-                continue
-            gj = torch.empty_like(j)
-            P.hinge_d_bwd(j[B:], j[:B], g, 1.0, gr=gj[B:], gf=gj[:B])
-            outs.append(gj)
-        return (None, None) + tuple(outs)
+        return (None, None) + tuple(disc_loss_cat_bwd(ctx.js, B, _c(g), need))
+
+
+def gen_loss_fwd(S, Lyr, weight, rf, ff, fj):
+    """sum_s mean(-fj_s) + weight * sum_{s,l} (1/S)(1/Lyr) l1(rf, ff) -> (0-d device tensor, fscale)."""
+    nf = S * Lyr
+    dev = fj[0].device
+    fscale = float(weight) * (1.0 / S) * (1.0 / Lyr)
+    if nf <= L.L1_MULTI_MAX:     # all feature-matching terms in one launch pair
+        if P.judge_multi_ok(fj):  # ... and the S adversarial terms in one launch
+            terms = torch.empty((2,), dtype=torch.float32, device=dev)
+            P.judge_loss_multi_fwd(L.JUDGE_NEG_MEAN, None, list(fj), terms[0:])
+            P.l1_mean_multi_fwd(rf, ff, [1.0] * nf, terms[1:])
+            return P.weighted_sum(terms, _coef([1.0, fscale], dev)), fscale
+        terms = torch.empty((S + 1,), dtype=torch.float32, device=dev)
+        for s in range(S):
+            P.neg_mean_fwd(fj[s], terms[s])
+        P.l1_mean_multi_fwd(rf, ff, [1.0] * nf, terms[S:])
+        return P.weighted_sum(terms, _coef([1.0] * S + [fscale], dev)), fscale
+    terms = torch.empty((S + nf,), dtype=torch.float32, device=dev)
+    for s in range(S):
+        P.neg_mean_fwd(fj[s], terms[s])
+    for i in range(nf):
+        P.l1_mean_fwd(rf[i], ff[i], terms[S + i])
+    return P.weighted_sum(terms, _coef([1.0] * S + [fscale] * nf, dev)), fscale
+
+
+def gen_loss_bwd(S, fscale, rf, ff, fj, g, need_r, need_f, need_j):
+    """-> (grads w.r.t. rf, ff, fj); entries are None where need_* is False."""
+    nf = len(rf)
+    if nf <= L.L1_MULTI_MAX:
+        g_rf = P.l1_mean_multi_bwd(ff, rf, [1.0] * nf, g, fscale, list(need_r)) if any(need_r) else [None] * nf
+        g_ff = P.l1_mean_multi_bwd(rf, ff, [1.0] * nf, g, fscale, list(need_f)) if any(need_f) else [None] * nf
+    else:
+        g_rf = [P.l1_mean_bwd(ff[i], rf[i], g, fscale) if need_r[i] else None for i in range(nf)]
+        g_ff = [P.l1_mean_bwd(rf[i], ff[i], g, fscale) if need_f[i] else None for i in range(nf)]
+    if P.judge_multi_ok(fj) and all(need_j):
+        g_fj = [torch.empty_like(t) for t in fj]
+        P.judge_loss_multi_bwd(L.JUDGE_NEG_MEAN, None, list(fj), g, 1.0, None, g_fj)
+    else:
+        g_fj = [P.neg_mean_bwd(fj[s], g) if need_j[s] else None for s in range(S)]
+    return g_rf, g_ff, g_fj
 
 
 class MelGanGenLossFn(Function):
@@ -320,47 +383,19 @@ class MelGanGenLossFn(Function):
     def forward(ctx, S, Lyr, weight, *ts):
         nf = S * Lyr
         rf, ff, fj = ts[:nf], ts[nf:2 * nf], ts[2 * nf:2 * nf + S]
-        dev = fj[0].device
-        fscale = float(weight) * (1.0 / S) * (1.0 / Lyr)
+        loss, fscale = gen_loss_fwd(S, Lyr, weight, rf, ff, fj)
         ctx.cfg = (S, nf, fscale)
         ctx.ts = ts
-        if nf <= L.L1_MULTI_MAX:     # all feature-matching terms in one launch pair
-            if P.judge_multi_ok(fj):  # ... and the S adversarial terms in one launch
-                terms = torch.empty((2,), dtype=torch.float32, device=dev)
-                P.judge_loss_multi_fwd(L.JUDGE_NEG_MEAN, None, list(fj), terms[0:])
-                P.l1_mean_multi_fwd(rf, ff, [1.0] * nf, terms[1:])
-                return P.weighted_sum(terms, _coef([1.0, fscale], dev))
-            terms = torch.empty((S + 1,), dtype=torch.float32, device=dev)
-            for s in range(S):
-                P.neg_mean_fwd(fj[s], terms[s])
-            P.l1_mean_multi_fwd(rf, ff, [1.0] * nf, terms[S:])
-            return P.weighted_sum(terms, _coef([1.0] * S + [fscale], dev))
-        terms = torch.empty((S + nf,), dtype=torch.float32, device=dev)
-        for s in range(S):
-            P.neg_mean_fwd(fj[s], terms[s])
-        for i in range(nf):
-            P.l1_mean_fwd(rf[i], ff[i], terms[S + i])
-        return P.weighted_sum(terms, _coef([1.0] * S + [fscale] * nf, dev))
+        return loss
 
     @staticmethod
     def backward(ctx, g):
         S, nf, fscale = ctx.cfg
         ts = ctx.ts
-        g = _c(g)
         rf, ff, fj = ts[:nf], ts[nf:2 * nf], ts[2 * nf:2 * nf + S]
         need = ctx.needs_input_grad[3:]
-        if nf <= L.L1_MULTI_MAX:
-            nr, nfk = list(need[:nf]), list(need[nf:2 * nf])
-            g_rf = P.l1_mean_multi_bwd(ff, rf, [1.0] * nf, g, fscale, nr) if any(nr) else [None] * nf
-            g_ff = P.l1_mean_multi_bwd(rf, ff, [1.0] * nf, g, fscale, nfk) if any(nfk) else [None] * nf
-        else:
-            g_rf = [P.l1_mean_bwd(ff[i], rf[i], g, fscale) if need[i] else None for i in range(nf)]
-            g_ff = [P.l1_mean_bwd(rf[i], ff[i], g, fscale) if need[nf + i] else None for i in range(nf)]
-        if P.judge_multi_ok(fj) and all(need[2 * nf + s] for s in range(S)):
-            g_fj = [torch.empty_like(t) for t in fj]
-            P.judge_loss_multi_bwd(L.JUDGE_NEG_MEAN, None, list(fj), g, 1.0, None, g_fj)
-        else:
-            g_fj = [P.neg_mean_bwd(fj[s], g) if need[2 * nf + s] else None for s in range(S)]
+        g_rf, g_ff, g_fj = gen_loss_bwd(S, fscale, rf, ff, fj, _c(g), need[:nf], need[nf:2 * nf],
+                                        [need[2 * nf + s] for s in range(S)])
         return (None, None, None) + tuple(g_rf) + tuple(g_ff) + tuple(g_fj)
 
 
@@ -392,7 +427,7 @@ class WeightNormMultiFn(Function):
         ctx.save_for_backward(*vg)
         # parameters bound to a FlatAdam bucket: gradients accumulate straight into their slots
         # (see _sink_for) instead of going through one AccumulateGrad add kernel per tensor
-        slots = [getattr(t, "_ms_slot", None) for t in vg]
+        slots = [_bound_slot(t) for t in vg]
         ctx.slots = slots if all(s is not None for s in slots) else None
         return tuple(P.weight_norm_multi_fwd(vs, gs))
 

@@ -9,6 +9,7 @@ derivative into the kernels' operand loaders (y_act), the skip/feature-gradient 
 backward-data epilogues (gx_add) and the cross-scale weight-grad sums into the weight-grad
 epilogue (accumulate), so no stand-alone elementwise pass remains.
 """
+import contextlib
 import os
 
 import torch
@@ -44,14 +45,37 @@ class GradSink:
 _FORK_DEPTH = 0     # > 0 while work is being issued on a forked stream (forks stay one level deep)
 
 
+@contextlib.contextmanager
+def forked(stream):
+    """`with torch.cuda.stream(stream)` that also counts the fork level: code issued inside must not
+    fork again (melgan_forward / melgan_backward / _WgradFork check `_may_fork`).  Forks are kept ONE
+    level deep under hipGraph capture: a fork inside a fork crashed graph instantiation on ROCm 7.2
+    ("Streams inside the graph")."""
+    global _FORK_DEPTH
+    _FORK_DEPTH += 1
+    try:
+        with torch.cuda.stream(stream):
+            yield
+    finally:
+        _FORK_DEPTH -= 1
+
+
+def _may_fork(device):
+    if not _concurrent_scales() or _on_aux(device):
+        return False
+    if _FORK_DEPTH == 0:
+        return True
+    # experiment switch (DESIGN.md): nested forks on their own stream pool (one pool per depth)
+    return _FORK_DEPTH == 1 and os.environ.get("MSYNTH_NESTED_FORK") == "1"
+
+
 class _WgradFork:
     """Weight gradients of the generator on a side stream (MSYNTH_WGSTREAM=0 disables): each layer's
     weight-grad only needs the incoming gradient, so it can run beside the backward-data chain.
     Tensors it reads are kept alive until the join (the caching allocator is per stream)."""
 
     def __init__(self, device):
-        self.on = (os.environ.get("MSYNTH_WGSTREAM", "1") == "1" and _concurrent_scales() and
-                   not _on_aux(device) and _FORK_DEPTH == 0)
+        self.on = os.environ.get("MSYNTH_WGSTREAM", "1") == "1" and _may_fork(device)
         self.keep = []
         if self.on:
             self.main = torch.cuda.current_stream(device)
@@ -62,7 +86,7 @@ class _WgradFork:
             return fn()
         self.keep.extend(t for t in tensors if t is not None)
         self.side.wait_stream(self.main)
-        with torch.cuda.stream(self.side):
+        with forked(self.side):
             return fn()
 
     def join(self):
@@ -149,12 +173,21 @@ def gen_forward(x, params, save):
     return y, (tape if save else None)
 
 
-def gen_backward(tape, params, gy, sink=None):
-    """Fills (and returns) a GradSink with the parameter grads in state_dict order."""
+G_TAIL_PARAM = 4        # first parameter behind the generator's "tail" (conv0 + the first transposed conv)
+
+
+def gen_backward(tape, params, gy, sink=None, need_gx=False, cut=None):
+    """Fills a GradSink with the parameter grads in state_dict order; returns (sink, gx) where gx =
+    d loss / d mel features when need_gx (a stage-1 feature generator in front, BASELINE config 5), else None.
+
+    cut: optional callback, called once every gradient of parameters G_TAIL_PARAM.. is final in the sink
+    (all stacks and transposed convs 2-4; 53 % of the bytes) and before the tail (first transposed conv,
+    conv0) is processed: the data-parallel trainer starts that slice's all-reduce there (train.py)."""
     L.require(gy, "generator grad_output")
     sink = sink if sink is not None else GradSink(G_NPARAMS)
     i = G_NPARAMS
     g = gy
+    gx = None
     fork = _WgradFork(gy.device)
     batch = [] if os.environ.get("MSYNTH_WMULTI", "1") == "1" else None
     deferred = []
@@ -175,6 +208,9 @@ def gen_backward(tape, params, gy, sink=None):
             _, dt, hin, h = rec
             i -= 2
             gw, gb, acc = sink.pair(i)
+            if i == 2 and cut is not None:
+                fork.join()                          # slots G_TAIL_PARAM.. are complete on the main stream
+                cut()
             if i == 2 and fork.on:
                 # the FIRST transposed conv is processed last: by then the side stream still holds the last
                 # stack's batched weight gradients while the main stream runs dry, so this one's weight
@@ -185,18 +221,20 @@ def gen_backward(tape, params, gy, sink=None):
             else:
                 fork.run(lambda: sink.put(i, *P.convt1d_bwd_weight(hin, g, h, dt, params[i].shape, gw, gb, acc)), hin, g, h)
             g = P.convt1d_bwd_data(g, h, params[i], dt)
-        else:  # conv0: no gradient flows to the mel features
+        else:  # conv0 (reflection-padded): the gradient reaches the mel features only on request
             _, d, x, h = rec
             i -= 2
             gw, gb, acc = sink.pair(i)
             fork.run(lambda: sink.put(i, *P.conv1d_bwd_weight(x, g, h, d, params[i].shape, gw, gb, acc)), x, g, h)
+            if need_gx:
+                gx = P.conv1d_bwd_data(g, h, params[i], d)
     if batch:
         flush_wgrad_batch(batch, sink, fork)
     for fn in deferred:
         fn()
     fork.join()
     assert i == 0
-    return sink
+    return sink, gx
 
 
 
@@ -223,23 +261,36 @@ def disc_forward(x, params):
     return feats, j, tape
 
 
-def disc_backward(tape, params, g_feats, g_judge, sink, need_gx=True, need_wgrad=True):
+D_HEAD_PARAM = 10      # first parameter of the discriminator's "head" (main.5 = the 1024 -> 1024 k5 conv, then judge)
+
+
+def disc_backward(tape, params, g_feats, g_judge, sink, need_gx=True, need_wgrad=True, phase=None, g_in=None):
     """g_feats: list of 6 (entries may be None) or None; g_judge may be None (treated as zero).
-    Parameter grads go to `sink` (GradSink of 14); returns d loss / d x (or None)."""
+    Parameter grads go to `sink` (GradSink of 14); returns d loss / d x (or None).
+
+    phase None: the whole pass.  phase "head": judge conv + the k5 layer only (93 % of the gradient bytes;
+    they are the FIRST thing the backward produces) -> returns the gradient w.r.t. feature 4;
+    phase "tail": layers 4..0, continuing from g_in.  (The split lets the data-parallel trainer all-reduce
+    the head's gradients while the tail still runs, train.py.)"""
     dj, h5, _ = tape[6]
 
     def own(li):  # the loss's own gradient on feature li (feature-matching term), if any
         return g_feats[li] if (g_feats is not None and li >= 0) else None
 
-    # g = total gradient w.r.t. feature 5 (judge path + its own loss term)
-    if g_judge is not None:
-        if need_wgrad:
-            gw, gb, acc = sink.pair(12)
-            sink.put(12, *P.conv1d_bwd_weight(h5, g_judge, None, dj, params[12].shape, gw, gb, acc))
-        g = P.conv1d_bwd_data(g_judge, None, params[12], dj, gx_add=own(5))
+    if phase != "tail":
+        # g = total gradient w.r.t. feature 5 (judge path + its own loss term)
+        if g_judge is not None:
+            if need_wgrad:
+                gw, gb, acc = sink.pair(12)
+                sink.put(12, *P.conv1d_bwd_weight(h5, g_judge, None, dj, params[12].shape, gw, gb, acc))
+            g = P.conv1d_bwd_data(g_judge, None, params[12], dj, gx_add=own(5))
+        else:
+            g = own(5)
+        layers = (5,) if phase == "head" else range(5, -1, -1)
     else:
-        g = own(5)
-    for li in range(5, -1, -1):
+        g = g_in
+        layers = range(4, -1, -1)
+    for li in layers:
         d, hin, h = tape[li]
         prev = own(li - 1) if li > 0 else None
         if g is None:           # nothing flows through this layer
@@ -269,14 +320,14 @@ def aux_stream(device):
 
 
 def _side_streams(device, n):
-    key = (device.index, n)
+    key = (device.index, n, _FORK_DEPTH)
     if key not in _SIDE_STREAMS:   # created on the first (eager) call, never during graph capture
         _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
     return _SIDE_STREAMS[key]
 
 
 def _on_aux(device):
-    return torch.cuda.current_stream(device) == aux_stream(device)
+    return _FORK_DEPTH == 0 and torch.cuda.current_stream(device) == aux_stream(device)
 
 
 def _concurrent_scales():
@@ -294,7 +345,7 @@ def melgan_forward(x, params, scales=2):
     for s in range(scales):
         xs.append(P.avg_pool_fwd(xs[-1]))
     res = [None] * (scales + 1)
-    if scales > 0 and _concurrent_scales() and not _on_aux(x.device):   # forks are kept one level deep
+    if scales > 0 and _may_fork(x.device):   # forks are kept one level deep
         main = torch.cuda.current_stream(x.device)
         side = _side_streams(x.device, scales)
         # longest job first: the full-rate pass is issued before the pooled ones, which fork off an event
@@ -307,7 +358,7 @@ def melgan_forward(x, params, scales=2):
         for s in range(1, scales + 1):
             st = side[s - 1]
             st.wait_event(fork_ev)
-            with torch.cuda.stream(st):
+            with forked(st):
                 res[s] = disc_forward(xs[s], params)
         if not first:
             res[0] = disc_forward(xs[0], params)
@@ -348,74 +399,89 @@ def _flat_view(sink, params):
     return base.as_strided((total,), (1,)), offs, total
 
 
-def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, need_wgrad=True):
+def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, need_wgrad=True, cut=None):
+    """cut: optional callback.  When given, every scale's head (judge + k5 layer, disc_backward phase
+    "head") runs first, all streams join, cut() is called -- at that point sink slots D_HEAD_PARAM.. are
+    final -- and the tails follow.  Without it each scale runs head and tail back to back."""
     tapes, xs = ctx
     n = len(tapes)
     sink = sink if sink is not None else GradSink(D_NPARAMS)
     gxs = [None] * n
-    if n > 1 and _concurrent_scales() and not _on_aux(xs[0].device):
-        dev = xs[0].device
-        main = torch.cuda.current_stream(dev)
-        side = _side_streams(dev, n - 1)
-        tmp = [None] * n
-        flat_tmp = [None] * n
-        # when the destination slots are one flat bucket (FlatAdam), every side scale writes into a private
-        # bucket of the same layout, folded in afterwards with ONE add instead of one per parameter
-        flat_main, offs, total = (_flat_view(sink, params) if need_wgrad else (None, None, 0))
-        # the full-rate scale has the most work: it is issued FIRST (longest job first), the side scales
-        # fork off the point before it through an event instead of waiting for the main stream's tail
-        fork_ev = torch.cuda.Event()
-        fork_ev.record(main)
-        first = os.environ.get("MSYNTH_SCALE0_FIRST", "1") == "1"
-        if first:
-            has, gf, gj = _scale_has_grad(g_feats, g_judges, 0)
-            if has:
-                gxs[0] = disc_backward(tapes[0], params, gf, gj, sink, need_gx=need_gx,
-                                       need_wgrad=need_wgrad)
-        for s in range(1, n):
-            has, gf, gj = _scale_has_grad(g_feats, g_judges, s)
-            if not has:
-                continue
-            st = side[s - 1]
-            st.wait_event(fork_ev)
-            with torch.cuda.stream(st):
-                if flat_main is not None:
-                    flat_tmp[s] = torch.zeros_like(flat_main)
-                    views = [flat_tmp[s][o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
-                    tmp[s] = GradSink(D_NPARAMS, views, [False] * D_NPARAMS)
-                else:
-                    tmp[s] = GradSink(D_NPARAMS)      # own slabs: no cross-stream accumulation
-                gxs[s] = disc_backward(tapes[s], params, gf, gj, tmp[s], need_gx=need_gx,
-                                       need_wgrad=need_wgrad)
-        if not first:
-            has, gf, gj = _scale_has_grad(g_feats, g_judges, 0)
-            if has:
-                gxs[0] = disc_backward(tapes[0], params, gf, gj, sink, need_gx=need_gx,
-                                       need_wgrad=need_wgrad)
-        for st in side:
-            main.wait_stream(st)
-        for s in range(1, n):                          # fold the side-stream weight grads in
-            if tmp[s] is None:
-                continue
-            if flat_tmp[s] is not None:
-                P.add_(flat_main, flat_tmp[s])
-                for i in range(D_NPARAMS):
-                    sink.acc[i] = True
-                continue
-            for i in range(D_NPARAMS):
-                if tmp[s].t[i] is None:
+    phases = (None,) if cut is None else ("head", "tail")
+    mid = [None] * n                                   # gradient w.r.t. feature 4 between the two phases
+    tmp = [None] * n
+    flat_tmp = [None] * n
+    grads = [_scale_has_grad(g_feats, g_judges, s) for s in range(n)]
+    fork = n > 1 and _may_fork(xs[0].device)
+    dev = xs[0].device
+    # when the destination slots are one flat bucket (FlatAdam), every side scale writes into a private
+    # bucket of the same layout, folded in afterwards with ONE add (per phase) instead of one per parameter
+    flat_main, offs, total = (_flat_view(sink, params) if (need_wgrad and fork) else (None, None, 0))
+
+    def run_scale(s, ph, dest):
+        has, gf, gj = grads[s]
+        if not has:
+            return
+        out = disc_backward(tapes[s], params, gf, gj, dest, need_gx=need_gx, need_wgrad=need_wgrad,
+                            phase=ph, g_in=mid[s])
+        if ph == "head":
+            mid[s] = out
+        else:
+            gxs[s] = out
+
+    for ph in phases:
+        if fork:
+            main = torch.cuda.current_stream(dev)
+            side = _side_streams(dev, n - 1)
+            # the full-rate scale has the most work: it is issued FIRST (longest job first), the side scales
+            # fork off the point before it through an event instead of waiting for the main stream's tail
+            fork_ev = torch.cuda.Event()
+            fork_ev.record(main)
+            first = os.environ.get("MSYNTH_SCALE0_FIRST", "1") == "1"
+            if first:
+                run_scale(0, ph, sink)
+            for s in range(1, n):
+                if not grads[s][0]:
                     continue
-                if sink.t[i] is None:
-                    sink.t[i] = tmp[s].t[i]
-                else:
-                    P.add_(sink.t[i], tmp[s].t[i])
-                sink.acc[i] = True
-    else:
-        for s in range(n - 1, -1, -1):
-            has, gf, gj = _scale_has_grad(g_feats, g_judges, s)
-            if has:
-                gxs[s] = disc_backward(tapes[s], params, gf, gj, sink, need_gx=need_gx,
-                                       need_wgrad=need_wgrad)
+                st = side[s - 1]
+                st.wait_event(fork_ev)
+                with forked(st):
+                    if tmp[s] is None:
+                        if flat_main is not None:
+                            flat_tmp[s] = torch.zeros_like(flat_main)
+                            views = [flat_tmp[s][o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
+                            tmp[s] = GradSink(D_NPARAMS, views, [False] * D_NPARAMS)
+                        else:
+                            tmp[s] = GradSink(D_NPARAMS)      # own slabs: no cross-stream accumulation
+                    run_scale(s, ph, tmp[s])
+            if not first:
+                run_scale(0, ph, sink)
+            for st in side:
+                main.wait_stream(st)
+            # fold the side-stream weight grads in: the parameters this phase has finished
+            lo, hi = {None: (0, D_NPARAMS), "head": (D_HEAD_PARAM, D_NPARAMS), "tail": (0, D_HEAD_PARAM)}[ph]
+            for s in range(1, n):
+                if tmp[s] is None or not need_wgrad:
+                    continue
+                if flat_tmp[s] is not None:
+                    a, b = offs[lo], (total if hi == D_NPARAMS else offs[hi])
+                    P.add_(flat_main[a:b], flat_tmp[s][a:b])
+                    for i in range(lo, hi):
+                        sink.acc[i] = True
+                    continue
+                for i in range(lo, hi):
+                    if tmp[s].t[i] is None:
+                        continue
+                    if sink.t[i] is None:
+                        sink.t[i] = tmp[s].t[i]
+                    else:
+                        P.add_(sink.t[i], tmp[s].t[i])
+                    sink.acc[i] = True
+        else:
+            for s in range(n - 1, -1, -1):
+                run_scale(s, ph, sink)
+        if ph == "head":
+            cut()
     gx_next = None
     for s in range(n - 1, -1, -1):
         gx = gxs[s]

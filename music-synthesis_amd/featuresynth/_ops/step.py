@@ -1,0 +1,89 @@
+"""Hand-scheduled D-step / G-step of the headline model: the forward and backward schedules of
+graph.py and the fused loss kernels called back to back, no autograd engine in between.
+
+What the reference executes per trainer call (train/train.py:26-42,63-74) minus the work whose
+results it discards (D-step: generator backward; G-step: real-path backward, discriminator weight
+gradients).  The trainers take this path when both networks are the native MelGanGenerator /
+MelGanDiscriminator, the losses are the stock hinge / feature-matching ones and both optimizers are
+FlatAdam (train.py); anything else goes through the autograd Functions of functional.py, which run
+the same kernels.
+
+Every function issues on the current stream (+ the fork/join side streams of graph.py) and is
+hipGraph-capturable.  `cut` (optional callback) marks the point where the "early" slice of the
+stepped network's gradient bucket is final, so the data-parallel trainer can start its all-reduce
+under the rest of the backward:
+    D-step: after every scale's judge + k5-layer weight gradients  (parameters D_HEAD_PARAM.. = 93 %)
+    G-step: before the first transposed conv / conv0 are processed  (parameters G_TAIL_PARAM.. = 47 %)
+"""
+import torch
+
+from . import functional as F_
+from . import graph as G
+
+_ONE = {}
+
+
+def _one(device):
+    t = _ONE.get(device)
+    if t is None:
+        t = torch.ones((), dtype=torch.float32, device=device)
+        _ONE[device] = t
+    return t
+
+
+def _slots(params):
+    """Gradient destinations = the parameters' FlatAdam bucket views (zeroed by zero_grad: accumulate)."""
+    slots = [F_._bound_slot(p) for p in params]
+    if any(s is None for s in slots):
+        raise RuntimeError("native train step: every parameter must be bound to a FlatAdam gradient bucket "
+                           "(call optim.zero_grad() before the step)")
+    return G.GradSink(len(slots), slots, [True] * len(slots))
+
+
+def d_step(gen_params, disc_params, samples, features, scales=2, cut=None, debug=None):
+    """-> d_loss (0-d device tensor); discriminator gradients accumulate into its bucket."""
+    fake, _ = G.gen_forward(features, gen_params, save=False)
+    B = fake.shape[0]
+    # one discriminator pass over [fake; real]: samples are independent (no batch coupling), so the
+    # judgements are the same and the shared weights' gradients are summed in-kernel
+    both = torch.cat([fake, samples], 0)
+    _, judges, ctx = G.melgan_forward(both, disc_params, scales)
+    loss = F_.disc_loss_cat_fwd(judges, B)
+    gjs = F_.disc_loss_cat_bwd(judges, B, _one(samples.device))
+    if debug is not None:
+        debug.update(fake=fake, judges=judges, disc_ctx=ctx, gjs=gjs)
+    G.melgan_backward(ctx, disc_params, None, gjs, _slots(disc_params), need_gx=False, need_wgrad=True, cut=cut)
+    return loss
+
+
+def g_step(gen_params, disc_params, samples, features, scales=2, weight=10.0, cut=None, debug=None):
+    """-> (g_loss, fake); generator gradients accumulate into its bucket."""
+    dev = samples.device
+    # the real path neither depends on the generator nor needs gradients: it runs on a forked stream
+    # (a parallel branch of the captured graph) beside G and D(fake)
+    main = torch.cuda.current_stream(dev)
+    side = G.aux_stream(dev)
+    fork_real = G._may_fork(dev)
+    if fork_real:
+        side.wait_stream(main)
+        with G.forked(side):
+            r_feats, r_judges, _ = G.melgan_forward(samples, disc_params, scales)
+    else:
+        r_feats, r_judges, _ = G.melgan_forward(samples, disc_params, scales)
+    fake, tape = G.gen_forward(features, gen_params, save=True)
+    f_feats, f_judges, ctx = G.melgan_forward(fake, disc_params, scales)
+    if fork_real:
+        main.wait_stream(side)
+    S, Lyr = len(f_feats), len(f_feats[0])
+    rf = [t for grp in r_feats for t in grp]
+    ff = [t for grp in f_feats for t in grp]
+    loss, fscale = F_.gen_loss_fwd(S, Lyr, weight, rf, ff, f_judges)
+    _, g_ff, g_fj = F_.gen_loss_bwd(S, fscale, rf, ff, f_judges, _one(dev), [False] * len(rf),
+                                    [True] * len(ff), [True] * S)
+    g_feats = [g_ff[Lyr * s:Lyr * s + Lyr] for s in range(S)]
+    gx, _ = G.melgan_backward(ctx, disc_params, g_feats, g_fj, None, need_gx=True, need_wgrad=False)
+    if debug is not None:
+        debug.update(fake=fake, gen_tape=tape, disc_ctx=ctx, r_feats=r_feats, f_feats=f_feats,
+                     f_judges=f_judges, g_fake=gx)
+    G.gen_backward(tape, gen_params, gx, _slots(gen_params), cut=cut)
+    return loss, fake

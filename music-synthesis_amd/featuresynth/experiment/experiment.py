@@ -93,12 +93,15 @@ class Experiment(BaseGanExperiment):
         return generator
 
     def checkpoint(self, prefix="", with_optimizers=False):
-        os.makedirs(os.path.dirname(self._gen_name(prefix)), exist_ok=True)
-        torch.save(self.generator.state_dict(), self._gen_name(prefix))
-        torch.save(self.discriminator.state_dict(), self._disc_name(prefix))
-        if with_optimizers:
-            torch.save({"g": _optim_state(self._g_optim), "d": _optim_state(self._d_optim)},
-                       self._optim_name(prefix))
+        """Under data parallelism the replicas are identical: rank 0 writes, everyone waits for it."""
+        if _dist.rank() == 0:
+            os.makedirs(os.path.dirname(self._gen_name(prefix)), exist_ok=True)
+            torch.save(self.generator.state_dict(), self._gen_name(prefix))
+            torch.save(self.discriminator.state_dict(), self._disc_name(prefix))
+            if with_optimizers:
+                torch.save({"g": _optim_state(self._g_optim), "d": _optim_state(self._d_optim)},
+                           self._optim_name(prefix))
+        _dist.barrier()
 
     def resume(self, prefix="", with_optimizers=False):
         self.generator.load_state_dict(torch.load(self._gen_name(prefix)))

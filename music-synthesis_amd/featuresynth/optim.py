@@ -108,7 +108,10 @@ class FlatAdam(torch.optim.Optimizer):
 
     def _gather_stray_grads(self):
         """A gradient produced outside the bucket (plain autograd assigns a fresh tensor when
-        .grad was None) is copied into its slot."""
+        .grad was None, e.g. after `net.zero_grad()`) is copied into its slot and .grad is re-bound
+        to the slot.  The backward kernels only ever write a slot while it IS p.grad
+        (functional._bound_slot), so a slot whose parameter has no .grad holds nothing of this step
+        and is cleared: such a parameter steps with a zero gradient (torch.optim.Adam would skip it)."""
         ps = self.param_groups[0]["params"]
         fg = self._flat[1]
         with torch.no_grad():
@@ -136,3 +139,24 @@ class FlatAdam(torch.optim.Optimizer):
 
     def step_count(self):
         return int(self._flat[4].item()) if self._flat is not None else 0
+
+    # ---- checkpoints: the moments and the step counter live in the flat bucket, not in self.state
+    def state_dict(self):
+        sd = super().state_dict()
+        if self._flat is not None:
+            _, _, m, v, step, offs = self._flat
+            sd["flat"] = {"exp_avg": m.detach().cpu(), "exp_avg_sq": v.detach().cpu(),
+                          "step": step.detach().cpu(), "layout": [tuple(o) for o in offs]}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        flat = state_dict.pop("flat", None)
+        super().load_state_dict(state_dict)
+        if flat is not None:
+            self.flatten()
+            _, _, m, v, step, offs = self._flat
+            if [tuple(o) for o in offs] != [tuple(o) for o in flat["layout"]]:
+                raise ValueError("FlatAdam.load_state_dict: the checkpoint's bucket layout does not match "
+                                 "these parameters")
+            m.copy_(flat["exp_avg"]); v.copy_(flat["exp_avg_sq"]); step.copy_(flat["step"])

@@ -8,9 +8,11 @@ Two execution paths, same numbers:
     change the result is skipped (D-step: no backward through the generator, which the reference
     performs only because `fake` is not detached, train.py:66-71; G-step: no real-path backward
     and no discriminator weight grads, train.py:36), and when both optimizers are FlatAdam the
-    whole step (zero_grad, forwards, backward, Adam) is captured once into a hipGraph and replayed.
-    Under torch.distributed the stepped network's flat gradient bucket is all-reduced (RCCL)
-    between the backward graph and the Adam graph.
+    whole step (zero_grad, forwards, backward, Adam) is captured once into a hipGraph and replayed;
+    for the headline model with its stock losses the step is hand-scheduled (_ops/step.py: no
+    autograd engine).  Under torch.distributed the stepped network's flat gradient bucket is
+    all-reduced (RCCL) in two slices: the slice that is final early in the backward travels while
+    the rest of the backward runs, the other one just before the Adam graph.
 """
 import os
 import sys
@@ -22,8 +24,10 @@ import torch
 from .. import _dist
 from .._ops import graph as _graph
 from .._ops import functional as _F
+from .._ops import step as _step
 from ..loss import hinge_discriminator_loss, hinge_generator_loss
 from ..loss import mel_gan_disc_loss as _mel_gan_disc_loss
+from ..loss import mel_gan_gen_loss as _mel_gan_gen_loss
 from ..optim import FlatAdam
 from ..util.modules import zero_grad
 
@@ -37,16 +41,69 @@ def _use_graph():
 
 
 class _GraphedStep:
-    """Runs `body(samples, features) -> dict of device tensors`: first call eager (loads the
-    code objects, sizes the buckets), second call captures into a hipGraph, later calls copy the
-    inputs into the static buffers and replay."""
+    """Runs `body(samples, features, cut) -> dict of device/host tensors`: first call eager (loads the
+    code objects, sizes the buckets), second call captures into hipGraphs, later calls copy the
+    inputs into the static buffers and replay.
 
-    def __init__(self, body, post=None):
+    `between` are eager host actions (the data-parallel all-reduces): the body calls `cut()` exactly
+    len(between) times, which ends one graph segment and starts the next; between[k]() runs after segment
+    k -- directly from cut() on an eager call, between two graph launches on a replay.  All segments
+    share one memory pool and are replayed in capture order."""
+
+    def __init__(self, body, between=()):
         self.body = body
-        self.post = post          # optional eager tail (all-reduce + second graph)
+        self.between = list(between)
         self.seen = {}
         self.graphs = {}
         self.disabled = False
+
+    def _eager(self, samples, features):
+        k = [0]
+
+        def cut():
+            self.between[k[0]]()
+            k[0] += 1
+        out = self.body(samples, features, cut)
+        assert k[0] == len(self.between), "train step: body made %d cuts, %d expected" % (k[0], len(self.between))
+        return out
+
+    def _capture(self, s_in, f_in):
+        torch.cuda.synchronize()
+        graphs = []
+        if not self.between:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self.body(s_in, f_in, None)
+            return [g], out
+        pool = torch.cuda.graph_pool_handle()
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        cur = [None]
+
+        def begin():
+            cur[0] = torch.cuda.CUDAGraph()
+            cur[0].capture_begin(pool=pool)
+
+        def end():
+            cur[0].capture_end()
+            graphs.append(cur[0])
+            cur[0] = None
+
+        def cut():
+            end()
+            begin()
+        with torch.cuda.stream(stream):
+            begin()
+            try:
+                out = self.body(s_in, f_in, cut)
+            finally:
+                if cur[0] is not None:
+                    end()
+        torch.cuda.current_stream().wait_stream(stream)
+        if len(graphs) != len(self.between) + 1:
+            raise RuntimeError("train step: %d graph segments captured, %d expected"
+                               % (len(graphs), len(self.between) + 1))
+        return graphs, out
 
     def __call__(self, samples, features):
         key = (tuple(samples.shape), tuple(features.shape), samples.device)
@@ -55,25 +112,25 @@ class _GraphedStep:
             n = self.seen.get(key, 0)
             self.seen[key] = n + 1
             if n == 0 or self.disabled or not _use_graph():
-                return self.body(samples, features)
+                return self._eager(samples, features)
             try:
                 s_in, f_in = samples.clone(), features.clone()
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    out = self.body(s_in, f_in)
-                entry = (g, s_in, f_in, out)
+                graphs, out = self._capture(s_in, f_in)
+                entry = (graphs, s_in, f_in, out)
                 self.graphs[key] = entry
             except Exception as e:  # perf-only fallback, reported loudly
                 self.disabled = True
                 torch.cuda.synchronize()
                 print("featuresynth: hipGraph capture failed (%s: %s); running the step eagerly"
                       % (type(e).__name__, e), file=sys.stderr)
-                return self.body(samples, features)
-        g, s_in, f_in, out = entry
+                return self._eager(samples, features)
+        graphs, s_in, f_in, out = entry
         s_in.copy_(samples)
         f_in.copy_(features)
-        g.replay()
+        for k, g in enumerate(graphs):
+            g.replay()
+            if k < len(self.between):
+                self.between[k]()
         return out
 
 
@@ -87,7 +144,8 @@ class _TrainerBase(object):
         self.g_optim = g_optim
         self.generator = generator
         self._runner = None
-        self._tail = None
+        self._runner_world = None
+        self.debug = None             # tests: a dict here receives the step's intermediate tensors (eager calls)
 
     def _native_ok(self, samples, features):
         return (_native(self.generator, self.discriminator) and isinstance(samples, torch.Tensor)
@@ -96,8 +154,23 @@ class _TrainerBase(object):
     def _stepped_optim(self):
         raise NotImplementedError
 
-    def _fwd_bwd(self, samples, features):
+    def _stock_losses(self):
         raise NotImplementedError
+
+    def _fwd_bwd(self, samples, features, cut=None):
+        raise NotImplementedError
+
+    def _direct_ok(self):
+        """The hand-scheduled step (_ops/step.py) applies: the headline model with its stock losses."""
+        from ..discriminator.melgan import MelGanDiscriminator
+        from ..generator.full import MelGanGenerator
+        return (os.environ.get("MSYNTH_DIRECT", "1") != "0"
+                and type(self.generator) is MelGanGenerator
+                and type(self.discriminator) is MelGanDiscriminator
+                and isinstance(self.g_optim, FlatAdam) and isinstance(self.d_optim, FlatAdam)
+                and self._stock_losses()
+                and all(p.requires_grad for p in self.generator.parameters())
+                and all(p.requires_grad for p in self.discriminator.parameters()))
 
     def _result(self, out, device, loss_key, with_fake):
         if out["loss"].is_cuda:                 # torch-optimizer path: plain device tensors
@@ -126,12 +199,22 @@ class _TrainerBase(object):
             host[k] = self._pins[key]
         return host
 
+    def _split_point(self, opt):
+        """Element offset in the stepped network's flat gradient bucket that separates the slice finished
+        LATE in the backward ([0, off): the layers nearest the input) from the slice finished EARLY
+        ([off, end)); 0 when the step has no cut point (one all-reduce of the whole bucket)."""
+        return 0
+
     def _native_step(self, samples, features):
-        """fwd+bwd graph -> (RCCL all-reduce of the stepped bucket) -> Adam graph."""
+        """world 1: ONE graph (zero_grad, forwards, backward, Adam).
+        Data parallel: [graph: zero_grad + forwards + backward up to the cut] -> all-reduce of the early
+        slice, asynchronous (RCCL) -> [graph: rest of the backward, overlapping it] -> all-reduce of the
+        late slice -> [graph: Adam with grad_scale = 1/world]."""
         opt = self._stepped_optim()
         flat = isinstance(opt, FlatAdam) and isinstance(self.g_optim, FlatAdam) and \
             isinstance(self.d_optim, FlatAdam)
         world = _dist.world_size()
+        force_dp = os.environ.get("MSYNTH_DP_FORCE") == "1"      # one-rank rehearsal of the N > 1 control flow
         if not flat:
             out = self._fwd_bwd(samples, features)
             if world > 1:
@@ -142,21 +225,49 @@ class _TrainerBase(object):
             opt.step()
             return out
         opt.grad_scale = 1.0 / world
-        if world == 1:
-            if self._runner is None:
-                def body(s, f):
+        self.g_optim.flat_grads, self.d_optim.flat_grads      # (builds the buckets: _split_point reads their layout)
+        if self._runner is not None and self._runner_world != (world, force_dp):
+            self._runner = None                   # the process group appeared / went away: re-plan
+        if self._runner is None:
+            self._runner_world = (world, force_dp)
+            if world == 1 and not force_dp:
+                def body(s, f, cut):
                     out = self._fwd_bwd(s, f)
                     opt.step()
                     return self._to_host(out)
                 self._runner = _GraphedStep(body)
-            return self._runner(samples, features)
-        if self._runner is None:
-            self._runner = _GraphedStep(lambda s, f: self._to_host(self._fwd_bwd(s, f)))
-            self._tail = _GraphedStep(lambda s, f: (opt.step(), {})[1])
-        out = self._runner(samples, features)
-        _dist.allreduce_sum_(opt.flat_grads)
-        self._tail(samples[:0], features[:0])
-        return out
+            else:
+                direct = self._direct_ok()
+                pending = []
+
+                def start_early():
+                    off = self._split_point(opt) if direct else 0
+                    fg = opt.flat_grads
+                    pending.append(_dist.allreduce_sum_async(fg[off:] if off else fg, force=force_dp))
+
+                def finish():
+                    off = self._split_point(opt) if direct else 0
+                    if off:
+                        pending.append(_dist.allreduce_sum_async(opt.flat_grads[:off], force=force_dp))
+                    for w in pending:
+                        w.wait()
+                    del pending[:]
+
+                if direct and self._split_point(opt):
+                    def body(s, f, cut):
+                        out = self._fwd_bwd(s, f, cut)     # calls cut() once, where the early slice is final
+                        cut()
+                        opt.step()
+                        return self._to_host(out)
+                    self._runner = _GraphedStep(body, [start_early, finish])
+                else:
+                    def body(s, f, cut):
+                        out = self._fwd_bwd(s, f)
+                        cut()
+                        opt.step()
+                        return self._to_host(out)
+                    self._runner = _GraphedStep(body, [lambda: (start_early(), finish())])
+        return self._runner(samples, features)
 
 
 class GeneratorTrainer(_TrainerBase):
@@ -167,8 +278,18 @@ class GeneratorTrainer(_TrainerBase):
     def _stepped_optim(self):
         return self.g_optim
 
-    def _fwd_bwd(self, samples, features):
+    def _stock_losses(self):
+        return self.loss is _mel_gan_gen_loss and self.sub_loss is hinge_generator_loss
+
+    def _split_point(self, opt):
+        return opt._flat[5][_graph.G_TAIL_PARAM][0] if opt._flat is not None else 0
+
+    def _fwd_bwd(self, samples, features, cut=None):
         zero_grad(self.g_optim, self.d_optim)
+        if self._direct_ok():
+            loss, fake = _step.g_step(list(self.generator.parameters()), list(self.discriminator.parameters()),
+                                      samples, features, self.discriminator.scales, cut=cut, debug=self.debug)
+            return {"loss": loss, "fake": fake}
         d_params = [p for p in self.discriminator.parameters() if p.requires_grad]
         for p in d_params:          # discriminator weight grads are never used by a G-step
             p.requires_grad_(False)
@@ -178,7 +299,7 @@ class GeneratorTrainer(_TrainerBase):
             main = torch.cuda.current_stream(samples.device)
             side = _graph.aux_stream(samples.device)
             side.wait_stream(main)
-            with torch.cuda.stream(side), torch.no_grad():
+            with _graph.forked(side), torch.no_grad():
                 r_features, r_score = self.discriminator(samples, features)
             fake = self.generator(features)
             f_features, f_score = self.discriminator(fake, features)
@@ -217,8 +338,18 @@ class DiscriminatorTrainer(_TrainerBase):
     def _stepped_optim(self):
         return self.d_optim
 
-    def _fwd_bwd(self, samples, features):
+    def _stock_losses(self):
+        return self.loss is _mel_gan_disc_loss and self.sub_loss is hinge_discriminator_loss
+
+    def _split_point(self, opt):
+        return opt._flat[5][_graph.D_HEAD_PARAM][0] if opt._flat is not None else 0
+
+    def _fwd_bwd(self, samples, features, cut=None):
         zero_grad(self.g_optim, self.d_optim)
+        if self._direct_ok():
+            loss = _step.d_step(list(self.generator.parameters()), list(self.discriminator.parameters()),
+                                samples, features, self.discriminator.scales, cut=cut, debug=self.debug)
+            return {"loss": loss}
         with torch.no_grad():       # generator grads of a D-step are discarded by the reference
             fake = self.generator(features)
         # one discriminator pass over [fake; real]: samples are independent (no batch coupling),
@@ -226,7 +357,7 @@ class DiscriminatorTrainer(_TrainerBase):
         B = fake.shape[0]
         both = torch.cat([fake, samples], 0)
         _, scores = self.discriminator(both, features)
-        if self.loss is _mel_gan_disc_loss and self.sub_loss is hinge_discriminator_loss:
+        if self._stock_losses():
             loss = _F.MelGanDiscLossCatFn.apply(len(scores), B, *scores)   # no per-slice autograd nodes
         else:
             f_score = [j[:B] for j in scores]

@@ -36,18 +36,3 @@ def stable_seed(name):
     """Seed from a test-case name that does not change between processes (str hash() is randomised)."""
     import zlib
     return zlib.crc32(name.encode()) & 0x7FFFFFFF
-
-
-def grad_close(a, b, tol):
-    """Gradient check that tolerates isolated LeakyReLU mask flips: an activation within fp32 rounding of
-    zero may take the other branch than in the float64 reference, which changes the gradient of a small
-    neighbourhood by O(1) while everything else agrees to rounding.  Passes when rel-L2 < tol, or when at
-    most 3 % of the elements are off (by more than 1e-4 of the largest value) and rel-L2 < 5e-2."""
-    import numpy as np
-    a = np.asarray(a, np.float64).reshape(-1)
-    b = np.asarray(b, np.float64).reshape(-1)
-    err = rel_l2(a, b)
-    if err < tol:
-        return True
-    off = np.abs(a - b) > 1e-4 * (np.abs(b).max() + 1e-300)
-    return bool(err < 5e-2 and off.mean() <= 0.03)

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 def test_host_side_queries(lib):
     L = lib.load()
-    assert L.ms_version() == 100
+    assert L.ms_version() == 200
     assert b"ok" == L.ms_status_string(0)
     assert b"unsupported" in L.ms_status_string(-2) or b"not supported" in L.ms_status_string(-2)
     # geometry of the hot-path layers (no kernel is launched)

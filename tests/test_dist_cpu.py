@@ -45,6 +45,18 @@ def _worker(rank, world, port, out_dir):
     m = _dist.allreduce_mean_scalar(torch.tensor(float(rank)))
     assert abs(float(m) - 0.5) < 1e-7
 
+    # 1b. the trainer's exchange: the bucket travels as two slices cut at a parameter boundary, the
+    #     early (tail) slice first and asynchronously, then the late (head) slice; same result as one
+    #     all-reduce of the whole bucket, and views of the bucket are reduced in place
+    bucket = (torch.arange(64, dtype=torch.float32) + 1) * (rank + 1)
+    whole = bucket.clone()
+    _dist.allreduce_sum_(whole)
+    w_early = _dist.allreduce_sum_async(bucket[40:])
+    bucket[:40] += 0.0                                   # (work issued while the early slice travels)
+    w_late = _dist.allreduce_sum_async(bucket[:40])
+    w_early.wait(); w_late.wait()
+    assert torch.equal(bucket, whole)
+
     # 2. shard-mean == global-batch gradient for the D-step (tiny window to stay fast)
     B, T = 2, 4
     gsd = synthetic_state_dict(O.generator_param_shapes(80), seed=7, bias_scale=0.02)
@@ -77,6 +89,44 @@ def test_two_rank_gloo(tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     err = float(np.load(str(tmp_path / "err.npy"))[0])
     assert err < 2e-4, err      # fp32 summation order only
+
+
+def test_graphed_step_eager_cut_sequence():
+    """_GraphedStep (train/train.py) on an eager call: the body's cut() points run the `between` actions
+    (the data-parallel all-reduces) in order, exactly once each, at the point of the cut."""
+    from featuresynth.train.train import _GraphedStep
+    log = []
+
+    def body(s, f, cut):
+        log.append("fwd+head")
+        cut()
+        log.append("tail")
+        cut()
+        log.append("adam")
+        return {"loss": 1.0}
+
+    step = _GraphedStep(body, [lambda: log.append("allreduce early"), lambda: log.append("allreduce late + wait")])
+    x = torch.zeros(2, 1, 8)
+    assert step(x, x) == {"loss": 1.0}
+    assert log == ["fwd+head", "allreduce early", "tail", "allreduce late + wait", "adam"]
+    bad = _GraphedStep(lambda s, f, cut: {"loss": 0.0}, [lambda: None])
+    with pytest.raises(AssertionError):
+        bad(x, x)
+
+
+def test_bucket_split_points():
+    """The cut points of the two buckets (graph.D_HEAD_PARAM / G_TAIL_PARAM) against the state_dict
+    order of the reference's modules: D head = main.5 (k5 conv) + judge = 93 % of the bytes; G tail =
+    main.1 (first conv) + main.3 (first transposed conv)."""
+    import featuresynth as fs
+    from featuresynth._ops import graph as G
+    d = [k for k, _ in fs.MelGanDiscriminator().named_parameters()]
+    g = [k for k, _ in fs.MelGanGenerator(32, 80).named_parameters()]
+    assert d[G.D_HEAD_PARAM] == "disc.main.5.weight" and d[G.D_HEAD_PARAM:] == [
+        "disc.main.5.weight", "disc.main.5.bias", "disc.judge.weight", "disc.judge.bias"]
+    assert g[:G.G_TAIL_PARAM] == ["main.1.weight", "main.1.bias", "main.3.weight", "main.3.bias"]
+    nd = [p.numel() for p in fs.MelGanDiscriminator().parameters()]
+    assert sum(nd[G.D_HEAD_PARAM:]) / sum(nd) > 0.92
 
 
 def test_single_process_helpers_are_noops():

@@ -1,7 +1,8 @@
 """Data-parallel trainer path on the GPU box: two ranks share cuda:0 (gloo backend, which stages
 device tensors through the host; RCCL refuses two ranks on one GPU).  Exercises exactly what
-bench.py --gpus N runs: [hipGraph fwd+bwd] -> all-reduce of the flat gradient bucket -> [hipGraph
-fused Adam with grad_scale = 1/world], and checks it against one process on the global batch."""
+bench.py --gpus N runs: [hipGraph fwd + backward up to the cut] -> all-reduce of the early slice of the
+flat gradient bucket -> [hipGraph rest of the backward] -> all-reduce of the late slice -> [hipGraph fused
+Adam with grad_scale = 1/world], and checks it against one process on the global batch."""
 import os
 import socket
 
@@ -63,8 +64,10 @@ def _worker(rank, world, port, out_dir):
     B, T = 2, 4
     losses, sd, (dt, gt) = _run_steps(synthetic_samples(B, T * 256, rank=rank),
                                       synthetic_features(B, 80, T, rank=rank), 6)
-    assert dt._tail is not None and gt._tail is not None, "distributed two-graph path not taken"
-    assert dt._runner.graphs and dt._tail.graphs, "graphs not captured under data parallelism"
+    assert len(dt._runner.between) == 2 and len(gt._runner.between) == 2, "split all-reduce path not taken"
+    for tr in (dt, gt):
+        assert tr._runner.graphs and not tr._runner.disabled, "graphs not captured under data parallelism"
+        assert all(len(e[0]) == 3 for e in tr._runner.graphs.values()), "expected 3 graph segments per step"
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=np.array(losses), **sd)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -97,3 +100,55 @@ def test_two_ranks_match_global_batch(tmp_path):
         assert d.max() <= 3 * 2.1e-4, (k, d.max())                           # 3 updates per net, +-lr each
         if k.endswith("weight"):
             assert rel_l2(r0[k], v) < 1e-2, k
+
+
+def _single_rank_worker(rank, port, out_dir, comm):
+    """One rank, RCCL for real: the "nccl" process group of torch.distributed (ProcessGroupNCCL = RCCL on
+    ROCm) or the C ABI's own communicator (ms_comm_init / ms_allreduce_f32), driving the data-parallel
+    control flow (3 graph segments, two slice all-reduces) through MSYNTH_DP_FORCE=1."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                      LOCAL_RANK="0", MSYNTH_DP_FORCE="1", MSYNTH_COMM=comm)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "music-synthesis_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.cuda.set_device(0)
+    from featuresynth import _dist
+    from featuresynth._synthetic import synthetic_features, synthetic_samples
+    _dist.init_from_env("nccl", force=True)
+    assert torch.distributed.get_backend() == "nccl" and _dist.world_size() == 1
+    # the collective itself, on a slice of a bucket like the trainer's
+    t = torch.arange(1000, dtype=torch.float32, device="cuda")
+    w = _dist.allreduce_sum_async(t[256:], force=True)
+    w.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(t, torch.arange(1000, dtype=torch.float32, device="cuda"))
+    if comm == "abi":
+        from featuresynth._ops import lib as L
+        c = _dist.abi_comm()
+        assert L.load().ms_comm_world(c) == 1 and L.load().ms_comm_rank(c) == 0
+    B, T = 2, 4
+    losses, sd, (dt, gt) = _run_steps(synthetic_samples(B, T * 256), synthetic_features(B, 80, T), 6)
+    assert len(dt._runner.between) == 2 and len(gt._runner.between) == 2
+    assert all(len(e[0]) == 3 for e in dt._runner.graphs.values()) and not dt._runner.disabled
+    np.savez(os.path.join(out_dir, "dp_%s.npz" % comm), losses=np.array(losses), **sd)
+    if comm == "abi":
+        _dist.abi_comm_destroy()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("comm", ["torch", "abi"])
+def test_single_rank_rccl_matches_plain_step(tmp_path, comm):
+    """World size 1 over RCCL: the sliced exchange is the identity, so the data-parallel schedule (head
+    phase -> cut -> tail phase, three graph segments) must reproduce the single-graph step bitwise."""
+    import torch.multiprocessing as mp
+    from featuresynth._synthetic import synthetic_features, synthetic_samples
+    mp.spawn(_single_rank_worker, args=(_free_port(), str(tmp_path), comm), nprocs=1, join=True)
+    r = np.load(str(tmp_path / ("dp_%s.npz" % comm)))
+    B, T = 2, 4
+    losses, sd, (dt, _) = _run_steps(synthetic_samples(B, T * 256), synthetic_features(B, 80, T), 6)
+    assert all(len(e[0]) == 1 for e in dt._runner.graphs.values())
+    assert list(r["losses"]) == list(losses), (r["losses"], losses)
+    for k, v in sd.items():
+        assert np.array_equal(r[k], v), k

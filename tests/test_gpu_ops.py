@@ -7,7 +7,7 @@ gradients within 1e-3 rel-L2 per tensor."""
 import numpy as np
 import pytest
 
-from conftest import grad_close, rel_l2, stable_seed
+from conftest import rel_l2, stable_seed
 
 pytestmark = pytest.mark.gpu
 

@@ -4,7 +4,7 @@ AvgPool1d(4,2,1,count_include_pad=False), weight norm."""
 import numpy as np
 import pytest
 
-from conftest import grad_close, rel_l2, stable_seed
+from conftest import rel_l2, stable_seed
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -18,8 +18,11 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-def _ref_conv(x, w, b, pad, dil, in_act, act, reflect, residual=None):
+def _ref_conv(x, w, b, pad, dil, in_act, act, reflect, residual=None, out_mask=None):
+    """out_mask: the LeakyReLU branch each output took ON THE DEVICE (oracle/torch_graph.py:_LReluMasked):
+    both backward passes then differentiate the same piecewise-linear function."""
     import torch.nn.functional as F
+    from oracle import torch_graph as TG
     h = F.leaky_relu(x, 0.2) if in_act else x
     if reflect and pad:
         h = F.pad(h, (pad, pad), mode="reflect")
@@ -27,7 +30,7 @@ def _ref_conv(x, w, b, pad, dil, in_act, act, reflect, residual=None):
     else:
         y = F.conv1d(h, w, b, padding=pad, dilation=dil)
     if act == 1:
-        y = F.leaky_relu(y, 0.2)
+        y = F.leaky_relu(y, 0.2) if out_mask is None else TG._LReluMasked.apply(y, out_mask)
     elif act == 2:
         y = torch.tanh(y)
     return y if residual is None else y + residual
@@ -71,14 +74,17 @@ def test_conv_ex_vs_torch_cpu(case):
     # double-precision CPU reference; LeakyReLU masks can only differ at rounding-level activations
     xc, wc, bc = [torch.from_numpy(a).double().requires_grad_(True) for a in (x, w, b)]
     rc = torch.from_numpy(res).double().requires_grad_(True) if with_res else None
-    yc = _ref_conv(xc, wc, bc, pad, dil, in_act, act, reflect, rc)
+    # (an output within fp32 rounding of zero may sit on the other LeakyReLU branch than in the float64
+    #  reference: the reference's backward takes the branch the device took; no case combines the
+    #  activation behind the conv with a residual, so the device output's sign IS that branch)
+    assert not (act == 1 and with_res)
+    mask = torch.from_numpy(host(y) > 0) if act == 1 else None
+    yc = _ref_conv(xc, wc, bc, pad, dil, in_act, act, reflect, rc, out_mask=mask)
     yc.backward(torch.from_numpy(gy).double())
     assert rel_l2(host(y), yc.detach().numpy()) < 1e-5
-    # (grad_close: an output within fp32 rounding of zero may sit on the other LeakyReLU branch than in the
-    #  float64 reference; that flips the gradient of its small neighbourhood and nothing else)
-    assert grad_close(host(xt.grad), xc.grad.numpy(), 1e-3), "gx"
-    assert grad_close(host(wt.grad), wc.grad.numpy(), 1e-3), "gw"
-    assert grad_close(host(bt.grad), bc.grad.numpy(), 1e-3), "gb"
+    assert rel_l2(host(xt.grad), xc.grad.numpy()) < 1e-4, "gx"
+    assert rel_l2(host(wt.grad), wc.grad.numpy()) < 1e-4, "gw"
+    assert rel_l2(host(bt.grad), bc.grad.numpy()) < 1e-4, "gb"
     if with_res:
         assert rel_l2(host(rt.grad), rc.grad.numpy()) < 1e-6
 
