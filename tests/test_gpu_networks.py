@@ -152,7 +152,8 @@ def _masked_oracle_step(kind, gsd, dsd, samples, feats, dbg, dtype=None):
 def _check_grads(kind, net, o_grads, max_tol=1e-3, median_tol=1e-4):
     """every parameter gradient within 1e-3 rel-L2 (typical layer 1e-4).  A gradient that
     cancels to rounding level (hinge gradient of the judge bias at init: sum(+1/n) - sum(1/n)) has no
-    meaningful relative error and is held to an absolute bound against the largest gradient instead."""
+    meaningful relative error and is held to an absolute bound instead: 1e-5 of the largest gradient, or
+    1e-6 where that is smaller (the cancelling terms sum to O(1) on either side: half an fp32 ulp of them)."""
     gmax = max(float(np.linalg.norm(r)) for r in o_grads.values())
     errs = {}
     for k, p in net.named_parameters():
@@ -160,7 +161,7 @@ def _check_grads(kind, net, o_grads, max_tol=1e-3, median_tol=1e-4):
         if np.linalg.norm(r) > 1e-5 * gmax:
             errs[k] = rel_l2(host(p.grad), r)
         else:
-            assert float(np.abs(host(p.grad) - r).max()) < 1e-5 * gmax, (kind, k)
+            assert float(np.abs(host(p.grad) - r).max()) < max(1e-5 * gmax, 1e-6), (kind, k)
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
     assert worst[0][1] < max_tol, (kind, worst)
     assert float(np.median(list(errs.values()))) < median_tol, (kind, worst)
@@ -439,29 +440,38 @@ def test_flat_adam_with_module_zero_grad():
         opt = (fs.FlatAdam if kind == "flat" else torch.optim.Adam)(d.parameters(), lr=1e-4, betas=(0.5, 0.9))
         with torch.no_grad():
             fake = g(f)
-        for it in range(2):
-            d.zero_grad()                              # NOT opt.zero_grad()
+
+        def backward():
             _, fj = d(fake)
             _, rj = d(s)
             loss = LS.mel_gan_disc_loss(rj, fj)
             loss.backward()
-            if it == 1:
-                grads = {k: host(p.grad).copy() for k, p in d.named_parameters()}
-            opt.step()
-        res[kind] = (loss.item(), grads, {k: host(v) for k, v in d.state_dict().items()}, opt)
+            return loss.item()
+        opt.zero_grad()
+        backward()                                     # flat: the bucket is bound and now holds this gradient
+        d.zero_grad()                                  # NOT opt.zero_grad(): .grad = None, the bucket is stale
+        loss = backward()
+        grads = {k: host(p.grad).copy() for k, p in d.named_parameters()}
+        opt.step()
+        if kind == "flat":                             # the step consumed THIS gradient, not stale + new
+            for (k, p), gv in zip(d.named_parameters(), opt.grad_views()):
+                assert np.array_equal(host(gv), grads[k]), k
+        res[kind] = (loss, grads, {k: host(v) for k, v in d.state_dict().items()}, opt)
     assert abs(res["flat"][0] - res["torch"][0]) <= 1e-6 * abs(res["torch"][0])
     for k, gt_ in res["torch"][1].items():
         assert rel_l2(res["flat"][1][k], gt_) < 1e-5 or np.linalg.norm(gt_) < 1e-12, k
     for k, v in res["torch"][2].items():
         assert np.abs(res["flat"][2][k] - v).max() <= 2.1e-4, k
-        assert rel_l2(res["flat"][2][k], v) < 1e-3 or not k.endswith("weight"), k
+        big = np.abs(res["torch"][1][k]) > 1e-3 * np.abs(res["torch"][1][k]).max()
+        if big.any():
+            assert np.abs(res["flat"][2][k] - v)[big].max() < 2e-5, k
     # optimizer checkpoint through the generic interface
     sd = res["flat"][3].state_dict()
-    assert "flat" in sd and int(sd["flat"]["step"]) == 2 and float(sd["flat"]["exp_avg"].abs().sum()) > 0
+    assert "flat" in sd and int(sd["flat"]["step"]) == 1 and float(sd["flat"]["exp_avg"].abs().sum()) > 0
     g, d, _, _ = make_nets(dict(seed=7, bias_scale=0.02), dict(seed=8, bias_scale=0.02))
     opt2 = fs.FlatAdam(d.parameters(), lr=1e-4, betas=(0.5, 0.9))
     opt2.load_state_dict(sd)
-    assert opt2.step_count() == 2 and torch.equal(opt2._flat[2].cpu(), sd["flat"]["exp_avg"])
+    assert opt2.step_count() == 1 and torch.equal(opt2._flat[2].cpu(), sd["flat"]["exp_avg"])
 
 
 def test_generator_feature_gradient_vs_oracle():

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 echo "== build" && python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -3
 echo "== pytest -m gpu"
-timeout -k 10 900 python -m pytest tests -m gpu -q -x --timeout=600 -p no:cacheprovider ${PYTEST_ARGS:-} > gpurun_out/pytest_gpu.log 2>&1
+timeout -k 10 900 python -m pytest tests -m gpu -q ${XFLAG--x} --timeout=600 -p no:cacheprovider ${PYTEST_ARGS:-} > gpurun_out/pytest_gpu.log 2>&1
 rc=$?; tail -n ${TAILN:-40} gpurun_out/pytest_gpu.log; echo "pytest rc=$rc"
 [ $rc -ne 0 ] && [ -z "$KEEP_GOING" ] && exit $rc
 echo "== smoke"
