@@ -1096,7 +1096,10 @@ bool rows_applicable(int M, int CK, int K, int L) {
     return L >= 1;
 }
 
-RowCfg pick_row_cfg(int M, int B, int L) {
+// dense = a plain stride-1 conv with 3 or 5 taps, i.e. a launch the split-bf16 kernel (conv_rows3.hip) may take:
+// its 128x128 tile needs 112 KiB of LDS (one workgroup per CU, every latency exposed); two co-resident 64x128
+// workgroups measured faster (C = 128, L = 2048, B = 32: 58 vs 68 us)
+RowCfg pick_row_cfg(int M, int B, int L, bool dense = false) {
     if (const char* e = getenv("MSYNTH_ROWCFG")) {      // tuning switch: force a tile shape
         const int v = atoi(e);
         if (v >= 0 && v <= 3 && (M > 32 || v == 3)) return v == 0 ? ROW_128x128 : (v == 1 ? ROW_64x128 : (v == 2 ? ROW_64x64 : ROW_32x256));
@@ -1104,7 +1107,9 @@ RowCfg pick_row_cfg(int M, int B, int L) {
     if (M <= 32) return ROW_32x256;
     if (L < 128) return (M >= 512 && (long long)B * L >= 512) ? ROW_64x128 : ROW_64x64;   // short rows: R = 128 / L rows per tile
     const long long N = (long long)B * L;
-    if (M >= 128 && (N / 128) * (M / 128) >= 384) return ROW_128x128;
+    const char* r3 = getenv("MSYNTH_ROWS3");
+    const bool split = dense && L % 4 == 0 && !(r3 && atoi(r3) == 0);
+    if (M >= 128 && (N / 128) * (M / 128) >= 384 && !split) return ROW_128x128;
     static const int t64 = getenv("MSYNTH_T64") ? atoi(getenv("MSYNTH_T64")) : 192;   // tuning switch
     if ((N / 128) * (M / 64) < t64) return ROW_64x64;   // small batches: more, smaller workgroups
     return ROW_64x128;
@@ -1172,7 +1177,7 @@ bool rows2_pick(RowCfg cfg, int K, int CC, bool has_act, int epi_s, int in_s, co
             return true;
         }
     }
-    return msr2_supported(*tile, K, CC, *am, epi_s, *q, in_s);
+    return msr3_supported(*tile, K, *am, epi_s, *q, in_s) || msr2_supported(*tile, K, CC, *am, epi_s, *q, in_s);
 }
 
 template <int K, bool HAS_ACT, int EPI_S = 0, int IN_S = 1, int CCMUL = 1>
@@ -1188,6 +1193,9 @@ int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, 
         Row2P q;
         int tile, am, in_s_eff;
         if (rows2_pick(cfg, K, CC, HAS_ACT, EPI_S, IN_S, p, X, Xact, W, res, Y, Yact, &q, &tile, &am, &in_s_eff)) {
+            if (msr3_supported(tile, K, am, EPI_S, q, in_s_eff))      // split-bf16 matrix pipe (conv_rows3.hip)
+                return msr3_launch(tile, K, am, q, X, Xact, am == 1 ? p.Wfwd : W, bias, res, Y, Yact, grid.x, grid.y,
+                                   grid.z, s);
             if (EPI_S == 0 && IN_S == 1 && in_s_eff == 1 && (cfg == ROW_128x128 || cfg == ROW_64x128) &&
                 msr2h_supported(K, CC, am, q, res != nullptr, Yact != nullptr))
                 return msr2h_launch(K, CC, am, q, X, Xact, am == 1 ? p.Wfwd : W, bias, res, Y, Yact, s);
@@ -1256,6 +1264,14 @@ const char* row_kname(RowCfg c, int K, bool act, int CK, int L = 0, int R = 1, i
         if (K == 5 && CC == 16 && epi_s == 0 && am == 1 && L < bn && L % 4 != 0 && c != ROW_32x256) {   // short-row mode
             snprintf(buf, sizeof(buf), "k_conv_rows2<%s, 5, 16, %d, 0, 0>", tile, am);
             return buf;
+        }
+        {
+            Row2P h = q;
+            h.B = B; h.M = M > 0 ? M : 64; h.CK = CK; h.CKs = CK; h.PX = R * SS; h.Lt = L >= bn ? bn : L;
+            if (msr3_supported(t2, K, am, epi_s, h)) {
+                snprintf(buf, sizeof(buf), "k_conv_rows3<%s, %d, %d>", tile, K, am);
+                return buf;
+            }
         }
         if (msr2_supported(t2, K, CC, am, epi_s, q)) {
             if (epi_s == 0 && (c == ROW_128x128 || c == ROW_64x128) && B > 0 && M > 0) {
@@ -1395,14 +1411,14 @@ bool msm_convt_fwd_applicable(const ConvP& p) {
 size_t msm_fwd_ws(const ConvP& p) {
     if (!rows_ok(p, false)) return 0;
     RowP r;
-    const RowCfg cfg = pick_row_cfg(p.Cout, p.B, p.Lin);
+    const RowCfg cfg = pick_row_cfg(p.Cout, p.B, p.Lin, p.K == 3 || p.K == 5);
     make_rowp(&r, cfg, p.B, p.Cin, p.Lin, p.Cout, p.K, p.dil, -p.pad, p.pad_mode, 0, 0, 0.f);
     return rows_split_ws(cfg, r, rows_cc_eff(p.K, p.Cin));
 }
 size_t msm_bwd_data_ws(const ConvP& p) {
     if (!rows_ok(p, true)) return 0;
     RowP r;
-    const RowCfg cfg = pick_row_cfg(p.Cin, p.B, p.Lin);
+    const RowCfg cfg = pick_row_cfg(p.Cin, p.B, p.Lin, p.K == 3 || p.K == 5);
     make_rowp(&r, cfg, p.B, p.Cout, p.Lin, p.Cin, p.K, p.dil, 0, 0, 0, 0, 0.f);
     return align16((size_t)p.Cin * p.Cout * p.K * sizeof(float)) + rows_split_ws(cfg, r, rows_cc_eff(p.K, p.Cout));
 }
@@ -1420,7 +1436,7 @@ size_t msm_convt_fwd_ws(const ConvP& p) {
 const char* msm_fwd_name(const ConvP& p) {
     if (rows_ok(p, false)) {
         RowP r;
-        const RowCfg cfg = pick_row_cfg(p.Cout, p.B, p.Lin);
+        const RowCfg cfg = pick_row_cfg(p.Cout, p.B, p.Lin, p.K == 3 || p.K == 5);
         make_rowp(&r, cfg, p.B, p.Cin, p.Lin, p.Cout, p.K, p.dil, -p.pad, p.pad_mode, 0, 0, 0.f);
         return row_kname(cfg, p.K, p.in_act != 0, p.Cin, p.Lin, r.R, r.SS, p.pad_mode, p.in_act ? MS_MOD_LRELU_FWD : 0, 0,
                          p.B, p.Cout);
@@ -1430,7 +1446,7 @@ const char* msm_fwd_name(const ConvP& p) {
 const char* msm_bwd_data_name(const ConvP& p) {
     if (rows_ok(p, true)) {
         RowP r;
-        const RowCfg cfg = pick_row_cfg(p.Cin, p.B, p.Lin);
+        const RowCfg cfg = pick_row_cfg(p.Cin, p.B, p.Lin, p.K == 3 || p.K == 5);
         make_rowp(&r, cfg, p.B, p.Cout, p.Lin, p.Cin, p.K, p.dil, 0, 0, 0, 0, 0.f);
         return row_kname(cfg, p.K, p.act != MS_ACT_NONE, p.Cout, p.Lin, r.R, r.SS, MS_PAD_ZERO, p.act, 0, p.B, p.Cin);
     }
@@ -1462,7 +1478,7 @@ int msm_conv1d_fwd(const ConvP& p, const float* x, const float* x_act, int x_act
                    float* y_act, void* ws, size_t ws_bytes, hipStream_t s) {
     if (rows_ok(p, false) && (((uintptr_t)w) & 15) == 0) {
         RowP r;
-        const RowCfg cfg = pick_row_cfg(p.Cout, p.B, p.Lin);
+        const RowCfg cfg = pick_row_cfg(p.Cout, p.B, p.Lin, p.K == 3 || p.K == 5);
         make_rowp(&r, cfg, p.B, p.Cin, p.Lin, p.Cout, p.K, p.dil, -p.pad, p.pad_mode, p.act,
                   x_act_kind, p.slope);
         const int K = p.K;
@@ -1486,7 +1502,7 @@ int msm_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, con
         const size_t total = (size_t)p.Cin * p.Cout * p.K;
         const size_t wbytes = align16(total * sizeof(float));
         RowP r;
-        const RowCfg cfg = pick_row_cfg(p.Cin, p.B, p.Lin);
+        const RowCfg cfg = pick_row_cfg(p.Cin, p.B, p.Lin, p.K == 3 || p.K == 5);
         make_rowp(&r, cfg, p.B, p.Cout, p.Lin, p.Cin, p.K, p.dil, p.pad - (p.K - 1) * p.dil,
                   MS_PAD_ZERO, MS_ACT_NONE, p.act, p.slope);
         r.Wfwd = w;

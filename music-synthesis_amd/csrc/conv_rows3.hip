@@ -1,0 +1,419 @@
+// Row-tile forward / backward-data convolution on the bf16 matrix pipe with fp32-exact operands
+// (third generation of the dense row-tile kernel; same contraction, tiling, staging geometry and
+// epilogue as k_conv_rows2 in conv_rows2.hip).
+//
+// Why: gfx950's fp32-input MFMA runs at the fp32 VECTOR rate (157 TFLOP/s peak, 1/16 of the bf16
+// matrix rate) and the second-generation K loop already keeps it ~96 % busy -- the fp32 pipe itself is
+// the ceiling.  Here every fp32 operand is split ON THE WAY INTO LDS into three bf16 pieces
+//     x = x1 + x2 + x3,   x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
+// (each subtraction is exact in fp32 and 3 x 8 significand bits cover fp32's 24, so the sum is EXACT),
+// and a product a*b is accumulated in fp32 as the six partial products with i + j <= 4
+//     a1 b3 + a3 b1 + a2 b2 + a1 b2 + a2 b1 + a1 b1
+// on v_mfma_f32_32x32x16_bf16; the three dropped ones are below 2^-24 |a b|, i.e. below the rounding
+// of the fp32 FMA chain this replaces (measured: rel-L2 error vs float64 1.3e-7..3e-7 against 5e-7
+// for the fmaf chain, K = 768).  Six bf16 MFMAs cover 16 k-elements in 6 x 32 cycles where eight
+// fp32 MFMAs (32x32x2) need 8 x 64: 2.67x fewer matrix-pipe cycles per FLOP at fp32-equivalent accuracy.
+// It is not a reduced-precision path: no operand is rounded, only sub-ulp cross terms are dropped.
+//
+// Layout: a chunk is CC = 16 input channels x K taps; MFMA k-step s = tap s (k = the 16 channels).
+//   A (weights)      LDS row m:      [tap j][piece p][16 channels] bf16, row stride K*96 + 16 bytes
+//   X (activations)  LDS column u:   [piece p][16 channels] bf16, column stride 112 bytes
+// (strides = odd multiples of 16 bytes: the 16-byte fragment reads of a lane group cover all banks).
+// A lane's fragment of k-step s is ONE 16-byte read per piece: channels 8h..8h+7 of row / column
+// (lane & 31) -- the dilation halo is a column offset s*dil, exactly as in the fp32 kernels.
+// Staging transposes in registers: a thread takes 4 channels x 4 consecutive samples (4 float4 loads)
+// or 4 channels x K taps of one weight row (K float4 loads), splits, and writes 8-byte [4 channels]
+// groups.  Two LDS buffers, one barrier per chunk; stores of chunk c+1 and loads of chunk c+2 are
+// spread between the MFMAs of chunk c.
+//
+// AM 0: forward (W = [M][CK][K]);  AM 1: backward data, LeakyReLU derivative from Xact applied on load,
+// W read in the forward layout W[co][ci][K] (GEMM row = ci, taps flipped).
+#include "conv_rows2.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int CC3 = 16;                     // channels per chunk = one k-step per tap
+constexpr int XRS = 112;                    // bytes per LDS activation column: 3 pieces x 32 + 16
+constexpr int a_row_bytes(int K) { return K * 96 + 16; }
+
+// (a, b) -> three packed bf16 pairs with a = h.lo + m.lo + l.lo exactly (same for b in the high halves)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    const f32x2 v = {a, b};
+    const bf16x2 hi = __builtin_convertvector(v, bf16x2);
+    const f32x2 r1 = v - __builtin_convertvector(hi, f32x2);
+    const bf16x2 mi = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(mi, f32x2);
+    const bf16x2 lo = __builtin_convertvector(r2, bf16x2);
+    h = __builtin_bit_cast(unsigned, hi);
+    m = __builtin_bit_cast(unsigned, mi);
+    l = __builtin_bit_cast(unsigned, lo);
+}
+
+// 4 values (4 consecutive channels of one (row|column, tap)) -> one 8-byte group per piece
+__device__ __forceinline__ void split_quad(const float (&e)[4], uint2 (&o)[3]) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_pair(e[0], e[1], h0, m0, l0);
+    split_pair(e[2], e[3], h1, m1, l1);
+    o[0] = make_uint2(h0, h1);
+    o[1] = make_uint2(m0, m1);
+    o[2] = make_uint2(l0, l1);
+}
+
+constexpr int msr3_nxu(int BN) { return (4 * (BN / 4 + 12) + 255) / 256; }   // activation units per thread
+
+template <int WGM, int WGN, int TM, int TN, int K, int AM>
+__global__ __launch_bounds__(256) void k_conv_rows3(Row2P p, const float* __restrict__ X,
+                                                   const float* __restrict__ Xact,
+                                                   const float* __restrict__ W,
+                                                   const float* __restrict__ bias,
+                                                   const float* __restrict__ res,
+                                                   float* __restrict__ Y,
+                                                   float* __restrict__ Yact) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int ARS = a_row_bytes(K);
+    constexpr int NAU = (BM * 4 + 255) / 256;        // weight units (row, channel quad) per thread
+    constexpr int NXU = msr3_nxu(BN);                // activation units (channel quad, 4-sample vector)
+    constexpr int NU = NAU + NXU;
+    static_assert(WGM * WGN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    const int tile_bytes = BM * ARS + p.PX * XRS;
+    unsigned char* scratch = smem3 + p.scratch_off;   // 256 x 8 bytes: sink for masked stores
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int m0 = blockIdx.y * BM;
+    int b0, t0;
+    if (p.R == 1) { b0 = blockIdx.x / p.tiles_per_row; t0 = (blockIdx.x - b0 * p.tiles_per_row) * BN; }
+    else { b0 = blockIdx.x * p.R; t0 = 0; }
+
+    // Operands are read through buffer descriptors: a lane whose unit lies outside the tensor (rows >= M,
+    // samples before / behind a row: the zero padding) carries an out-of-range byte offset and the hardware
+    // range check returns 0.0f for it -- no per-element selects in the staging code.  The chunk's channel
+    // offset travels in the (unchecked) scalar offset.
+    constexpr unsigned OOB = 0xF0000000u;
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0x80000000u, 0x00020000);
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, 0x80000000u, 0x00020000);
+    const auto rsXa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(AM == 1 ? Xact : X), 0, 0x80000000u, 0x00020000);
+
+    // ---- chunk-invariant unit descriptors
+    // weight unit i: row = e / 4, channel quad cq = e % 4
+    unsigned a_goff[NAU];
+    int a_loff[NAU];
+#pragma unroll
+    for (int i = 0; i < NAU; ++i) {
+        const int e = i * 256 + tid;
+        const int row = e >> 2, cq = e & 3;
+        const bool in = row < BM;
+        const bool ok = in && m0 + row < p.M;
+        if (AM == 0) a_goff[i] = ok ? 4u * (unsigned)((m0 + row) * p.KG + 4 * cq * K) : OOB;       // + c0*K per chunk
+        else a_goff[i] = ok ? 4u * (unsigned)((4 * cq * p.M + m0 + row) * K) : OOB;                // + c0*M*K per chunk
+        a_loff[i] = in ? row * ARS + cq * 8 : -1;
+    }
+    // activation unit q: channel quad cq, aligned 4-sample vector v of the tile's R segments
+    const int sh = ((p.off0 % 4) + 4) % 4;           // segment start within its 16-byte vector
+    const int NVS = (p.SS + 6) >> 2;                 // aligned vectors covering one segment
+    const int NVT = p.R * NVS;
+    unsigned x_goff[NXU];
+    int x_lcol[NXU];
+    unsigned x_em[NXU];
+    int x_cq8[NXU];
+#pragma unroll
+    for (int q = 0; q < NXU; ++q) {
+        // 16 consecutive lanes = 4 channel quads x 4 consecutive vectors: their 8-byte LDS stores (column stride
+        // 112 bytes, 4 columns apart) then fall into 16 different bank pairs (lanes that differ only in the
+        // vector index would hit 4)
+        const int i = tid + 256 * q;
+        const int cq = (i >> 2) & 3, v = (i >> 4) * 4 + (i & 3);
+        const int r = v / NVS, sv = v - r * NVS;
+        const int u0 = 4 * sv - sh;
+        const int t = t0 + p.off0 + u0;                // multiple of 4: the vector is all in or all out
+        const bool in = v < NVT;
+        const bool ok = in && b0 + r < p.B && t >= 0 && t < p.L;
+        x_goff[q] = ok ? 4u * (unsigned)(((b0 + r) * p.CK + 4 * cq) * p.L + t) : OOB;
+        x_lcol[q] = r * p.SS + u0;
+        x_cq8[q] = cq * 8;
+        unsigned em = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (in && u0 + e >= 0 && u0 + e < p.SS) em |= 1u << e;
+        x_em[q] = em;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int bbase[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = wn * TN * 32 + j * 32 + (lane & 31);
+        const int r = nl / p.Lt, tc = nl - r * p.Lt;
+        const bool ok = r < p.R && b0 + r < p.B && t0 + tc < p.L;
+        bbase[j] = ok ? r * p.SS + tc : 0;
+    }
+
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 ra[NAU][AM == 1 ? 1 : K];
+    float rad[NAU][AM == 1 ? 4 * K : 1];
+    f32x4 rx[NXU][4], rxa[AM == 1 ? NXU : 1][4];
+    auto load_unit = [&](int u, int c0, bool live) {          // c0: first channel of the chunk
+        if (u < NAU) {
+            const int i = u;
+            if (AM == 0) {
+                const int so = live ? 4 * c0 * K : 0;
+#pragma unroll
+                for (int k4 = 0; k4 < K; ++k4)
+                    ra[i][k4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, a_goff[i] + 16 * k4, so, 0));
+            } else {
+                const int qs = 4 * p.M * K;           // byte stride between the quad's 4 contraction channels
+                const int so = live ? c0 * qs : 0;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                    for (int j = 0; j < K; ++j)
+                        rad[i][qq * K + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsW, a_goff[i] + 4 * j, so + qq * qs, 0));
+            }
+        } else {
+            const int q = u - NAU;
+            const int cs = 4 * p.L;
+            const int so = live ? c0 * cs : 0;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                rx[q][cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, x_goff[q], so + cc * cs, 0));
+                if (AM == 1) rxa[q][cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsXa, x_goff[q], so + cc * cs, 0));
+            }
+        }
+    };
+    // part t of unit u's registers -> LDS: weight units store tap t (t < K), activation units sample t (t < 4)
+    auto store_part = [&](int u, int t, unsigned char* buf) {
+        if (u < NAU) {
+            if (t >= K) return;
+            const int i = u, j = t;
+            const bool in = a_loff[i] >= 0;
+            unsigned char* base = in ? buf + a_loff[i] + j * 96 : scratch + tid * 8;
+            const int pstep = in ? 32 : 0;
+            float e[4];
+            if (AM == 0) {
+                // element (channel qq, tap j) of the unit = float index qq*K + j of its K float4s
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) e[qq] = ra[i][(qq * K + j) >> 2][(qq * K + j) & 3];
+            } else {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) e[qq] = rad[i][qq * K + (K - 1 - j)];   // taps flipped
+            }
+            uint2 o3[3];
+            split_quad(e, o3);
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(base + pp * pstep) = o3[pp];
+        } else {
+            if (t >= 4) return;
+            const int q = u - NAU, e = t;
+            const bool in = (x_em[q] >> e) & 1u;
+            unsigned char* base = in ? buf + BM * ARS + (x_lcol[q] + e) * XRS + x_cq8[q] : scratch + tid * 8;
+            const int pstep = in ? 32 : 0;
+            float c4[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                c4[cc] = rx[q][cc][e];
+                if (AM == 1) c4[cc] = rxa[q][cc][e] > 0.f ? c4[cc] : c4[cc] * p.slope;
+            }
+            uint2 o3[3];
+            split_quad(c4, o3);
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(base + pp * pstep) = o3[pp];
+        }
+    };
+    auto store_unit = [&](int u, unsigned char* buf) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) store_part(u, t, buf);
+    };
+
+    // split-K: slice z contracts channels [z*CKs, min((z+1)*CKs, CK)) into its own output slab
+    const int cbeg = blockIdx.z * p.CKs;
+    const int nchunks = ((cbeg + p.CKs < p.CK ? cbeg + p.CKs : p.CK) - cbeg) / CC3;
+    Y += (size_t)blockIdx.z * p.zstride;
+
+    // prologue: chunk 0 -> buffer 0, chunk 1 -> registers
+#pragma unroll
+    for (int u = 0; u < NU; ++u) load_unit(u, cbeg, true);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) store_unit(u, smem3);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) load_unit(u, cbeg + CC3, nchunks > 1);
+    __syncthreads();
+
+    const int arow = (wm * TM * 32 + (lane & 31)) * ARS + h * 16;
+    static_assert(K == 3 || K == 5, "taps");
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const unsigned char* As = smem3 + (ch & 1) * tile_bytes;
+        const unsigned char* Xs = As + BM * ARS + h * 16;
+        unsigned char* nbuf = smem3 + ((ch & 1) ^ 1) * tile_bytes;
+        const bool live2 = ch + 2 < nchunks;
+        const int c2 = cbeg + (ch + 2) * CC3;
+        bf16x8 fa[2][TM][3], fb[2][TN][3];
+        auto frag = [&](int s, bf16x8 (&a)[TM][3], bf16x8 (&b)[TN][3]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+                    a[i][pp] = *reinterpret_cast<const bf16x8*>(As + arow + i * 32 * ARS + s * 96 + pp * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+                    b[j][pp] = *reinterpret_cast<const bf16x8*>(Xs + (bbase[j] + s * p.dil) * XRS + pp * 32);
+        };
+        frag(0, fa[0], fb[0]);
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            if (s + 1 < K) frag(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+            // the six partial products with piece indices i + j <= 4 (1-based), smallest first; between them the
+            // staging parts of the units that belong to this k-step (chunk ch+1: registers -> the other buffer;
+            // chunk ch+2: loads into the registers just freed)
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i][PA[t]], fb[s & 1][j][PB[t]], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int u = s; u < NU; u += K) {
+                    store_part(u, t, nbuf);
+                    if (t == 5) load_unit(u, c2, live2);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (as k_conv_rows2, EPI_S == 0): the tile goes through LDS -- bias + activation on the way
+    // in, then 16-byte rows out: residual loads and both output stores are 16 bytes per lane
+    constexpr int TP = BN + 4;
+    float* Ts = reinterpret_cast<float*>(smem3);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mb = wm * TM * 32 + i * 32 + 4 * h;
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + mb + (r & 3) + 8 * (r >> 2);
+            bv[r] = bias ? bias[m < p.M ? m : 0] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * TN * 32 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Ts[(mb + (r & 3) + 8 * (r >> 2)) * TP + col] = ms_apply_act(acc[i][j][r] + bv[r], p.act, p.slope);
+        }
+    }
+    __syncthreads();
+    constexpr int V4 = BN / 4;
+    constexpr int NQ = BM * V4 / 256;
+    float4 tv[NQ], rv[NQ];
+    size_t go[NQ];
+    bool ok[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int idx = tid + 256 * q;
+        const int row = idx / V4, c4 = idx - row * V4;
+        const int nl = 4 * c4;
+        const int r = nl / p.Lt, tc = nl - r * p.Lt;     // Lt % 4 == 0: the 4 samples share a row
+        ok[q] = m0 + row < p.M && r < p.R && b0 + r < p.B && t0 + tc < p.L;
+        go[q] = ok[q] ? ((size_t)(b0 + r) * p.M + m0 + row) * p.L + t0 + tc : 0;
+        tv[q] = *reinterpret_cast<const float4*>(Ts + row * TP + nl);
+        if (res) rv[q] = *reinterpret_cast<const float4*>(res + go[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (!ok[q]) continue;
+        if (Yact) *reinterpret_cast<float4*>(Yact + go[q]) = tv[q];
+        float4 v = tv[q];
+        if (res) { v.x += rv[q].x; v.y += rv[q].y; v.z += rv[q].z; v.w += rv[q].w; }
+        *reinterpret_cast<float4*>(Y + go[q]) = v;
+    }
+}
+
+template <int WGM, int WGN, int TM, int TN, int K, int AM>
+size_t lds_bytes(const Row2P& p) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    size_t by = (size_t)2 * (BM * a_row_bytes(K) + p.PX * XRS);
+    const size_t epi = (size_t)BM * (BN + 4) * sizeof(float);
+    if (by < epi) by = epi;
+    return by;
+}
+
+template <int WGM, int WGN, int TM, int TN, int K, int AM>
+int launch_inst(const Row2P& p, const float* X, const float* Xact, const float* W, const float* bias,
+                const float* res, float* Y, float* Yact, dim3 grid, hipStream_t s) {
+    const size_t by = lds_bytes<WGM, WGN, TM, TN, K, AM>(p);
+    const size_t lds = by + 256 * 8;
+    if (lds > 156 * 1024) return MS_ERR_UNSUPPORTED;
+    static bool attr_set = false;                    // > 64 KiB of dynamic LDS needs the opt-in once
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rows3<WGM, WGN, TM, TN, K, AM>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        attr_set = true;
+    }
+    Row2P pp = p;
+    pp.scratch_off = (int)by;
+    hipLaunchKernelGGL((k_conv_rows3<WGM, WGN, TM, TN, K, AM>), grid, dim3(256), lds, s, pp, X, Xact, W, bias, res,
+                       Y, Yact);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+template <int K, int AM>
+int launch_tile(int tile, const Row2P& p, const float* X, const float* Xact, const float* W, const float* bias,
+                const float* res, float* Y, float* Yact, dim3 grid, hipStream_t s) {
+    switch (tile) {
+        case MSR2_128x128: return launch_inst<2, 2, 2, 2, K, AM>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+        case MSR2_64x128: return launch_inst<2, 2, 1, 2, K, AM>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+        case MSR2_64x64: return launch_inst<2, 2, 1, 1, K, AM>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+        case MSR2_32x256: return launch_inst<1, 4, 1, 2, K, AM>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+        default: return MS_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace
+
+// Same contract as msr2_supported / msr2_launch (conv_rows2.h) for the subset: stride-1 plain rows
+// (in_s == 1), zero padding, L % 4 == 0, K in {3, 5}, chunks of 16 channels, act_mode 0 / 1, plain epilogue.
+bool msr3_supported(int tile, int K, int act_mode, int epi_s, const Row2P& p, int in_s) {
+    const char* sw = getenv("MSYNTH_ROWS3");         // tuning / test switch (0: stay on the fp32-MFMA kernels)
+    if (sw && atoi(sw) == 0) return false;
+    if (tile < 0 || tile >= MSR2_32x256) return false;      // (32 x 256: measured no faster than the fp32 kernel)
+    if (in_s != 1 || epi_s != 0 || (act_mode != 0 && act_mode != 1)) return false;
+    if (K != 3 && K != 5) return false;
+    if (p.L % 4 || p.Lt % 4 || p.CK % CC3 || p.CKs % CC3) return false;
+    if (act_mode == 1 && p.M % 4) return false;
+    const int bn = tile == MSR2_32x256 ? 256 : (tile == MSR2_64x64 ? 64 : 128);
+    const int bm = tile == MSR2_128x128 ? 128 : (tile == MSR2_32x256 ? 32 : 64);
+    const int nvt = p.R * ((p.SS + 6) / 4);
+    if (16 * ((nvt + 3) / 4) > 256 * msr3_nxu(bn)) return false;
+    size_t by = (size_t)2 * (bm * a_row_bytes(K) + p.PX * XRS);
+    const size_t epi = (size_t)bm * (bn + 4) * sizeof(float);
+    if (by < epi) by = epi;
+    return by + 256 * 8 <= 156 * 1024;
+}
+
+int msr3_launch(int tile, int K, int act_mode, const Row2P& p, const float* X, const float* Xact, const float* W,
+                const float* bias, const float* res, float* Y, float* Yact, unsigned gx, unsigned gy, unsigned gz,
+                hipStream_t s) {
+    const dim3 grid(gx, gy, gz);
+    if (K == 3 && act_mode == 0) return launch_tile<3, 0>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    if (K == 3 && act_mode == 1) return launch_tile<3, 1>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    if (K == 5 && act_mode == 0) return launch_tile<5, 0>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    if (K == 5 && act_mode == 1) return launch_tile<5, 1>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    return MS_ERR_UNSUPPORTED;
+}

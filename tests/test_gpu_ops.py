@@ -231,6 +231,16 @@ HOT_CONVS = [
     ("d_k5_l17_b9", 9, 128, 17, 64, 5, 1, 2, 1, 1, 1, False),
     ("d_k5_l33", 5, 128, 33, 128, 5, 1, 2, 1, 1, 1, False),
     ("d_k5_l101", 3, 128, 101, 64, 5, 1, 2, 1, 1, 1, False),
+    # 16-byte aligned rows: the split-bf16 row kernel (conv_rows3.hip) in every tile shape, with M / channel /
+    # row tails, packed short rows, dilation halos
+    ("r3_c128_l2048", 2, 128, 2048, 128, 3, 1, 1, 1, 1, 1, False),
+    ("r3_c256_l256_d9", 3, 256, 256, 256, 3, 1, 9, 9, 1, 1, False),
+    ("r3_c64_l4096_d3", 1, 64, 4096, 64, 3, 1, 3, 3, 1, 1, False),
+    ("r3_c32_l1024_d9", 3, 32, 1024, 32, 3, 1, 9, 9, 1, 1, False),
+    ("r3_m96_ck48_l132", 2, 48, 132, 96, 3, 1, 3, 3, 1, 1, False),
+    ("r3_k5_l32", 5, 256, 32, 320, 5, 1, 2, 1, 1, 1, False),
+    ("r3_k5_l64_noact", 3, 128, 64, 128, 5, 1, 2, 1, 1, 0, False),
+    ("r3_k3_l16_r8", 9, 64, 16, 64, 3, 1, 1, 1, 1, 1, False),
     ("d_judge", 2, 1024, 9, 1, 3, 1, 1, 1, 1, 0, False),
     ("d_judge_l32", 5, 1024, 32, 1, 3, 1, 1, 1, 1, 0, False),
     ("d_judge_l17", 3, 1024, 17, 1, 3, 1, 1, 1, 1, 0, False),
@@ -363,16 +373,26 @@ def test_kernel_generations_agree(shape, monkeypatch):
     gy = dev(rng.standard_normal((B, C, Lg)).astype(np.float32))
     d, lo = P.conv_desc(x.shape, w.shape, pad=dil * (K - 1) // 2, dil=dil, act=1)
     out = {}
-    for gen in ("0", "1"):
-        monkeypatch.setenv("MSYNTH_ROWS2", gen)
-        monkeypatch.setenv("MSYNTH_WROWS", gen)
+    monkeypatch.setenv("MSYNTH_ROWS3", "0")
+    for gen in ("0", "1", "3"):
+        monkeypatch.setenv("MSYNTH_ROWS2", "1" if gen == "3" else gen)
+        monkeypatch.setenv("MSYNTH_WROWS", "1" if gen == "3" else gen)
+        monkeypatch.setenv("MSYNTH_ROWS3", "1" if gen == "3" else "0")
         y, ya = P.conv1d_fwd(x, w, b, d, lo, residual=res, want_y_act=True)
-        gx = P.conv1d_bwd_data(gy, ya, w, d, gx_add=res)
+        gx = P.conv1d_bwd_data(gy, out["1"][1] if gen == "3" else ya, w, d, gx_add=res)
         gw, gb = P.conv1d_bwd_weight(x, gy, ya, d, w.shape)
-        out[gen] = [host(t) for t in (y, ya, gx, gw, gb)]
-    for i in range(3):
+        out[gen] = [host(t) for t in (y, ya, gx, gw, gb)] if gen != "3" else [y, ya, gx]
+        if gen == "1":
+            out["1"][1] = ya                       # (device tensor: the third generation's backward uses this mask)
+    for i in (0, 2):
         assert np.array_equal(out["0"][i], out["1"][i])
+    assert np.array_equal(out["0"][1], host(out["1"][1]))
     assert rel_l2(out["1"][3], out["0"][3]) < 2e-6 and rel_l2(out["1"][4], out["0"][4]) < 2e-6
+    # third generation (conv_rows3.hip): fp32 operands split exactly into three bf16 pieces, six partial
+    # products on the bf16 matrix pipe -- not the same rounding sequence as the fmaf chain, same accuracy
+    y3, ya3, gx3 = out["3"]
+    assert rel_l2(host(y3), out["1"][0]) < 1e-6 and rel_l2(host(ya3), host(out["1"][1])) < 1e-6
+    assert rel_l2(host(gx3), out["1"][2]) < 1e-6
 
 
 @pytest.mark.parametrize("case", [
