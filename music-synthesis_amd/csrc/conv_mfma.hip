@@ -1180,6 +1180,18 @@ bool rows2_pick(RowCfg cfg, int K, int CC, bool has_act, int epi_s, int in_s, co
     return msr3_supported(*tile, K, *am, epi_s, *q, in_s) || msr2_supported(*tile, K, CC, *am, epi_s, *q, in_s);
 }
 
+// Paired eight-wave split-bf16 kernel (k_conv_rows3p): rows per workgroup (128 / 64) when the launch should take
+// it -- supported and its grid (half as many, twice as wide workgroups) still fills most of the 256 CUs -- else 0.
+int rows3p_bm(const Row2P& q, int bn, int K, int am, int epi_s, int in_s, unsigned gz) {
+    if (bn != 128) return 0;                     // (q's tiling must be the 128-column one the kernel's groups own)
+    static const int min_wgs = getenv("MSYNTH_R3P_MIN") ? atoi(getenv("MSYNTH_R3P_MIN")) : 192;   // tuning switch
+    const int bm = (q.M >= 128 && K == 3) ? 128 : 64;
+    if (!msr3p_supported(bm, K, am, epi_s, q, in_s)) return 0;
+    const long long ntiles = q.R == 1 ? (long long)q.B * q.tiles_per_row : (q.B + q.R - 1) / q.R;
+    const long long wgs = ((ntiles + 1) / 2) * ((q.M + bm - 1) / bm) * gz;
+    return wgs >= min_wgs ? bm : 0;
+}
+
 template <int K, bool HAS_ACT, int EPI_S = 0, int IN_S = 1, int CCMUL = 1>
 int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, const float* W,
                   const float* bias, const float* res, float* Y, float* Yact, hipStream_t s) {
@@ -1193,6 +1205,8 @@ int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, 
         Row2P q;
         int tile, am, in_s_eff;
         if (rows2_pick(cfg, K, CC, HAS_ACT, EPI_S, IN_S, p, X, Xact, W, res, Y, Yact, &q, &tile, &am, &in_s_eff)) {
+            if (const int bmp = rows3p_bm(q, bn, K, am, EPI_S, in_s_eff, grid.z))
+                return msr3p_launch(bmp, K, am, q, X, Xact, am == 1 ? p.Wfwd : W, bias, res, Y, Yact, grid.z, s);
             if (msr3_supported(tile, K, am, EPI_S, q, in_s_eff))      // split-bf16 matrix pipe (conv_rows3.hip)
                 return msr3_launch(tile, K, am, q, X, Xact, am == 1 ? p.Wfwd : W, bias, res, Y, Yact, grid.x, grid.y,
                                    grid.z, s);
@@ -1268,6 +1282,11 @@ const char* row_kname(RowCfg c, int K, bool act, int CK, int L = 0, int R = 1, i
         {
             Row2P h = q;
             h.B = B; h.M = M > 0 ? M : 64; h.CK = CK; h.CKs = CK; h.PX = R * SS; h.Lt = L >= bn ? bn : L;
+            h.tiles_per_row = L >= bn ? (L + bn - 1) / bn : 1;
+            if (const int bmp = B > 0 ? rows3p_bm(h, bn, K, am, epi_s, 1, 1) : 0) {
+                snprintf(buf, sizeof(buf), "k_conv_rows3p<%d, %d, %d>", bmp / 64, K, am);
+                return buf;
+            }
             if (msr3_supported(t2, K, am, epi_s, h)) {
                 snprintf(buf, sizeof(buf), "k_conv_rows3<%s, %d, %d>", tile, K, am);
                 return buf;

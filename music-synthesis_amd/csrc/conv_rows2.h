@@ -36,3 +36,8 @@ bool msr3_supported(int tile, int K, int act_mode, int epi_s, const Row2P& p, in
 int msr3_launch(int tile, int K, int act_mode, const Row2P& p, const float* X, const float* Xact, const float* W,
                 const float* bias, const float* res, float* Y, float* Yact, unsigned gx, unsigned gy, unsigned gz,
                 hipStream_t s);
+// paired eight-wave form: bm (64 or 128) rows x two adjacent 128-column tiles per workgroup, the two wave groups
+// alternating between the matrix pipe and the staging work (MSYNTH_ROWS3P=0 disables it)
+bool msr3p_supported(int bm, int K, int act_mode, int epi_s, const Row2P& p, int in_s = 1);
+int msr3p_launch(int bm, int K, int act_mode, const Row2P& p, const float* X, const float* Xact, const float* W,
+                 const float* bias, const float* res, float* Y, float* Yact, unsigned gz, hipStream_t s);

@@ -344,6 +344,310 @@ __global__ __launch_bounds__(256) void k_conv_rows3(Row2P p, const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Paired form: 8 waves = two groups of four.  Group g owns output tile 2*blockIdx.x + g of the 128-column
+// tiling (same rows m0.., same channel chunks: ONE weight tile in LDS serves both), and the groups alternate
+// roles slot by slot:
+//     slot 2c    group 0: MFMAs of chunk c        | group 1: split + store X1[c] and its half of A[c+1]
+//     slot 2c+1  group 1: MFMAs of chunk c        | group 0: split + store X0[c+1] and its half of A[c+1]
+// so on every SIMD one wave feeds the matrix pipe while its partner does the vector work of the staging
+// (separate pipes, they co-issue), and a workgroup barrier ends each slot.  Against the four-wave kernel at
+// 64x128 this halves the vector work per MFMA (each activation column meets 128 rows, each weight row 256
+// columns) -- that kernel is bound by vector issue, not by the matrix pipe.  Weights are double-buffered
+// (chunk c+1 is written while chunk c is read), each group's activation tile is single-buffered (written and
+// read by the same group in consecutive slots).  Global loads are issued at the start of a group's MFMA
+// slot and consumed in its next staging slot.
+template <int TM, int K, int AM>
+__global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __restrict__ X,
+                                                    const float* __restrict__ Xact,
+                                                    const float* __restrict__ W,
+                                                    const float* __restrict__ bias,
+                                                    const float* __restrict__ res,
+                                                    float* __restrict__ Y,
+                                                    float* __restrict__ Yact) {
+    constexpr int TN = 2, BM = 64 * TM, BN = 128;
+    constexpr int ARS = a_row_bytes(K);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    const int a_bytes = BM * ARS, x_bytes = p.PX * XRS;
+    unsigned char* const Abuf = smem3;                         // A[0] | A[1]
+    unsigned char* scratch = smem3 + p.scratch_off;            // 512 x 8 bytes: sink for masked stores
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5;
+    const int g = __builtin_amdgcn_readfirstlane(wid >> 2), gt = tid & 255, gw = wid & 3;
+    const int wm = gw >> 1, wn = gw & 1;
+    unsigned char* const Xg = smem3 + 2 * a_bytes + g * x_bytes;
+    const int m0 = blockIdx.y * BM;
+    const int ti = 2 * blockIdx.x + g;
+    int b0, t0;
+    if (p.R == 1) { b0 = ti / p.tiles_per_row; t0 = (ti - b0 * p.tiles_per_row) * BN; }
+    else { b0 = ti * p.R; t0 = 0; }
+
+    constexpr unsigned OOB = 0xF0000000u;
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0x80000000u, 0x00020000);
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, 0x80000000u, 0x00020000);
+    const auto rsXa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(AM == 1 ? Xact : X), 0, 0x80000000u, 0x00020000);
+
+    // weight unit of this thread: group g stages rows [g*BM/2, (g+1)*BM/2), unit = (row, channel quad)
+    unsigned a_goff;
+    int a_loff;
+    {
+        const int rl = gt >> 2, cq = gt & 3;
+        const int row = g * (BM / 2) + rl;
+        const bool in = rl < BM / 2;
+        const bool ok = in && m0 + row < p.M;
+        if (AM == 0) a_goff = ok ? 4u * (unsigned)((m0 + row) * p.KG + 4 * cq * K) : OOB;
+        else a_goff = ok ? 4u * (unsigned)((4 * cq * p.M + m0 + row) * K) : OOB;
+        a_loff = in ? row * ARS + cq * 8 : -1;
+    }
+    // activation unit of this thread (of its group's tile): as k_conv_rows3
+    const int sh = ((p.off0 % 4) + 4) % 4;
+    const int NVS = (p.SS + 6) >> 2;
+    const int NVT = p.R * NVS;
+    unsigned x_goff, x_em;
+    int x_lcol, x_cq8;
+    {
+        const int cq = (gt >> 2) & 3, v = (gt >> 4) * 4 + (gt & 3);
+        const int r = v / NVS, sv = v - r * NVS;
+        const int u0 = 4 * sv - sh;
+        const int t = t0 + p.off0 + u0;
+        const bool in = v < NVT;
+        const bool ok = in && b0 + r < p.B && t >= 0 && t < p.L;
+        x_goff = ok ? 4u * (unsigned)(((b0 + r) * p.CK + 4 * cq) * p.L + t) : OOB;
+        x_lcol = r * p.SS + u0;
+        x_cq8 = cq * 8;
+        unsigned em = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (in && u0 + e >= 0 && u0 + e < p.SS) em |= 1u << e;
+        x_em = em;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int bbase[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = wn * TN * 32 + j * 32 + (lane & 31);
+        const int r = nl / p.Lt, tc = nl - r * p.Lt;
+        const bool ok = r < p.R && b0 + r < p.B && t0 + tc < p.L;
+        bbase[j] = ok ? r * p.SS + tc : 0;
+    }
+
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 ra[AM == 1 ? 1 : K];
+    float rad[AM == 1 ? 4 * K : 1];
+    f32x4 rx[4], rxa[AM == 1 ? 4 : 1];
+    auto load_a = [&](int c0, bool live) {
+        if (AM == 0) {
+            const int so = live ? 4 * c0 * K : 0;
+#pragma unroll
+            for (int k4 = 0; k4 < K; ++k4)
+                ra[k4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, a_goff + 16 * k4, so, 0));
+        } else {
+            const int qs = 4 * p.M * K;
+            const int so = live ? c0 * qs : 0;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+                    rad[qq * K + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsW, a_goff + 4 * j, so + qq * qs, 0));
+        }
+    };
+    auto load_x = [&](int c0, bool live) {
+        const int cs = 4 * p.L;
+        const int so = live ? c0 * cs : 0;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            rx[cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, x_goff, so + cc * cs, 0));
+            if (AM == 1) rxa[cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsXa, x_goff, so + cc * cs, 0));
+        }
+    };
+    auto store_a = [&](unsigned char* abuf) {
+        const bool in = a_loff >= 0;
+        unsigned char* base0 = in ? abuf + a_loff : scratch + tid * 8;
+        const int jstep = in ? 96 : 0, pstep = in ? 32 : 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            float e[4];
+            if (AM == 0) {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) e[qq] = ra[(qq * K + j) >> 2][(qq * K + j) & 3];
+            } else {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) e[qq] = rad[qq * K + (K - 1 - j)];   // taps flipped
+            }
+            uint2 o3[3];
+            split_quad(e, o3);
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(base0 + j * jstep + pp * pstep) = o3[pp];
+        }
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool in = (x_em >> e) & 1u;
+            unsigned char* base = in ? Xg + (x_lcol + e) * XRS + x_cq8 : scratch + tid * 8;
+            const int pstep = in ? 32 : 0;
+            float c4[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                c4[cc] = rx[cc][e];
+                if (AM == 1) c4[cc] = rxa[cc][e] > 0.f ? c4[cc] : c4[cc] * p.slope;
+            }
+            uint2 o3[3];
+            split_quad(c4, o3);
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(base + pp * pstep) = o3[pp];
+        }
+    };
+
+    const int cbeg = blockIdx.z * p.CKs;
+    const int nchunks = ((cbeg + p.CKs < p.CK ? cbeg + p.CKs : p.CK) - cbeg) / CC3;
+    Y += (size_t)blockIdx.z * p.zstride;
+
+    const int arow = (wm * TM * 32 + (lane & 31)) * ARS + h * 16;
+    auto compute = [&](const unsigned char* As) {
+        const unsigned char* Xs = Xg + h * 16;
+        bf16x8 fa[2][TM][3], fb[2][TN][3];
+        auto frag = [&](int s, bf16x8 (&a)[TM][3], bf16x8 (&b)[TN][3]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+                    a[i][pp] = *reinterpret_cast<const bf16x8*>(As + arow + i * 32 * ARS + s * 96 + pp * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+                    b[j][pp] = *reinterpret_cast<const bf16x8*>(Xs + (bbase[j] + s * p.dil) * XRS + pp * 32);
+        };
+        frag(0, fa[0], fb[0]);
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            if (s + 1 < K) frag(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i][PA[t]], fb[s & 1][j][PB[t]], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // prologue: everybody stages its half of A[0]; group 0 its X0[0]; group 1 then holds X1[0] and its half of
+    // A[1] in registers for slot 0
+    load_a(cbeg, true);
+    if (g == 0) load_x(cbeg, true);
+    store_a(Abuf);
+    if (g == 0) store_x();
+    else { load_x(cbeg, true); load_a(cbeg + CC3, nchunks > 1); }
+    __syncthreads();
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const unsigned char* As = Abuf + (ch & 1) * a_bytes;
+        unsigned char* An = Abuf + ((ch & 1) ^ 1) * a_bytes;
+        // slot 2*ch
+        if (g == 0) {
+            load_x(cbeg + (ch + 1) * CC3, ch + 1 < nchunks);     // staged in slot 2*ch + 1
+            load_a(cbeg + (ch + 1) * CC3, ch + 1 < nchunks);
+            compute(As);
+        } else {
+            store_x();                                           // X1[ch]
+            store_a(An);                                         // its half of A[ch + 1]
+        }
+        __syncthreads();
+        // slot 2*ch + 1
+        if (g == 1) {
+            load_x(cbeg + (ch + 1) * CC3, ch + 1 < nchunks);     // staged in slot 2*ch + 2
+            load_a(cbeg + (ch + 2) * CC3, ch + 2 < nchunks);
+            compute(As);
+        } else {
+            store_x();                                           // X0[ch + 1]
+            store_a(An);                                         // its half of A[ch + 1]
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: each group transposes its tile through its own LDS region (the K-loop buffers are dead)
+    constexpr int TP = BN + 4;
+    float* Ts = reinterpret_cast<float*>(smem3) + g * BM * TP;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mb = wm * TM * 32 + i * 32 + 4 * h;
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + mb + (r & 3) + 8 * (r >> 2);
+            bv[r] = bias ? bias[m < p.M ? m : 0] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * TN * 32 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Ts[(mb + (r & 3) + 8 * (r >> 2)) * TP + col] = ms_apply_act(acc[i][j][r] + bv[r], p.act, p.slope);
+        }
+    }
+    __syncthreads();
+    constexpr int V4 = BN / 4;
+    constexpr int NQ = BM * V4 / 256;
+    float4 tv[NQ], rv[NQ];
+    size_t go[NQ];
+    bool ok[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int idx = gt + 256 * q;
+        const int row = idx / V4, c4 = idx - row * V4;
+        const int nl = 4 * c4;
+        const int r = nl / p.Lt, tc = nl - r * p.Lt;
+        ok[q] = m0 + row < p.M && r < p.R && b0 + r < p.B && t0 + tc < p.L;
+        go[q] = ok[q] ? ((size_t)(b0 + r) * p.M + m0 + row) * p.L + t0 + tc : 0;
+        tv[q] = *reinterpret_cast<const float4*>(Ts + row * TP + nl);
+        if (res) rv[q] = *reinterpret_cast<const float4*>(res + go[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (!ok[q]) continue;
+        if (Yact) *reinterpret_cast<float4*>(Yact + go[q]) = tv[q];
+        float4 v = tv[q];
+        if (res) { v.x += rv[q].x; v.y += rv[q].y; v.z += rv[q].z; v.w += rv[q].w; }
+        *reinterpret_cast<float4*>(Y + go[q]) = v;
+    }
+}
+
+template <int TM, int K>
+size_t ldsp_bytes(const Row2P& p) {
+    constexpr int BM = 64 * TM;
+    size_t by = (size_t)2 * BM * a_row_bytes(K) + (size_t)2 * p.PX * XRS;
+    const size_t epi = (size_t)2 * BM * (128 + 4) * sizeof(float);
+    return by < epi ? epi : by;
+}
+
+template <int TM, int K, int AM>
+int launch_pair(const Row2P& p, const float* X, const float* Xact, const float* W, const float* bias,
+                const float* res, float* Y, float* Yact, dim3 grid, hipStream_t s) {
+    const size_t by = ldsp_bytes<TM, K>(p);
+    const size_t lds = by + 512 * 8;
+    if (lds > 158 * 1024) return MS_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rows3p<TM, K, AM>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        attr_set = true;
+    }
+    Row2P pp = p;
+    pp.scratch_off = (int)by;
+    hipLaunchKernelGGL((k_conv_rows3p<TM, K, AM>), grid, dim3(512), lds, s, pp, X, Xact, W, bias, res, Y, Yact);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
 template <int WGM, int WGN, int TM, int TN, int K, int AM>
 size_t lds_bytes(const Row2P& p) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
@@ -415,5 +719,37 @@ int msr3_launch(int tile, int K, int act_mode, const Row2P& p, const float* X, c
     if (K == 3 && act_mode == 1) return launch_tile<3, 1>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
     if (K == 5 && act_mode == 0) return launch_tile<5, 0>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
     if (K == 5 && act_mode == 1) return launch_tile<5, 1>(tile, p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    return MS_ERR_UNSUPPORTED;
+}
+
+// Paired eight-wave form (k_conv_rows3p): bm = 128 (K = 3) or 64 rows x two adjacent 128-column tiles per
+// workgroup.  The caller uses it where the grid still fills the chip: msr3p_grid gives the workgroup count.
+bool msr3p_supported(int bm, int K, int act_mode, int epi_s, const Row2P& p, int in_s) {
+    const char* sw = getenv("MSYNTH_ROWS3P");        // tuning / test switch (0: four-wave kernel only)
+    if (sw && atoi(sw) == 0) return false;
+    if (!msr3_supported(bm == 128 ? MSR2_128x128 : MSR2_64x128, K, act_mode, epi_s, p, in_s)) return false;
+    if (bm != 64 && bm != 128) return false;
+    const size_t by = bm == 128 ? (K == 3 ? ldsp_bytes<2, 3>(p) : ldsp_bytes<2, 5>(p))
+                                : (K == 3 ? ldsp_bytes<1, 3>(p) : ldsp_bytes<1, 5>(p));
+    return by + 512 * 8 <= 158 * 1024;
+}
+
+int msr3p_launch(int bm, int K, int act_mode, const Row2P& p, const float* X, const float* Xact, const float* W,
+                 const float* bias, const float* res, float* Y, float* Yact, unsigned gz, hipStream_t s) {
+    const unsigned ntiles = p.R == 1 ? (unsigned)(p.B * p.tiles_per_row) : (unsigned)((p.B + p.R - 1) / p.R);
+    const dim3 grid((ntiles + 1) / 2, (unsigned)((p.M + bm - 1) / bm), gz);
+#define MS3P(TM_, K_, A_) return launch_pair<TM_, K_, A_>(p, X, Xact, W, bias, res, Y, Yact, grid, s)
+    if (bm == 128) {
+        if (K == 3 && act_mode == 0) MS3P(2, 3, 0);
+        if (K == 3 && act_mode == 1) MS3P(2, 3, 1);
+        if (K == 5 && act_mode == 0) MS3P(2, 5, 0);
+        if (K == 5 && act_mode == 1) MS3P(2, 5, 1);
+    } else {
+        if (K == 3 && act_mode == 0) MS3P(1, 3, 0);
+        if (K == 3 && act_mode == 1) MS3P(1, 3, 1);
+        if (K == 5 && act_mode == 0) MS3P(1, 5, 0);
+        if (K == 5 && act_mode == 1) MS3P(1, 5, 1);
+    }
+#undef MS3P
     return MS_ERR_UNSUPPORTED;
 }
