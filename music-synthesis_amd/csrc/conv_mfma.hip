@@ -1166,6 +1166,7 @@ bool rows2_pick(RowCfg cfg, int K, int CC, bool has_act, int epi_s, int in_s, co
     q->PX = p.RSZ; q->CKs = p.CKs; q->zstride = p.zstride; q->slope = p.slope; q->scratch_off = 0;
     *tile = cfg == ROW_128x128 ? MSR2_128x128 : (cfg == ROW_64x128 ? MSR2_64x128 :
             (cfg == ROW_64x64 ? MSR2_64x64 : MSR2_32x256));
+    if (in_s == 1 && msr3_supported(*tile, K, *am, epi_s, *q, 1)) return true;   // split-bf16 kernel: rows of any length
     // short rows of a length that is not a multiple of 4 (k5 conv at L = 17 / 9): whole-row staging
     // (MSYNTH_SR=1 also sends the aligned short rows there: tuning switch)
     if (in_s == 1 && in_s_out && K == 5 && p.tiles_per_row == 1 && p.Lt == p.L) {
@@ -1184,7 +1185,7 @@ bool rows2_pick(RowCfg cfg, int K, int CC, bool has_act, int epi_s, int in_s, co
 // it -- supported and its grid (half as many, twice as wide workgroups) still fills most of the 256 CUs -- else 0.
 int rows3p_bm(const Row2P& q, int bn, int K, int am, int epi_s, int in_s, unsigned gz) {
     if (bn != 128) return 0;                     // (q's tiling must be the 128-column one the kernel's groups own)
-    static const int min_wgs = getenv("MSYNTH_R3P_MIN") ? atoi(getenv("MSYNTH_R3P_MIN")) : 192;   // tuning switch
+    static const int min_wgs = getenv("MSYNTH_R3P_MIN") ? atoi(getenv("MSYNTH_R3P_MIN")) : 128;   // tuning switch
     const int bm = (q.M >= 128 && K == 3) ? 128 : 64;
     if (!msr3p_supported(bm, K, am, epi_s, q, in_s)) return 0;
     const long long ntiles = q.R == 1 ? (long long)q.B * q.tiles_per_row : (q.B + q.R - 1) / q.R;
@@ -1275,10 +1276,6 @@ const char* row_kname(RowCfg c, int K, bool act, int CK, int L = 0, int R = 1, i
         const int t2 = c == ROW_128x128 ? MSR2_128x128 : (c == ROW_64x128 ? MSR2_64x128 : (c == ROW_64x64 ? MSR2_64x64 : MSR2_32x256));
         int bm, bn;
         row_tile(c, &bm, &bn);
-        if (K == 5 && CC == 16 && epi_s == 0 && am == 1 && L < bn && L % 4 != 0 && c != ROW_32x256) {   // short-row mode
-            snprintf(buf, sizeof(buf), "k_conv_rows2<%s, 5, 16, %d, 0, 0>", tile, am);
-            return buf;
-        }
         {
             Row2P h = q;
             h.B = B; h.M = M > 0 ? M : 64; h.CK = CK; h.CKs = CK; h.PX = R * SS; h.Lt = L >= bn ? bn : L;
@@ -1288,9 +1285,14 @@ const char* row_kname(RowCfg c, int K, bool act, int CK, int L = 0, int R = 1, i
                 return buf;
             }
             if (msr3_supported(t2, K, am, epi_s, h)) {
-                snprintf(buf, sizeof(buf), "k_conv_rows3<%s, %d, %d>", tile, K, am);
+                snprintf(buf, sizeof(buf), "k_conv_rows3<%s, %d, %d, %s>", tile, K, am,
+                         (L % 4 == 0 && h.Lt % 4 == 0) ? "true" : "false");
                 return buf;
             }
+        }
+        if (K == 5 && CC == 16 && epi_s == 0 && am == 1 && L < bn && L % 4 != 0 && c != ROW_32x256) {   // short-row mode
+            snprintf(buf, sizeof(buf), "k_conv_rows2<%s, 5, 16, %d, 0, 0>", tile, am);
+            return buf;
         }
         if (msr2_supported(t2, K, CC, am, epi_s, q)) {
             if (epi_s == 0 && (c == ROW_128x128 || c == ROW_64x128) && B > 0 && M > 0) {
@@ -1354,6 +1356,7 @@ RowSplit plan_rows_split(RowCfg cfg, const RowP& p, int CC) {
     while (ns > 1 && (size_t)ns * q.out_floats * sizeof(float) > ((size_t)64 << 20)) --ns;
     if (ns <= 1) return q;
     q.cks = ms_ceil_div(nchunks, ns) * CC;
+    if (p.CK % 16 == 0 && q.cks % 16) q.cks += 16 - q.cks % 16;   // slices in whole 16-channel chunks (conv_rows3.hip)
     q.ns = ms_ceil_div(p.CK, q.cks);
     return q;
 }

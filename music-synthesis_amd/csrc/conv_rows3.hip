@@ -66,7 +66,10 @@ __device__ __forceinline__ void split_quad(const float (&e)[4], uint2 (&o)[3]) {
 
 constexpr int msr3_nxu(int BN) { return (4 * (BN / 4 + 12) + 255) / 256; }   // activation units per thread
 
-template <int WGM, int WGN, int TM, int TN, int K, int AM>
+// VEC: rows are 16-byte aligned (L % 4 == 0): activations are staged with aligned float4 loads and the
+// epilogue moves 16-byte vectors.  !VEC (any L: the 1024 -> 1024 k5 conv at L = 17 / 9): dword loads with a
+// per-sample range check and dword stores -- those layers are small and L2-resident.
+template <int WGM, int WGN, int TM, int TN, int K, int AM, bool VEC>
 __global__ __launch_bounds__(256) void k_conv_rows3(Row2P p, const float* __restrict__ X,
                                                    const float* __restrict__ Xact,
                                                    const float* __restrict__ W,
@@ -113,11 +116,11 @@ __global__ __launch_bounds__(256) void k_conv_rows3(Row2P p, const float* __rest
         else a_goff[i] = ok ? 4u * (unsigned)((4 * cq * p.M + m0 + row) * K) : OOB;                // + c0*M*K per chunk
         a_loff[i] = in ? row * ARS + cq * 8 : -1;
     }
-    // activation unit q: channel quad cq, aligned 4-sample vector v of the tile's R segments
-    const int sh = ((p.off0 % 4) + 4) % 4;           // segment start within its 16-byte vector
-    const int NVS = (p.SS + 6) >> 2;                 // aligned vectors covering one segment
+    // activation unit q: channel quad cq, 4-sample vector v of the tile's R segments (VEC: the ALIGNED vector)
+    const int sh = VEC ? ((p.off0 % 4) + 4) % 4 : 0; // segment start within its 16-byte vector
+    const int NVS = (p.SS + 3 + sh) >> 2;            // vectors covering one segment
     const int NVT = p.R * NVS;
-    unsigned x_goff[NXU];
+    unsigned x_goff[NXU][VEC ? 1 : 4];
     int x_lcol[NXU];
     unsigned x_em[NXU];
     int x_cq8[NXU];
@@ -130,10 +133,19 @@ __global__ __launch_bounds__(256) void k_conv_rows3(Row2P p, const float* __rest
         const int cq = (i >> 2) & 3, v = (i >> 4) * 4 + (i & 3);
         const int r = v / NVS, sv = v - r * NVS;
         const int u0 = 4 * sv - sh;
-        const int t = t0 + p.off0 + u0;                // multiple of 4: the vector is all in or all out
+        const int t = t0 + p.off0 + u0;                // VEC: multiple of 4, the vector is all in or all out
         const bool in = v < NVT;
-        const bool ok = in && b0 + r < p.B && t >= 0 && t < p.L;
-        x_goff[q] = ok ? 4u * (unsigned)(((b0 + r) * p.CK + 4 * cq) * p.L + t) : OOB;
+        const int base = ((b0 + r) * p.CK + 4 * cq) * p.L + t;
+        if (VEC) {
+            const bool ok = in && b0 + r < p.B && t >= 0 && t < p.L;
+            x_goff[q][0] = ok ? 4u * (unsigned)base : OOB;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = in && b0 + r < p.B && t + e >= 0 && t + e < p.L && u0 + e < p.SS;
+                x_goff[q][VEC ? 0 : e] = ok ? 4u * (unsigned)(base + e) : OOB;
+            }
+        }
         x_lcol[q] = r * p.SS + u0;
         x_cq8[q] = cq * 8;
         unsigned em = 0;
@@ -187,8 +199,16 @@ __global__ __launch_bounds__(256) void k_conv_rows3(Row2P p, const float* __rest
             const int so = live ? c0 * cs : 0;
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
-                rx[q][cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, x_goff[q], so + cc * cs, 0));
-                if (AM == 1) rxa[q][cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsXa, x_goff[q], so + cc * cs, 0));
+                if (VEC) {
+                    rx[q][cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, x_goff[q][0], so + cc * cs, 0));
+                    if (AM == 1) rxa[q][cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsXa, x_goff[q][0], so + cc * cs, 0));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        rx[q][cc][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, x_goff[q][VEC ? 0 : e], so + cc * cs, 0));
+                        if (AM == 1) rxa[q][cc][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsXa, x_goff[q][VEC ? 0 : e], so + cc * cs, 0));
+                    }
+                }
             }
         }
     };
@@ -318,29 +338,44 @@ __global__ __launch_bounds__(256) void k_conv_rows3(Row2P p, const float* __rest
         }
     }
     __syncthreads();
-    constexpr int V4 = BN / 4;
-    constexpr int NQ = BM * V4 / 256;
-    float4 tv[NQ], rv[NQ];
-    size_t go[NQ];
-    bool ok[NQ];
+    if (VEC) {
+        constexpr int V4 = BN / 4;
+        constexpr int NQ = BM * V4 / 256;
+        float4 tv[NQ], rv[NQ];
+        size_t go[NQ];
+        bool ok[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int idx = tid + 256 * q;
-        const int row = idx / V4, c4 = idx - row * V4;
-        const int nl = 4 * c4;
-        const int r = nl / p.Lt, tc = nl - r * p.Lt;     // Lt % 4 == 0: the 4 samples share a row
-        ok[q] = m0 + row < p.M && r < p.R && b0 + r < p.B && t0 + tc < p.L;
-        go[q] = ok[q] ? ((size_t)(b0 + r) * p.M + m0 + row) * p.L + t0 + tc : 0;
-        tv[q] = *reinterpret_cast<const float4*>(Ts + row * TP + nl);
-        if (res) rv[q] = *reinterpret_cast<const float4*>(res + go[q]);
-    }
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = tid + 256 * q;
+            const int row = idx / V4, c4 = idx - row * V4;
+            const int nl = 4 * c4;
+            const int r = nl / p.Lt, tc = nl - r * p.Lt;     // Lt % 4 == 0: the 4 samples share a row
+            ok[q] = m0 + row < p.M && r < p.R && b0 + r < p.B && t0 + tc < p.L;
+            go[q] = ok[q] ? ((size_t)(b0 + r) * p.M + m0 + row) * p.L + t0 + tc : 0;
+            tv[q] = *reinterpret_cast<const float4*>(Ts + row * TP + nl);
+            if (res) rv[q] = *reinterpret_cast<const float4*>(res + go[q]);
+        }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        if (!ok[q]) continue;
-        if (Yact) *reinterpret_cast<float4*>(Yact + go[q]) = tv[q];
-        float4 v = tv[q];
-        if (res) { v.x += rv[q].x; v.y += rv[q].y; v.z += rv[q].z; v.w += rv[q].w; }
-        *reinterpret_cast<float4*>(Y + go[q]) = v;
+        for (int q = 0; q < NQ; ++q) {
+            if (!ok[q]) continue;
+            if (Yact) *reinterpret_cast<float4*>(Yact + go[q]) = tv[q];
+            float4 v = tv[q];
+            if (res) { v.x += rv[q].x; v.y += rv[q].y; v.z += rv[q].z; v.w += rv[q].w; }
+            *reinterpret_cast<float4*>(Y + go[q]) = v;
+        }
+    } else {
+        // any row length: one dword per lane, 32 consecutive samples of a tile row per half-wave
+#pragma unroll 4
+        for (int idx = tid; idx < BM * BN; idx += 256) {
+            const int row = idx / BN, nl = idx - row * BN;
+            const int r = nl / p.Lt, tc = nl - r * p.Lt;
+            if (!(m0 + row < p.M && r < p.R && b0 + r < p.B && t0 + tc < p.L)) continue;
+            const size_t o = ((size_t)(b0 + r) * p.M + m0 + row) * p.L + t0 + tc;
+            float v = Ts[row * TP + nl];
+            if (Yact) Yact[o] = v;
+            if (res) v += res[o];
+            Y[o] = v;
+        }
     }
 }
 
@@ -648,7 +683,7 @@ int launch_pair(const Row2P& p, const float* X, const float* Xact, const float* 
     return MS_OK;
 }
 
-template <int WGM, int WGN, int TM, int TN, int K, int AM>
+template <int WGM, int WGN, int TM, int TN, int K, int AM, bool VEC = true>
 size_t lds_bytes(const Row2P& p) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     size_t by = (size_t)2 * (BM * a_row_bytes(K) + p.PX * XRS);
@@ -657,7 +692,7 @@ size_t lds_bytes(const Row2P& p) {
     return by;
 }
 
-template <int WGM, int WGN, int TM, int TN, int K, int AM>
+template <int WGM, int WGN, int TM, int TN, int K, int AM, bool VEC>
 int launch_inst(const Row2P& p, const float* X, const float* Xact, const float* W, const float* bias,
                 const float* res, float* Y, float* Yact, dim3 grid, hipStream_t s) {
     const size_t by = lds_bytes<WGM, WGN, TM, TN, K, AM>(p);
@@ -665,26 +700,34 @@ int launch_inst(const Row2P& p, const float* X, const float* Xact, const float* 
     if (lds > 156 * 1024) return MS_ERR_UNSUPPORTED;
     static bool attr_set = false;                    // > 64 KiB of dynamic LDS needs the opt-in once
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rows3<WGM, WGN, TM, TN, K, AM>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rows3<WGM, WGN, TM, TN, K, AM, VEC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
         attr_set = true;
     }
     Row2P pp = p;
     pp.scratch_off = (int)by;
-    hipLaunchKernelGGL((k_conv_rows3<WGM, WGN, TM, TN, K, AM>), grid, dim3(256), lds, s, pp, X, Xact, W, bias, res,
-                       Y, Yact);
+    hipLaunchKernelGGL((k_conv_rows3<WGM, WGN, TM, TN, K, AM, VEC>), grid, dim3(256), lds, s, pp, X, Xact, W, bias,
+                       res, Y, Yact);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }
 
+bool rows_vec(const Row2P& p) { return p.L % 4 == 0 && p.Lt % 4 == 0; }
+
 template <int K, int AM>
 int launch_tile(int tile, const Row2P& p, const float* X, const float* Xact, const float* W, const float* bias,
                 const float* res, float* Y, float* Yact, dim3 grid, hipStream_t s) {
-    switch (tile) {
-        case MSR2_128x128: return launch_inst<2, 2, 2, 2, K, AM>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
-        case MSR2_64x128: return launch_inst<2, 2, 1, 2, K, AM>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
-        case MSR2_64x64: return launch_inst<2, 2, 1, 1, K, AM>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
-        case MSR2_32x256: return launch_inst<1, 4, 1, 2, K, AM>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    if (rows_vec(p)) {
+        switch (tile) {
+            case MSR2_128x128: return launch_inst<2, 2, 2, 2, K, AM, true>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+            case MSR2_64x128: return launch_inst<2, 2, 1, 2, K, AM, true>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+            case MSR2_64x64: return launch_inst<2, 2, 1, 1, K, AM, true>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+            default: return MS_ERR_UNSUPPORTED;
+        }
+    }
+    switch (tile) {      // rows of any length (dword loader / epilogue)
+        case MSR2_64x128: return launch_inst<2, 2, 1, 2, K, AM, false>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+        case MSR2_64x64: return launch_inst<2, 2, 1, 1, K, AM, false>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
         default: return MS_ERR_UNSUPPORTED;
     }
 }
@@ -699,7 +742,8 @@ bool msr3_supported(int tile, int K, int act_mode, int epi_s, const Row2P& p, in
     if (tile < 0 || tile >= MSR2_32x256) return false;      // (32 x 256: measured no faster than the fp32 kernel)
     if (in_s != 1 || epi_s != 0 || (act_mode != 0 && act_mode != 1)) return false;
     if (K != 3 && K != 5) return false;
-    if (p.L % 4 || p.Lt % 4 || p.CK % CC3 || p.CKs % CC3) return false;
+    if (p.CK % CC3 || p.CKs % CC3) return false;
+    if (!rows_vec(p) && tile != MSR2_64x128 && tile != MSR2_64x64) return false;
     if (act_mode == 1 && p.M % 4) return false;
     const int bn = tile == MSR2_32x256 ? 256 : (tile == MSR2_64x64 ? 64 : 128);
     const int bm = tile == MSR2_128x128 ? 128 : (tile == MSR2_32x256 ? 32 : 64);
@@ -728,6 +772,7 @@ bool msr3p_supported(int bm, int K, int act_mode, int epi_s, const Row2P& p, int
     const char* sw = getenv("MSYNTH_ROWS3P");        // tuning / test switch (0: four-wave kernel only)
     if (sw && atoi(sw) == 0) return false;
     if (!msr3_supported(bm == 128 ? MSR2_128x128 : MSR2_64x128, K, act_mode, epi_s, p, in_s)) return false;
+    if (!rows_vec(p)) return false;
     if (bm != 64 && bm != 128) return false;
     const size_t by = bm == 128 ? (K == 3 ? ldsp_bytes<2, 3>(p) : ldsp_bytes<2, 5>(p))
                                 : (K == 3 ? ldsp_bytes<1, 3>(p) : ldsp_bytes<1, 5>(p));

@@ -241,6 +241,11 @@ HOT_CONVS = [
     ("r3_k5_l32", 5, 256, 32, 320, 5, 1, 2, 1, 1, 1, False),
     ("r3_k5_l64_noact", 3, 128, 64, 128, 5, 1, 2, 1, 1, 0, False),
     ("r3_k3_l16_r8", 9, 64, 16, 64, 3, 1, 1, 1, 1, 1, False),
+    # ... and rows of any length through its dword loader: the k5 conv at the pooled scales (L = 17 / 9, packed
+    # 7 / 14 rows per tile), batch and M tails
+    ("r3_k5_l17", 9, 128, 17, 192, 5, 1, 2, 1, 1, 1, False),
+    ("r3_k5_l9_m1024", 15, 64, 9, 1024, 5, 1, 2, 1, 1, 1, False),
+    ("r3_k3_l131_d9", 2, 64, 131, 64, 3, 1, 9, 9, 1, 1, False),
     ("d_judge", 2, 1024, 9, 1, 3, 1, 1, 1, 1, 0, False),
     ("d_judge_l32", 5, 1024, 32, 1, 3, 1, 1, 1, 1, 0, False),
     ("d_judge_l17", 3, 1024, 17, 1, 3, 1, 1, 1, 1, 0, False),

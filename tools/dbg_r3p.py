@@ -4,30 +4,24 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis
 import torch
 from featuresynth._ops import prims as P, lib as L
 torch.manual_seed(0)
-def run(B, C, Lg, K, dil, env):
-    for k, v in env.items(): os.environ[k] = v
-    x = torch.randn(B, C, Lg, device="cuda"); w = torch.randn(C, C, K, device="cuda") * 0.05; b = torch.randn(C, device="cuda")
+def run(B, Cin, Lg, Cout, K, dil):
+    x = torch.randn(B, Cin, Lg, device="cuda"); w = torch.randn(Cout, Cin, K, device="cuda") * 0.1; b = torch.randn(Cout, device="cuda")
     d, lo = P.conv_desc(x.shape, w.shape, pad=dil * (K - 1) // 2, dil=dil, act=1)
+    gy = torch.randn(B, Cout, lo, device="cuda")
     outs = {}
-    for mode in ("fp32", "4w", "pair"):
-        os.environ["MSYNTH_ROWS3"] = "0" if mode == "fp32" else "1"
-        os.environ["MSYNTH_ROWS3P"] = "1" if mode == "pair" else "0"
-        name = L.load().ms_conv1d_kernel_name(d, 0).decode()
+    for mode in ("0", "1"):
+        os.environ["MSYNTH_ROWS3"] = mode
+        names = [L.load().ms_conv1d_kernel_name(d, k).decode() for k in (0, 1)]
         y, _ = P.conv1d_fwd(x, w, b, d, lo)
+        gx = P.conv1d_bwd_data(gy, y if mode == "0" else outs["0"][0], w, d)
         torch.cuda.synchronize()
-        outs[mode] = (y.clone(), name)
-    ref = outs["fp32"][0]
-    for mode in ("4w", "pair"):
-        y, name = outs[mode]
-        err = (y - ref).abs()
-        # per (batch, 128-col tile) max error
-        nt = (Lg + 127) // 128
-        per = [[float(err[bb, :, t * 128:(t + 1) * 128].max()) for t in range(nt)] for bb in range(B)]
-        bad = [(bb, t) for bb in range(B) for t in range(nt) if per[bb][t] > 1e-3]
-        print(env, (B, C, Lg, K, dil), mode, name, "rel", float((y - ref).norm() / ref.norm()), "bad tiles", bad[:40], len(bad), flush=True)
-os.environ["MSYNTH_R3P_MIN"] = "1"
-run(2, 128, 2048, 3, 1, {"MSYNTH_SPLIT_WGS": "0"})
-run(2, 128, 2048, 3, 1, {"MSYNTH_SPLIT_WGS": "192"})
-run(32, 128, 2048, 3, 1, {"MSYNTH_SPLIT_WGS": "192"})
-run(1, 128, 300, 3, 3, {"MSYNTH_SPLIT_WGS": "0"})
-run(2, 64, 1028, 3, 1, {"MSYNTH_SPLIT_WGS": "0"})
+        outs[mode] = (y.clone(), gx.clone(), names)
+    for i, nm in ((0, "fwd"), (1, "bwd")):
+        a, c = outs["0"][i], outs["1"][i]
+        print((B, Cin, Lg, Cout, K, dil), nm, outs["0"][2][i], "|", outs["1"][2][i], "rel", float((a - c).norm() / a.norm()),
+              "max|ref|", float(a.abs().max()), "max|new|", float(c.abs().max()), flush=True)
+run(11, 96, 9, 80, 3, 3)
+run(11, 96, 9, 96, 3, 3)
+run(11, 96, 9, 80, 3, 1)
+run(7, 96, 12, 80, 3, 3)
+run(9, 128, 17, 192, 5, 1)

@@ -40,3 +40,11 @@ for (B, C, Lg, K, dil) in ((32, 128, 2048, 3, 1), (32, 128, 2048, 3, 9), (32, 25
     c = both("bwd_data %s" % ((B, C, Lg, K, dil),), fl, lambda: P.conv1d_bwd_data(gy, ya, w, d, gx_add=res), d, 1)
     tot[0] += a[0] + c[0]; tot[1] += a[1] + c[1]
 print("totals us: fp32 %.0f split-bf16 %.0f" % tuple(tot))
+print("-- the k5 conv at the pooled scales (rows of 17 / 9 samples)")
+for (B, C, Lg, K, dil) in ((64, 1024, 17, 5, 1), (32, 1024, 17, 5, 1), (64, 1024, 9, 5, 1), (32, 1024, 9, 5, 1)):
+    x = torch.randn(B, C, Lg, device="cuda"); w = torch.randn(C, C, K, device="cuda") * 0.02; b = torch.randn(C, device="cuda")
+    d, lo = P.conv_desc(x.shape, w.shape, pad=dil * (K - 1) // 2, dil=dil, act=1)
+    fl = 2.0 * B * C * Lg * C * K
+    both("fwd %s" % ((B, C, Lg, K, dil),), fl, lambda: P.conv1d_fwd(x, w, b, d, lo), d, 0)
+    gy = torch.randn(B, C, Lg, device="cuda"); ya = torch.randn(B, C, Lg, device="cuda")
+    both("bwd_data %s" % ((B, C, Lg, K, dil),), fl, lambda: P.conv1d_bwd_data(gy, ya, w, d), d, 1)
