@@ -87,9 +87,11 @@ def main():
     ap.add_argument("--mels", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--model", default="melgan", choices=["melgan", "realmelgan"],
+    ap.add_argument("--model", default="melgan", choices=["melgan", "realmelgan", "twostage"],
                     help="melgan = the north-star variant (headline); realmelgan = the weight-normed "
-                         "variant of experiment/realmelgan.py (SURVEY.md 8(f) row 1, 128 mels)")
+                         "variant of experiment/realmelgan.py (SURVEY.md 8(f) row 1, 128 mels); twostage = "
+                         "BASELINE config 5: every step is one stage-1 trainer call (2-D conv mel GAN, "
+                         "featureexperiment.py) plus one stage-2 trainer call (the headline vocoder, 128 mels)")
     ap.add_argument("--no-gforward", action="store_true",
                     help="skip the BASELINE config-2 leg (generator forward, B=1): keeps its B=1 dispatches out "
                          "of a rocprofv3 trace of the train step")
@@ -140,6 +142,9 @@ def main():
         gen_loss = R.mel_gan_gen_loss
         args.no_roofline = args.no_cpu_baseline = True     # priced for the headline model only
     else:
+        if args.model == "twostage":
+            args.mels = 128                     # the stage-1 generator emits 128-bin spectrograms
+            args.no_roofline = args.no_cpu_baseline = True     # priced for the headline model only
         g = fs.MelGanGenerator(T, args.mels)
         d = fs.MelGanDiscriminator()
     gsd = synthetic_state_dict(module_param_shapes(g), seed=7)
@@ -157,8 +162,28 @@ def main():
                 torch.from_numpy(synthetic_features(B, args.mels, T, rank=rank * 16 + i)).to(device))
                for i in range(nbatches)]
 
+    stage1 = None
+    if args.model == "twostage":
+        # The reference trains stage 1 on its own against a frozen vocoder (featureexperiment.py:94-100,280-284)
+        # and has no joint step: here a step = the stage-1 trainer call of this phase (D or G) on a batch of
+        # real spectrograms + fresh noise, followed by the stage-2 trainer call of the same phase.
+        from featuresynth.experiment import TwoDimGeneratorFeatureExperiment
+        torch.manual_seed(7)
+        stage1 = TwoDimGeneratorFeatureExperiment(vocoder_network=g).to(device)
+        s1_batches = []
+        for i in range(nbatches):
+            rng = np.random.default_rng(300 + rank * 16 + i)
+            s1_batches.append((torch.from_numpy((rng.standard_normal((B, 128, 512)) * 0.5).astype(np.float32)).to(device),
+                               torch.from_numpy(rng.standard_normal((B, 128, 1)).astype(np.float32)).to(device)))
+
     def call(i):
         s, f = batches[i % nbatches]
+        if stage1 is not None:
+            spec, noise = s1_batches[i % nbatches]
+            r1 = (stage1.d_trainer if i % 2 == 0 else stage1.g_trainer).train(spec, noise)
+            r2 = dt.train(s, f) if i % 2 == 0 else gt.train(s, f)
+            r2.update({"s1_" + k: v for k, v in r1.items() if k != "fake"})
+            return r2
         return dt.train(s, f) if i % 2 == 0 else gt.train(s, f)
 
     def barrier():
@@ -199,7 +224,11 @@ def main():
                                 "generator + 3-scale discriminator + feature-matching loss "
                                 "(BASELINE.json configs[2]%s)" % ("" if world == 1 else "/[3]"))
                                if args.model == "melgan" else
-                               "weight-normed MelGAN of experiment/realmelgan.py (SURVEY.md 8(f) row 1), same step",
+                               ("two-stage (BASELINE.json configs[4]): per step one stage-1 trainer call (2-D conv mel "
+                                "GAN, 128 x 512 spectrograms, least-squares losses) + one stage-2 trainer call (the "
+                                "headline vocoder at 128 mels); samples/s counts the stage-2 windows"
+                                if args.model == "twostage" else
+                                "weight-normed MelGAN of experiment/realmelgan.py (SURVEY.md 8(f) row 1), same step"),
                    "per_gpu_batch": B, "global_batch": world * B, "window": WINDOW,
                    "mels": args.mels, "optimizer": "FlatAdam(1e-4,(0.5,0.9))",
                    "parallelism": "dp%d" % world, "hipgraph": graphs,

@@ -197,6 +197,10 @@ int ms_act_bwd(const float* y_act, const float* gy, float* gpre, int64_t n, int3
                float slope, ms_stream_t stream);
 /* out = a + b */
 int ms_add(const float* a, const float* b, float* out, int64_t n, ms_stream_t stream);
+/* out = act(a + b): the residual layer of DilatedStack -- the activation is applied OVER the skip sum
+ * (util/modules.py:131-134: x = activation(z + x)); its backward is ms_act_bwd on the saved output */
+int ms_add_act(const float* a, const float* b, float* out, int64_t n, int32_t act, float slope,
+               ms_stream_t stream);
 
 /*
  * Losses (loss/loss.py).  Every *_fwd writes ONE float to `out` (device); every *_bwd reads

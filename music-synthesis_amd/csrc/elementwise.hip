@@ -224,6 +224,22 @@ __global__ __launch_bounds__(256) void k_add(const float* __restrict__ a,
         out[i] = a[i] + b[i];
 }
 
+// out = act(a + b): the residual DilatedStack layer (activation OVER the skip sum, util/modules.py:131-134)
+__global__ __launch_bounds__(256) void k_add_act(const float* __restrict__ a, const float* __restrict__ b,
+                                                float* __restrict__ out, int64_t n4, int64_t n, int act,
+                                                float slope) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+        float4 o;
+        o.x = ms_apply_act(x.x + y.x, act, slope); o.y = ms_apply_act(x.y + y.y, act, slope);
+        o.z = ms_apply_act(x.z + y.z, act, slope); o.w = ms_apply_act(x.w + y.w, act, slope);
+        reinterpret_cast<float4*>(out)[i] = o;
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        out[i] = ms_apply_act(a[i] + b[i], act, slope);
+}
+
 // ---- reductions: per-element term selected by MODE, two deterministic stages
 enum { R_HINGE_D = 0, R_NEG = 1, R_L1 = 2, R_LS_G = 3, R_LS_D = 4 };
 
@@ -607,6 +623,17 @@ int ms_act_bwd(const float* y_act, const float* gy, float* gpre, int64_t n, int3
 int ms_add(const float* a, const float* b, float* out, int64_t n, ms_stream_t stream) {
     if (!a || !b || !out || n <= 0) return MS_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_add, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_add_act(const float* a, const float* b, float* out, int64_t n, int32_t act, float slope,
+               ms_stream_t stream) {
+    if (!a || !b || !out || n <= 0) return MS_ERR_INVALID_ARG;
+    const bool al = ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)out)) & 15) == 0;
+    const int64_t n4 = al ? n / 4 : 0;
+    hipLaunchKernelGGL(k_add_act, dim3(grid_for(n4 > 0 ? n4 : n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n4,
+                       n, act, slope);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }

@@ -5,7 +5,8 @@ JohnVinyard/music-synthesis, behind the reference's own module surface
 All arithmetic runs in hand-written gfx950 HIP kernels reached through the C ABI in
 include/msynth.h (libmsynth_hip.so); there is no CPU or PyTorch-op fallback.
 """
-from . import discriminator, experiment, feature, generator, loss, train, util  # noqa: F401
+from . import (discriminator, experiment, feature, featurediscriminator, featuregenerator, generator, loss,  # noqa: F401
+               train, util)
 from .discriminator import FullDiscriminator, MelGanDiscriminator  # noqa: F401
 from .generator import MelGanGenerator  # noqa: F401
 from .optim import FlatAdam  # noqa: F401

@@ -115,6 +115,23 @@ class ResidualAtomFn(Function):
         return (gx,) + tuple(sink.t) + (None,)
 
 
+class AddActFn(Function):
+    """act(a + b): DilatedStack's residual layer applies the activation over the skip sum."""
+
+    @staticmethod
+    def forward(ctx, a, b, act):
+        y = P.add_act(a, b, act)
+        ctx.act = act
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        g = P.act_bwd(y, _c(gy), ctx.act)
+        return (g if ctx.needs_input_grad[0] else None), (g if ctx.needs_input_grad[1] else None), None
+
+
 class AvgPoolFn(Function):
     @staticmethod
     def forward(ctx, x):

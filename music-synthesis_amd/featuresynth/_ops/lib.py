@@ -103,6 +103,7 @@ SIGNATURES = {
     "ms_weight_norm_multi_bwd": (_c_int, [ctypes.POINTER(WnMultiDesc), _c_f, _vp]),
     "ms_act_bwd": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _c_f, _vp]),
     "ms_add": (_c_int, [_vp, _vp, _vp, _c_i64, _vp]),
+    "ms_add_act": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _c_f, _vp]),
     "ms_reduce_workspace_bytes": (_sz, [_c_i64]),
     "ms_hinge_d_fwd": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _sz, _vp]),
     "ms_hinge_d_bwd": (_c_int, [_vp, _vp, _c_i64, _vp, _c_f, _vp, _vp, _vp]),

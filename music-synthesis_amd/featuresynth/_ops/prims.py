@@ -320,6 +320,17 @@ def add(a, b):
     return out
 
 
+def add_act(a, b, act):
+    """act(a + b)."""
+    L.require(a, "add_act lhs"); L.require(b, "add_act rhs")
+    if a.shape != b.shape:
+        raise RuntimeError("add_act: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+    out = torch.empty_like(a)
+    L.call("ms_add_act", _scost(a.numel(), 2, 1, 2), a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), act,
+           SLOPE, L.stream())
+    return out
+
+
 def add_(a, b):
     """a += b (in place)."""
     L.require(a, "add_ lhs"); L.require(b, "add_ rhs")

@@ -72,7 +72,8 @@ class _GraphedStep:
         graphs = []
         if not self.between:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # (thread-local error mode: other threads -- the RCCL watchdog polling its events -- stay legal)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 out = self.body(s_in, f_in, None)
             return [g], out
         pool = torch.cuda.graph_pool_handle()
@@ -82,7 +83,7 @@ class _GraphedStep:
 
         def begin():
             cur[0] = torch.cuda.CUDAGraph()
-            cur[0].capture_begin(pool=pool)
+            cur[0].capture_begin(pool=pool, capture_error_mode="thread_local")
 
         def end():
             cur[0].capture_end()
@@ -359,6 +360,8 @@ class DiscriminatorTrainer(_TrainerBase):
         _, scores = self.discriminator(both, features)
         if self._stock_losses():
             loss = _F.MelGanDiscLossCatFn.apply(len(scores), B, *scores)   # no per-slice autograd nodes
+        elif isinstance(scores, torch.Tensor):      # single-judgement discriminators (stage 1)
+            loss = self.loss(scores[B:], scores[:B], gan_loss=self.sub_loss)
         else:
             f_score = [j[:B] for j in scores]
             r_score = [j[B:] for j in scores]

@@ -335,3 +335,68 @@ def test_realmelgan_oracle_matches_golden(golden):
     for k in gp:
         # LeakyReLU-mask flips at rounding-level activations accumulate through ~30 layers
         assert rel_l2(strided_sample(gp[k].grad.numpy()), z["step/ggrad_smp/" + k]) < 1e-2, k
+
+
+# ---------------------------------------------------------------- stage-1 2-D conv mel GAN
+
+def _stage1_params(dtype):
+    import torch
+    from featuresynth._synthetic import synthetic_state_dict
+    from oracle import torch_graph_stage1 as S1
+    gsd = synthetic_state_dict(S1.generator_param_shapes(), seed=31, weight_scale=0.03, bias_scale=0.02)
+    dsd = synthetic_state_dict(S1.discriminator_param_shapes(), seed=32, weight_scale=0.03, bias_scale=0.02)
+    return S1, gsd, dsd, S1.to_params(gsd, dtype=dtype), S1.to_params(dsd, dtype=dtype)
+
+
+def test_stage1_oracle_forward_golden(golden):
+    """oracle/torch_graph_stage1.py against the imported reference classes: parameter names / shapes,
+    generator output, discriminator judgement and the seven feature maps."""
+    import torch
+    from featuresynth._synthetic import strided_sample
+    z = golden("stage1")
+    S1, gsd, dsd, gp, dp = _stage1_params(torch.float64)
+    assert [k for k, _ in S1.generator_param_shapes()] == list(z["g_param_names"])
+    assert [str(tuple(v)) for _, v in S1.generator_param_shapes()] == list(z["g_param_shapes"])
+    assert [k for k, _ in S1.discriminator_param_shapes()] == list(z["d_param_names"])
+    assert [str(tuple(v)) for _, v in S1.discriminator_param_shapes()] == list(z["d_param_shapes"])
+    noise = np.random.default_rng(6).standard_normal((2, 128, 1)).astype(np.float32)
+    real = (np.random.default_rng(7).standard_normal((2, 128, 512)) * 0.5).astype(np.float32)
+    with torch.no_grad():
+        y = S1.generator(gp, torch.from_numpy(noise).double())
+        feats, judge = S1.discriminator(dp, torch.from_numpy(real).double())
+    assert tuple(y.shape) == tuple(z["g/shape"])
+    assert rel_l2(strided_sample(y.numpy(), 8192), z["g/y_smp_ref64"]) < 1e-12
+    assert rel_l2(strided_sample(y.numpy(), 8192), z["g/y_smp_ref32"]) < 2e-6
+    assert abs(float(np.linalg.norm(y.numpy())) - z["g/y_sum_ref64"][0]) < 1e-9 * z["g/y_sum_ref64"][0]
+    assert rel_l2(judge.numpy(), z["d/j_ref64"]) < 1e-12 and rel_l2(judge.numpy(), z["d/j_ref32"]) < 2e-6
+    for i, f in enumerate(feats):
+        assert tuple(f.shape) == tuple(z["d/f%d_shape" % i])
+        assert rel_l2(strided_sample(f.numpy(), 2048), z["d/f%d_smp_ref64" % i]) < 1e-12
+
+
+def test_stage1_oracle_train_steps_golden(golden):
+    """One D-step and one G-step with the least-squares losses (featureexperiment.py:289-293) against the
+    reference's own trainers: losses and every parameter gradient."""
+    import torch
+    from featuresynth._synthetic import strided_sample
+    z = golden("stage1")
+    S1, gsd, dsd, _, _ = _stage1_params(torch.float32)
+    noise = torch.from_numpy(np.random.default_rng(6).standard_normal((2, 128, 1)).astype(np.float32))
+    real = torch.from_numpy((np.random.default_rng(7).standard_normal((2, 128, 512)) * 0.5).astype(np.float32))
+    for kind in ("d", "g"):
+        gp, dp = S1.to_params(gsd), S1.to_params(dsd)
+        fake = S1.generator(gp, noise)
+        _, fj = S1.discriminator(dp, fake)
+        if kind == "d":
+            _, rj = S1.discriminator(dp, real)
+            loss, net = S1.ls_disc_loss(rj, fj), dp
+        else:
+            loss, net = S1.ls_gen_loss(fj), gp
+            assert rel_l2(strided_sample(fake.detach().numpy(), 8192), z["step/fake_smp"]) < 2e-6
+        loss.backward()
+        assert abs(loss.item() - float(z["step/%s_loss" % kind][0])) <= 2e-6 * abs(loss.item())
+        for k, p in net.items():
+            ref = z["step/%sgrad_smp/%s" % (kind, k)]
+            assert rel_l2(strided_sample(p.grad.numpy()), ref) < 5e-5 or np.linalg.norm(ref) < 1e-12, (kind, k)
+            s = z["step/%sgrad_sum/%s" % (kind, k)]
+            assert abs(float(np.linalg.norm(p.grad.numpy().astype(np.float64))) - s[0]) <= 5e-5 * s[0] + 1e-12, (kind, k)

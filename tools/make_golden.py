@@ -12,6 +12,8 @@ Fixtures:
   g_fwd.npz      MelGanGenerator forward, BASELINE config 2 (B=1, 80 mel, 8192 samples)
   d_fwd.npz      MelGanDiscriminator forward: judgements + summaries of the 18 feature maps
   train.npz      losses, grads and parameters across alternating D,G,D,G Adam steps
+  stage1.npz     stage-1 spectrogram GAN (featuregenerator/featurediscriminator upscale.py): forwards and
+                 one D-step / G-step of the reference's trainers with its least-squares losses
   audio2mel.npz  Audio2Mel on 1 s of noise (STFT part via torch.stft(return_complex=True),
                  mel basis cross-checked against transformers.audio_utils slaney filter bank)
 Each expected value is stored as computed by the reference in float32 ("*_ref32",
@@ -426,10 +428,72 @@ def realmelgan():
                                                                  out["step/d_loss"][0], out["step/g_loss"][0]))
 
 
+def stage1():
+    """Stage-1 2-D conv mel GAN (SURVEY.md 8(f) row 2 / BASELINE config 5): forward passes of the reference's
+    SpectrogramFeatureGenerator / SpectrogramFeatureDiscriminator and one D-step + one G-step of its own
+    trainers with the least-squares losses of experiment/featureexperiment.py:289-293."""
+    ns = ref_import.load_stage1()
+    out = {}
+    g = ns.SpectrogramFeatureGenerator(out_channels=128, noise_dim=128)
+    d = ns.SpectrogramFeatureDiscriminator(feature_channels=128, channels=256)
+    gshapes, dshapes = SYN.module_param_shapes(g), SYN.module_param_shapes(d)
+    out["g_param_names"] = np.array([k for k, _ in gshapes])
+    out["g_param_shapes"] = np.array([str(tuple(v)) for _, v in gshapes])
+    out["d_param_names"] = np.array([k for k, _ in dshapes])
+    out["d_param_shapes"] = np.array([str(tuple(v)) for _, v in dshapes])
+    load_sd(g, SYN.synthetic_state_dict(gshapes, seed=31, weight_scale=0.03, bias_scale=0.02))
+    load_sd(d, SYN.synthetic_state_dict(dshapes, seed=32, weight_scale=0.03, bias_scale=0.02))
+    B = 2
+    z = np.random.default_rng(6).standard_normal((B, 128, 1)).astype(np.float32)
+    real = (np.random.default_rng(7).standard_normal((B, 128, 512)) * 0.5).astype(np.float32)
+    with torch.no_grad():
+        y = g(torch.from_numpy(z))
+        y64 = copy.deepcopy(g).double()(torch.from_numpy(z).double())
+        feats, judge = d(torch.from_numpy(real), None)
+        feats64, judge64 = copy.deepcopy(d).double()(torch.from_numpy(real).double(), None)
+    out["g/shape"] = np.array(y.shape, np.int64)
+    out["g/y_smp_ref32"] = SYN.strided_sample(t2n(y), 8192)
+    out["g/y_smp_ref64"] = SYN.strided_sample(t2n(y64), 8192)
+    out["g/y_sum_ref64"] = summary(t2n(y64))
+    out["d/j_ref32"], out["d/j_ref64"] = t2n(judge), t2n(judge64)
+    for i, (f32, f64) in enumerate(zip(feats, feats64)):
+        out["d/f%d_shape" % i] = np.array(f32.shape, np.int64)
+        out["d/f%d_smp_ref32" % i] = SYN.strided_sample(t2n(f32), 2048)
+        out["d/f%d_smp_ref64" % i] = SYN.strided_sample(t2n(f64), 2048)
+
+    def gen_loss(r_features, f_features, r_score, f_score, gan_loss):
+        return ns.loss.least_squares_generator_loss(f_score)
+
+    def disc_loss(r_score, f_score, gan_loss):
+        return ns.loss.least_squares_disc_loss(r_score, f_score)
+
+    for kind in ("d", "g"):
+        g2, d2 = copy.deepcopy(g), copy.deepcopy(d)
+        go = torch.optim.Adam(g2.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        do = torch.optim.Adam(d2.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        if kind == "d":
+            tr = ns.train.DiscriminatorTrainer(g2, go, d2, do, disc_loss, sub_loss=None)
+            r = tr.train(torch.from_numpy(real), torch.from_numpy(z))
+            out["step/d_loss"] = np.array([r["d_loss"]])
+            net = d2
+        else:
+            tr = ns.train.GeneratorTrainer(g2, go, d2, do, gen_loss, sub_loss=None)
+            r = tr.train(torch.from_numpy(real), torch.from_numpy(z))
+            out["step/g_loss"] = np.array([r["g_loss"]])
+            out["step/fake_smp"] = SYN.strided_sample(r["fake"], 8192)
+            net = g2
+        for k, p in net.named_parameters():
+            out["step/%sgrad_sum/%s" % (kind, k)] = summary(t2n(p.grad))
+            out["step/%sgrad_smp/%s" % (kind, k)] = SYN.strided_sample(t2n(p.grad))
+    np.savez_compressed(os.path.join(OUT, "stage1.npz"), **out)
+    print("stage1: |y|max %.4g, d_loss %.6f, g_loss %.6f" % (np.abs(out["g/y_smp_ref32"]).max(),
+                                                              out["step/d_loss"][0], out["step/g_loss"][0]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_import.load_reference()
-    which = sys.argv[1:] or ["ops", "g", "d", "train", "mel", "real"]
+    which = sys.argv[1:] or ["ops", "g", "d", "train", "mel", "real", "stage1"]
     if "ops" in which:
         ops_tiny(ns)
     if "g" in which:
@@ -442,6 +506,8 @@ def main():
         audio2mel()
     if "real" in which:
         realmelgan()
+    if "stage1" in which:
+        stage1()
 
 
 if __name__ == "__main__":

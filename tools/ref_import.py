@@ -89,6 +89,20 @@ def load_realmelgan():
     return importlib.import_module("featuresynth.experiment.realmelgan")
 
 
+def load_stage1():
+    """The reference's stage-1 spectrogram GAN classes: the unmodified leaf files
+    featuregenerator/upscale.py and featurediscriminator/upscale.py (their only package-relative import is
+    util/modules.py:DilatedStack)."""
+    ns = load_reference()
+    _pkg("featuresynth.featuregenerator", "featuresynth/featuregenerator")
+    _pkg("featuresynth.featurediscriminator", "featuresynth/featurediscriminator")
+    gen = importlib.import_module("featuresynth.featuregenerator.upscale")
+    disc = importlib.import_module("featuresynth.featurediscriminator.upscale")
+    ns.SpectrogramFeatureGenerator = gen.SpectrogramFeatureGenerator
+    ns.SpectrogramFeatureDiscriminator = disc.SpectrogramFeatureDiscriminator
+    return ns
+
+
 def unload_reference():
     for k in [k for k in sys.modules if k == "featuresynth" or k.startswith("featuresynth.")]:
         del sys.modules[k]
