@@ -41,6 +41,25 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def code_version():
+    """Hash of the kernel sources and the scheduling layer: stamps profiles/*.json so that a PMC traffic file
+    is only quoted for the code it was measured on (the GPU box has no .git)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    pkg = os.path.join(ROOT, "music-synthesis_amd")
+    files = sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.h")) +
+                   glob.glob(os.path.join(pkg, "featuresynth", "_ops", "*.py")) +
+                   [os.path.join(pkg, "featuresynth", "train", "train.py"), os.path.join(ROOT, "include", "msynth.h")])
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
+
+
+BF16_PEAK = 2500.0e12    # FLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
 def host_cpu_share(cap=16):
     """Threads this process may really use: affinity mask, cgroup CPU quota, and the GPU box's
     per-GPU share (16) -- os.cpu_count() reports the whole host and oversubscribes."""
@@ -303,28 +322,44 @@ def main():
             roof = {"bound": "hbm", "achieved": by / avg_s / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
+        if compute_bound and k.startswith("k_conv_rows3"):
+            # fp32 FLOPs executed on the bf16 matrix pipe: every fp32 operand split exactly into three bf16
+            # pieces, six partial products per multiply (conv_rows3.hip).  `peak` stays the fp32 roofline the
+            # workload is priced against; the pipe's own ceiling for this scheme is bf16 / 6.
+            roof["pipe"] = "bf16 MFMA, exact 3-way operand split, 6 products per fp32 multiply, fp32 accumulate"
+            roof["pipe_peak"] = BF16_PEAK / 6 / 1e12
+            roof["pipe_frac"] = roof["achieved"] / roof["pipe_peak"]
         roof["traffic"] = None
-        # HBM bytes per launch of that kernel from the TCC counters (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE in separate passes, gfx950 x2 fetch correction: tools/pmc_traffic.sh), collected
-        # on this same workload and committed under profiles/ (averaged over the template's dispatches)
-        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        # HBM bytes per launch of that kernel from the TCC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # in separate passes, gfx950 x2 fetch correction: tools/pmc_traffic.sh), quoted only when the file was
+        # collected on THIS code (code_version stamp)
+        ver = code_version()
+        roof["code_version"] = ver
+        pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as fh:
                 pmc = json.load(fh)
-            tb, nd = 0.0, 0
-            for name, rec_ in pmc.items():
-                if ("::" + k + "<") in name or ("::" + k + "(") in name or name.startswith(k):
-                    tb += rec_["hbm_bytes_per_launch"] * rec_["dispatches"]
-                    nd += rec_["dispatches"]
-            if nd:
-                roof["traffic"] = tb / nd
-                roof["traffic_source"] = "profiles/r01_pmc_traffic.json (%d dispatches)" % nd
+            if pmc.get("code_version") == ver:
+                tb, nd = 0.0, 0
+                for name, rec_ in pmc.get("kernels", {}).items():
+                    if ("::" + k + "<") in name or ("::" + k + "(") in name or name.startswith(k):
+                        tb += rec_["hbm_bytes_per_launch"] * rec_["dispatches"]
+                        nd += rec_["dispatches"]
+                if nd:
+                    roof["traffic"] = tb / nd
+                    roof["traffic_source"] = "profiles/r02_pmc_traffic.json (%d dispatches, code %s)" % (nd, ver)
+            else:
+                roof["traffic_source"] = "profiles/r02_pmc_traffic.json is for code %s, benched code is %s: not quoted" % (
+                    pmc.get("code_version"), ver)
         roof.update({"kernel": k, "launches_per_DG_pair": a["n"], "avg_launch_us": avg_s * 1e6,
                      "avg_launch_us_uncorrected": 1e3 * raw_ms.get(k, 0.0) / a["n"],
                      "event_pair_overhead_us": ev_ms * 1e3,
                      "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
                      "share_of_kernel_time": a["ms"] / tot_ms,
-                     "instantiations": dict(sorted(a["inst"].items(), key=lambda kv: -kv[1]["launches"] * kv[1]["avg_launch_us"]))})
+                     "instantiations": dict(sorted(a["inst"].items(), key=lambda kv: -kv[1]["launches"] * kv[1]["avg_launch_us"])),
+                     "families": {kf: {"ms_per_DG_pair": round(v["ms"], 4), "launches": v["n"],
+                                       "tflops": round(v["flops"] / v["ms"] / 1e9, 2) if v["ms"] else 0.0}
+                                  for kf, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:12]}})
         result["roofline"] = roof
         launches = W.d_step_launches(B, args.mels, T) + W.g_step_launches(B, args.mels, T)
         ideal = W.roofline_seconds(launches, HBM_PEAK, F32_PEAK)
@@ -353,8 +388,14 @@ def main():
                 gg.replay()
             e1.record(); torch.cuda.synchronize()
             us = 1e3 * e0.elapsed_time(e1) / n_it
+        g1 = W.generator_launches(1, args.mels, T, "fwd")
+        ideal1 = W.roofline_seconds(g1, HBM_PEAK, F32_PEAK)
         result["generator_forward_b1"] = {"latency_us": us, "samples_per_s": WINDOW / (us * 1e-6),
-                                          "note": "BASELINE config 2 (hipGraph replay of the 30-layer forward)"}
+                                          "ideal_us": ideal1 * 1e6 if ideal1 else None,
+                                          "roofline_frac": ideal1 / (us * 1e-6) if ideal1 else None,
+                                          "note": "BASELINE config 2 (hipGraph replay of the 30-layer forward); the "
+                                                  "ideal is sum over layers of max(bytes / 8 TB/s, flops / 157.3 TFLOP/s): "
+                                                  "at B=1 the chain is launch- and latency-bound, not roofline-bound"}
         log("[bench] generator forward B=1: %.1f us -> %.4g samples/s" % (us, WINDOW / (us * 1e-6)))
         del gg, y1
 

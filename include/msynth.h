@@ -160,6 +160,10 @@ int ms_avg_pool1d_4_2_2_bwd(const float* gy, const float* gx_add, float* gx, int
 int ms_avg_pool1d_4_2_1_fwd(const float* x, float* y, int64_t rows, int32_t Lin, ms_stream_t stream);
 int ms_avg_pool1d_4_2_1_bwd(const float* gy, const float* gx_add, float* gx, int64_t rows,
                             int32_t Lin, ms_stream_t stream);
+/* F.avg_pool1d(x, k): window = stride = k, no padding (the conditioning branch of the weight-normed MelGAN's
+ * discriminators, experiment/realmelgan.py:150-151).  x (rows, Lin) -> y (rows, Lin / k). */
+int ms_avg_pool1d_k_fwd(const float* x, float* y, int64_t rows, int32_t Lin, int32_t k, ms_stream_t stream);
+int ms_avg_pool1d_k_bwd(const float* gy, float* gx, int64_t rows, int32_t Lin, int32_t k, ms_stream_t stream);
 
 /*
  * torch.nn.utils.weight_norm (experiment/realmelgan.py:24-29): w[r, :] = g[r] * v[r, :] / ||v[r, :]||_2

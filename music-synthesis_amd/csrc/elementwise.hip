@@ -83,6 +83,35 @@ __global__ __launch_bounds__(256) void k_pool421_fwd(const float* __restrict__ x
     }
 }
 
+// ---- F.avg_pool1d(x, k): window = stride = k, no padding, Lout = Lin / k (the conditioning branch of the
+// weight-normed MelGAN's discriminators pools the mel features down to the feature map's rate,
+// experiment/realmelgan.py:150-151)
+__global__ __launch_bounds__(256) void k_poolk_fwd(const float* __restrict__ x, float* __restrict__ y,
+                                                  int64_t rows, int Lin, int Lout, int k) {
+    const int64_t total = rows * Lout;
+    const float inv = 1.f / (float)k;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / Lout;
+        const int o = (int)(i - r * Lout);
+        const float* xr = x + r * Lin + (int64_t)o * k;
+        float a = 0.f;
+        for (int j = 0; j < k; ++j) a += xr[j];
+        y[i] = a * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_poolk_bwd(const float* __restrict__ gy, float* __restrict__ gx,
+                                                  int64_t rows, int Lin, int Lout, int k) {
+    const int64_t total = rows * Lin;
+    const float inv = 1.f / (float)k;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / Lin;
+        const int p = (int)(i - r * Lin);
+        const int o = p / k;
+        gx[i] = o < Lout ? gy[r * Lout + o] * inv : 0.f;     // (samples behind the last full window get no gradient)
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pool421_bwd(const float* __restrict__ gy,
                                                     const float* __restrict__ gx_add,
                                                     float* __restrict__ gx, int64_t rows, int Lin,
@@ -562,6 +591,24 @@ int ms_avg_pool1d_4_2_1_bwd(const float* gy, const float* gx_add, float* gx, int
     const int Lout = (Lin + 2 - 4) / 2 + 1;
     hipLaunchKernelGGL(k_pool421_bwd, dim3(grid_for(rows * Lin)), dim3(256), 0, (hipStream_t)stream,
                        gy, gx_add, gx, rows, Lin, Lout);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_avg_pool1d_k_fwd(const float* x, float* y, int64_t rows, int32_t Lin, int32_t k, ms_stream_t stream) {
+    if (!x || !y || rows <= 0 || k < 1 || Lin < k) return MS_ERR_INVALID_ARG;
+    const int Lout = Lin / k;
+    hipLaunchKernelGGL(k_poolk_fwd, dim3(grid_for(rows * Lout)), dim3(256), 0, (hipStream_t)stream, x, y, rows, Lin,
+                       Lout, k);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_avg_pool1d_k_bwd(const float* gy, float* gx, int64_t rows, int32_t Lin, int32_t k, ms_stream_t stream) {
+    if (!gy || !gx || rows <= 0 || k < 1 || Lin < k) return MS_ERR_INVALID_ARG;
+    const int Lout = Lin / k;
+    hipLaunchKernelGGL(k_poolk_bwd, dim3(grid_for(rows * Lin)), dim3(256), 0, (hipStream_t)stream, gy, gx, rows, Lin,
+                       Lout, k);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }

@@ -528,6 +528,20 @@ class ConvTranspose1dExFn(Function):
         return gx, gw, (gb if ctx.has_bias else None), None, None, None, None
 
 
+class AvgPoolKFn(Function):
+    """F.avg_pool1d(x, k)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.cfg = (tuple(x.shape), k)
+        return P.avg_poolk_fwd(x, k)
+
+    @staticmethod
+    def backward(ctx, gy):
+        shape, k = ctx.cfg
+        return P.avg_poolk_bwd(_c(gy), shape, k), None
+
+
 class AvgPool421Fn(Function):
     @staticmethod
     def forward(ctx, x):

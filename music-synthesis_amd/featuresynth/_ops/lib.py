@@ -95,6 +95,8 @@ SIGNATURES = {
     "ms_avg_pool1d_4_2_2_bwd": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _vp]),
     "ms_avg_pool1d_4_2_1_fwd": (_c_int, [_vp, _vp, _c_i64, _c_int, _vp]),
     "ms_avg_pool1d_4_2_1_bwd": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _vp]),
+    "ms_avg_pool1d_k_fwd": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _vp]),
+    "ms_avg_pool1d_k_bwd": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _vp]),
     "ms_weight_norm_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _vp]),
     "ms_weight_norm_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_f, _vp]),
     "ms_judge_loss_multi_fwd": (_c_int, [ctypes.POINTER(JudgeMultiDesc), _vp, _vp]),

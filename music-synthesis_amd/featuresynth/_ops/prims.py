@@ -236,6 +236,25 @@ def avg_pool421_bwd(gy, x_shape, gx_add=None):
     return gx
 
 
+def avg_poolk_fwd(x, k):
+    """F.avg_pool1d(x, k)."""
+    L.require(x, "avg_pool1d input")
+    B, C, Lin = x.shape
+    if k < 1 or Lin < k:
+        raise RuntimeError("avg_pool1d: window %d does not fit %d samples" % (k, Lin))
+    y = torch.empty((B, C, Lin // k), dtype=torch.float32, device=x.device)
+    L.call("ms_avg_pool1d_k_fwd", _scost(x.numel(), 1, 1.0 / k), x.data_ptr(), y.data_ptr(), B * C, Lin, k, L.stream())
+    return y
+
+
+def avg_poolk_bwd(gy, x_shape, k):
+    L.require(gy, "avg_pool1d grad_output")
+    B, C, Lin = x_shape
+    gx = torch.empty((B, C, Lin), dtype=torch.float32, device=gy.device)
+    L.call("ms_avg_pool1d_k_bwd", _scost(gx.numel(), 1.0 / k, 1), gy.data_ptr(), gx.data_ptr(), B * C, Lin, k, L.stream())
+    return gx
+
+
 def weight_norm_fwd(v, g):
     """w = g * v / ||v|| over all dims but 0 (torch.nn.utils.weight_norm, dim=0)."""
     L.require(v, "weight_v"); L.require(g, "weight_g")

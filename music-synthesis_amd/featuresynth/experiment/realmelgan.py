@@ -161,8 +161,6 @@ class Generator(nn.Module):
 class NLayerDiscriminator(nn.Module):
     def __init__(self, ndf, n_layers, downsampling_factor, conditioning_channels=0):
         super().__init__()
-        if conditioning_channels:
-            raise NotImplementedError("the conditioning branch (layer_cond) is not built yet")
         self.conditioning_channels = conditioning_channels
         model = nn.ModuleDict()
         model["layer_0"] = nn.Sequential(
@@ -182,12 +180,23 @@ class NLayerDiscriminator(nn.Module):
         model["layer_%d" % (n_layers + 1)] = nn.Sequential(
             WNConv1d(nf_prev, nf, kernel_size=5, stride=1, padding=2, activation="lrelu"),
             Fused("LeakyReLU(0.2) fused behind the conv"))
+        if self.conditioning_channels > 0:      # realmelgan.py:128-136
+            model["layer_cond"] = nn.Sequential(
+                WNConv1d(nf + conditioning_channels, nf, 3, 1, 1, activation="lrelu"),
+                Fused("LeakyReLU(0.2) fused behind the conv"),
+                WNConv1d(nf, nf, 3, 1, 1, activation="lrelu"),
+                Fused("LeakyReLU(0.2) fused behind the conv"),
+                WNConv1d(nf, nf, 3, 1, 1, activation="lrelu"),
+                Fused("LeakyReLU(0.2) fused behind the conv"))
         model["layer_%d" % (n_layers + 2)] = WNConv1d(nf, 1, kernel_size=3, stride=1, padding=1)
         self.model = model
 
     def forward(self, x, feat=None):
         results = []
         for key, layer in self.model.items():
+            if 'cond' in key:                   # realmelgan.py:149-152: mel features pooled to this rate, stacked in front
+                feat = F_.AvgPoolKFn.apply(feat.contiguous(), feat.shape[-1] // x.shape[-1])
+                x = torch.cat([feat, x], dim=1)
             x = layer(x)
             results.append(x)
         return results

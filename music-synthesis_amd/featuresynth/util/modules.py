@@ -238,21 +238,46 @@ class Fused(nn.Module):
         return self.what
 
 
+class HipWNConv1d(nn.Module):
+    """torch.nn.utils.weight_norm(nn.Conv1d(...)) drop-in for the ResidualAtom: parameters `bias`, `weight_g`
+    (out, 1, 1), `weight_v` (out, in, k) in the reference's state_dict order, initialised like weight_norm
+    does (v = the conv's default init, g = ||v|| per output channel); the effective weight g * v / ||v|| is
+    derived by the HIP weight-norm kernel (and its backward) on every forward."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation = (kernel_size,), (stride,), (padding,), (dilation,)
+        ref = torch.empty(out_channels, in_channels, kernel_size)
+        nn.init.kaiming_uniform_(ref, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_channels * kernel_size)
+        self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        self.weight_g = nn.Parameter(ref.reshape(out_channels, -1).norm(dim=1).reshape(out_channels, 1, 1))
+        self.weight_v = nn.Parameter(ref)
+
+    @property
+    def weight(self):
+        return F_.WeightNormFn.apply(self.weight_v, self.weight_g)
+
+
 class ResidualAtom(nn.Module):
     """Reference util/modules.py:350-388: x + lrelu(conv(lrelu(conv_dilated(x)))), zero padding =
-    dilation, bias on both convs; `add_weight_norm` is accepted (the reference shadows
-    weight_norm with the identity at generator/full.py:12-13 for this model)."""
+    dilation, bias on both convs; with `add_weight_norm` both convs are weight-normed (:364-366; the
+    MelGAN generator shadows weight_norm with the identity at generator/full.py:12-13, so the hot path
+    runs without)."""
 
     def __init__(self, channels, dilation, add_weight_norm=False):
         super().__init__()
-        if add_weight_norm:
-            raise NotImplementedError("weight-normed ResidualAtom is not on the stage-2 hot path")
         self.add_weight_norm = add_weight_norm
         self.dilation = dilation
         self.channels = channels
-        first = HipConv1d(channels, channels, 3, 1, dilation=dilation, padding=dilation,
-                          activation="lrelu")
-        second = HipConv1d(channels, channels, 3, 1, 1, activation="lrelu")
+        if add_weight_norm:
+            first = HipWNConv1d(channels, channels, 3, 1, dilation=dilation, padding=dilation)
+            second = HipWNConv1d(channels, channels, 3, 1, 1)
+        else:
+            first = HipConv1d(channels, channels, 3, 1, dilation=dilation, padding=dilation,
+                              activation="lrelu")
+            second = HipConv1d(channels, channels, 3, 1, 1, activation="lrelu")
         self.main = nn.Sequential(first, second)
 
     def forward(self, x):

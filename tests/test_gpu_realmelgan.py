@@ -269,3 +269,56 @@ def test_realmelgan_native_graph_path(monkeypatch):
         out[mode] = losses
     for a, b in zip(out["0"], out["1"]):
         assert abs(a - b) <= 1e-4 * abs(a) + 1e-6, (out["0"], out["1"])
+
+
+@pytest.mark.parametrize("d", [1, 9])
+def test_weight_normed_residual_atom_golden(golden, d):
+    """ResidualAtom(add_weight_norm=True) (reference util/modules.py:350-388 with torch weight_norm on both
+    convs): state_dict keys, forward, input gradient and the gradients of bias / weight_g / weight_v."""
+    from featuresynth.util.modules import ResidualAtom
+    z = golden("partial_rows")
+    nm = "atom_wn_d%d" % d
+    atom = ResidualAtom(8, d, add_weight_norm=True)
+    assert list(atom.state_dict().keys()) == list(z[nm + "/param_names"])
+    atom.load_state_dict({k: torch.from_numpy(z[nm + "/sd/" + k]) for k in z[nm + "/param_names"]})
+    atom.cuda()
+    x = dev(z[nm + "/x"]).requires_grad_(True)
+    y = atom(x)
+    assert rel_l2(host(y), z[nm + "/y"]) < 1e-5
+    y.backward(dev(z[nm + "/gy"]))
+    assert rel_l2(host(x.grad), z[nm + "/gx"]) < 1e-4
+    for k, p in atom.named_parameters():
+        assert rel_l2(host(p.grad), z[nm + "/grad/" + k]) < 1e-4, k
+
+
+def test_discriminator_conditioning_branch_golden(golden):
+    """Discriminator(conditioning_channels=128): the `layer_cond` branch (realmelgan.py:128-136,149-152) --
+    mel features average-pooled to the feature map's rate (HIP avg_pool1d(k)), stacked in front of it, three
+    weight-normed k3 convs -- against the imported reference: outputs and gradients."""
+    from featuresynth._synthetic import (module_param_shapes, strided_sample, synthetic_features, synthetic_samples,
+                                         synthetic_state_dict)
+    from featuresynth.experiment import realmelgan as R
+    z = golden("partial_rows")
+    disc = R.Discriminator(3, 16, 4, 4, conditioning_channels=128)
+    assert list(disc.state_dict().keys()) == list(z["cond/param_names"])
+    disc.load_state_dict({k: torch.from_numpy(v) for k, v in
+                          synthetic_state_dict(module_param_shapes(disc), seed=45, weight_scale=0.3, bias_scale=0.05).items()})
+    disc.cuda()
+    x = dev(synthetic_samples(2, 2048, rank=11)).requires_grad_(True)
+    feat = dev(synthetic_features(2, 128, 8, rank=11)).requires_grad_(True)
+    feats, judges = disc(x, feat)
+    assert len(feats[0]) == int(z["cond/nfeat"][0])
+    loss = sum(j.mean() for j in judges) + 0.1 * sum(f.abs().mean() for grp in feats for f in grp)
+    assert abs(loss.item() - float(z["cond/loss"][0])) <= 1e-4 * abs(float(z["cond/loss"][0]))
+    for s in range(3):
+        assert rel_l2(host(judges[s]), z["cond/j%d" % s]) < 1e-4
+        for i, f in enumerate(feats[s]):
+            assert tuple(f.shape) == tuple(z["cond/f%d_%d_shape" % (s, i)])
+            assert rel_l2(strided_sample(host(f)), z["cond/f%d_%d_smp" % (s, i)]) < 1e-4
+    loss.backward()
+    assert rel_l2(host(feat.grad), z["cond/gfeat"]) < 1e-3
+    assert rel_l2(strided_sample(host(x.grad), 1024), z["cond/gx_smp"]) < 1e-2     # (|.| features: sign flips at zero crossings)
+    for k, p in disc.named_parameters():
+        if "cond" in k or "layer_6" in k:
+            s = z["cond/grad_sum/" + k]
+            assert abs(float(np.linalg.norm(host(p.grad).astype(np.float64))) - s[0]) <= 1e-3 * s[0] + 1e-9, k

@@ -490,10 +490,58 @@ def stage1():
                                                               out["step/d_loss"][0], out["step/g_loss"][0]))
 
 
+def partial_rows():
+    """Rows finished in round 2: the weight-normed ResidualAtom (util/modules.py:350-388 with add_weight_norm) and
+    the conditioning branch `layer_cond` of the weight-normed MelGAN's discriminators (realmelgan.py:128-152),
+    both from the imported reference classes."""
+    ns = ref_import.load_reference()
+    rm = ref_import.load_realmelgan()
+    out = {}
+    rng = np.random.default_rng(41)
+    for d in (1, 9):
+        atom = ns.ResidualAtom(8, d, True)
+        sd = SYN.synthetic_state_dict(SYN.module_param_shapes(atom), seed=40 + d, weight_scale=0.3, bias_scale=0.1)
+        load_sd(atom, sd)
+        out["atom_wn_d%d/param_names" % d] = np.array(list(sd.keys()))
+        for k, v in sd.items():
+            out["atom_wn_d%d/sd/%s" % (d, k)] = v
+        x = torch.from_numpy(rng.standard_normal((2, 8, 37)).astype(np.float32)).requires_grad_(True)
+        y = atom(x)
+        gy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+        y.backward(gy)
+        out["atom_wn_d%d/x" % d], out["atom_wn_d%d/y" % d] = t2n(x), t2n(y)
+        out["atom_wn_d%d/gy" % d], out["atom_wn_d%d/gx" % d] = t2n(gy), t2n(x.grad)
+        for k, p in atom.named_parameters():
+            out["atom_wn_d%d/grad/%s" % (d, k)] = t2n(p.grad)
+    disc = rm.Discriminator(3, 16, 4, 4, conditioning_channels=128)
+    dshapes = SYN.module_param_shapes(disc)
+    out["cond/param_names"] = np.array([k for k, _ in dshapes])
+    load_sd(disc, SYN.synthetic_state_dict(dshapes, seed=45, weight_scale=0.3, bias_scale=0.05))
+    x = torch.from_numpy(SYN.synthetic_samples(2, 2048, rank=11)).requires_grad_(True)
+    feat = torch.from_numpy(SYN.synthetic_features(2, 128, 8, rank=11)).requires_grad_(True)
+    feats, judges = disc(x, feat)
+    loss = sum(j.mean() for j in judges) + 0.1 * sum(f.abs().mean() for grp in feats for f in grp)
+    loss.backward()
+    out["cond/loss"] = np.array([loss.item()])
+    out["cond/nfeat"] = np.array([len(feats[0])])
+    for s in range(3):
+        out["cond/j%d" % s] = t2n(judges[s])
+        for i, f in enumerate(feats[s]):
+            out["cond/f%d_%d_shape" % (s, i)] = np.array(f.shape, np.int64)
+            out["cond/f%d_%d_smp" % (s, i)] = SYN.strided_sample(t2n(f))
+    out["cond/gx_smp"], out["cond/gfeat"] = SYN.strided_sample(t2n(x.grad), 1024), t2n(feat.grad)
+    for k, p in disc.named_parameters():
+        if "cond" in k or "layer_6" in k:
+            out["cond/grad_smp/" + k] = SYN.strided_sample(t2n(p.grad))
+            out["cond/grad_sum/" + k] = summary(t2n(p.grad))
+    np.savez_compressed(os.path.join(OUT, "partial_rows.npz"), **out)
+    print("partial_rows: cond loss %.6f, %d features per scale" % (loss.item(), len(feats[0])))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_import.load_reference()
-    which = sys.argv[1:] or ["ops", "g", "d", "train", "mel", "real", "stage1"]
+    which = sys.argv[1:] or ["ops", "g", "d", "train", "mel", "real", "stage1", "partial"]
     if "ops" in which:
         ops_tiny(ns)
     if "g" in which:
@@ -508,6 +556,8 @@ def main():
         realmelgan()
     if "stage1" in which:
         stage1()
+    if "partial" in which:
+        partial_rows()
 
 
 if __name__ == "__main__":
