@@ -307,6 +307,19 @@ int ms_audio2mel_fwd(const float* audio, int32_t B, int32_t N, const float* wind
                      ms_stream_t stream);
 
 /*
+ * audio() front-end of the dataset pass (feature/feature.py:64-71): librosa.resample (default 'kaiser_best':
+ * resampy's interpolated Kaiser-windowed sinc) and librosa.util.normalize(x) * 0.95.
+ * x (rows, n_in) -> y (rows, n_out) with n_out = ceil(n_in * ratio), ratio = target_sr / orig_sr.
+ * interp_win / interp_delta: the half window (nwin entries, num_table per zero crossing, already multiplied by
+ * min(1, ratio)) and its first differences, built on the host as resampy does.
+ * ms_peak_normalize scales every row in place by scale / max|row| (rows of all zeros stay); workspace = rows floats.
+ */
+int ms_resample_sinc_fwd(const float* x, int32_t rows, int32_t n_in, float* y, int32_t n_out, double ratio,
+                         const float* interp_win, const float* interp_delta, int32_t nwin, int32_t num_table,
+                         ms_stream_t stream);
+int ms_peak_normalize(float* x, int32_t rows, int32_t n, float scale, float* workspace, ms_stream_t stream);
+
+/*
  * Data-parallel gradient exchange (the reference is single-process, so these
  * replace nothing in it: they are what its training loop would call between loss.backward() and
  * optim.step(), train/train.py:37-38,72-73, once the batch is sharded over ranks).

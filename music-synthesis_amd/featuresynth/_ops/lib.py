@@ -124,6 +124,8 @@ SIGNATURES = {
     "ms_adam_step": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _vp, _vp]),
     "ms_audio2mel_frames": (_c_int, [_c_int, _c_int, _c_int]),
     "ms_audio2mel_fwd": (_c_int, [_vp, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _c_int, _vp, _vp]),
+    "ms_resample_sinc_fwd": (_c_int, [_vp, _c_int, _c_int, _vp, _c_int, ctypes.c_double, _vp, _vp, _c_int, _c_int, _vp]),
+    "ms_peak_normalize": (_c_int, [_vp, _c_int, _c_int, _c_f, _vp, _vp]),
     "ms_comm_unique_id": (_c_int, [_vp]),
     "ms_comm_init": (_c_int, [_vp, _c_int, _c_int, ctypes.POINTER(_vp)]),
     "ms_comm_world": (_c_int, [_vp]),

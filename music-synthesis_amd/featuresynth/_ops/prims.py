@@ -1,5 +1,6 @@
 """Tensor-level wrappers of the C-ABI kernels: shape checks, output allocation, launch on the
 current stream.  No autograd here (see functional.py)."""
+import numpy as np
 import torch
 
 from . import lib as L
@@ -533,3 +534,23 @@ def audio2mel(audio, window, basis, n_fft, hop):
     L.call("ms_audio2mel_fwd", None, audio.data_ptr(), B, N, window.data_ptr(), n_fft, hop,
            basis.data_ptr(), n_mel, out.data_ptr(), L.stream())
     return out
+
+
+def resample_sinc(x, ratio, interp_win, interp_delta, num_table):
+    """x (rows, n_in) -> (rows, ceil(n_in * ratio)): band-limited sinc interpolation with the given half window."""
+    L.require(x, "audio"); L.require(interp_win, "interp_win"); L.require(interp_delta, "interp_delta")
+    rows, n_in = x.shape
+    n_out = int(np.ceil(n_in * ratio))
+    y = torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
+    L.call("ms_resample_sinc_fwd", None, x.data_ptr(), rows, n_in, y.data_ptr(), n_out, float(ratio),
+           interp_win.data_ptr(), interp_delta.data_ptr(), interp_win.numel(), int(num_table), L.stream())
+    return y
+
+
+def peak_normalize_(x, scale):
+    """rows of x scaled in place to max|row| = scale."""
+    L.require(x, "audio")
+    rows, n = x.shape
+    ws = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    L.call("ms_peak_normalize", None, x.data_ptr(), rows, n, float(scale), ws.data_ptr(), L.stream())
+    return x

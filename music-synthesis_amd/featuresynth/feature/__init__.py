@@ -1,1 +1,1 @@
-from .feature import Audio2Mel
+from .feature import Audio2Mel, audio_from_samples, resample  # noqa: F401

@@ -9,8 +9,13 @@ feature.py:27-29 with librosa < 0.10 positional arguments, i.e. htk=False, norm=
 does; the per-frame arithmetic (window, FFT, magnitude, mel projection, log10) runs in one
 HIP kernel (csrc/audio2mel.hip).
 
-The reference's dataset-side helpers in the same file (`audio`, `spectrogram`, the LMDB cache,
-:62-85) are file I/O and out of scope of this build.
+The reference's dataset-side helpers in the same file (:62-85) are `audio` (read a file chunk with zounds,
+librosa.resample to the target rate, librosa.util.normalize * 0.95) and `spectrogram` (Audio2Mel of that).
+The file / LMDB part is out of scope; the arithmetic -- resampling and peak
+normalisation -- is `audio_from_samples` below, on the device: librosa's default resampler is resampy's
+'kaiser_best' interpolated Kaiser-windowed sinc, restated from its published algorithm (resampy and librosa are
+third-party, un-pinned and absent here: parity unpinned, checked against a numpy restatement and against
+scipy.signal.resample_poly).
 """
 import numpy as np
 import torch
@@ -84,3 +89,57 @@ class Audio2Mel(nn.Module):
             raise RuntimeError("Audio2Mel expects (B, 1, N) audio, got %s" % (tuple(audio.shape),))
         a = audio.reshape(audio.shape[0], audio.shape[2]).contiguous().float()
         return P.audio2mel(a, self.window, self.mel_basis, self.n_fft, self.hop_length)
+
+
+# resampy 'kaiser_best' (librosa.resample's default res_type in librosa < 0.10): published filter parameters
+KAISER_BEST = dict(num_zeros=64, precision=9, rolloff=0.9475937167399596, beta=14.769656459379492)
+
+
+def sinc_window(num_zeros, precision, rolloff, beta):
+    """Right half of the Kaiser-windowed sinc low-pass, 2**precision samples per zero crossing
+    (resampy.filters.sinc_window) -> (interp_win float64, samples per zero crossing)."""
+    from scipy.signal.windows import kaiser
+    num_bits = 2 ** precision
+    n = num_bits * num_zeros
+    sinc_win = rolloff * np.sinc(rolloff * np.linspace(0, num_zeros, num=n + 1, endpoint=True))
+    taper = kaiser(2 * n + 1, beta)[n:]
+    return taper * sinc_win, num_bits
+
+
+_FILTERS = {}
+
+
+def _filter_for(ratio, device):
+    key = (round(float(ratio), 12), str(device))
+    if key not in _FILTERS:
+        win, num_table = sinc_window(**KAISER_BEST)
+        if ratio < 1:
+            win = win * ratio
+        delta = np.zeros_like(win)
+        delta[:-1] = np.diff(win)
+        _FILTERS[key] = (torch.from_numpy(win.astype(np.float32)).to(device),
+                         torch.from_numpy(delta.astype(np.float32)).to(device), num_table)
+    return _FILTERS[key]
+
+
+def resample(samples, orig_sr, target_sr):
+    """librosa.resample(samples, orig_sr, target_sr) (res_type 'kaiser_best', fix=True, scale=False) on the
+    device: (B, N) or (B, 1, N) float tensor -> same rank with ceil(N * target_sr / orig_sr) samples."""
+    if orig_sr == target_sr:
+        return samples
+    ratio = float(target_sr) / float(orig_sr)
+    shape = samples.shape
+    x = samples.reshape(-1, shape[-1]).contiguous().float()
+    win, delta, num_table = _filter_for(ratio, x.device)
+    y = P.resample_sinc(x, ratio, win, delta, num_table)
+    return y.reshape(shape[:-1] + (y.shape[-1],))
+
+
+def audio_from_samples(samples, orig_sr, samplerate):
+    """The arithmetic of the reference's `audio()` (feature.py:64-71) after the file read: resample to
+    `samplerate`, then librosa.util.normalize(axis=-1) * 0.95 (peak 0.95 per chunk)."""
+    y = resample(samples, orig_sr, samplerate)
+    shape = y.shape
+    y2 = y.reshape(-1, shape[-1]).contiguous().clone() if y is samples else y.reshape(-1, shape[-1])
+    P.peak_normalize_(y2, 0.95)
+    return y2.reshape(shape)

@@ -555,3 +555,53 @@ def g_step(gw, dw, g_adam, samples, features, update=True):
         for k in gw:
             gw[k] = G.w[k]
     return loss, fake, grads
+
+
+# ----------------------------------------------------------------- audio() front-end (feature/feature.py:64-71)
+# librosa.resample (default res_type 'kaiser_best') = resampy.resample with its published kaiser_best filter;
+# librosa.util.normalize(axis=-1) * 0.95.  librosa / resampy are third-party, un-pinned and absent in this
+# container: the algorithm is restated from resampy's published sources (filters.sinc_window, interpn.resample_f)
+# -- PARITY UNPINNED for this function.
+
+def resample_kaiser_best(x, orig_sr, target_sr):
+    from scipy.signal.windows import kaiser
+    x = np.asarray(x, np.float64)
+    ratio = float(target_sr) / float(orig_sr)
+    num_zeros, precision, rolloff, beta = 64, 9, 0.9475937167399596, 14.769656459379492
+    num_table = 2 ** precision
+    n = num_table * num_zeros
+    win = kaiser(2 * n + 1, beta)[n:] * rolloff * np.sinc(rolloff * np.linspace(0, num_zeros, num=n + 1, endpoint=True))
+    if ratio < 1:
+        win = win * ratio
+    win = win.astype(np.float32).astype(np.float64)          # (the table is stored in float32)
+    delta = np.zeros_like(win)
+    delta[:-1] = np.diff(win)
+    n_out = int(np.ceil(x.shape[-1] * ratio))
+    scale = min(1.0, ratio)
+    index_step = int(scale * num_table)
+    nwin, n_in = win.shape[0], x.shape[-1]
+    y = np.zeros(x.shape[:-1] + (n_out,), np.float64)
+    for t in range(n_out):
+        time_register = t / ratio
+        nn = int(time_register)
+        frac = scale * (time_register - nn)
+        index_frac = frac * num_table
+        offset = int(index_frac)
+        eta = index_frac - offset
+        i_max = min(nn + 1, (nwin - offset) // index_step)
+        idx = offset + index_step * np.arange(i_max)
+        y[..., t] += ((win[idx] + eta * delta[idx]) * x[..., nn - np.arange(i_max)]).sum(-1)
+        frac = scale - frac
+        index_frac = frac * num_table
+        offset = int(index_frac)
+        eta = index_frac - offset
+        k_max = min(n_in - nn - 1, (nwin - offset) // index_step)
+        idx = offset + index_step * np.arange(k_max)
+        y[..., t] += ((win[idx] + eta * delta[idx]) * x[..., nn + 1 + np.arange(k_max)]).sum(-1)
+    return y.astype(np.float32)
+
+
+def audio_from_samples(x, orig_sr, samplerate):
+    y = resample_kaiser_best(x, orig_sr, samplerate).astype(np.float64)
+    peak = np.abs(y).max(axis=-1, keepdims=True)
+    return (y / np.where(peak > np.finfo(np.float32).tiny, peak, 1.0) * 0.95).astype(np.float32)

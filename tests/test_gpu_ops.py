@@ -491,3 +491,30 @@ def test_judge_loss_multi_matches_single_terms():
                 assert np.array_equal(host(grs[i]), host(er)) and np.array_equal(host(gfs[i]), host(ef))
             else:
                 assert np.array_equal(host(gfs[i]), host(P.neg_mean_bwd(fs[i], g)))
+
+
+@pytest.mark.parametrize("rates", [(44100, 22050), (48000, 22050), (11025, 22050)], ids=["down2", "down_147_320", "up2"])
+def test_audio_frontend_vs_oracle(rates):
+    """feature.audio_from_samples (HIP sinc resampler + peak normalisation: the arithmetic of the reference's
+    audio(), feature/feature.py:64-71) against the numpy restatement of resampy 'kaiser_best' (parity unpinned:
+    librosa / resampy are absent), plus Audio2Mel on the result (the reference's spectrogram(), :78-85)."""
+    from featuresynth.feature import Audio2Mel, audio_from_samples, resample
+    from oracle import oracle as O
+    orig, target = rates
+    rng = np.random.default_rng(stable_seed("audio%s" % (rates,)))
+    n = 6000
+    t = np.arange(n) / orig
+    x = np.stack([0.4 * np.sin(2 * np.pi * 220 * t) + 0.1 * rng.standard_normal(n),
+                  0.05 * rng.standard_normal(n), np.zeros(n)]).astype(np.float32)
+    y = resample(dev(x), orig, target)
+    ref = O.resample_kaiser_best(x, orig, target)
+    assert tuple(y.shape) == ref.shape
+    assert np.abs(host(y) - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    a = audio_from_samples(dev(x).view(3, 1, n), orig, target)
+    ra = O.audio_from_samples(x, orig, target)
+    assert tuple(a.shape) == (3, 1, ref.shape[-1])
+    assert np.abs(host(a)[:, 0] - ra).max() < 5e-5
+    assert abs(float(a[0].abs().max()) - 0.95) < 1e-5 and float(a[2].abs().max()) == 0.0
+    if a.shape[-1] >= 1024 and target == 22050:
+        mel = Audio2Mel(n_mel_channels=128).cuda()(a[:1].contiguous())
+        assert mel.shape[1] == 128 and torch.isfinite(mel).all()

@@ -400,3 +400,22 @@ def test_stage1_oracle_train_steps_golden(golden):
             assert rel_l2(strided_sample(p.grad.numpy()), ref) < 5e-5 or np.linalg.norm(ref) < 1e-12, (kind, k)
             s = z["step/%sgrad_sum/%s" % (kind, k)]
             assert abs(float(np.linalg.norm(p.grad.numpy().astype(np.float64))) - s[0]) <= 5e-5 * s[0] + 1e-12, (kind, k)
+
+
+def test_audio_frontend_oracle_sanity():
+    """oracle.resample_kaiser_best / audio_from_samples (restatement of librosa.resample's default resampy
+    'kaiser_best' + librosa.util.normalize * 0.95, feature/feature.py:64-71; parity unpinned: librosa absent):
+    output length ceil(n * ratio), agreement with scipy's polyphase resampler away from the edges, peak 0.95."""
+    from scipy.signal import resample_poly
+    from oracle import oracle as O
+    sr = 44100
+    t = np.arange(4410) / sr
+    x = (0.5 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 3000 * t)).astype(np.float32)
+    y = O.resample_kaiser_best(x, 44100, 22050)
+    assert y.shape == (2205,)
+    z = resample_poly(x.astype(np.float64), 1, 2)
+    assert np.abs(y[200:-200] - z[200:-200]).max() < 2e-3
+    y2 = O.resample_kaiser_best(x[:1000], 48000, 22050)
+    assert y2.shape == (int(np.ceil(1000 * 22050 / 48000)),)
+    a = O.audio_from_samples(np.stack([x, 0.1 * x]), 44100, 22050)
+    assert a.shape == (2, 2205) and np.allclose(np.abs(a).max(axis=-1), 0.95, atol=1e-6)
