@@ -1186,11 +1186,23 @@ bool rows2_pick(RowCfg cfg, int K, int CC, bool has_act, int epi_s, int in_s, co
 int rows3p_bm(const Row2P& q, int bn, int K, int am, int epi_s, int in_s, unsigned gz) {
     if (bn != 128) return 0;                     // (q's tiling must be the 128-column one the kernel's groups own)
     static const int min_wgs = getenv("MSYNTH_R3P_MIN") ? atoi(getenv("MSYNTH_R3P_MIN")) : 128;   // tuning switch
-    const int bm = (q.M >= 128 && K == 3) ? 128 : 64;
-    if (!msr3p_supported(bm, K, am, epi_s, q, in_s)) return 0;
     const long long ntiles = q.R == 1 ? (long long)q.B * q.tiles_per_row : (q.B + q.R - 1) / q.R;
+    // (C = 256 at L = 256, B = 32: 64 workgroups of 128 rows or 128 of 64 rows both measured slower than the
+    //  four-wave kernel's 256 workgroups: 61 / 44 vs 30 us -- no fallback to narrower workgroups)
+    const int bm = (q.M >= 128 && K == 3) ? 128 : (q.M <= 32 ? 32 : 64);
+    if (!msr3p_supported(bm, K, am, epi_s, q, in_s)) return 0;
     const long long wgs = ((ntiles + 1) / 2) * ((q.M + bm - 1) / bm) * gz;
     return wgs >= min_wgs ? bm : 0;
+}
+
+Row2P rows3p_retile(const Row2P& q, int K) {
+    Row2P r = q;
+    r.Lt = 128;
+    r.tiles_per_row = (q.L + 127) / 128;
+    r.SS = 128 + (K - 1) * q.dil;
+    r.RSZ = r.SS;
+    r.PX = r.SS;
+    return r;
 }
 
 template <int K, bool HAS_ACT, int EPI_S = 0, int IN_S = 1, int CCMUL = 1>
@@ -1208,6 +1220,11 @@ int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, 
         if (rows2_pick(cfg, K, CC, HAS_ACT, EPI_S, IN_S, p, X, Xact, W, res, Y, Yact, &q, &tile, &am, &in_s_eff)) {
             if (const int bmp = rows3p_bm(q, bn, K, am, EPI_S, in_s_eff, grid.z))
                 return msr3p_launch(bmp, K, am, q, X, Xact, am == 1 ? p.Wfwd : W, bias, res, Y, Yact, grid.z, s);
+            if (cfg == ROW_32x256 && q.R == 1 && q.Lt == 256) {      // 32-channel layers: the same rows as 128-column tiles
+                Row2P q2 = rows3p_retile(q, K);
+                if (const int bmp = rows3p_bm(q2, 128, K, am, EPI_S, in_s_eff, grid.z))
+                    return msr3p_launch(bmp, K, am, q2, X, Xact, am == 1 ? p.Wfwd : W, bias, res, Y, Yact, grid.z, s);
+            }
             if (msr3_supported(tile, K, am, EPI_S, q, in_s_eff))      // split-bf16 matrix pipe (conv_rows3.hip)
                 return msr3_launch(tile, K, am, q, X, Xact, am == 1 ? p.Wfwd : W, bias, res, Y, Yact, grid.x, grid.y,
                                    grid.z, s);
@@ -1281,8 +1298,17 @@ const char* row_kname(RowCfg c, int K, bool act, int CK, int L = 0, int R = 1, i
             h.B = B; h.M = M > 0 ? M : 64; h.CK = CK; h.CKs = CK; h.PX = R * SS; h.Lt = L >= bn ? bn : L;
             h.tiles_per_row = L >= bn ? (L + bn - 1) / bn : 1;
             if (const int bmp = B > 0 ? rows3p_bm(h, bn, K, am, epi_s, 1, 1) : 0) {
-                snprintf(buf, sizeof(buf), "k_conv_rows3p<%d, %d, %d>", bmp / 64, K, am);
+                snprintf(buf, sizeof(buf), "k_conv_rows3p<%s, %d, %d>", bmp == 128 ? "2, 2, 2" : (bmp == 64 ? "2, 1, 2" : "1, 1, 1"), K, am);
                 return buf;
+            }
+            if (c == ROW_32x256 && R == 1 && L >= 256 && B > 0) {
+                Row2P h2 = h;
+                h2.Lt = 256;
+                h2 = rows3p_retile(h2, K);
+                if (const int bmp = rows3p_bm(h2, 128, K, am, epi_s, 1, 1)) {
+                    snprintf(buf, sizeof(buf), "k_conv_rows3p<%s, %d, %d>", bmp == 128 ? "2, 2, 2" : (bmp == 64 ? "2, 1, 2" : "1, 1, 1"), K, am);
+                    return buf;
+                }
             }
             if (msr3_supported(t2, K, am, epi_s, h)) {
                 snprintf(buf, sizeof(buf), "k_conv_rows3<%s, %d, %d, %s>", tile, K, am,

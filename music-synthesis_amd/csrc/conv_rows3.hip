@@ -392,7 +392,9 @@ __global__ __launch_bounds__(256) void k_conv_rows3(Row2P p, const float* __rest
 // (chunk c+1 is written while chunk c is read), each group's activation tile is single-buffered (written and
 // read by the same group in consecutive slots).  Global loads are issued at the start of a group's MFMA
 // slot and consumed in its next staging slot.
-template <int TM, int K, int AM>
+// Group layout: WGM x (4 / WGM) waves of TM x TN sub-tiles: 2 x 2 waves of TM x 2 (64 or 128 rows) or, for the
+// 32-channel layers, 1 x 4 waves of 1 x 1 (32 rows); 128 columns per group either way.
+template <int WGM, int TM, int TN, int K, int AM>
 __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __restrict__ X,
                                                     const float* __restrict__ Xact,
                                                     const float* __restrict__ W,
@@ -400,7 +402,8 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
                                                     const float* __restrict__ res,
                                                     float* __restrict__ Y,
                                                     float* __restrict__ Yact) {
-    constexpr int TN = 2, BM = 64 * TM, BN = 128;
+    constexpr int WGN = 4 / WGM, BM = WGM * TM * 32, BN = WGN * TN * 32;
+    static_assert(BN == 128, "a group owns one 128-column tile");
     constexpr int ARS = a_row_bytes(K);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     const int a_bytes = BM * ARS, x_bytes = p.PX * XRS;
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
     unsigned char* scratch = smem3 + p.scratch_off;            // 512 x 8 bytes: sink for masked stores
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5;
     const int g = __builtin_amdgcn_readfirstlane(wid >> 2), gt = tid & 255, gw = wid & 3;
-    const int wm = gw >> 1, wn = gw & 1;
+    const int wm = gw / WGN, wn = gw % WGN;
     unsigned char* const Xg = smem3 + 2 * a_bytes + g * x_bytes;
     const int m0 = blockIdx.y * BM;
     const int ti = 2 * blockIdx.x + g;
@@ -632,6 +635,7 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
     __syncthreads();
     constexpr int V4 = BN / 4;
     constexpr int NQ = BM * V4 / 256;
+    static_assert(NQ >= 1, "tile too small");
     float4 tv[NQ], rv[NQ];
     size_t go[NQ];
     bool ok[NQ];
@@ -656,29 +660,29 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
     }
 }
 
-template <int TM, int K>
+template <int BM, int K>
 size_t ldsp_bytes(const Row2P& p) {
-    constexpr int BM = 64 * TM;
     size_t by = (size_t)2 * BM * a_row_bytes(K) + (size_t)2 * p.PX * XRS;
     const size_t epi = (size_t)2 * BM * (128 + 4) * sizeof(float);
     return by < epi ? epi : by;
 }
 
-template <int TM, int K, int AM>
+template <int WGM, int TM, int TN, int K, int AM>
 int launch_pair(const Row2P& p, const float* X, const float* Xact, const float* W, const float* bias,
                 const float* res, float* Y, float* Yact, dim3 grid, hipStream_t s) {
-    const size_t by = ldsp_bytes<TM, K>(p);
+    const size_t by = ldsp_bytes<WGM * TM * 32, K>(p);
     const size_t lds = by + 512 * 8;
     if (lds > 158 * 1024) return MS_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rows3p<TM, K, AM>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rows3p<WGM, TM, TN, K, AM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
         attr_set = true;
     }
     Row2P pp = p;
     pp.scratch_off = (int)by;
-    hipLaunchKernelGGL((k_conv_rows3p<TM, K, AM>), grid, dim3(512), lds, s, pp, X, Xact, W, bias, res, Y, Yact);
+    hipLaunchKernelGGL((k_conv_rows3p<WGM, TM, TN, K, AM>), grid, dim3(512), lds, s, pp, X, Xact, W, bias, res, Y,
+                       Yact);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }
@@ -771,11 +775,12 @@ int msr3_launch(int tile, int K, int act_mode, const Row2P& p, const float* X, c
 bool msr3p_supported(int bm, int K, int act_mode, int epi_s, const Row2P& p, int in_s) {
     const char* sw = getenv("MSYNTH_ROWS3P");        // tuning / test switch (0: four-wave kernel only)
     if (sw && atoi(sw) == 0) return false;
+    if (bm != 32 && bm != 64 && bm != 128) return false;
     if (!msr3_supported(bm == 128 ? MSR2_128x128 : MSR2_64x128, K, act_mode, epi_s, p, in_s)) return false;
     if (!rows_vec(p)) return false;
-    if (bm != 64 && bm != 128) return false;
-    const size_t by = bm == 128 ? (K == 3 ? ldsp_bytes<2, 3>(p) : ldsp_bytes<2, 5>(p))
-                                : (K == 3 ? ldsp_bytes<1, 3>(p) : ldsp_bytes<1, 5>(p));
+    if (bm == 32 && K != 3) return false;
+    const size_t by = bm == 128 ? (K == 3 ? ldsp_bytes<128, 3>(p) : ldsp_bytes<128, 5>(p))
+                    : bm == 64 ? (K == 3 ? ldsp_bytes<64, 3>(p) : ldsp_bytes<64, 5>(p)) : ldsp_bytes<32, 3>(p);
     return by + 512 * 8 <= 158 * 1024;
 }
 
@@ -783,17 +788,20 @@ int msr3p_launch(int bm, int K, int act_mode, const Row2P& p, const float* X, co
                  const float* bias, const float* res, float* Y, float* Yact, unsigned gz, hipStream_t s) {
     const unsigned ntiles = p.R == 1 ? (unsigned)(p.B * p.tiles_per_row) : (unsigned)((p.B + p.R - 1) / p.R);
     const dim3 grid((ntiles + 1) / 2, (unsigned)((p.M + bm - 1) / bm), gz);
-#define MS3P(TM_, K_, A_) return launch_pair<TM_, K_, A_>(p, X, Xact, W, bias, res, Y, Yact, grid, s)
+#define MS3P(WGM_, TM_, TN_, K_, A_) return launch_pair<WGM_, TM_, TN_, K_, A_>(p, X, Xact, W, bias, res, Y, Yact, grid, s)
     if (bm == 128) {
-        if (K == 3 && act_mode == 0) MS3P(2, 3, 0);
-        if (K == 3 && act_mode == 1) MS3P(2, 3, 1);
-        if (K == 5 && act_mode == 0) MS3P(2, 5, 0);
-        if (K == 5 && act_mode == 1) MS3P(2, 5, 1);
+        if (K == 3 && act_mode == 0) MS3P(2, 2, 2, 3, 0);
+        if (K == 3 && act_mode == 1) MS3P(2, 2, 2, 3, 1);
+        if (K == 5 && act_mode == 0) MS3P(2, 2, 2, 5, 0);
+        if (K == 5 && act_mode == 1) MS3P(2, 2, 2, 5, 1);
+    } else if (bm == 64) {
+        if (K == 3 && act_mode == 0) MS3P(2, 1, 2, 3, 0);
+        if (K == 3 && act_mode == 1) MS3P(2, 1, 2, 3, 1);
+        if (K == 5 && act_mode == 0) MS3P(2, 1, 2, 5, 0);
+        if (K == 5 && act_mode == 1) MS3P(2, 1, 2, 5, 1);
     } else {
-        if (K == 3 && act_mode == 0) MS3P(1, 3, 0);
-        if (K == 3 && act_mode == 1) MS3P(1, 3, 1);
-        if (K == 5 && act_mode == 0) MS3P(1, 5, 0);
-        if (K == 5 && act_mode == 1) MS3P(1, 5, 1);
+        if (K == 3 && act_mode == 0) MS3P(1, 1, 1, 3, 0);
+        if (K == 3 && act_mode == 1) MS3P(1, 1, 1, 3, 1);
     }
 #undef MS3P
     return MS_ERR_UNSUPPORTED;
