@@ -18,6 +18,7 @@
 #include "conv_mfma.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -391,6 +392,296 @@ __global__ __launch_bounds__(256) void k_wgrad_rows(WrP p, const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same weight gradient on the bf16 matrix pipe with fp32-exact operands (see conv_rows3.hip for the
+// scheme: every fp32 value = the exact sum of three bf16 pieces, six partial products per multiply, fp32
+// accumulate) for the generator's k3 atom convs: K = 3, pad = dil in {1, 3, 9}, 16-byte aligned rows of at
+// least 64 samples, LeakyReLU derivative on the gradient operand, 64 | Cin, 64*TM | Cout.
+//
+// The contraction runs over TIME, so an MFMA k-step is 16 consecutive samples: both operands keep their
+// natural row-major layout in LDS ([row][piece][time] bf16, no transposes).  The input rows are staged ONCE
+// with their halo; the B fragment of tap j starts j*dil - pad samples off the 16-byte grid, so it is read as
+// the two aligned 16-byte vectors around it and funnelled together in registers (v_alignbit for odd shifts;
+// the shift is a compile-time constant per dilation and tap).
+//
+// 8 waves = two groups of four.  Both groups own the SAME output tile and split the contraction: of every
+// 64-sample chunk of the plan, group g takes samples [32g, 32g + 32).  The groups alternate between the
+// matrix pipe and the vector work of the staging slot by slot (as k_conv_rows3p), each with its own
+// single-buffered LDS tiles; at the end group 1's accumulators are added to group 0's through LDS and
+// the tile goes to the split-K slab in the layout of k_wgrad_rows (same reduce kernels).
+typedef __bf16 w3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 w3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float w3_f32x2 __attribute__((ext_vector_type(2)));
+typedef float w3_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void w3_split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    const w3_f32x2 v = {a, b};
+    const w3_bf16x2 hi = __builtin_convertvector(v, w3_bf16x2);
+    const w3_f32x2 r1 = v - __builtin_convertvector(hi, w3_f32x2);
+    const w3_bf16x2 mi = __builtin_convertvector(r1, w3_bf16x2);
+    const w3_f32x2 r2 = r1 - __builtin_convertvector(mi, w3_f32x2);
+    const w3_bf16x2 lo = __builtin_convertvector(r2, w3_bf16x2);
+    h = __builtin_bit_cast(unsigned, hi);
+    m = __builtin_bit_cast(unsigned, mi);
+    l = __builtin_bit_cast(unsigned, lo);
+}
+
+// 4 consecutive samples -> one 8-byte group per piece
+__device__ __forceinline__ void w3_split_quad(const float (&e)[4], uint2 (&o)[3]) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    w3_split_pair(e[0], e[1], h0, m0, l0);
+    w3_split_pair(e[2], e[3], h1, m1, l1);
+    o[0] = make_uint2(h0, h1);
+    o[1] = make_uint2(m0, m1);
+    o[2] = make_uint2(l0, l1);
+}
+
+// the 8 bf16 that start E elements into the 16 elements of (lo, hi)
+template <int E>
+__device__ __forceinline__ w3_bf16x8 w3_funnel(const uint4& lo, const uint4& hi) {
+    const unsigned d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint4 o;
+    if (E % 2 == 0) {
+        o = make_uint4(d[E / 2], d[E / 2 + 1], d[E / 2 + 2], d[E / 2 + 3]);
+    } else {
+        o.x = __builtin_amdgcn_alignbit(d[(E + 1) / 2], d[(E - 1) / 2], 16);
+        o.y = __builtin_amdgcn_alignbit(d[(E + 1) / 2 + 1], d[(E - 1) / 2 + 1], 16);
+        o.z = __builtin_amdgcn_alignbit(d[(E + 1) / 2 + 2], d[(E - 1) / 2 + 2], 16);
+        o.w = __builtin_amdgcn_alignbit(d[(E + 1) / 2 + 3], d[(E - 1) / 2 + 3], 16);
+    }
+    return __builtin_bit_cast(w3_bf16x8, o);
+}
+
+constexpr int W3_GRS = 208;                // bytes per gradient row: 3 pieces x 32 samples x 2 + 16
+constexpr int W3_XPB = 128;                // bytes per input-row piece: 64 samples (32 + halo + funnel over-read)
+constexpr int W3_XRS = 3 * W3_XPB + 16;    // 400
+constexpr size_t w3_lds_bytes(int BM) {
+    const size_t kloop = (size_t)2 * (BM * W3_GRS + 64 * W3_XRS);
+    const size_t merge = (size_t)4 * (BM / 64) * 3 * 16 * 64 * sizeof(float) + (size_t)2 * BM * sizeof(float);
+    return kloop > merge ? kloop : merge;
+}
+
+template <int TM>
+__global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restrict__ X_,
+                                                    const float* __restrict__ G_,
+                                                    const float* __restrict__ Gact_,
+                                                    float* __restrict__ partial, size_t pstride, WrMulti mp) {
+    const float* __restrict__ X = X_;
+    const float* __restrict__ G = G_;
+    const float* __restrict__ Gact = Gact_;
+    int by = blockIdx.y;
+    if (mp.n > 0) {                                  // batched launch: this workgroup's problem
+        const int prob = by / mp.tiles_m;
+        by -= prob * mp.tiles_m;
+        X = mp.x[prob]; G = mp.g[prob]; Gact = mp.gact[prob];
+        p.dil = mp.dil[prob]; p.pad = mp.pad[prob];
+        partial += (size_t)prob * mp.slab_stride;
+    }
+    constexpr int K = 3, BM = 64 * TM, NGU = BM / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5;
+    const int g = __builtin_amdgcn_readfirstlane(wid >> 2), gt = tid & 255, gw = wid & 3;
+    const int wm = gw >> 1, wn = gw & 1;
+    unsigned char* const Gs = smem3 + g * (BM * W3_GRS + 64 * W3_XRS);
+    unsigned char* const Xs = Gs + BM * W3_GRS;
+    const int m0 = by * BM, c0 = blockIdx.x * CB;
+    const int NG = p.CK * K;
+    const int PADA = (p.pad + 3) & ~3;               // halo in front of the row tile, rounded to whole vectors
+
+    constexpr unsigned OOB = 0xF0000000u;
+    const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G), 0, 0x80000000u, 0x00020000);
+    const auto rsGa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Gact), 0, 0x80000000u, 0x00020000);
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, 0x80000000u, 0x00020000);
+
+    // staging units of this thread: gradient (row (gt >> 3) + 32 q, vector gt & 7), input (row (gt >> 4) + 16 q,
+    // vector gt & 15 of the 64-sample window that starts PADA samples in front of the tile)
+    const int g_row = gt >> 3, g_t = 4 * (gt & 7);
+    const int x_row = gt >> 4, x_u = 4 * (gt & 15);
+    w3_f32x4 gv[NGU], ga[NGU], xv[4];
+    float bs[NGU];
+#pragma unroll
+    for (int q = 0; q < NGU; ++q) bs[q] = 0.f;
+
+    auto load_chunk = [&](int ch, int c_end) {
+        const int b = ch / p.tiles_per_row;
+        const int t0 = (ch - b * p.tiles_per_row) * p.Lt + 32 * g;
+        const bool live = ch < c_end && b < p.B;
+        const int tg = t0 + g_t, tx = t0 - PADA + x_u;        // multiples of 4: a vector is all in or all out
+        const unsigned go = (live && tg < p.L) ? 4u * (unsigned)((b * p.M + m0 + g_row) * p.L + tg) : OOB;
+        const unsigned xo = (live && tx >= 0 && tx < p.L) ? 4u * (unsigned)((b * p.CK + c0 + x_row) * p.L + tx) : OOB;
+#pragma unroll
+        for (int q = 0; q < NGU; ++q) {
+            gv[q] = __builtin_bit_cast(w3_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, go, q * 32 * 4 * p.L, 0));
+            ga[q] = __builtin_bit_cast(w3_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsGa, go, q * 32 * 4 * p.L, 0));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            xv[q] = __builtin_bit_cast(w3_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, xo, q * 16 * 4 * p.L, 0));
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < NGU; ++q) {
+            float e[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e[i] = ga[q][i] > 0.f ? gv[q][i] : gv[q][i] * p.slope;
+            bs[q] += (e[0] + e[1]) + (e[2] + e[3]);
+            uint2 o3[3];
+            w3_split_quad(e, o3);
+            unsigned char* d = Gs + (g_row + 32 * q) * W3_GRS + g_t * 2;
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(d + pp * 64) = o3[pp];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float e[4] = {xv[q][0], xv[q][1], xv[q][2], xv[q][3]};
+            uint2 o3[3];
+            w3_split_quad(e, o3);
+            unsigned char* d = Xs + (x_row + 16 * q) * W3_XRS + x_u * 2;
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(d + pp * W3_XPB) = o3[pp];
+        }
+    };
+
+    f32x16 acc[TM][K];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const unsigned char* const ap = Gs + (wm * TM * 32 + (lane & 31)) * W3_GRS + h * 16;
+    const unsigned char* const bp = Xs + (wn * 32 + (lane & 31)) * W3_XRS + h * 16;
+    auto compute = [&](auto dilc) __attribute__((always_inline)) {
+        constexpr int DIL = decltype(dilc)::value;
+        constexpr int PA_ = (DIL + 3) & ~3;
+        constexpr int O0 = PA_ - DIL, O2 = PA_ + DIL;       // first sample of taps 0 / 2 in window coordinates (tap 1: PA_)
+        constexpr int V0 = O0 / 8, NV = (O2 + 7) / 8 - V0 + 1;   // aligned 8-sample vectors the three taps touch
+        constexpr int PAI[6] = {0, 2, 1, 0, 1, 0}, PBI[6] = {2, 0, 1, 1, 0, 0};
+        // fragments of k-step s: the A rows and, per piece, the NV aligned vectors that hold all three taps'
+        // windows (2 for dilations 1 / 3, 4 for dilation 9) -- each tap is funnelled out of two neighbours
+        w3_bf16x8 a[2][TM][3];
+        uint4 v[2][3][NV];
+        auto frag = [&](int s, w3_bf16x8 (&af)[TM][3], uint4 (&vf)[3][NV]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+                    af[i][pp] = *reinterpret_cast<const w3_bf16x8*>(ap + i * 32 * W3_GRS + pp * 64 + s * 32);
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+                    vf[pp][k] = *reinterpret_cast<const uint4*>(bp + pp * W3_XPB + (s * 16 + (V0 + k) * 8) * 2);
+        };
+        frag(0, a[0], v[0]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s == 0) frag(1, a[1], v[1]);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int o = j * DIL - DIL + PA_;
+                const int k = o / 8 - V0;
+                w3_bf16x8 b[3];
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp) {
+                    const uint4 lo = v[s][pp][k];
+                    const uint4 hi = v[s][pp][k + 1 < NV ? k + 1 : k];
+                    switch (o & 7) {
+                        case 0: b[pp] = w3_funnel<0>(lo, hi); break;
+                        case 1: b[pp] = w3_funnel<1>(lo, hi); break;
+                        case 2: b[pp] = w3_funnel<2>(lo, hi); break;
+                        case 3: b[pp] = w3_funnel<3>(lo, hi); break;
+                        case 4: b[pp] = w3_funnel<4>(lo, hi); break;
+                        case 5: b[pp] = w3_funnel<5>(lo, hi); break;
+                        case 6: b[pp] = w3_funnel<6>(lo, hi); break;
+                        default: b[pp] = w3_funnel<7>(lo, hi); break;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i][PAI[t]], b[PBI[t]], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    auto compute_dil = [&]() __attribute__((always_inline)) {
+        if (p.dil == 1) compute(std::integral_constant<int, 1>());
+        else if (p.dil == 3) compute(std::integral_constant<int, 3>());
+        else compute(std::integral_constant<int, 9>());
+    };
+
+    const int c_begin = blockIdx.z * p.cps;
+    const int c_end = min(c_begin + p.cps, p.nchunks);
+    // Slot 2i: group 0 multiplies its half of chunk i while group 1 stages its half and at once fetches the next;
+    // slot 2i + 1: the roles swap.  A fetch so has the rest of its staging slot plus the whole multiply slot to
+    // land (one slot did not cover the HBM latency under load).  One straight-line loop per group (the group is
+    // wave-uniform): the compiler then waits for a fetch where it is first used, not at a merged back edge.
+    const int n = c_end - c_begin;
+    load_chunk(c_begin, c_end);
+    if (g == 0) {
+        stage();
+        load_chunk(c_begin + 1, c_end);
+        __syncthreads();
+        for (int i = 0; i < n; ++i) {
+            compute_dil();
+            __syncthreads();
+            stage();
+            load_chunk(c_begin + i + 2, c_end);
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+        for (int i = 0; i < n; ++i) {
+            stage();
+            load_chunk(c_begin + i + 1, c_end);
+            __syncthreads();
+            compute_dil();
+            __syncthreads();
+        }
+    }
+
+    // ---- merge the two groups and write the slab (layout of k_wgrad_rows)
+    float* const mrg = reinterpret_cast<float*>(smem3);                 // [wave][tile][reg][lane]
+    float* const bsum = mrg + 4 * TM * K * 16 * 64;                      // [group][row]
+#pragma unroll
+    for (int q = 0; q < NGU; ++q) {     // row sums of the gradient tile: the 8 lanes that share a row
+        float v = bs[q];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+        bs[q] = v;
+    }
+    if (g == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mrg[((gw * TM * K + i * K + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    if ((gt & 7) == 0) {
+#pragma unroll
+        for (int q = 0; q < NGU; ++q) bsum[g * BM + g_row + 32 * q] = bs[q];
+    }
+    __syncthreads();
+    float* part = partial + (size_t)blockIdx.z * pstride;
+    if (g == 0) {
+        const int c = c0 + wn * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+                    part[(size_t)m * NG + (size_t)c * K + j] =
+                        acc[i][j][r] + mrg[((gw * TM * K + i * K + j) * 16 + r) * 64 + lane];
+            }
+    } else if (blockIdx.x == 0 && gt < BM) {
+        part[(size_t)p.M * NG + m0 + gt] = bsum[gt] + bsum[BM + gt];
+    }
+}
+
 // Split-K slice count: fill the resident workgroup slots without a mostly empty extra round
 // (160 tiles x 4 slices = 640 workgroups on 512 slots ran 63 % longer than 128 x 4).
 int pick_slices(int tiles, int slots, int ns_max) {
@@ -487,9 +778,47 @@ void launch_wrows_ak(const WrPlan& q, const float* x, const float* gy, const flo
                        (const float*)nullptr, gy, y_act, partial, q.stride_floats, q.mp);
 }
 
+// the split-bf16 kernel takes: the k3 atom convs (pad = dil in {1, 3, 9}), aligned rows of >= 64 samples, whole tiles
+bool wrows3_ok(const WrPlan& q, int K, int TM, bool vec, bool has_yact) {
+    const char* sw = getenv("MSYNTH_WROWS3");        // tuning / test switch (0: fp32-MFMA kernel)
+    if (sw && atoi(sw) == 0) return false;
+    const WrP& p = q.p;
+    if (K != 3 || !vec || q.refl || !has_yact || p.g_kind != MS_ACT_LRELU || p.x_kind != MS_ACT_NONE) return false;
+    if (p.R != 1 || p.Lt != KMAX || p.L % 64 || p.CK % CB || p.M % 64) return false;
+    if (q.mp.n > 0) {
+        for (int i = 0; i < q.mp.n; ++i)
+            if (q.mp.pad[i] != q.mp.dil[i] || !(q.mp.dil[i] == 1 || q.mp.dil[i] == 3 || q.mp.dil[i] == 9)) return false;
+    } else if (p.pad != p.dil || !(p.dil == 1 || p.dil == 3 || p.dil == 9)) {
+        return false;
+    }
+    return true;
+}
+
+// Always 64 output channels per workgroup (TM = 1): with 128 the kernel needs more than the 256 registers a wave
+// of a 512-thread workgroup may hold (96 accumulators + fragments + the chunk in flight) and spills.  The
+// plan's grid / batching descriptor are re-derived for 64-row tiles; the slab layout does not depend on it.
+void launch_wrows3(const WrPlan& q, const float* x, const float* gy, const float* y_act, float* partial, hipStream_t s) {
+    const size_t lds = w3_lds_bytes(64);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_rows3<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    WrMulti mp = q.mp;
+    const int tiles_m = q.p.M / 64;
+    if (mp.n > 0) mp.tiles_m = tiles_m;
+    const dim3 grid(q.grid.x, (unsigned)((mp.n > 0 ? mp.n : 1) * tiles_m), q.grid.z);
+    hipLaunchKernelGGL((k_wgrad_rows3<1>), grid, dim3(512), lds, s, q.p, x, gy, y_act, partial, q.stride_floats, mp);
+}
+
 template <int K, int TM, bool VEC, int KPI>
 void launch_wrows_inst(const WrPlan& q, const float* x, const float* gy, const float* y_act,
                        float* partial, hipStream_t s) {
+    if (wrows3_ok(q, K, TM, VEC, y_act != nullptr)) {
+        launch_wrows3(q, x, gy, y_act, partial, s);
+        return;
+    }
     const int gk = y_act ? q.p.g_kind : MS_ACT_NONE;
     if (q.refl) {
         if constexpr (VEC && K == 3) launch_wrows_ak<3, TM, true, KPI, 4>(q, x, gy, y_act, partial, s);
@@ -536,6 +865,10 @@ size_t msw_bwd_weight_ws(const ConvP& p) {
 const char* msw_bwd_weight_name(const ConvP& p) {
     static thread_local char buf[64];
     const WrPlan q = plan_wrows(p);
+    if (wrows3_ok(q, p.K, q.tm, q.vec, p.act == MS_ACT_LRELU)) {
+        snprintf(buf, sizeof(buf), "k_wgrad_rows3<1>");
+        return buf;
+    }
     snprintf(buf, sizeof(buf), "k_wgrad_rows<%d, %d, %s, %d>", p.K, q.tm, q.vec ? "true" : "false", q.p.kcols / 4);
     return buf;
 }
