@@ -1228,9 +1228,6 @@ int launch_rows_k(RowCfg cfg, const RowP& p, const float* X, const float* Xact, 
             if (msr3_supported(tile, K, am, EPI_S, q, in_s_eff))      // split-bf16 matrix pipe (conv_rows3.hip)
                 return msr3_launch(tile, K, am, q, X, Xact, am == 1 ? p.Wfwd : W, bias, res, Y, Yact, grid.x, grid.y,
                                    grid.z, s);
-            if (EPI_S == 0 && IN_S == 1 && in_s_eff == 1 && (cfg == ROW_128x128 || cfg == ROW_64x128) &&
-                msr2h_supported(K, CC, am, q, res != nullptr, Yact != nullptr))
-                return msr2h_launch(K, CC, am, q, X, Xact, am == 1 ? p.Wfwd : W, bias, res, Y, Yact, s);
             return msr2_launch(tile, K, CC, am, EPI_S, q, X, Xact, am == 1 ? p.Wfwd : W, bias, res, Y, Yact, grid.x,
                                grid.y, grid.z, s, in_s_eff);
         }
@@ -1321,14 +1318,6 @@ const char* row_kname(RowCfg c, int K, bool act, int CK, int L = 0, int R = 1, i
             return buf;
         }
         if (msr2_supported(t2, K, CC, am, epi_s, q)) {
-            if (epi_s == 0 && (c == ROW_128x128 || c == ROW_64x128) && B > 0 && M > 0) {
-                Row2P h = q;
-                h.B = B; h.M = M; h.CK = CK; h.CKs = CK; h.PX = SS;
-                if (msr2h_supported(K, CC, am, h, false, false)) {
-                    snprintf(buf, sizeof(buf), "k_conv_rows2h<%d, %d, %d>", K, CC, am);
-                    return buf;
-                }
-            }
             snprintf(buf, sizeof(buf), "k_conv_rows2<%s, %d, %d, %d, %d>", tile, K, CC, am, epi_s);
             return buf;
         }

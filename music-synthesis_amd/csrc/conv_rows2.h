@@ -23,12 +23,6 @@ int msr2_launch(int tile, int K, int CC, int act_mode, int epi_s, const Row2P& p
                 const float* Xact, const float* W, const float* bias, const float* res, float* Y,
                 float* Yact, unsigned gx, unsigned gy, unsigned gz, hipStream_t s, int in_s = 1);
 
-// two-half variant for 8-chunk contractions (conv_rows2h.hip): the first half's output phase runs under the
-// second half's K loop
-bool msr2h_supported(int K, int CC, int act_mode, const Row2P& p, bool has_res, bool has_yact);
-int msr2h_launch(int K, int CC, int act_mode, const Row2P& p, const float* X, const float* Xact, const float* W,
-                 const float* bias, const float* res, float* Y, float* Yact, hipStream_t s);
-
 // third generation (conv_rows3.hip): the same row tiles on the bf16 matrix pipe with every fp32 operand split
 // exactly into three bf16 pieces (six partial products, fp32 accumulate): stride-1 plain rows, K in {3, 5},
 // 16-channel chunks, act_mode 0 / 1, plain epilogue.  MSYNTH_ROWS3=0 disables it.

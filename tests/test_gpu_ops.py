@@ -436,39 +436,6 @@ def test_wgrad_multi_matches_single_calls(case):
         assert rel_l2(host(gb), host(rb)) < 2e-6
 
 
-@pytest.mark.parametrize("shape", [(4, 128, 512, 3), (2, 64, 1024, 9), (3, 128, 256, 1), (2, 64, 256, 1)],
-                         ids=["c128_d3", "c64_d9", "c128_one_tile", "c64_edges"])
-def test_two_half_row_kernel_matches(shape, monkeypatch):
-    """conv_rows2h.hip (two 64x128 halves per workgroup, the first half's stores under the second half's K
-    loop) against k_conv_rows2: same accumulation order, so forward and backward data are bit-identical --
-    with and without residual / y_act / gx_add, at both row edges."""
-    from featuresynth._ops import prims as P
-    B, C, Lg, dil = shape
-    rng = np.random.default_rng(C + dil)
-    x = dev(rng.standard_normal((B, C, Lg)).astype(np.float32))
-    w = dev((rng.standard_normal((C, C, 3)) * 0.05).astype(np.float32))
-    b = dev(rng.standard_normal((C,)).astype(np.float32))
-    res = dev(rng.standard_normal((B, C, Lg)).astype(np.float32))
-    gy = dev(rng.standard_normal((B, C, Lg)).astype(np.float32))
-    d, lo = P.conv_desc(x.shape, w.shape, pad=dil, dil=dil, act=1)
-    out = {}
-    monkeypatch.setenv("MSYNTH_ROWCFG", "1")            # 64x128 tiles also at these small batch sizes
-    monkeypatch.setenv("MSYNTH_ROWS3", "0")             # (the split-bf16 kernel would take these shapes first)
-    from featuresynth._ops import lib as L_
-    for mode in ("0", "2"):
-        monkeypatch.setenv("MSYNTH_ROWS2H", mode)
-        names = [L_.load().ms_conv1d_kernel_name(d, wh).decode() for wh in (0, 1)]
-        assert all(("rows2h" in nm) == (mode == "2") for nm in names), names
-        y1, _ = P.conv1d_fwd(x, w, b, d, lo)
-        y2, ya2 = P.conv1d_fwd(x, w, b, d, lo, residual=res, want_y_act=True)
-        y3, _ = P.conv1d_fwd(x, w, b, d, lo, residual=res)
-        g1 = P.conv1d_bwd_data(gy, ya2, w, d)
-        g2 = P.conv1d_bwd_data(gy, ya2, w, d, gx_add=res)
-        out[mode] = [host(t) for t in (y1, y2, ya2, y3, g1, g2)]
-    for a, c in zip(out["0"], out["2"]):
-        assert np.array_equal(a, c)
-
-
 def test_judge_loss_multi_matches_single_terms():
     """The hinge-D / negative-mean terms of all scales in one launch == the sum of the per-scale kernels,
     forward value and gradients (loss/loss.py:9-25 on judgements of 32 / 17 / 9 frames)."""
