@@ -152,3 +152,52 @@ def test_single_rank_rccl_matches_plain_step(tmp_path, comm):
     assert list(r["losses"]) == list(losses), (r["losses"], losses)
     for k, v in sd.items():
         assert np.array_equal(r[k], v), k
+
+
+def _stage1_rccl_worker(rank, port, out_dir):
+    """Stage-1 (autograd path, whole-bucket exchange) and RealMelGan-style non-hand-scheduled models take the
+    data-parallel branch without cut points: [graph: forwards + backward] -> all-reduce of the whole bucket ->
+    [graph: Adam].  One rank over a real RCCL communicator."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                      LOCAL_RANK="0", MSYNTH_DP_FORCE="1")
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "music-synthesis_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.cuda.set_device(0)
+    from featuresynth import _dist
+    import featuresynth.experiment as E
+    _dist.init_from_env("nccl", force=True)
+    torch.manual_seed(3)
+    exp = E.TwoDimGeneratorFeatureExperiment().to(torch.device("cuda", 0))
+    losses = []
+    for i, (spec,) in enumerate(exp.synthetic_batch_stream(2, n_batches=6)):
+        spec_np, noise = exp.preprocess_batch((spec,))
+        noise = np.random.default_rng(50 + i).standard_normal(noise.shape).astype(np.float32)
+        s, f = torch.from_numpy(spec_np).cuda(), torch.from_numpy(noise).cuda()
+        r = exp.d_trainer.train(s, f) if i % 2 == 0 else exp.g_trainer.train(s, f)
+        losses.append(r["d_loss"] if i % 2 == 0 else r["g_loss"])
+    for tr in (exp.d_trainer, exp.g_trainer):
+        assert len(tr._runner.between) == 1 and tr._runner.graphs and not tr._runner.disabled
+        assert all(len(e[0]) == 2 for e in tr._runner.graphs.values()), "expected 2 graph segments per step"
+    np.save(os.path.join(out_dir, "s1_losses.npy"), np.array(losses))
+    torch.distributed.destroy_process_group()
+
+
+def test_single_rank_rccl_stage1(tmp_path):
+    """BASELINE config 5's stage-1 step under the data-parallel control flow (one RCCL rank) reproduces the plain
+    single-process trajectory."""
+    import torch.multiprocessing as mp
+    import featuresynth.experiment as E
+    mp.spawn(_stage1_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    dp = np.load(str(tmp_path / "s1_losses.npy"))
+    torch.manual_seed(3)
+    exp = E.TwoDimGeneratorFeatureExperiment().to(torch.device("cuda", 0))
+    losses = []
+    for i, (spec,) in enumerate(exp.synthetic_batch_stream(2, n_batches=6)):
+        noise = np.random.default_rng(50 + i).standard_normal((2, 128, 1)).astype(np.float32)
+        s, f = torch.from_numpy(spec).cuda(), torch.from_numpy(noise).cuda()
+        r = exp.d_trainer.train(s, f) if i % 2 == 0 else exp.g_trainer.train(s, f)
+        losses.append(r["d_loss"] if i % 2 == 0 else r["g_loss"])
+    assert np.allclose(dp, np.array(losses), rtol=1e-6, atol=0), (dp, losses)
