@@ -143,3 +143,53 @@ def test_experiment_surface(tmp_path, monkeypatch):
         assert torch.equal(a, b), k
     real = E.RealMelGanExperiment(optimizer="torch")
     assert real._name() == "realmelgan" and isinstance(real._d_optim, torch.optim.Adam)
+
+
+def test_stage1_module_surface(golden):
+    """class names, constructor signatures and state_dict keys / shapes of the stage-1 modules
+    against the imported reference classes (tests/golden/stage1.npz); weights_init touches the conv layers only."""
+    import featuresynth as fs
+    from featuresynth.experiment.init import weights_init
+    z = golden("stage1")
+    g = fs.featuregenerator.SpectrogramFeatureGenerator(out_channels=128, noise_dim=128)
+    d = fs.featurediscriminator.SpectrogramFeatureDiscriminator(feature_channels=128, channels=256)
+    assert list(g.state_dict().keys()) == list(z["g_param_names"])
+    assert [str(tuple(v.shape)) for v in g.state_dict().values()] == list(z["g_param_shapes"])
+    assert list(d.state_dict().keys()) == list(z["d_param_names"])
+    assert [str(tuple(v.shape)) for v in d.state_dict().values()] == list(z["d_param_shapes"])
+    lin_before = g.initial.weight.detach().clone()
+    g.apply(weights_init)
+    assert torch.equal(g.initial.weight, lin_before)                     # nn.Linear is not a "Conv" (init.py:4)
+    assert abs(float(g.stack[0].weight.detach().std()) - 0.02) < 2e-3 and float(g.stack[0].bias.detach().abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        d(torch.zeros(1, 128, 512))                                      # CPU tensor: no fallback
+    from featuresynth.util.modules import HipConvTranspose2d
+    with pytest.raises(NotImplementedError):
+        HipConvTranspose2d(8, 8, (3, 3), (1, 1), (1, 1))
+
+
+def test_stage1_experiment_surface():
+    import featuresynth.experiment as E
+    exp = E.TwoDimGeneratorFeatureExperiment()
+    assert exp.condition_shape == (128, 1) and exp.feature_spec == {"spectrogram": (512, 128)}
+    spec, cond = exp.preprocess_batch((np.zeros((3, 128, 512), np.float32),))
+    assert spec.shape == (3, 128, 512) and cond.shape == (3, 128, 1) and cond.dtype == np.float32
+    (batch,) = next(exp.synthetic_batch_stream(2))
+    assert batch.shape == (2, 128, 512)
+    assert exp._gen_name() == "trained_models/twodimgeneratorfeature_gen.dat"
+    d_step, g_step = next(exp.training_steps), next(exp.training_steps)
+    assert d_step.__self__ is exp.d_trainer and g_step.__self__ is exp.g_trainer
+    with pytest.raises(NotImplementedError):
+        exp.batch_stream("/x", "*.wav", 2)
+
+
+def test_kaiser_best_filter_table():
+    """feature.sinc_window with resampy's published kaiser_best parameters: table size, unit DC gain after the
+    rolloff scaling, monotone main lobe."""
+    from featuresynth.feature.feature import KAISER_BEST, sinc_window
+    win, num_table = sinc_window(**KAISER_BEST)
+    assert num_table == 512 and win.shape == (512 * 64 + 1,)
+    assert abs(win[0] - KAISER_BEST["rolloff"]) < 1e-12
+    assert np.all(np.diff(win[:512]) < 0)
+    full = np.concatenate([win[:0:-1], win])          # symmetric filter sampled at 512 per zero crossing
+    assert abs(full.sum() / 512 - 1.0) < 1e-3
