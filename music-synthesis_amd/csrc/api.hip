@@ -86,6 +86,7 @@ int ms_conv1d_fwd(const ms_conv1d_desc* d, const float* x, const float* w, const
         return mst_conv1d_fwd(p, x, w, bias, residual, y, s);
     if (msm_fwd_applicable(p))
         return msm_conv1d_fwd(p, x, xa, xk, w, bias, residual, y, y_act, workspace, workspace_bytes, s);
+    if (msg3_fwd_applicable(p) && !residual && !y_act && !p.in_act) return msg3_conv1d_fwd(p, x, w, bias, y, s);
     if (msg_fwd_applicable(p) && !residual && !y_act && !p.in_act) return msg_conv1d_fwd(p, x, w, bias, y, s);
     if (mst_fwd_applicable(p) && !y_act) return mst_conv1d_fwd(p, x, w, bias, residual, y, s);
     return msk_conv1d_fwd_direct(p, x, xa, xk, w, bias, residual, y, y_act, s);
@@ -137,6 +138,8 @@ int ms_conv1d_bwd_weight(const ms_conv1d_desc* d, const float* x, const float* g
     if (msm_bwd_weight_applicable(p))
         return msm_conv1d_bwd_weight(p, x, xa, xk, gy, y_act, p.act, gw, gb, beta, workspace,
                                      workspace_bytes, s);
+    if (msg3_bwd_weight_applicable(p) && !p.in_act)
+        return msg3_conv1d_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
     if (msg_bwd_weight_applicable(p) && !p.in_act)
         return msg_conv1d_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
     return msk_conv1d_bwd_weight_direct(p, x, xa, xk, gy, y_act, p.act, gw, gb, beta, workspace,
@@ -217,7 +220,8 @@ const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which) {
     if (which == 0 && mst_fwd_short_applicable(p)) return mst_fwd_name(p);
     if (which == 0)
         return msm_fwd_applicable(p) ? msm_fwd_name(p)
-               : (msg_fwd_applicable(p) ? msg_fwd_name(p)
+               : (msg3_fwd_applicable(p) ? msg3_fwd_name(p)
+                  : msg_fwd_applicable(p) ? msg_fwd_name(p)
                   : (mst_fwd_applicable(p) ? mst_fwd_name(p) : msk_conv1d_fwd_direct_name(p)));
     if (which == 1 && p.pad_mode == MS_PAD_REFLECT && p.stride == 1 && p.groups == 1) {
         ConvP z = p;
@@ -234,7 +238,8 @@ const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which) {
     if (which == 2 && msw_bwd_weight_applicable(p)) return msw_bwd_weight_name(p);
     if (which == 2)
         return msm_bwd_weight_applicable(p) ? msm_bwd_weight_name(p)
-               : (msg_bwd_weight_applicable(p) ? msg_bwd_weight_name(p) : msk_conv1d_bwd_weight_direct_name(p));
+               : (msg3_bwd_weight_applicable(p) ? msg3_bwd_weight_name(p)
+                  : msg_bwd_weight_applicable(p) ? msg_bwd_weight_name(p) : msk_conv1d_bwd_weight_direct_name(p));
     return "";
 }
 

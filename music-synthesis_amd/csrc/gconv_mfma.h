@@ -17,3 +17,16 @@ size_t msg_bwd_weight_ws(const ConvP& p);
 const char* msg_bwd_weight_name(const ConvP& p);
 int msg_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act,
                           float* gw, float* gb, float beta, void* ws, size_t ws_bytes, hipStream_t s);
+int msg_wgrad_gridx(const ConvP& p);       // workgroup columns of the weight-gradient kernels (4 slabs each)
+int msg_reduce_slabs(const ConvP& p, const float* partial, size_t stride, int nslabs, float* gw, float* gb,
+                     float beta, hipStream_t s);
+
+// split-bf16 generation (gconv_split.hip); MSYNTH_GCONV3=0 falls back to the fp32-MFMA kernels above
+bool msg3_fwd_applicable(const ConvP& p);
+const char* msg3_fwd_name(const ConvP& p);
+int msg3_conv1d_fwd(const ConvP& p, const float* x, const float* w, const float* bias, float* y,
+                    hipStream_t s);
+const char* msg3_bwd_weight_name(const ConvP& p);
+bool msg3_bwd_weight_applicable(const ConvP& p);
+int msg3_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act,
+                           float* gw, float* gb, float beta, void* ws, size_t ws_bytes, hipStream_t s);

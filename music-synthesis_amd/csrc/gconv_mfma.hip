@@ -560,18 +560,18 @@ bool msg_bwd_weight_applicable(const ConvP& p) {
            p.Og <= 16 && p.groups <= 65535;
 }
 
-static int wgrad_gridx(const ConvP& p) {
+int msg_wgrad_gridx(const ConvP& p) {
     const size_t slab = ((size_t)p.Cout * GCG * GK + p.Cout) * sizeof(float);
     const int nchunks = ms_ceil_div(p.B * ms_ceil_div(p.Lout, WU), 4);   // 4 wave units per workgroup pass
     int gx = ms_ceil_div(512, p.groups);                 // ~2 workgroups per CU
-    const size_t cap = (size_t)16 << 20;                 // slabs (4 per workgroup column) <= 16 MiB
+    const size_t cap = (size_t)32 << 20;                 // slabs (4 per workgroup column) <= 32 MiB
     while (gx > 1 && (size_t)gx * 4 * slab > cap) --gx;
     if (gx > nchunks) gx = nchunks;
     return gx < 1 ? 1 : gx;
 }
 
 size_t msg_bwd_weight_ws(const ConvP& p) {
-    return (size_t)wgrad_gridx(p) * 4 * ((size_t)p.Cout * GCG * GK + p.Cout) * sizeof(float);
+    return (size_t)msg_wgrad_gridx(p) * 4 * ((size_t)p.Cout * GCG * GK + p.Cout) * sizeof(float);
 }
 
 const char* msg_bwd_weight_name(const ConvP&) { return "k_gconv_mfma_wgrad"; }
@@ -580,16 +580,21 @@ int msg_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const
                           float* gw, float* gb, float beta, void* ws, size_t ws_bytes,
                           hipStream_t s) {
     if (!ws || ws_bytes < msg_bwd_weight_ws(p)) return MS_ERR_WORKSPACE;
-    const int gxn = wgrad_gridx(p);
+    const int gxn = msg_wgrad_gridx(p);
     const size_t stride = (size_t)p.Cout * GCG * GK + p.Cout;
     float* partial = (float*)ws;
     hipLaunchKernelGGL(k_gconv_mfma_wgrad, dim3(gxn, p.groups), dim3(256), 0, s, p, x, gy, y_act,
                        partial, stride);
     MS_CHECK_LAUNCH();
+    return msg_reduce_slabs(p, partial, stride, gxn * 4, gw, gb, beta, s);
+}
+
+int msg_reduce_slabs(const ConvP& p, const float* partial, size_t stride, int nslabs, float* gw, float* gb,
+                     float beta, hipStream_t s) {
     const size_t wsize = (size_t)p.Cout * GCG * GK;
     const size_t total = wsize + p.Cout;
     hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, partial,
-                       stride, gxn * 4, wsize, p.Cout, gw, gb, beta);
+                       stride, nslabs, wsize, p.Cout, gw, gb, beta);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }

@@ -1,0 +1,662 @@
+// Grouped strided conv (the discriminator's k41 / stride-4 / 4-channels-per-group layers, reference
+// discriminator/full.py:15-18) on the bf16 matrix pipe with fp32-exact operands: second generation
+// of gconv_mfma.hip, same operand split as conv_rows3.hip (x = x1 + x2 + x3 in bf16 pieces, the six
+// partial products with i + j <= 4 accumulated in fp32).
+//
+// Forward.  Per group the layer is a GEMM  y[co, t] = sum_{ci, j} w[co, ci, j] x[ci, 4t + j - pad],
+// M = 16 outputs (4 for the 256-group layer), contraction = 4 channels x 41 taps.
+// v_mfma_f32_16x16x32_bf16 contracts 4 lane groups x 8 elements: lane group = input channel ci, the
+// 8 elements = 8 CONSECUTIVE taps j = 8G .. 8G+7 (6 tap groups, taps 41..47 carry zero weights), so a
+// lane's B fragment is 8 consecutive input samples starting at 4t + 8G.
+// The 64 outputs of a unit are four INTERLEAVED column tiles, t = 4n + s (tile s, column n):
+//   * fragment start = 16n + 4s + 8G: always a multiple of 4 samples, so with the inputs kept in LDS as
+//     8-byte quads (4 samples x bf16) a fragment is two aligned ds_read_b64 -- no phase-split gather;
+//   * tiles s and s+2 read the same quads one tap group apart: 14 fragment reads feed 24 (tile, G) steps;
+//   * a lane's accumulator row r of the four tiles is y[co][4n .. 4n+3]: one 16-byte store per row.
+// LDS image of a wave (private, no workgroup barrier): [piece][row = (ci, segment)][Q mod 4][Q div 4]
+// quads; the 16 lanes of a column tile read consecutive quads, the rows sit 16 / 8 / 4 quads apart
+// modulo the 32-quad bank window: conflict-free for ds_read_b64.
+// Short rows (the coarse scales: Lout = 9 .. 65) are covered by RB = 2 / 4 segments of 32 / 16 outputs
+// per unit, taken from consecutive (batch row, segment) pairs.
+#include "ms_common.h"
+#include "gconv_mfma.h"
+#include <stdint.h>
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int GK = 41, GS = 4, GCG = 4;
+constexpr int NG = 6;                         // tap groups of 8
+
+// (a, b) -> three packed bf16 pairs with a = h.lo + m.lo + l.lo exactly (same for b in the high halves)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    const f32x2 v = {a, b};
+    const bf16x2 hi = __builtin_convertvector(v, bf16x2);
+    const f32x2 r1 = v - __builtin_convertvector(hi, f32x2);
+    const bf16x2 mi = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(mi, f32x2);
+    const bf16x2 lo = __builtin_convertvector(r2, bf16x2);
+    h = __builtin_bit_cast(unsigned, hi);
+    m = __builtin_bit_cast(unsigned, mi);
+    l = __builtin_bit_cast(unsigned, lo);
+}
+
+template <int RB>
+struct GF {
+    static constexpr int NR = 16 / RB;               // MFMA columns per segment
+    static constexpr int TS = 64 / RB;               // outputs per segment
+    static constexpr int SUBP = NR + 3;              // quads per (row, Q mod 4) sub-row
+    static constexpr int NQR = 4 * SUBP;             // quads staged per (segment, channel) row
+    static constexpr int RP = RB == 1 ? 80 : (RB == 2 ? 56 : 28);   // row pitch in quads (see header)
+    static constexpr int ROWS = 4 * RB;
+    static constexpr int PIECE_BYTES = ROWS * RP * 8;
+    static constexpr int WAVE_BYTES = 3 * PIECE_BYTES;
+    static constexpr int NIT = (ROWS * NQR + 63) / 64;              // staged quads per lane
+    static_assert(NQR <= RP, "row pitch");
+    static_assert(NQR < RP || (ROWS * NQR) % 64 == 0, "a spare quad for the lanes without an item");
+};
+
+// Per unit: loads (issued one unit ahead) -> split -> LDS image -> 7 tap-group steps of MFMAs -> stores.
+// PMC on the first version: wave cycles = MFMA cycles + vector-ALU cycles (an MFMA leaves room for ~2 vector
+// instructions in its 16 cycles, nothing more overlaps), so the per-unit vector work is kept small: interior
+// units load through lane-constant offsets + a scalar unit base, fragments arrive as whole operands
+// (ds_read2_b64), LeakyReLU is mul + max.  (A software-pipelined variant -- next unit split and written to a
+// second LDS image between the tap-group steps, two register sets of loads in flight -- measured 5-10 %
+// SLOWER at 4-8 units per wave: its longer prologue costs more than the in-wave overlap returns; removed.)
+template <int RB, bool VEC, bool VOUT>
+__global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, int nseg, int nunits,
+                                                           const float* __restrict__ x,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ bias,
+                                                           float* __restrict__ y) {
+    using C = GF<RB>;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * C::WAVE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = blockIdx.y;
+    const int n = lane & 15, kg = lane >> 4;
+    const int sgl = n / C::NR, np = n % C::NR;
+    const unsigned wv_off = wid * C::WAVE_BYTES;                                  // the wave's image within lds[]
+    const unsigned lw = (unsigned)(uintptr_t)lds + wv_off;                        // ... as an LDS byte address
+    const unsigned rb0 = lw + ((kg * RB + sgl) * C::RP + np) * 8;               // this lane's fragment base, piece 0
+
+    // ---- staging items of this lane: quad Q of row (segment sg, channel ci)
+    int it_lds[C::NIT];            // LDS byte offset of the quad in piece 0
+    unsigned it_x[C::NIT];         // ci * Lin
+    int it_qs[C::NIT];             // 4 Q | sg  (< 0: no item)
+    unsigned it_c[C::NIT];         // interior units: byte offset of the quad relative to the unit's first sample
+#pragma unroll
+    for (int i = 0; i < C::NIT; ++i) {
+        const int idx = lane + 64 * i;
+        const int row = idx / C::NQR, Q = idx - row * C::NQR;
+        const int sg = row >> 2, ci = row & 3;
+        const bool act = row < C::ROWS;
+        // lanes past the last item stage zeros into a spare quad of row 0 (no divergent branch in the pipeline)
+        it_lds[i] = act ? ((ci * RB + sg) * C::RP + (Q & 3) * C::SUBP + (Q >> 2)) * 8 : C::NQR * 8;
+        it_x[i] = (unsigned)(ci * p.Lin);
+        it_qs[i] = act ? 4 * Q + sg : -4;
+        it_c[i] = act ? (unsigned)(ci * p.Lin + 4 * Q) * 4u : 0xF0000000u;
+    }
+    const int wstride = gridDim.x * 4;
+    const int sstride = wstride * RB;
+    const int dsb = sstride / spr, dst = sstride - dsb * spr;     // segment index += sstride, in (b, ts) form
+    struct Cur { int seg, b, ts; };
+    auto advance = [&](Cur& c) {
+        c.seg += sstride; c.b += dsb; c.ts += dst;
+        if (c.ts >= spr) { c.ts -= spr; ++c.b; }
+    };
+
+    // Inputs are read through a buffer descriptor: a quad that lies outside its row (the zero padding) or
+    // behind the last segment carries an out-of-range offset and the hardware range check returns 0.0f.
+    constexpr unsigned OOB = 0xF0000000u;
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x80000000u, 0x00020000);
+    auto gload = [&](auto& xr, const Cur& c) {
+        if (RB == 1 && VEC) {
+            // interior unit (every quad inside its row): lane-constant offsets + scalar unit base, no vector math
+            const int s0 = c.ts * (C::TS * GS) - p.pad;
+            if (c.seg < nseg && s0 >= 0 && s0 + 4 * C::NQR <= p.Lin) {
+                const unsigned ub = (unsigned)__builtin_amdgcn_readfirstlane(((c.b * p.Cin + g * GCG) * p.Lin + s0) * 4);
+#pragma unroll
+                for (int i = 0; i < C::NIT; ++i)
+                    xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, it_c[i], ub, 0));
+                return;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::NIT; ++i) {
+            const int sg = RB == 1 ? 0 : (it_qs[i] & 3), Q4 = it_qs[i] & ~3;
+            int ts = c.ts + sg, b = c.b;
+            if (spr == 1) { b += ts; ts = 0; }               // whole rows: segment index = batch row
+            else if (ts >= spr) { ts -= spr; ++b; }           // spr >= RB otherwise (pick_rb): one wrap at most
+            const bool segok = c.seg + sg < nseg && it_qs[i] >= 0;
+            const int sidx = ts * (C::TS * GS) - p.pad + Q4;          // first sample of the quad within its row
+            const unsigned rowoff = (unsigned)((b * p.Cin + g * GCG) * p.Lin) + it_x[i];
+            if (VEC) {
+                const bool ok = segok && sidx >= 0 && sidx < p.Lin;
+                xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      rsX, ok ? (rowoff + (unsigned)sidx) * 4u : OOB, 0, 0));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = segok && sidx + e >= 0 && sidx + e < p.Lin;
+                    xr[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                             rsX, ok ? (rowoff + (unsigned)(sidx + e)) * 4u : OOB, 0, 0));
+                }
+            }
+        }
+    };
+    // registers -> LDS: split into pieces, one 8-byte quad per piece
+    auto stage_item = [&](const f32x4& v, int lds_off) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split_pair(v[0], v[1], h0, m0, l0);
+        split_pair(v[2], v[3], h1, m1, l1);
+        unsigned char* d = lds + wv_off + lds_off;
+        *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(d + C::PIECE_BYTES) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(d + 2 * C::PIECE_BYTES) = make_uint2(l0, l1);
+    };
+
+    int unit = blockIdx.x * 4 + wid;
+    Cur ld, ep;
+    ld.seg = unit * RB; ld.b = ld.seg / spr; ld.ts = ld.seg - ld.b * spr;
+    ep = ld;
+    f32x4 xp[C::NIT];
+    gload(xp, ld); advance(ld);
+
+    // ---- weight fragments: lane (co = n, ci = kg) holds w[g*Og + co][ci][8G .. 8G+7] in three pieces
+    bf16x8 A[NG][3];
+    {
+        const bool ok = n < p.Og;
+        const float* wr = w + ((size_t)(g * p.Og + (ok ? n : 0)) * GCG + kg) * GK;
+        float wv[NG * 8];
+#pragma unroll
+        for (int j = 0; j < NG * 8; ++j) wv[j] = j < GK ? wr[j] : 0.f;
+#pragma unroll
+        for (int G = 0; G < NG; ++G) {
+            u32x4 h, m, l;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned hh, mm, ll;
+                split_pair(ok ? wv[8 * G + 2 * q] : 0.f, ok ? wv[8 * G + 2 * q + 1] : 0.f, hh, mm, ll);
+                h[q] = hh; m[q] = mm; l[q] = ll;
+            }
+            A[G][0] = __builtin_bit_cast(bf16x8, h);
+            A[G][1] = __builtin_bit_cast(bf16x8, m);
+            A[G][2] = __builtin_bit_cast(bf16x8, l);
+        }
+    }
+    const float eslope = p.act == MS_ACT_LRELU ? p.slope : 1.f;      // in [0, 1] (msg3_fwd_applicable)
+    float bq[4];
+    bool rok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        rok[r] = kg * 4 + r < p.Og;
+        bq[r] = (bias && rok[r]) ? bias[g * p.Og + kg * 4 + r] : 0.f;
+    }
+
+    auto unit_mfma_store = [&]() {
+        unsigned rbo[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) rbo[pc] = rb0 + pc * C::PIECE_BYTES;
+        f32x4 acc[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // Fragment reads are hand-issued ds_read2_b64 (two quads -> one 4-register operand; the compiler's own
+        // pairing of the 8-byte reads put the halves in unrelated registers and paid ~140 v_mov per unit).  The
+        // reads of step H+1 are in flight during the MFMAs of step H: counted wait on the older six.
+        u32x4 f[2][2][3];
+#define MS_G3_READ(H_, buf)                                                                                     \
+    _Pragma("unroll") for (int par = 0; par < 2; ++par) {                                                       \
+        const int c0 = 2 * (H_) + par, c1 = c0 + 1;                                                             \
+        _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                                        \
+            asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3"                                            \
+                         : "=v"(f[buf][par][pc])                                                                \
+                         : "v"(rbo[pc]), "n"((c0 & 3) * C::SUBP + (c0 >> 2)), "n"((c1 & 3) * C::SUBP + (c1 >> 2))); \
+    }
+        MS_G3_READ(0, 0);
+#pragma unroll
+        for (int H = 0; H <= NG; ++H) {
+            const int cur = H & 1;
+            if (H < NG) {
+                MS_G3_READ(H + 1, cur ^ 1);
+                asm volatile("s_waitcnt lgkmcnt(6)"
+                             : "+v"(f[cur][0][0]), "+v"(f[cur][0][1]), "+v"(f[cur][0][2]), "+v"(f[cur][1][0]),
+                               "+v"(f[cur][1][1]), "+v"(f[cur][1][2]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(f[cur][0][0]), "+v"(f[cur][0][1]), "+v"(f[cur][0][2]), "+v"(f[cur][1][0]),
+                               "+v"(f[cur][1][1]), "+v"(f[cur][1][2]));
+            }
+            // six partial products, smallest first: (a1 b3) (a3 b1) (a2 b2) (a1 b2) (a2 b1) (a1 b1); the four
+            // tiles' accumulator chains are interleaved so that dependent MFMAs sit 2-4 issues apart
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+                const bf16x8 f0 = __builtin_bit_cast(bf16x8, f[cur][0][PB[i]]);
+                const bf16x8 f1 = __builtin_bit_cast(bf16x8, f[cur][1][PB[i]]);
+                if (H < NG) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[H][PA[i]], f0, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[H][PA[i]], f1, acc[1], 0, 0, 0);
+                }
+                if (H >= 1) {
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[H - 1][PA[i]], f0, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[H - 1][PA[i]], f1, acc[3], 0, 0, 0);
+                }
+            }
+        }
+#undef MS_G3_READ
+
+        // ---- epilogue: row r of the four tiles = 4 consecutive outputs
+        int ets = ep.ts + sgl, eb = ep.b;
+        if (spr == 1) { eb += ets; ets = 0; }
+        else if (ets >= spr) { ets -= spr; ++eb; }
+        const bool eok = ep.seg + sgl < nseg;
+        const int t = ets * C::TS + 4 * np;
+        if (eok && t < p.Lout) {
+            float* yr = y + ((size_t)eb * p.Cout + (size_t)g * p.Og + kg * 4) * p.Lout + t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (!rok[r]) continue;
+                float v[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float pre = acc[s][r] + bq[r];
+                    v[s] = fmaxf(pre, pre * eslope);                // LeakyReLU (slope in [0, 1]) / identity
+                }
+                if (VOUT) {
+                    *reinterpret_cast<float4*>(yr + (size_t)r * p.Lout) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        if (t + s < p.Lout) yr[(size_t)r * p.Lout + s] = v[s];
+                }
+            }
+        }
+        advance(ep);
+    };
+
+    for (; unit < nunits; unit += wstride) {
+#pragma unroll
+        for (int i = 0; i < C::NIT; ++i) stage_item(xp[i], it_lds[i]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (unit + wstride < nunits) gload(xp, ld);     // next unit's inputs: in flight across the MFMA loop
+        advance(ld);
+        unit_mfma_store();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------- backward weight
+// gw[co, ci, k] = sum_{b, t} gp[b, co, t] * x[b, g*4 + ci, 4t + k - pad]   (gp = gy * act'(y_act))
+// Per group and input channel: M = co (16), N = tap k (3 tiles of 16: 41 taps + 7 discarded columns), the MFMA
+// contraction runs over 32 consecutive outputs t.  The B operand B[t][k] = x[4t + k - pad] is a Toeplitz view
+// of the LINEAR input row: row t of a 16-tap tile is 16 consecutive samples starting at 4t + k0 - pad, 8 bytes
+// (4 bf16) further on for every t -- exactly what gfx950's transposing LDS read wants (ds_read_b64_tr_b16: 16
+// lanes supply 4 row addresses x 4 column quads and receive column-major data), so the stride-4 gather of the
+// fp32 kernel's phase-split image becomes two transposing reads per operand on a plain bf16 copy of the row.
+// The A operand A[co][t] is read as 16-byte rows of the gradient image [t / 8][co][8 t] (a lane group's
+// 8-output blocks sit 256 bytes apart: conflict-free).
+// Work unit of a WAVE = 64 consecutive outputs of one (batch row, group), as in the fp32 kernel: private LDS
+// image, next unit's loads in flight during the MFMAs; at the end the four waves' 12 accumulator tiles are summed
+// through LDS into one slab per workgroup, slabs combined by the deterministic split-K reduce (k_reduce_slabs).
+constexpr int WU = 64;                        // outputs per unit
+constexpr int WXQ = 75;                       // input quads per (unit, channel): 4 * 63 + 48 = 300 samples
+constexpr int WXROW = 608;                    // bytes per LDS input row (300 bf16 + pad, multiple of 8)
+constexpr int WX_PIECE = GCG * WXROW;
+constexpr int WG_PIECE = 8 * 16 * 16;         // gradient image of a piece: [t / 8][co][8 t] bf16
+constexpr int W_WAVE = 3 * (WG_PIECE + WX_PIECE);
+constexpr int NKT = 3;                        // 16-tap column tiles
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const float* __restrict__ x,
+                                                             const float* __restrict__ gy,
+                                                             const float* __restrict__ y_act,
+                                                             float* __restrict__ partial, size_t partial_stride) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * W_WAVE];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = blockIdx.y;
+    const int kind = y_act ? p.act : MS_ACT_NONE;
+    unsigned char* gimg = lds + wid * W_WAVE;          // gradient pieces, then input pieces
+    unsigned char* ximg = gimg + 3 * WG_PIECE;
+
+    // ---- staging items
+    // gradient: 16 co x 16 quads of 4 outputs; item i of a lane: co = (lane >> 4) + 4 i, quad tq = lane & 15
+    const int tq = lane & 15, co0 = lane >> 4;
+    // (the co slot of 8-output block tb is XORed with tb: the 16 quads a lane group stores for one co would
+    // otherwise sit 256 bytes apart -- one bank)
+    const int g_tb = tq >> 1;
+    // input: 4 ci x 75 quads of 4 samples, 5 items per lane
+    int x_lds[5];
+    unsigned x_c[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int idx = lane + 64 * i;
+        const int ci = idx / WXQ, Q = idx - ci * WXQ;
+        const bool act = ci < GCG;
+        x_lds[i] = act ? ci * WXROW + Q * 8 : 3 * WXROW + WXQ * 8;        // spare quad behind the last row's data
+        x_c[i] = act ? (unsigned)(ci * p.Lin + 4 * Q) : 0x3C000000u;      // (elements; x4 = out of range)
+    }
+    constexpr unsigned OOB = 0xF0000000u;
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x80000000u, 0x00020000);
+    const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy), 0, 0x80000000u, 0x00020000);
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(y_act ? y_act : gy), 0, 0x80000000u, 0x00020000);
+
+    const int tiles = (p.Lout + WU - 1) / WU;
+    const int nunits = p.B * tiles;
+    const int ustride = gridDim.x * 4;
+    const int db = ustride / tiles, dt = ustride - db * tiles;     // unit += ustride, in (b, tile) form
+
+    // interior units (all 64 outputs and all 300 inputs inside their rows): lane-constant byte offsets + a
+    // scalar unit base -- no vector address math
+    unsigned g_c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g_c[i] = co0 + 4 * i < p.Og ? (unsigned)((co0 + 4 * i) * p.Lout + 4 * tq) * 4u : OOB;
+    f32x4 gv[4], ga[4], xv[5];
+    auto gload = [&](int b, int ti) {
+        const int t0 = ti * WU, u0 = t0 * GS - p.pad;
+        const unsigned gbase = (unsigned)((b * p.Cout + g * p.Og) * p.Lout + t0);
+        const unsigned xbase = (unsigned)((b * p.Cin + g * GCG) * p.Lin);
+        if (VEC && t0 + WU <= p.Lout && u0 >= 0 && u0 + 4 * WXQ <= p.Lin) {
+            const unsigned gs = (unsigned)__builtin_amdgcn_readfirstlane((int)(gbase * 4u));
+            const unsigned xs = (unsigned)__builtin_amdgcn_readfirstlane((int)((xbase + (unsigned)u0) * 4u));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                gv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, g_c[i], gs, 0));
+                ga[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, g_c[i], gs, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      rsX, x_c[i] < 0x3C000000u ? x_c[i] * 4u : OOB, xs, 0));
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = co0 + 4 * i;
+            const unsigned off = gbase + (unsigned)(co * p.Lout + 4 * tq);
+            if (VEC) {
+                const bool ok = co < p.Og && t0 + 4 * tq < p.Lout;
+                const unsigned vo = ok ? off * 4u : OOB;
+                gv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vo, 0, 0));
+                ga[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = co < p.Og && t0 + 4 * tq + e < p.Lout;
+                    const unsigned vo = ok ? (off + e) * 4u : OOB;
+                    gv[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsG, vo, 0, 0));
+                    ga[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, vo, 0, 0));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int Q4 = 4 * ((lane + 64 * i) % WXQ);
+            const int sidx = u0 + Q4;
+            if (VEC) {
+                const bool ok = x_c[i] < 0x3C000000u && sidx >= 0 && sidx < p.Lin;
+                xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      rsX, ok ? (xbase + x_c[i] + (unsigned)u0) * 4u : OOB, 0, 0));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = x_c[i] < 0x3C000000u && sidx + e >= 0 && sidx + e < p.Lin;
+                    xv[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                             rsX, ok ? (xbase + x_c[i] + (unsigned)(u0 + e)) * 4u : OOB, 0, 0));
+                }
+            }
+        }
+    };
+
+    f32x4 acc[GCG][NKT];
+#pragma unroll
+    for (int c = 0; c < GCG; ++c)
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) acc[c][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses of this lane
+    const int m = lane & 15, kg = lane >> 4;
+    // A rows: block tb = 4 step + kg, slot m ^ tb = (m ^ kg) ^ 4 step
+    const unsigned char* a_rd0 = gimg + (kg * 16 + (m ^ kg)) * 16;
+    const unsigned char* a_rd1 = gimg + 1024 + (kg * 16 + (m ^ kg ^ 4)) * 16;
+    // transposing read: lane 4q + p of a 16-lane group supplies row q (output t), column quad p (4 taps)
+    const unsigned b_rd = (unsigned)(uintptr_t)ximg + 64 * kg + 8 * ((lane & 15) >> 2) + 8 * (lane & 3);
+
+    int unit = blockIdx.x * 4 + wid;
+    int b = unit / tiles, ti = unit - b * tiles;
+    if (unit < nunits) gload(b, ti);
+    for (; unit < nunits; unit += ustride) {
+        // ---- registers -> LDS: activation derivative, split, 8-byte quads
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float e[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] = ms_act_grad(gv[i][k], ga[i][k], kind, p.slope);
+            bsum[i] += (e[0] + e[1]) + (e[2] + e[3]);
+            unsigned h0, m0, l0, h1, m1, l1;
+            split_pair(e[0], e[1], h0, m0, l0);
+            split_pair(e[2], e[3], h1, m1, l1);
+            unsigned char* d = gimg + (g_tb * 16 + ((co0 + 4 * i) ^ g_tb)) * 16 + (tq & 1) * 8;
+            *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(d + WG_PIECE) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(d + 2 * WG_PIECE) = make_uint2(l0, l1);
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            split_pair(xv[i][0], xv[i][1], h0, m0, l0);
+            split_pair(xv[i][2], xv[i][3], h1, m1, l1);
+            unsigned char* d = ximg + x_lds[i];
+            *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(d + WX_PIECE) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(d + 2 * WX_PIECE) = make_uint2(l0, l1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int tvalid = min(WU, p.Lout - ti * WU);
+        int nb = b + db, nti = ti + dt;
+        if (nti >= tiles) { nti -= tiles; ++nb; }
+        if (unit + ustride < nunits) gload(nb, nti);
+
+        // (step, channel) iterations, each in three read groups -- the lo / hi transposing reads of the three
+        // column tiles for one piece, in the order the partial products need them: piece 3, piece 1, piece 2.
+        // Reads are hand-issued two groups (12 reads; lgkmcnt counts to 15) ahead of the MFMAs they feed, with
+        // counted waits.  Left to the compiler, the reads of a tile were shared with its neighbour (rows t+4.. of
+        // tile j = rows t.. of tile j+1) at the price of ~70 v_mov per unit, and every MFMA group waited for its
+        // own reads.
+        const int niter = tvalid > 32 ? 2 * GCG : GCG;              // wave-uniform: outputs 32.. are all zero
+        bf16x8 A[2][3];
+#pragma unroll
+        for (int step = 0; step < 2; ++step)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                A[step][pc] = *reinterpret_cast<const bf16x8*>((step ? a_rd1 : a_rd0) + pc * WG_PIECE);
+        u32x2 Bl[2][3][NKT], Bh[2][3][NKT];              // [iteration parity][piece][tile]
+#define MS_W3_READ(it_, pc)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < NKT; ++j) {                                                         \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                                    \
+                     : "=v"(Bl[(it_) & 1][pc][j])                                                             \
+                     : "v"(b_rd), "n"((pc) * WX_PIECE + ((it_) & 3) * WXROW + ((it_) >> 2) * 256 + j * 32));  \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                                    \
+                     : "=v"(Bh[(it_) & 1][pc][j])                                                             \
+                     : "v"(b_rd), "n"((pc) * WX_PIECE + ((it_) & 3) * WXROW + ((it_) >> 2) * 256 + j * 32 + 32)); \
+    }
+#define MS_W3_WAIT(cnt, it_, pc)                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                \
+                 : "+v"(Bl[(it_) & 1][pc][0]), "+v"(Bl[(it_) & 1][pc][1]), "+v"(Bl[(it_) & 1][pc][2]),        \
+                   "+v"(Bh[(it_) & 1][pc][0]), "+v"(Bh[(it_) & 1][pc][1]), "+v"(Bh[(it_) & 1][pc][2]))
+#define MS_W3_MMA(it_, pa, pb)                                                                                \
+    _Pragma("unroll") for (int j = 0; j < NKT; ++j) {                                                         \
+        const u32x4 bv = {Bl[(it_) & 1][pb][j][0], Bl[(it_) & 1][pb][j][1], Bh[(it_) & 1][pb][j][0],          \
+                          Bh[(it_) & 1][pb][j][1]};                                                           \
+        acc[(it_) & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                          \
+            A[(it_) >> 2][pa], __builtin_bit_cast(bf16x8, bv), acc[(it_) & 3][j], 0, 0, 0);                   \
+    }
+        // partial products, smallest first: (a1 b3) | (a3 b1) | (a2 b2) (a1 b2) (a2 b1) (a1 b1)
+#define MS_W3_ITER(it_)                                                                                       \
+    if ((it_) < niter) {                                                                                      \
+        MS_W3_READ(it_, 1);                                                                                   \
+        MS_W3_WAIT(12, it_, 2);                                                                               \
+        MS_W3_MMA(it_, 0, 2);                                                                                 \
+        if ((it_) + 1 < niter) {                                                                              \
+            MS_W3_READ((it_) + 1, 2);                                                                         \
+            MS_W3_WAIT(12, it_, 0);                                                                           \
+        } else {                                                                                              \
+            MS_W3_WAIT(6, it_, 0);                                                                            \
+        }                                                                                                     \
+        MS_W3_MMA(it_, 2, 0);                                                                                 \
+        if ((it_) + 1 < niter) {                                                                              \
+            MS_W3_READ((it_) + 1, 0);                                                                         \
+            MS_W3_WAIT(12, it_, 1);                                                                           \
+        } else {                                                                                              \
+            MS_W3_WAIT(0, it_, 1);                                                                            \
+        }                                                                                                     \
+        MS_W3_MMA(it_, 1, 1);                                                                                 \
+        MS_W3_MMA(it_, 0, 1);                                                                                 \
+        MS_W3_MMA(it_, 1, 0);                                                                                 \
+        MS_W3_MMA(it_, 0, 0);                                                                                 \
+    }
+        MS_W3_READ(0, 2);
+        MS_W3_READ(0, 0);
+        MS_W3_ITER(0) MS_W3_ITER(1) MS_W3_ITER(2) MS_W3_ITER(3)
+        MS_W3_ITER(4) MS_W3_ITER(5) MS_W3_ITER(6) MS_W3_ITER(7)
+#undef MS_W3_ITER
+#undef MS_W3_MMA
+#undef MS_W3_READ
+#undef MS_W3_WAIT
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        b = nb; ti = nti;
+    }
+
+    // ---- one slab per WORKGROUP: the four waves' accumulators are summed through LDS (the staging images are
+    // free now), wave c writes input channel c.  D[co][k]: lane (k = lane & 15, co quad = lane >> 4), rows r.
+    __syncthreads();
+    static_assert((4 * GCG * NKT * 4 * 64 + 64) * 4 <= 4 * W_WAVE, "reduction scratch fits the staging images");
+    float* red = reinterpret_cast<float*>(lds);                   // [wave][c][tile][r][lane]
+#pragma unroll
+    for (int c = 0; c < GCG; ++c)
+#pragma unroll
+        for (int j = 0; j < NKT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(((wid * GCG + c) * NKT + j) * 4 + r) * 64 + lane] = acc[c][j][r];
+    float* redb = red + 4 * GCG * NKT * 4 * 64;                   // [wave][16 co]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = bsum[i];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        if ((lane & 15) == 0) redb[wid * 16 + co0 + 4 * i] = v;
+    }
+    __syncthreads();
+    float* part = partial + (size_t)blockIdx.x * partial_stride;
+    const int J = GCG * GK;
+    {
+        const int c = wid;
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) {
+            const int kk = j * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) v += red[(((wv * GCG + c) * NKT + j) * 4 + r) * 64 + lane];
+                const int co = (lane >> 4) * 4 + r;
+                if (kk < GK && co < p.Og) part[(size_t)(g * p.Og + co) * J + c * GK + kk] = v;
+            }
+        }
+    }
+    if (wid == 0 && lane < 16 && lane < p.Og)
+        part[(size_t)p.Cout * J + g * p.Og + lane] = (redb[lane] + redb[16 + lane]) + (redb[32 + lane] + redb[48 + lane]);
+}
+
+int pick_rb(int Lout) {
+    if (Lout <= 16) return 4;
+    if (Lout <= 32) return 2;
+    if (Lout <= 64) return 1;
+    // long rows: padded work of 64- / 32- / 16-output segments; prefer the widest within 6 %
+    const int w64 = ms_ceil_div(Lout, 64) * 64, w32 = ms_ceil_div(Lout, 32) * 32, w16 = ms_ceil_div(Lout, 16) * 16;
+    if (w64 * 100 <= w16 * 106) return 1;
+    if (w32 * 100 <= w16 * 106) return 2;
+    return 4;
+}
+
+}  // namespace
+
+bool msg3_fwd_applicable(const ConvP& p) {
+    const char* e = getenv("MSYNTH_GCONV3");          // read per call: the micro-benchmarks flip it
+    const bool on = !e || atoi(e) != 0;
+    return on && p.K == GK && p.stride == GS && p.Cg == GCG && p.dil == 1 && p.pad_mode == MS_PAD_ZERO &&
+           p.Og <= 16 && p.groups <= 65535 &&
+           (p.act == MS_ACT_NONE || (p.act == MS_ACT_LRELU && p.slope >= 0.f && p.slope <= 1.f)) &&
+           (long long)p.B * p.Cin * p.Lin * 4 < (1ll << 31) &&
+           (long long)p.B * p.Cout * p.Lout < (1ll << 31);
+}
+
+const char* msg3_fwd_name(const ConvP&) { return "k_gconv_split_fwd"; }
+
+int msg3_conv1d_fwd(const ConvP& p, const float* x, const float* w, const float* bias, float* y,
+                    hipStream_t s) {
+    const int rb = pick_rb(p.Lout);
+    const int ts = 64 / rb;
+    const int spr = ms_ceil_div(p.Lout, ts), nseg = p.B * spr, nunits = ms_ceil_div(nseg, rb);
+    const char* tw = getenv("MSYNTH_GW");
+    const int target_waves = tw ? atoi(tw) : 2048;
+    const long long total_units = (long long)nunits * p.groups;
+    const int upw = (int)((total_units + target_waves - 1) / target_waves);
+    const int gxn = ms_ceil_div(nunits, 4 * (upw > 0 ? upw : 1));
+    const dim3 grid(gxn, p.groups);
+    const bool vec = p.Lin % 4 == 0 && p.pad % 4 == 0 && (((uintptr_t)x) & 15) == 0;
+    const bool vout = p.Lout % 4 == 0 && (((uintptr_t)y) & 15) == 0;
+#define MS_G3(RBV, V, VO) \
+    hipLaunchKernelGGL((k_gconv_split_fwd<RBV, V, VO>), grid, dim3(256), 0, s, p, spr, nseg, nunits, x, w, bias, y)
+#define MS_G3V(RBV)                                   \
+    do {                                              \
+        if (vec && vout) MS_G3(RBV, true, true);      \
+        else if (vec) MS_G3(RBV, true, false);        \
+        else if (vout) MS_G3(RBV, false, true);       \
+        else MS_G3(RBV, false, false);                \
+    } while (0)
+    if (rb == 1) MS_G3V(1);
+    else if (rb == 2) MS_G3V(2);
+    else MS_G3V(4);
+#undef MS_G3V
+#undef MS_G3
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+bool msg3_bwd_weight_applicable(const ConvP& p) {
+    const char* e = getenv("MSYNTH_GCONV3");
+    const bool on = !e || atoi(e) != 0;
+    return on && p.K == GK && p.stride == GS && p.Cg == GCG && p.dil == 1 && p.pad_mode == MS_PAD_ZERO &&
+           p.Og <= 16 && p.groups <= 65535 && (long long)p.B * p.Cin * p.Lin * 4 < (1ll << 30) &&
+           (long long)p.B * p.Cout * p.Lout * 4 < (1ll << 31);
+}
+
+const char* msg3_bwd_weight_name(const ConvP&) { return "k_gconv_split_wgrad"; }
+
+int msg3_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act,
+                           float* gw, float* gb, float beta, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!ws || ws_bytes < msg_bwd_weight_ws(p)) return MS_ERR_WORKSPACE;
+    const int gxn = msg_wgrad_gridx(p);
+    const size_t stride = (size_t)p.Cout * GCG * GK + p.Cout;
+    float* partial = (float*)ws;
+    const bool vec = p.Lin % 4 == 0 && p.pad % 4 == 0 && p.Lout % 4 == 0 && (((uintptr_t)x) & 15) == 0 &&
+                     (((uintptr_t)gy) & 15) == 0 && (!y_act || (((uintptr_t)y_act) & 15) == 0);
+    if (vec) hipLaunchKernelGGL((k_gconv_split_wgrad<true>), dim3(gxn, p.groups), dim3(256), 0, s, p, x, gy, y_act, partial, stride);
+    else hipLaunchKernelGGL((k_gconv_split_wgrad<false>), dim3(gxn, p.groups), dim3(256), 0, s, p, x, gy, y_act, partial, stride);
+    MS_CHECK_LAUNCH();
+    return msg_reduce_slabs(p, partial, stride, gxn, gw, gb, beta, s);      // one slab per workgroup
+}
