@@ -106,6 +106,8 @@ int ms_conv1d_bwd_data(const ms_conv1d_desc* d, const float* gy, const float* y_
     int rc;
     if (msm_bwd_data_applicable(p))
         rc = msm_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, workspace, workspace_bytes, s);
+    else if (msg3_bwd_data_applicable(p))
+        rc = msg3_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, s);
     else if (msg_bwd_data_applicable(p))
         rc = msg_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, s);
     else if (mst_bwd_data_applicable(p) && !reflect)
@@ -230,7 +232,8 @@ const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which) {
     }
     if (which == 1)
         return msm_bwd_data_applicable(p) ? msm_bwd_data_name(p)
-               : (msg_bwd_data_applicable(p) ? msg_bwd_data_name(p)
+               : (msg3_bwd_data_applicable(p) ? msg3_bwd_data_name(p)
+                  : msg_bwd_data_applicable(p) ? msg_bwd_data_name(p)
                   : (mst_bwd_data_applicable(p) && p.pad_mode == MS_PAD_ZERO ? mst_bwd_data_name(p)
                                                                               : msk_conv1d_bwd_data_direct_name(p)));
     if (which == 2 && mst_bwd_weight_applicable(p)) return mst_bwd_weight_name(p);

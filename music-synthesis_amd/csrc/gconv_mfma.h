@@ -30,3 +30,7 @@ const char* msg3_bwd_weight_name(const ConvP& p);
 bool msg3_bwd_weight_applicable(const ConvP& p);
 int msg3_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act,
                            float* gw, float* gb, float beta, void* ws, size_t ws_bytes, hipStream_t s);
+bool msg3_bwd_data_applicable(const ConvP& p);
+const char* msg3_bwd_data_name(const ConvP& p);
+int msg3_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, const float* w,
+                         const float* gx_add, float* gx, hipStream_t s);

@@ -581,6 +581,208 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const flo
         part[(size_t)p.Cout * J + g * p.Og + lane] = (redb[lane] + redb[16 + lane]) + (redb[32 + lane] + redb[48 + lane]);
 }
 
+// ---------------------------------------------------------------- backward data (16 outputs per group)
+// gx[b, g*4+ci, 4q + r] = gx_add + sum_{co, jj} w[co, ci, r + 4 jj] * gp[b, co, q + 5 - jj]     (pad = 20)
+// GEMM per group and q-tile: M = (ci, r) = 16 rows, N = 16 consecutive q, contraction = 16 co x 12 taps jj (the
+// 12th carries zero weights) in 6 MFMA steps of (2 taps x 16 co).  A lane's B fragment is 8 output channels at ONE
+// gradient position, so the gradient tile is kept position-major in LDS: [co octet][position][8 co] bf16, 16 bytes
+// per (octet, position).  Lane group kg = (octet = kg >> 1, tap parity = kg & 1): the two lane groups that share a
+// ds_read_b128 bank group read the SAME octet at positions one apart -- consecutive 16-byte slots, conflict-free.
+// Staging transposes in registers: a lane loads 4 co x 4 positions (4 + 4 float4 of gy / y_act), applies the
+// activation derivative, and per position writes the 4 co as one 8-byte quad per piece (octet images 32 bytes
+// off a 128-byte multiple apart: 2-way at worst).  A lane's 4 accumulator rows are the 4 phases r of one (ci, q):
+// 4 consecutive samples of gx, one 16-byte store.  Work unit of a WAVE: 48 consecutive q (192 samples x 4 input
+// channels) of one (batch row, group): a 64-position window = exactly one staging item per lane.
+constexpr int BQ = 48;                        // q's per unit (3 MFMA column tiles)
+constexpr int BNP = 64;                       // gradient positions staged per unit: q0 - 8 .. q0 + 55
+constexpr int BOCT = BNP * 16 + 32;           // bytes per octet image (== 32 mod 128)
+constexpr int B_PIECE = 2 * BOCT;
+constexpr int B_WAVE = 3 * B_PIECE;
+constexpr int BJ = 6;                         // MFMA steps: taps 2J, 2J+1
+
+template <bool VEC, bool VOUT>
+__global__ __launch_bounds__(256, 2) void k_gconv_split_bwd_data(ConvP p, int tiles, int nunits,
+                                                                const float* __restrict__ gy,
+                                                                const float* __restrict__ y_act,
+                                                                const float* __restrict__ w,
+                                                                const float* __restrict__ gx_add,
+                                                                float* __restrict__ gx) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * B_WAVE];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = blockIdx.y;
+    const int kind = y_act ? p.act : MS_ACT_NONE;
+    unsigned char* img = lds + wid * B_WAVE;
+    const int n = lane & 15, kg = lane >> 4;
+    const int oct = kg >> 1, tp = kg & 1;
+    const int wstride = gridDim.x * 4;
+    const int db = wstride / tiles, dt = wstride - db * tiles;
+
+    // staging item of this lane: co quad cq, position quad pq
+    const int cq = lane & 3, pq = lane >> 2;
+    unsigned char* wr = img + (cq >> 1) * BOCT + (4 * pq) * 16 + (cq & 1) * 8;       // + j * 16 (position), + piece
+    constexpr unsigned OOB = 0xF0000000u;
+    const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy), 0, 0x80000000u, 0x00020000);
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(y_act ? y_act : gy), 0, 0x80000000u, 0x00020000);
+    unsigned g_c[4];                              // interior units: byte offset of row 4 cq + k, position quad pq
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g_c[k] = (unsigned)((4 * cq + k) * p.Lout + 4 * pq) * 4u;
+    f32x4 gv[4], ga[4];
+    auto gload = [&](int b, int ti) {
+        const int ws = ti * BQ - 8;                                   // first staged gradient position
+        const unsigned base = (unsigned)((b * p.Cout + g * 16) * p.Lout);
+        if (VEC && ws >= 0 && ws + BNP <= p.Lout) {
+            const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((base + (unsigned)ws) * 4u));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                gv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, g_c[k], sb, 0));
+                ga[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, g_c[k], sb, 0));
+            }
+            return;
+        }
+        const int t = ws + 4 * pq;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned off = base + (unsigned)((4 * cq + k) * p.Lout);
+            if (VEC) {
+                const unsigned vo = (t >= 0 && t < p.Lout) ? (off + (unsigned)t) * 4u : OOB;
+                gv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vo, 0, 0));
+                ga[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned vo = (t + e >= 0 && t + e < p.Lout) ? (off + (unsigned)(t + e)) * 4u : OOB;
+                    gv[k][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsG, vo, 0, 0));
+                    ga[k][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, vo, 0, 0));
+                }
+            }
+        }
+    };
+    int unit = blockIdx.x * 4 + wid;
+    int b = unit / tiles, ti = unit - b * tiles;
+    if (unit < nunits) gload(b, ti);
+
+    // ---- weight fragments: lane (m = (ci, r), kg = (octet, tap parity)) holds w[g*16 + 8 oct + e][ci][r + 4 (2J + tp)]
+    bf16x8 A[BJ][3];
+    {
+        const int ci = n >> 2, r = n & 3;
+#pragma unroll
+        for (int J = 0; J < BJ; ++J) {
+            const int tap = r + 4 * (2 * J + tp);
+            const bool ok = tap < GK;
+            float wv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = w[((size_t)(g * 16 + 8 * oct + e) * GCG + ci) * GK + (ok ? tap : 0)];
+                wv[e] = ok ? v : 0.f;
+            }
+            u32x4 h, m, l;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned hh, mm, ll;
+                split_pair(wv[2 * q], wv[2 * q + 1], hh, mm, ll);
+                h[q] = hh; m[q] = mm; l[q] = ll;
+            }
+            A[J][0] = __builtin_bit_cast(bf16x8, h);
+            A[J][1] = __builtin_bit_cast(bf16x8, m);
+            A[J][2] = __builtin_bit_cast(bf16x8, l);
+        }
+    }
+    // B fragment of (tile tq, step J): position (q0 + 16 tq + n) + 5 - 2J - tp, window index = that - (q0 - 8)
+    const unsigned rd = (unsigned)(uintptr_t)img + oct * BOCT + (n + 3 - tp) * 16;       // + tq * 256 + (5 - J) * 32 + piece
+    const int Lq = (p.Lin + GS - 1) / GS;
+
+    for (; unit < nunits; unit += wstride) {
+        // ---- registers -> LDS: activation derivative, 4 x 4 transpose, split, one 8-byte co quad per position
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float e[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] = ms_act_grad(gv[k][j], ga[k][j], kind, p.slope);
+            unsigned h0, m0, l0, h1, m1, l1;
+            split_pair(e[0], e[1], h0, m0, l0);
+            split_pair(e[2], e[3], h1, m1, l1);
+            *reinterpret_cast<uint2*>(wr + j * 16) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(wr + j * 16 + B_PIECE) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(wr + j * 16 + 2 * B_PIECE) = make_uint2(l0, l1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int q0 = ti * BQ;
+        const size_t rowoff = ((size_t)b * p.Cin + (size_t)g * GCG + kg) * p.Lin;       // D rows 4 kg + r: ci = kg
+        f32x4 addv[3];
+        if (VOUT && gx_add) {
+#pragma unroll
+            for (int tq = 0; tq < 3; ++tq) {
+                const int sidx = (q0 + tq * 16 + n) * GS;
+                addv[tq] = *reinterpret_cast<const f32x4*>(gx_add + (sidx < p.Lin ? rowoff + sidx : 0));
+            }
+        }
+        int nb = b + db, nti = ti + dt;
+        if (nti >= tiles) { nti -= tiles; ++nb; }
+        if (unit + wstride < nunits) gload(nb, nti);
+
+        f32x4 acc[3];
+#pragma unroll
+        for (int tq = 0; tq < 3; ++tq) acc[tq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // read groups (one piece, three tiles) two groups ahead of the MFMAs they feed; partial products smallest
+        // first: (a1 b3) | (a3 b1) | (a2 b2) (a1 b2) (a2 b1) (a1 b1)
+        u32x4 Bf[2][3][3];                            // [step parity][piece][tile]
+#define MS_B3_READ(J_, pc)                                                                                    \
+    _Pragma("unroll") for (int tq = 0; tq < 3; ++tq)                                                          \
+        asm volatile("ds_read_b128 %0, %1 offset:%2"                                                          \
+                     : "=v"(Bf[(J_) & 1][pc][tq])                                                             \
+                     : "v"(rd), "n"((pc) * B_PIECE + tq * 256 + (BJ - 1 - (J_)) * 32));
+#define MS_B3_WAIT(cnt, J_, pc)                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                \
+                 : "+v"(Bf[(J_) & 1][pc][0]), "+v"(Bf[(J_) & 1][pc][1]), "+v"(Bf[(J_) & 1][pc][2]))
+#define MS_B3_MMA(J_, pa, pb)                                                                                 \
+    _Pragma("unroll") for (int tq = 0; tq < 3; ++tq)                                                          \
+        acc[tq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                                    \
+            A[J_][pa], __builtin_bit_cast(bf16x8, Bf[(J_) & 1][pb][tq]), acc[tq], 0, 0, 0);
+#define MS_B3_STEP(J_, last)                                                                                  \
+    MS_B3_READ(J_, 1);                                                                                        \
+    MS_B3_WAIT(6, J_, 2);                                                                                     \
+    MS_B3_MMA(J_, 0, 2);                                                                                      \
+    if (!(last)) { MS_B3_READ((J_) + 1, 2); MS_B3_WAIT(6, J_, 0); } else { MS_B3_WAIT(3, J_, 0); }            \
+    MS_B3_MMA(J_, 2, 0);                                                                                      \
+    if (!(last)) { MS_B3_READ((J_) + 1, 0); MS_B3_WAIT(6, J_, 1); } else { MS_B3_WAIT(0, J_, 1); }            \
+    MS_B3_MMA(J_, 1, 1);                                                                                      \
+    MS_B3_MMA(J_, 0, 1);                                                                                      \
+    MS_B3_MMA(J_, 1, 0);                                                                                      \
+    MS_B3_MMA(J_, 0, 0);
+        MS_B3_READ(0, 2);
+        MS_B3_READ(0, 0);
+        MS_B3_STEP(0, false) MS_B3_STEP(1, false) MS_B3_STEP(2, false)
+        MS_B3_STEP(3, false) MS_B3_STEP(4, false) MS_B3_STEP(5, true)
+#undef MS_B3_STEP
+#undef MS_B3_MMA
+#undef MS_B3_WAIT
+#undef MS_B3_READ
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int tq = 0; tq < 3; ++tq) {
+            const int sidx = (q0 + tq * 16 + n) * GS;
+            if (q0 + tq * 16 + n >= Lq || sidx >= p.Lin) continue;
+            if (VOUT) {                                    // Lin % 4 == 0: the 4 samples exist together
+                f32x4 v = acc[tq];
+                if (gx_add) v += addv[tq];
+                *reinterpret_cast<f32x4*>(gx + rowoff + sidx) = v;
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    if (sidx + rr < p.Lin) {
+                        float v = acc[tq][rr];
+                        if (gx_add) v += gx_add[rowoff + sidx + rr];
+                        gx[rowoff + sidx + rr] = v;
+                    }
+                }
+            }
+        }
+        b = nb; ti = nti;
+    }
+}
+
 int pick_rb(int Lout) {
     if (Lout <= 16) return 4;
     if (Lout <= 32) return 2;
@@ -659,4 +861,35 @@ int msg3_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, cons
     else hipLaunchKernelGGL((k_gconv_split_wgrad<false>), dim3(gxn, p.groups), dim3(256), 0, s, p, x, gy, y_act, partial, stride);
     MS_CHECK_LAUNCH();
     return msg_reduce_slabs(p, partial, stride, gxn, gw, gb, beta, s);      // one slab per workgroup
+}
+
+bool msg3_bwd_data_applicable(const ConvP& p) {
+    const char* e = getenv("MSYNTH_GCONV3");
+    const bool on = !e || atoi(e) != 0;
+    return on && p.K == GK && p.stride == GS && p.Cg == GCG && p.dil == 1 && p.pad == 20 &&
+           p.pad_mode == MS_PAD_ZERO && p.Og == 16 && p.groups <= 65535 &&
+           (long long)p.B * p.Cout * p.Lout * 4 < (1ll << 31);
+}
+
+const char* msg3_bwd_data_name(const ConvP&) { return "k_gconv_split_bwd_data"; }
+
+int msg3_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, const float* w,
+                         const float* gx_add, float* gx, hipStream_t s) {
+    const int Lq = ms_ceil_div(p.Lin, GS);
+    const int tiles = ms_ceil_div(Lq, BQ), nunits = p.B * tiles;
+    const long long total_units = (long long)nunits * p.groups;
+    const int upw = (int)((total_units + 2047) / 2048);             // ~2 waves per SIMD, `upw` units per wave
+    const int gxn = ms_ceil_div(nunits, 4 * (upw > 0 ? upw : 1));
+    const dim3 grid(gxn, p.groups);
+    const bool vec = p.Lout % 4 == 0 && (((uintptr_t)gy) & 15) == 0 && (!y_act || (((uintptr_t)y_act) & 15) == 0);
+    const bool vout = p.Lin % 4 == 0 && (((uintptr_t)gx) & 15) == 0 && (!gx_add || (((uintptr_t)gx_add) & 15) == 0);
+#define MS_B3(V, VO) \
+    hipLaunchKernelGGL((k_gconv_split_bwd_data<V, VO>), grid, dim3(256), 0, s, p, tiles, nunits, gy, y_act, w, gx_add, gx)
+    if (vec && vout) MS_B3(true, true);
+    else if (vec) MS_B3(true, false);
+    else if (vout) MS_B3(false, true);
+    else MS_B3(false, false);
+#undef MS_B3
+    MS_CHECK_LAUNCH();
+    return MS_OK;
 }

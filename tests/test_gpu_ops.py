@@ -224,6 +224,17 @@ HOT_CONVS = [
     ("d_k41_g16", 2, 64, 513, 256, 41, 4, 20, 1, 16, 1, False),
     ("d_k41_g64", 1, 256, 129, 1024, 41, 4, 20, 1, 64, 1, False),
     ("d_k41_g256", 2, 1024, 33, 1024, 41, 4, 20, 1, 256, 1, False),
+    # split-bf16 grouped kernels (gconv_split.hip): 16-byte paths with whole-row / multi-segment units, segments of
+    # 64 / 32 / 16 outputs (1 / 2 / 4 per unit) incl. units that straddle batch rows and a ragged last unit, the
+    # 4-outputs-per-group layer, no activation
+    ("g3_vec_l2048", 3, 16, 2048, 64, 41, 4, 20, 1, 4, 1, False),
+    ("g3_vec_l512_noact", 2, 64, 512, 256, 41, 4, 20, 1, 16, 0, False),
+    ("g3_l128_two_rows", 5, 256, 128, 1024, 41, 4, 20, 1, 64, 1, False),
+    ("g3_l64_four_rows", 5, 64, 64, 256, 41, 4, 20, 1, 16, 1, False),
+    ("g3_l260_wrap", 3, 16, 260, 64, 41, 4, 20, 1, 4, 1, False),
+    ("g3_l1025", 2, 16, 1025, 64, 41, 4, 20, 1, 4, 1, False),
+    ("g3_og4_l128", 3, 1024, 128, 1024, 41, 4, 20, 1, 256, 1, False),
+    ("g3_og4_l65", 2, 512, 65, 512, 41, 4, 20, 1, 128, 1, False),
     ("d_k5", 2, 1024, 17, 1024, 5, 1, 2, 1, 1, 1, False),
     # short-row mode of the pipelined kernel (rows of a length that is not a multiple of 4): partial
     # last tile, partial M tile, 1 / 3 / 14 rows per tile
@@ -398,6 +409,37 @@ def test_kernel_generations_agree(shape, monkeypatch):
     y3, ya3, gx3 = out["3"]
     assert rel_l2(host(y3), out["1"][0]) < 1e-6 and rel_l2(host(ya3), host(out["1"][1])) < 1e-6
     assert rel_l2(host(gx3), out["1"][2]) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 2048, 64, 4), (2, 64, 513, 256, 16), (5, 256, 128, 1024, 64), (3, 1024, 36, 1024, 256)],
+                         ids=["g4_vec", "g16_l513", "g64_two_rows", "g256_og4"])
+def test_grouped_kernel_generations_agree(shape, monkeypatch):
+    """Split-bf16 grouped kernels (gconv_split.hip) against the fp32-MFMA ones they replace (MSYNTH_GCONV3=0):
+    forward, backward data with a residual gradient added, weight gradient accumulated into existing values."""
+    from featuresynth._ops import prims as P
+    B, Cin, Lin, Cout, groups = shape
+    rng = np.random.default_rng(23)
+    x = dev(rng.standard_normal((B, Cin, Lin)).astype(np.float32))
+    w = dev((rng.standard_normal((Cout, 4, 41)) * 0.05).astype(np.float32))
+    b = dev(rng.standard_normal((Cout,)).astype(np.float32))
+    d, lo = P.conv_desc(x.shape, w.shape, stride=4, pad=20, groups=groups, act=1)
+    gy = dev(rng.standard_normal((B, Cout, lo)).astype(np.float32))
+    res = dev(rng.standard_normal((B, Cin, Lin)).astype(np.float32))
+    gw0 = dev(rng.standard_normal((Cout, 4, 41)).astype(np.float32))
+    gb0 = dev(rng.standard_normal((Cout,)).astype(np.float32))
+    lib = P.L.load()
+    out = {}
+    for gen in ("0", "1"):
+        monkeypatch.setenv("MSYNTH_GCONV3", gen)
+        names = [lib.ms_conv1d_kernel_name(d, k).decode() for k in range(3)]
+        assert all(("split" in nm) == (gen == "1") or (k == 1 and Cout // groups != 16) for k, nm in enumerate(names)), names
+        y, _ = P.conv1d_fwd(x, w, b, d, lo)
+        ya = y if gen == "0" else out["0"][0]                 # one activation mask for both generations
+        gx = P.conv1d_bwd_data(gy, ya, w, d, gx_add=res)
+        gw, gb = P.conv1d_bwd_weight(x, gy, ya, d, w.shape, gw=gw0.clone(), gb=gb0.clone(), accumulate=True)
+        out[gen] = (y, gx, gw, gb)
+    for a, c in zip(out["1"], out["0"]):
+        assert rel_l2(host(a), host(c)) < 1e-6
 
 
 @pytest.mark.parametrize("case", [
