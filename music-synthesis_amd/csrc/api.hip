@@ -1,6 +1,7 @@
 // extern "C" entry points for the convolution family: argument validation, geometry, and the
 // dispatch between the direct (vector FMA) kernels and the f32-MFMA implicit-GEMM kernels.
 #include "ms_common.h"
+#include <stdlib.h>
 #include "conv_mfma.h"
 #include "gconv_mfma.h"
 #include "conv_thin.h"
@@ -68,6 +69,69 @@ const char* ms_status_string(int status) {
     }
 }
 
+// ---- rows whose length is not a multiple of 4 on the 16-byte kernels
+// The D 1024 -> 1024 k5 conv at the pooled scales runs on rows of 17 / 9 samples: no row is 16-byte aligned, so the
+// split-bf16 row kernel takes its dword loader (4x the load instructions, four-wave form only): 58-74 TFLOP/s against
+// 160-170 for the same layer at L = 32.  For such layers the operands are copied into rows padded with zeros to
+// L' = 4 ceil(L / 4) (a few MB: microseconds), the conv runs on the padded problem through the aligned paired kernel,
+// and the valid columns are copied back.  Zero columns behind a row are what the conv's zero padding reads anyway, so
+// the valid outputs are unchanged; the padded outputs are discarded.  Measured (tools/microbench_pad4.py, B = 64):
+// L = 17 forward 197 -> 150 us, backward 232 -> 164 us; L = 33: 267 -> 212 / 379 -> 241 us.  With fewer than ~1000
+// columns (B = 32 at L = 17, any batch at L = 9) the extra columns cost more than the loader saves: not padded.
+namespace {
+
+__global__ __launch_bounds__(256) void k_pad_rows(const float* __restrict__ src, float* __restrict__ dst,
+                                                 size_t n_dst, int L, int Lp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_dst) return;
+    const size_t row = i / (unsigned)Lp;
+    const int t = (int)(i - row * (unsigned)Lp);
+    dst[i] = t < L ? src[row * (unsigned)L + t] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_unpad_rows(const float* __restrict__ src, const float* __restrict__ add,
+                                                   float* __restrict__ dst, size_t n_dst, int L, int Lp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_dst) return;
+    const size_t row = i / (unsigned)L;
+    const int t = (int)(i - row * (unsigned)L);
+    const float v = src[row * (unsigned)Lp + t];
+    dst[i] = add ? v + add[i] : v;
+}
+
+bool pad4_applicable(const ConvP& p) {
+    const char* e = getenv("MSYNTH_PAD4");
+    if (e && atoi(e) == 0) return false;
+    return p.groups == 1 && p.stride == 1 && p.Lout == p.Lin && (p.Lin & 3) != 0 && p.Lin >= 5 && p.Lin <= 256 &&
+           (long long)p.B * p.Lin >= 1000 &&
+           p.K == 5 && p.Cin >= 256 && p.Cout >= 256 && p.Cin % 16 == 0 && p.Cout % 16 == 0 &&
+           p.pad_mode == MS_PAD_ZERO && !p.in_act;
+}
+
+ConvP pad4_conv(const ConvP& p) {
+    ConvP q = p;
+    q.Lin = q.Lout = (p.Lin + 3) & ~3;
+    return q;
+}
+
+size_t pad4_bytes(const ConvP& q, int channels) { return (size_t)q.B * channels * q.Lin * sizeof(float); }
+
+int pad_rows(const float* src, float* dst, size_t rows, int L, int Lp, hipStream_t s) {
+    const size_t n = rows * (size_t)Lp;
+    hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n, L, Lp);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int unpad_rows(const float* src, const float* add, float* dst, size_t rows, int L, int Lp, hipStream_t s) {
+    const size_t n = rows * (size_t)L;
+    hipLaunchKernelGGL(k_unpad_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, add, dst, n, L, Lp);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+}  // namespace
+
 int ms_conv1d_out_len(const ms_conv1d_desc* d) {
     ConvP p;
     return make_conv(d, &p) ? p.Lout : MS_ERR_INVALID_ARG;
@@ -84,6 +148,20 @@ int ms_conv1d_fwd(const ms_conv1d_desc* d, const float* x, const float* w, const
     const int xk = p.in_act ? MS_MOD_LRELU_FWD : 0;
     if (mst_fwd_short_applicable(p) && !y_act && !residual)   // judge conv: a 12-MFLOP reduction, not a GEMM
         return mst_conv1d_fwd(p, x, w, bias, residual, y, s);
+    if (msm_fwd_applicable(p) && pad4_applicable(p) && !residual && !y_act) {
+        const ConvP q = pad4_conv(p);
+        const size_t xb = pad4_bytes(q, p.Cin), yb = pad4_bytes(q, p.Cout);
+        if (workspace && workspace_bytes >= xb + yb + msm_fwd_ws(q) && (((uintptr_t)workspace) & 15) == 0) {
+            float* xp = (float*)workspace;
+            float* yp = (float*)((char*)workspace + xb);
+            int rc = pad_rows(x, xp, (size_t)p.B * p.Cin, p.Lin, q.Lin, s);
+            if (rc != MS_OK) return rc;
+            rc = msm_conv1d_fwd(q, xp, nullptr, 0, w, bias, nullptr, yp, nullptr, (char*)workspace + xb + yb,
+                                workspace_bytes - xb - yb, s);
+            if (rc != MS_OK) return rc;
+            return unpad_rows(yp, nullptr, y, (size_t)p.B * p.Cout, p.Lin, q.Lin, s);
+        }
+    }
     if (msm_fwd_applicable(p))
         return msm_conv1d_fwd(p, x, xa, xk, w, bias, residual, y, y_act, workspace, workspace_bytes, s);
     if (msg3_fwd_applicable(p) && !residual && !y_act && !p.in_act) return msg3_conv1d_fwd(p, x, w, bias, y, s);
@@ -104,7 +182,27 @@ int ms_conv1d_bwd_data(const ms_conv1d_desc* d, const float* gy, const float* y_
     if (reflect && (p.stride != 1 || p.groups != 1)) return MS_ERR_UNSUPPORTED;
     p.pad_mode = MS_PAD_ZERO;
     int rc;
-    if (msm_bwd_data_applicable(p))
+    bool padded = false;
+    if (msm_bwd_data_applicable(p) && pad4_applicable(p)) {
+        const ConvP q = pad4_conv(p);
+        const size_t gb = pad4_bytes(q, p.Cout), xb = pad4_bytes(q, p.Cin);
+        const size_t need = gb * (y_act ? 2 : 1) + xb + msm_bwd_data_ws(q);
+        if (workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 15) == 0) {
+            char* wsp = (char*)workspace;
+            float* gp = (float*)wsp; wsp += gb;
+            float* ap = nullptr;
+            if (y_act) { ap = (float*)wsp; wsp += gb; }
+            float* xp = (float*)wsp; wsp += xb;
+            rc = pad_rows(gy, gp, (size_t)p.B * p.Cout, p.Lin, q.Lin, s);
+            if (rc == MS_OK && y_act) rc = pad_rows(y_act, ap, (size_t)p.B * p.Cout, p.Lin, q.Lin, s);
+            if (rc == MS_OK)
+                rc = msm_conv1d_bwd_data(q, gp, ap, w, nullptr, xp, wsp, workspace_bytes - (size_t)(wsp - (char*)workspace), s);
+            if (rc == MS_OK) rc = unpad_rows(xp, gx_add, gx, (size_t)p.B * p.Cin, p.Lin, q.Lin, s);
+            padded = true;
+        }
+    }
+    if (padded) {
+    } else if (msm_bwd_data_applicable(p))
         rc = msm_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, workspace, workspace_bytes, s);
     else if (msg3_bwd_data_applicable(p))
         rc = msg3_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, s);
@@ -191,11 +289,27 @@ int ms_conv1d_bwd_weight_multi(const ms_wgrad_multi_desc* d, void* workspace, si
 size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which) {
     ConvP p;
     if (!make_conv(d, &p)) return 0;
-    if (which == 0) return msm_fwd_applicable(p) ? msm_fwd_ws(p) : 0;
+    if (which == 0) {
+        if (!msm_fwd_applicable(p)) return 0;
+        size_t n = msm_fwd_ws(p);
+        if (pad4_applicable(p)) {         // padded copies of x and y + the padded problem's own workspace
+            const ConvP q = pad4_conv(p);
+            const size_t m = pad4_bytes(q, p.Cin) + pad4_bytes(q, p.Cout) + msm_fwd_ws(q);
+            if (m > n) n = m;
+        }
+        return n;
+    }
     if (which == 1) {
         // (reflection padding runs the zero-padded backward + the edge fold, see ms_conv1d_bwd_data)
         if (p.pad_mode == MS_PAD_REFLECT && p.stride == 1 && p.groups == 1) p.pad_mode = MS_PAD_ZERO;
-        return msm_bwd_data_applicable(p) ? msm_bwd_data_ws(p) : 0;
+        if (!msm_bwd_data_applicable(p)) return 0;
+        size_t n = msm_bwd_data_ws(p);
+        if (pad4_applicable(p)) {         // padded copies of gy, y_act and gx + the padded problem's own workspace
+            const ConvP q = pad4_conv(p);
+            const size_t m = 2 * pad4_bytes(q, p.Cout) + pad4_bytes(q, p.Cin) + msm_bwd_data_ws(q);
+            if (m > n) n = m;
+        }
+        return n;
     }
     if (which == 2) {
         if (mst_bwd_weight_applicable(p)) return mst_bwd_weight_ws(p);
@@ -220,6 +334,9 @@ const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which) {
     ConvP p;
     if (!make_conv(d, &p)) return "";
     if (which == 0 && mst_fwd_short_applicable(p)) return mst_fwd_name(p);
+    // (rows padded to a multiple of 4, see pad4_applicable: the kernel of the padded problem)
+    if (which == 0 && msm_fwd_applicable(p) && pad4_applicable(p)) return msm_fwd_name(pad4_conv(p));
+    if (which == 1 && msm_bwd_data_applicable(p) && pad4_applicable(p)) return msm_bwd_data_name(pad4_conv(p));
     if (which == 0)
         return msm_fwd_applicable(p) ? msm_fwd_name(p)
                : (msg3_fwd_applicable(p) ? msg3_fwd_name(p)

@@ -236,6 +236,9 @@ HOT_CONVS = [
     ("g3_og4_l128", 3, 1024, 128, 1024, 41, 4, 20, 1, 256, 1, False),
     ("g3_og4_l65", 2, 512, 65, 512, 41, 4, 20, 1, 128, 1, False),
     ("d_k5", 2, 1024, 17, 1024, 5, 1, 2, 1, 1, 1, False),
+    # >= 1000 columns of an odd row length: rows padded to a multiple of 4 for the 16-byte kernels (api.hip pad4)
+    ("d_k5_l17_padded", 61, 256, 17, 272, 5, 1, 2, 1, 1, 1, False),
+    ("d_k5_l33_padded", 31, 256, 33, 256, 5, 1, 2, 1, 1, 0, False),
     # short-row mode of the pipelined kernel (rows of a length that is not a multiple of 4): partial
     # last tile, partial M tile, 1 / 3 / 14 rows per tile
     ("d_k5_l9_ragged", 17, 256, 9, 328, 5, 1, 2, 1, 1, 1, False),
