@@ -1195,6 +1195,18 @@ int rows3p_bm(const Row2P& q, int bn, int K, int am, int epi_s, int in_s, unsign
     return wgs >= min_wgs ? bm : 0;
 }
 
+// ... and for the transposed-conv forward (two-tap form, conv_rows3.hip HS): 128 rows where that still fills the chip
+int rows3p_convt_bm(const Row2P& q, int bn, int S, unsigned gz) {
+    if (bn != 128) return 0;
+    static const int min_wgs = getenv("MSYNTH_R3P_MIN") ? atoi(getenv("MSYNTH_R3P_MIN")) : 128;
+    const long long ntiles = q.R == 1 ? (long long)q.B * q.tiles_per_row : (q.B + q.R - 1) / q.R;
+    for (int bm = 128; bm >= 64; bm >>= 1) {
+        if (q.M < bm || !msr3p_convt_supported(bm, S, q)) continue;
+        if (((ntiles + 1) / 2) * ((q.M + bm - 1) / bm) * gz >= min_wgs) return bm;
+    }
+    return 0;
+}
+
 Row2P rows3p_retile(const Row2P& q, int K) {
     Row2P r = q;
     r.Lt = 128;
@@ -1498,6 +1510,27 @@ const char* msm_convt_fwd_name(const ConvP& p) {
     const RowCfg c = pick_row_cfg(p.Cin * p.stride, p.B, p.Lout);
     RowP r;
     make_rowp(&r, c, p.B, p.Cout, p.Lout, p.Cin * p.stride, 3, 1, -1, 0, 0, 0, 0.f);
+    {   // the paired split-bf16 kernel, decided exactly as msm_convt1d_fwd does (dummy 16-byte aligned pointers)
+        RowP r2 = r;
+        if (p.in_act) r2.in_act = MS_MOD_LRELU_FWD;
+        const float* D = reinterpret_cast<const float*>(uintptr_t(64));
+        Row2P q;
+        int tile = 0, am = 0, bm = 0, bn = 0;
+        if (rows2_pick(c, 2, 8, p.in_act != 0, p.stride, 1, r2, D, p.in_act ? D : nullptr, D, nullptr, D, nullptr, &q, &tile, &am)) {
+            q.KG = r.CK * 2;
+            const RowSplit sp = plan_rows_split(c, r, row_cc(3));
+            if (sp.ns > 1) q.CKs = sp.cks;
+            const unsigned gz = (unsigned)((q.CK + q.CKs - 1) / q.CKs);
+            row_tile(c, &bm, &bn);
+            int b3 = rows3p_convt_bm(q, bn, p.stride, gz);
+            if (!b3 && c == ROW_32x256 && q.R == 1 && q.Lt == 256) b3 = rows3p_convt_bm(rows3p_retile(q, 3), 128, p.stride, gz);
+            if (b3) {
+                snprintf(buf, sizeof(buf), "k_conv_rows3p<2, %d, 2, 3, 0, %d, %s>", b3 == 128 ? 2 : 1, p.stride,
+                         p.in_act ? "true" : "false");
+                return buf;
+            }
+        }
+    }
     if (c == ROW_128x128 || c == ROW_64x128) {
         Row2P q;
         q.L = p.Lout; q.R = r.R; q.SS = r.SS; q.M = p.Cin * p.stride;
@@ -1647,6 +1680,16 @@ int msm_convt1d_fwd(const ConvP& p, const float* x, const float* w, const float*
                                         return (int)MS_ERR_UNSUPPORTED;
                                     q.KG = rp.CK * 2;
                                     row_tile(cfg, &bm, &bn);
+                                    const unsigned gz_ = (unsigned)((rp.CK + rp.CKs - 1) / rp.CKs);
+                                    if (!r_ && !ya_) {     // paired split-bf16 kernel where its grid fills the chip
+                                        if (const int b3 = rows3p_convt_bm(q, bn, S, gz_))
+                                            return msr3p_convt_launch(b3, S, ia, q, x, wp, b_, y_, gz_, s);
+                                        if (cfg == ROW_32x256 && q.R == 1 && q.Lt == 256) {
+                                            Row2P q3 = rows3p_retile(q, 3);
+                                            if (const int b3 = rows3p_convt_bm(q3, 128, S, gz_))
+                                                return msr3p_convt_launch(b3, S, ia, q3, x, wp, b_, y_, gz_, s);
+                                        }
+                                    }
                                     const unsigned gx_ = rp.R == 1 ? (unsigned)(rp.B * rp.tiles_per_row)
                                                                    : (unsigned)((rp.B + rp.R - 1) / rp.R);
                                     return msr2_launch(tile, 2, 8, am, S, q, x, nullptr, wp, b_, r_, y_, ya_, gx_,

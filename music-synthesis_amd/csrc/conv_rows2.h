@@ -35,3 +35,8 @@ int msr3_launch(int tile, int K, int act_mode, const Row2P& p, const float* X, c
 bool msr3p_supported(int bm, int K, int act_mode, int epi_s, const Row2P& p, int in_s = 1);
 int msr3p_launch(int bm, int K, int act_mode, const Row2P& p, const float* X, const float* Xact, const float* W,
                  const float* bias, const float* res, float* Y, float* Yact, unsigned gz, hipStream_t s);
+
+// transposed-conv forward on the paired split-bf16 kernel (two live taps per phase; see k_conv_rows3p, HS form)
+bool msr3p_convt_supported(int bm, int S, const Row2P& p);
+int msr3p_convt_launch(int bm, int S, bool in_act, const Row2P& p, const float* X, const float* W, const float* bias,
+                       float* Y, unsigned gz, hipStream_t s);

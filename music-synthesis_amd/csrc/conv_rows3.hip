@@ -394,7 +394,14 @@ __global__ __launch_bounds__(256) void k_conv_rows3(Row2P p, const float* __rest
 // slot and consumed in its next staging slot.
 // Group layout: WGM x (4 / WGM) waves of TM x TN sub-tiles: 2 x 2 waves of TM x 2 (64 or 128 rows) or, for the
 // 32-channel layers, 1 x 4 waves of 1 x 1 (32 rows); 128 columns per group either way.
-template <int WGM, int TM, int TN, int K, int AM>
+//
+// HS = S > 0: ConvTranspose1d forward (stride S = 2 / 8, kernel 2S, padding S/2) as a conv over the input rows with
+// M = Cout * S GEMM rows packed by k_pack_convt_w2 in blocks of 64 = [32 low-phase | 32 high-phase] rows: every
+// phase has TWO live taps of the 3-column window -- columns {0, 1} for the low phases, {1, 2} for the high ones --
+// so a 32-row sub-tile multiplies two weight taps (A has K = 2) against the window columns offset by its half.
+// The epilogue scatters row (co, phase) / column q to y[co][q S + phase]: four consecutive samples per store.
+// INA: LeakyReLU applied to the input on its way into LDS (the activation in front of the transposed conv).
+template <int WGM, int TM, int TN, int K, int AM, int HS = 0, bool INA = false>
 __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __restrict__ X,
                                                     const float* __restrict__ Xact,
                                                     const float* __restrict__ W,
@@ -404,7 +411,9 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
                                                     float* __restrict__ Yact) {
     constexpr int WGN = 4 / WGM, BM = WGM * TM * 32, BN = WGN * TN * 32;
     static_assert(BN == 128, "a group owns one 128-column tile");
-    constexpr int ARS = a_row_bytes(K);
+    constexpr int KA = HS ? 2 : K;                             // weight taps per row
+    static_assert(!HS || (K == 3 && AM == 0 && BM >= 64), "transposed-conv form: 3-column window, forward weights");
+    constexpr int ARS = a_row_bytes(KA);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     const int a_bytes = BM * ARS, x_bytes = p.PX * XRS;
     unsigned char* const Abuf = smem3;                         // A[0] | A[1]
@@ -432,7 +441,7 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
         const int row = g * (BM / 2) + rl;
         const bool in = rl < BM / 2;
         const bool ok = in && m0 + row < p.M;
-        if (AM == 0) a_goff = ok ? 4u * (unsigned)((m0 + row) * p.KG + 4 * cq * K) : OOB;
+        if (AM == 0) a_goff = ok ? 4u * (unsigned)((m0 + row) * p.KG + 4 * cq * KA) : OOB;
         else a_goff = ok ? 4u * (unsigned)((4 * cq * p.M + m0 + row) * K) : OOB;
         a_loff = in ? row * ARS + cq * 8 : -1;
     }
@@ -476,14 +485,14 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
     }
 
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 ra[AM == 1 ? 1 : K];
+    f32x4 ra[AM == 1 ? 1 : KA];
     float rad[AM == 1 ? 4 * K : 1];
     f32x4 rx[4], rxa[AM == 1 ? 4 : 1];
     auto load_a = [&](int c0, bool live) {
         if (AM == 0) {
-            const int so = live ? 4 * c0 * K : 0;
+            const int so = live ? 4 * c0 * KA : 0;
 #pragma unroll
-            for (int k4 = 0; k4 < K; ++k4)
+            for (int k4 = 0; k4 < KA; ++k4)
                 ra[k4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, a_goff + 16 * k4, so, 0));
         } else {
             const int qs = 4 * p.M * K;
@@ -509,11 +518,11 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
         unsigned char* base0 = in ? abuf + a_loff : scratch + tid * 8;
         const int jstep = in ? 96 : 0, pstep = in ? 32 : 0;
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
+        for (int j = 0; j < KA; ++j) {
             float e[4];
             if (AM == 0) {
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) e[qq] = ra[(qq * K + j) >> 2][(qq * K + j) & 3];
+                for (int qq = 0; qq < 4; ++qq) e[qq] = ra[(qq * KA + j) >> 2][(qq * KA + j) & 3];
             } else {
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) e[qq] = rad[qq * K + (K - 1 - j)];   // taps flipped
@@ -535,6 +544,7 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
             for (int cc = 0; cc < 4; ++cc) {
                 c4[cc] = rx[cc][e];
                 if (AM == 1) c4[cc] = rxa[cc][e] > 0.f ? c4[cc] : c4[cc] * p.slope;
+                if (INA) c4[cc] = c4[cc] > 0.f ? c4[cc] : c4[cc] * p.slope;
             }
             uint2 o3[3];
             split_quad(c4, o3);
@@ -550,6 +560,39 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
     const int arow = (wm * TM * 32 + (lane & 31)) * ARS + h * 16;
     auto compute = [&](const unsigned char* As) {
         const unsigned char* Xs = Xg + h * 16;
+        if constexpr (HS != 0) {
+            // two weight taps; sub-tile i reads the window columns (tap + its half): TM == 1: the wave's 32 rows
+            // are one half (wm), TM == 2: sub-tile 0 = low, 1 = high phases
+            constexpr int NO = TM == 1 ? 2 : 3;
+            const int hb = TM == 1 ? (wm & 1) : 0;
+            bf16x8 fa[TM][2][3], fb[TN][NO][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int sa = 0; sa < 2; ++sa)
+#pragma unroll
+                    for (int pp = 0; pp < 3; ++pp)
+                        fa[i][sa][pp] = *reinterpret_cast<const bf16x8*>(As + arow + i * 32 * ARS + sa * 96 + pp * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int o = 0; o < NO; ++o)
+#pragma unroll
+                    for (int pp = 0; pp < 3; ++pp)
+                        fb[j][o][pp] = *reinterpret_cast<const bf16x8*>(Xs + (bbase[j] + hb + o) * XRS + pp * 32);
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int sa = 0; sa < 2; ++sa)
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                fa[i][sa][PA[t]], fb[j][sa + (TM == 1 ? 0 : (i & 1))][PB[t]], acc[i][j], 0, 0, 0);
+            return;
+        }
         bf16x8 fa[2][TM][3], fb[2][TN][3];
         auto frag = [&](int s, bf16x8 (&a)[TM][3], bf16x8 (&b)[TN][3]) {
 #pragma unroll
@@ -621,8 +664,10 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
         float bv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + mb + (r & 3) + 8 * (r >> 2);
-            bv[r] = bias ? bias[m < p.M ? m : 0] : 0.f;
+            int m = m0 + mb + (r & 3) + 8 * (r >> 2);
+            if (m >= p.M) m = 0;
+            if (HS) m = (m >> 6) * (64 / (HS ? HS : 1)) + (m & 31) / ((HS ? HS : 2) / 2);    // GEMM row -> output channel
+            bv[r] = bias ? bias[m] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -636,6 +681,33 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
     constexpr int V4 = BN / 4;
     constexpr int NQ = BM * V4 / 256;
     static_assert(NQ >= 1, "tile too small");
+    if constexpr (HS != 0) {
+        constexpr int S = HS, SH = S / 2, CPB = 64 / S;            // channels per 64-row block
+        constexpr int V4C = 32 * S;                                 // 16-byte vectors per channel of the tile
+        const int Cout = p.M / S;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = gt + 256 * q;
+            const int chl = idx / V4C, t4 = idx - chl * V4C;
+            const int b64 = chl / CPB, cl = chl - b64 * CPB;
+            const int nl = (4 * t4) / S, ph0 = (4 * t4) % S;
+            const int r = nl / p.Lt, tc = nl - r * p.Lt;
+            const int co = (m0 >> 6) * CPB + chl;
+            const bool okq = co < Cout && r < p.R && b0 + r < p.B && t0 + tc < p.L;
+            float4 v;
+            if (S == 8) {
+                const float* tr = Ts + (b64 * 64 + (ph0 / SH) * 32 + cl * SH) * TP + nl;
+                v = make_float4(tr[0], tr[TP], tr[2 * TP], tr[3 * TP]);
+            } else {
+                const float* tr = Ts + (b64 * 64 + cl) * TP + nl;
+                v = make_float4(tr[0], tr[32 * TP], tr[1], tr[32 * TP + 1]);
+            }
+            if (okq)
+                *reinterpret_cast<float4*>(Y + ((size_t)(b0 + r) * Cout + co) * ((size_t)p.L * S) +
+                                           (size_t)(t0 + tc) * S + ph0) = v;
+        }
+        return;
+    }
     float4 tv[NQ], rv[NQ];
     size_t go[NQ];
     bool ok[NQ];
@@ -667,22 +739,22 @@ size_t ldsp_bytes(const Row2P& p) {
     return by < epi ? epi : by;
 }
 
-template <int WGM, int TM, int TN, int K, int AM>
+template <int WGM, int TM, int TN, int K, int AM, int HS = 0, bool INA = false>
 int launch_pair(const Row2P& p, const float* X, const float* Xact, const float* W, const float* bias,
                 const float* res, float* Y, float* Yact, dim3 grid, hipStream_t s) {
-    const size_t by = ldsp_bytes<WGM * TM * 32, K>(p);
+    const size_t by = ldsp_bytes<WGM * TM * 32, HS ? 2 : K>(p);
     const size_t lds = by + 512 * 8;
     if (lds > 158 * 1024) return MS_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rows3p<WGM, TM, TN, K, AM>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rows3p<WGM, TM, TN, K, AM, HS, INA>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
         attr_set = true;
     }
     Row2P pp = p;
     pp.scratch_off = (int)by;
-    hipLaunchKernelGGL((k_conv_rows3p<WGM, TM, TN, K, AM>), grid, dim3(512), lds, s, pp, X, Xact, W, bias, res, Y,
-                       Yact);
+    hipLaunchKernelGGL((k_conv_rows3p<WGM, TM, TN, K, AM, HS, INA>), grid, dim3(512), lds, s, pp, X, Xact, W, bias, res,
+                       Y, Yact);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }
@@ -805,4 +877,37 @@ int msr3p_launch(int bm, int K, int act_mode, const Row2P& p, const float* X, co
     }
 #undef MS3P
     return MS_ERR_UNSUPPORTED;
+}
+
+// Transposed-conv forward on the paired kernel (HS form).  p: the row description of the mirrored conv with the
+// 3-column window (rows2_pick(.., K = 2, ..)), p.M = Cout * S GEMM rows, p.KG = 2 CK; W packed by k_pack_convt_w2.
+bool msr3p_convt_supported(int bm, int S, const Row2P& p) {
+    const char* sw = getenv("MSYNTH_ROWS3P");
+    if (sw && atoi(sw) == 0) return false;
+    const char* sc = getenv("MSYNTH_CONVT3");        // tuning / test switch (0: fp32-MFMA transposed-conv kernel)
+    if (sc && atoi(sc) == 0) return false;
+    if ((S != 2 && S != 8) || (bm != 64 && bm != 128)) return false;
+    if (p.M % 64 || p.CK % CC3 || p.CKs % CC3 || p.dil != 1 || p.off0 != -1) return false;
+    if (!rows_vec(p) || (long long)p.B * (p.M / S) * p.L * S >= (1ll << 31)) return false;
+    const int nvt = p.R * ((p.SS + 6) / 4);
+    if (16 * ((nvt + 3) / 4) > 256 * msr3_nxu(128)) return false;
+    const size_t by = bm == 128 ? ldsp_bytes<128, 2>(p) : ldsp_bytes<64, 2>(p);
+    return by + 512 * 8 <= 158 * 1024;
+}
+
+int msr3p_convt_launch(int bm, int S, bool in_act, const Row2P& p, const float* X, const float* W, const float* bias,
+                       float* Y, unsigned gz, hipStream_t s) {
+    const unsigned ntiles = p.R == 1 ? (unsigned)(p.B * p.tiles_per_row) : (unsigned)((p.B + p.R - 1) / p.R);
+    const dim3 grid((ntiles + 1) / 2, (unsigned)((p.M + bm - 1) / bm), gz);
+#define MS3T(WGM_, TM_, S_, IA_) \
+    return launch_pair<WGM_, TM_, 2, 3, 0, S_, IA_>(p, X, nullptr, W, bias, nullptr, Y, nullptr, grid, s)
+    if (bm == 128) {
+        if (S == 8) { if (in_act) MS3T(2, 2, 8, true); MS3T(2, 2, 8, false); }
+        if (in_act) MS3T(2, 2, 2, true);
+        MS3T(2, 2, 2, false);
+    }
+    if (S == 8) { if (in_act) MS3T(2, 1, 8, true); MS3T(2, 1, 8, false); }
+    if (in_act) MS3T(2, 1, 2, true);
+    MS3T(2, 1, 2, false);
+#undef MS3T
 }

@@ -343,6 +343,31 @@ def test_convt_hot_shapes_vs_oracle(case):
     assert rel_l2(host(gb), gb_ref) < GRAD_TOL
 
 
+@pytest.mark.parametrize("shape", [(8, 64, 4100, 32, 4, 2), (16, 256, 260, 128, 16, 8), (32, 512, 36, 256, 16, 8),
+                                   (32, 128, 516, 64, 4, 2)],
+                         ids=["s2_m64_tail", "s8_m1024_tail", "s8_packed_rows", "s2_m128"])
+@pytest.mark.parametrize("in_act", [0, 1])
+def test_convt_paired_split_kernel(shape, in_act):
+    """ConvTranspose1d forward on the paired split-bf16 kernel (conv_rows3.hip, two-tap form: needs >= 128 workgroups,
+    hence the larger batches) against a float64 reference: column-tile tails, rows packed 3 per tile, both strides,
+    64- and 128-row workgroups, with and without the LeakyReLU in front (generator/full.py: LeakyReLU -> ConvTranspose1d)."""
+    import torch.nn.functional as TF
+    from featuresynth._ops import prims as P
+    B, Cin, Lin, Cout, K, S = shape
+    g = torch.Generator(device="cuda").manual_seed(stable_seed("convt3%s%d" % (shape, in_act)) % (1 << 31))
+    x = torch.randn(B, Cin, Lin, device="cuda", generator=g)
+    w = torch.randn(Cin, Cout, K, device="cuda", generator=g) * 0.05
+    b = torch.randn(Cout, device="cuda", generator=g)
+    d, lo = P.convt_desc(x.shape, w.shape, S, S // 2, act=1, in_act=in_act)
+    assert "k_conv_rows3p" in P.L.load().ms_convt1d_kernel_name(d, 0).decode()
+    y = P.convt1d_fwd(x, w, b, d, lo)
+    y = y[0] if isinstance(y, tuple) else y
+    xin = TF.leaky_relu(x.double(), 0.2) if in_act else x.double()
+    ref = TF.leaky_relu(TF.conv_transpose1d(xin, w.double(), b.double(), stride=S, padding=S // 2), 0.2)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert float((y.double() - ref).norm() / ref.norm()) < 1e-6
+
+
 def test_bad_arguments_raise():
     from featuresynth._ops import functional as F_
     x = torch.zeros(1, 4, 16, device="cuda")
