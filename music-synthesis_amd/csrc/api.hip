@@ -231,6 +231,8 @@ int ms_conv1d_bwd_weight(const ms_conv1d_desc* d, const float* x, const float* g
         const int rc = msw32_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
         if (rc != MS_ERR_UNSUPPORTED) return rc;
     }
+    if (msw5_applicable(p) && workspace && workspace_bytes >= msw5_ws(p))    // 1024 -> 1024 k5 on short rows
+        return msw5_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
     if (msw_bwd_weight_applicable(p)) { // dense stride-1 convs: row-tile MFMA form
         const int rc = msw_conv1d_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
         if (rc != MS_ERR_UNSUPPORTED) return rc;     // (unaligned operands: the im2col form below)
@@ -319,7 +321,8 @@ size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which) {
             return a32 > rest ? a32 : rest;
         }
         if (msw_bwd_weight_applicable(p)) {
-            const size_t a = msw_bwd_weight_ws(p);
+            size_t a = msw_bwd_weight_ws(p);
+            if (msw5_applicable(p) && msw5_ws(p) > a) a = msw5_ws(p);
             const size_t rest = msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p)
                                 : (msg_bwd_weight_applicable(p) ? msg_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p));
             return a > rest ? a : rest;
@@ -355,6 +358,7 @@ const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which) {
                                                                               : msk_conv1d_bwd_data_direct_name(p)));
     if (which == 2 && mst_bwd_weight_applicable(p)) return mst_bwd_weight_name(p);
     if (which == 2 && msw32_applicable(p)) return p.act == MS_ACT_LRELU ? "k_wgrad32<1>" : "k_wgrad32<0>";
+    if (which == 2 && msw5_applicable(p)) return msw5_name(p);
     if (which == 2 && msw_bwd_weight_applicable(p)) return msw_bwd_weight_name(p);
     if (which == 2)
         return msm_bwd_weight_applicable(p) ? msm_bwd_weight_name(p)

@@ -43,6 +43,13 @@ int msm_convt1d_bwd_weight(const ConvP& p, const float* x, const float* gy, cons
 int msm_wgrad_reduce(const float* partial, size_t stride_floats, int nsplit, size_t wsize, int nbias,
                      float* gw, float* gb, float beta, hipStream_t s);
 
+// split-bf16 weight gradient of the many-channel k5 conv on short rows (wgrad_k5.hip); MSYNTH_WGRAD5=0 disables it
+bool msw5_applicable(const ConvP& p);
+size_t msw5_ws(const ConvP& p);
+const char* msw5_name(const ConvP& p);
+int msw5_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act, float* gw, float* gb,
+                    float beta, void* ws, size_t ws_bytes, hipStream_t s);
+
 // row-tile weight gradient (wgrad_rows.hip)
 bool msw_bwd_weight_applicable(const ConvP& p);
 size_t msw_bwd_weight_ws(const ConvP& p);

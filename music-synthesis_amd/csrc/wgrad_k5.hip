@@ -1,0 +1,294 @@
+// Weight gradient of the dense k5 conv with many channels and short rows (the discriminator's 1024 -> 1024 k5 layer
+// at L = 32 / 17 / 9, reference discriminator/full.py:19) on the bf16 matrix pipe with fp32-exact operands
+// (x = x1 + x2 + x3 in bf16 pieces, the six partial products with i + j <= 4 accumulated in fp32: conv_rows3.hip).
+//
+//   gw[co, ci, k] = sum_{b, t} gp[b, co, t] * x[b, ci, t + k - 2],      gp = gy * act'(y_act)
+//
+// GEMM: M = co, N = (ci, k), contraction over (b, t).  v_mfma_f32_16x16x32_bf16 contracts 4 lane groups x 8
+// elements: a lane group is one OCTET of 8 consecutive outputs of one batch row (rows are cut into ceil(L / 8)
+// octets, zero-padded), so a step contracts 4 octets -- from one row (L = 32) or from consecutive rows.
+//   A operand: gp[co][t0 .. t0+7]: one 16-byte LDS read of the image [octet][co][8 t].
+//   B operand of tap k: x[ci][t0 + k - 2 .. t0 + k + 5] -- the same 12 staged samples shifted by k - 2 elements.
+//     The lane reads the 6 dwords D0..D5 (samples t0-2 .. t0+9) once per piece and funnels the five operands in
+//     registers: taps 0 / 2 / 4 are the dword windows D0-3 / D1-4 / D2-5, taps 1 / 3 are v_alignbit by 16 bits of
+//     neighbouring dwords -- ~12 vector instructions per piece for 5 x 4 x 6 = 120 MFMAs.
+// Workgroup = 64 co x 64 ci (wave w owns 16 ci, all four share the gp image), 20 accumulator tiles per wave held
+// across all steps; the batch is cut into `nsplit` slabs (deterministic reduce: msm_wgrad_reduce).  Staging: every
+// thread owns one (co, octet) and one (ci, octet) item per step -- global loads of step s+1 are in flight during the
+// MFMAs of step s, two LDS images, one barrier per step.
+#include "ms_common.h"
+#include "conv_mfma.h"
+#include <stdint.h>
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    const f32x2 v = {a, b};
+    const bf16x2 hi = __builtin_convertvector(v, bf16x2);
+    const f32x2 r1 = v - __builtin_convertvector(hi, f32x2);
+    const bf16x2 mi = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(mi, f32x2);
+    const bf16x2 lo = __builtin_convertvector(r2, bf16x2);
+    h = __builtin_bit_cast(unsigned, hi);
+    m = __builtin_bit_cast(unsigned, mi);
+    l = __builtin_bit_cast(unsigned, lo);
+}
+
+struct W5P {
+    int B, M, C, L, NO, nsteps, sps, act;     // NO octets per row, nsteps = ceil(B * NO / 4), sps steps per slab
+    float slope;
+    size_t stride;                            // floats per slab
+};
+
+constexpr int TCO = 64, TCI = 64;
+constexpr int A_PIECE = 4 * TCO * 16;        // [octet slot][co][8 t] bf16
+constexpr int B_PIECE = 4 * TCI * 32;        // [octet slot][ci][16 samples bf16: 12 used, halves swizzled by slot]
+constexpr int IMG = 3 * (A_PIECE + B_PIECE);
+constexpr int EPI_FLOATS = 32 * TCI * 5;     // half a tile staged for the coalesced slab write
+static_assert(2 * IMG >= EPI_FLOATS * 4, "epilogue staging fits the images");
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void k_wgrad_k5_split(W5P p, const float* __restrict__ x,
+                                                          const float* __restrict__ gy,
+                                                          const float* __restrict__ y_act,
+                                                          float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem5[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int m0 = blockIdx.x * TCO, c0 = blockIdx.y * TCI, z = blockIdx.z;
+    const int kind = y_act ? p.act : MS_ACT_NONE;
+    const int r64 = tid & 63, oc = tid >> 6;            // staging item: row (co / ci) r64 of octet slot oc
+    constexpr unsigned OOB = 0xF0000000u;
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x80000000u, 0x00020000);
+    const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy), 0, 0x80000000u, 0x00020000);
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(y_act ? y_act : gy), 0, 0x80000000u, 0x00020000);
+
+    float gv[8], ga[8], xv[12];
+    auto gload = [&](int step) {
+        const int o = 4 * step + oc;
+        const int b = o / p.NO, t0 = (o - b * p.NO) * 8;
+        const bool ov = b < p.B;
+        const unsigned grow = (unsigned)((b * p.M + m0 + r64) * p.L);
+        const unsigned xrow = (unsigned)((b * p.C + c0 + r64) * p.L);
+        if (VEC) {                                       // L % 4 == 0: aligned 16- / 8-byte loads, all-or-nothing
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned vo = (ov && t0 + 4 * j < p.L) ? (grow + (unsigned)(t0 + 4 * j)) * 4u : OOB;
+                const f32x4 g4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vo, 0, 0));
+                const f32x4 a4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { gv[4 * j + e] = g4[e]; ga[4 * j + e] = a4[e]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int t = t0 - 2 + 2 * j;
+                const unsigned vo = (ov && t >= 0 && t < p.L) ? (xrow + (unsigned)t) * 4u : OOB;
+                const f32x2 v2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsX, vo, 0, 0));
+                xv[2 * j] = v2[0]; xv[2 * j + 1] = v2[1];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned vo = (ov && t0 + e < p.L) ? (grow + (unsigned)(t0 + e)) * 4u : OOB;
+                gv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsG, vo, 0, 0));
+                ga[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, vo, 0, 0));
+            }
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                const int t = t0 - 2 + e;
+                const unsigned vo = (ov && t >= 0 && t < p.L) ? (xrow + (unsigned)t) * 4u : OOB;
+                xv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, vo, 0, 0));
+            }
+        }
+    };
+    float bsum = 0.f;
+    auto stage = [&](unsigned char* img) {
+        // gradient octet: activation derivative, split, 16 bytes per piece
+        float e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { e[k] = ms_act_grad(gv[k], ga[k], kind, p.slope); bsum += e[k]; }
+        u32x4 h, m, l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned hh, mm, ll;
+            split_pair(e[2 * q], e[2 * q + 1], hh, mm, ll);
+            h[q] = hh; m[q] = mm; l[q] = ll;
+        }
+        unsigned char* a = img + (oc * TCO + r64) * 16;
+        *reinterpret_cast<u32x4*>(a) = h;
+        *reinterpret_cast<u32x4*>(a + A_PIECE) = m;
+        *reinterpret_cast<u32x4*>(a + 2 * A_PIECE) = l;
+        // input samples t0-2 .. t0+9: dwords D0..D5, the two 16-byte halves swapped for odd slots (bank spread)
+        unsigned dh[6], dm[6], dl[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) split_pair(xv[2 * q], xv[2 * q + 1], dh[q], dm[q], dl[q]);
+        unsigned char* bq = img + 3 * A_PIECE + (oc * TCI + r64) * 32;
+        const int h0 = (oc & 1) * 16, h1 = 16 - h0;
+        *reinterpret_cast<u32x4*>(bq + h0) = (u32x4){dh[0], dh[1], dh[2], dh[3]};
+        *reinterpret_cast<u32x2*>(bq + h1) = (u32x2){dh[4], dh[5]};
+        *reinterpret_cast<u32x4*>(bq + B_PIECE + h0) = (u32x4){dm[0], dm[1], dm[2], dm[3]};
+        *reinterpret_cast<u32x2*>(bq + B_PIECE + h1) = (u32x2){dm[4], dm[5]};
+        *reinterpret_cast<u32x4*>(bq + 2 * B_PIECE + h0) = (u32x4){dl[0], dl[1], dl[2], dl[3]};
+        *reinterpret_cast<u32x2*>(bq + 2 * B_PIECE + h1) = (u32x2){dl[4], dl[5]};
+    };
+
+    f32x4 acc[4][5];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[mt][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int n = lane & 15, kg = lane >> 4;
+    const int a_rd = (kg * TCO + n) * 16;                                  // + mt * 256 + piece
+    const int b_rd = 3 * A_PIECE + (kg * TCI + 16 * wid + n) * 32;         // + piece
+    const int bh0 = (kg & 1) * 16, bh1 = 16 - bh0;
+    auto compute = [&](const unsigned char* img) {
+        bf16x8 A[4][3];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                A[mt][pc] = *reinterpret_cast<const bf16x8*>(img + a_rd + mt * 256 + pc * A_PIECE);
+        unsigned D[3][6];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(img + b_rd + pc * B_PIECE + bh0);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(img + b_rd + pc * B_PIECE + bh1);
+            D[pc][0] = lo[0]; D[pc][1] = lo[1]; D[pc][2] = lo[2]; D[pc][3] = lo[3]; D[pc][4] = hi[0]; D[pc][5] = hi[1];
+        }
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            bf16x8 Bo[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                u32x4 v;
+                if ((k & 1) == 0) {
+                    v = (u32x4){D[pc][k / 2], D[pc][k / 2 + 1], D[pc][k / 2 + 2], D[pc][k / 2 + 3]};
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        v[q] = __builtin_amdgcn_alignbit(D[pc][k / 2 + q + 1], D[pc][k / 2 + q], 16);
+                }
+                Bo[pc] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt][PA[i]], Bo[PB[i]], acc[mt][k], 0, 0, 0);
+        }
+    };
+
+    const int s_beg = z * p.sps, s_end = min(p.nsteps, s_beg + p.sps);
+    unsigned char* img0 = smem5;
+    unsigned char* img1 = smem5 + IMG;
+    if (s_beg < s_end) {
+        gload(s_beg);
+        stage(img0);
+    }
+    __syncthreads();
+    for (int s = s_beg; s < s_end; ++s) {
+        const bool more = s + 1 < s_end;
+        unsigned char* cur = ((s - s_beg) & 1) ? img1 : img0;
+        unsigned char* nxt = ((s - s_beg) & 1) ? img0 : img1;
+        if (more) gload(s + 1);
+        compute(cur);
+        if (more) stage(nxt);
+        __syncthreads();
+    }
+
+    // ---- slab: the tile is staged through LDS in two halves of 32 co so that rows of 64 ci x 5 taps (1280
+    // contiguous bytes of gw) leave as 16-byte vectors
+    float* part = partial + (size_t)z * p.stride;
+    float* ts = reinterpret_cast<float*>(smem5);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ts[((ml * 16 + 4 * kg + r) * TCI + 16 * wid + n) * 5 + k] = acc[2 * half + ml][k][r];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < EPI_FLOATS / 4 / 256; ++q) {
+            const int idx = tid + 256 * q;                 // 16-byte vector of the half tile: row = idx / 80
+            const int row = idx / 80, c4 = idx - row * 80;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ts + row * 320 + 4 * c4);
+            *reinterpret_cast<f32x4*>(part + ((size_t)(m0 + 32 * half + row) * p.C + c0) * 5 + 4 * c4) = v;
+        }
+        __syncthreads();
+    }
+    // bias gradient (ci tile 0 only): the four octet slots of a co sit in the four waves
+    if (blockIdx.y == 0) {
+        ts[oc * TCO + r64] = bsum;
+        __syncthreads();
+        if (tid < TCO)
+            part[(size_t)p.M * p.C * 5 + m0 + tid] = (ts[tid] + ts[TCO + tid]) + (ts[2 * TCO + tid] + ts[3 * TCO + tid]);
+    }
+}
+
+int pick_nsplit(const ConvP& p, int nsteps) {
+    const int tiles = (p.Cout / TCO) * (p.Cin / TCI);
+    int ns = (512 + tiles - 1) / tiles;                     // ~2 workgroups per CU
+    if (ns > nsteps / 4) ns = nsteps / 4;                   // at least 4 steps per slab
+    const size_t slab = ((size_t)p.Cout * p.Cin * 5 + p.Cout) * sizeof(float);
+    while (ns > 1 && (size_t)ns * slab > ((size_t)96 << 20)) --ns;
+    return ns < 1 ? 1 : ns;
+}
+
+}  // namespace
+
+bool msw5_applicable(const ConvP& p) {
+    const char* e = getenv("MSYNTH_WGRAD5");          // tuning / test switch (0: fp32-MFMA row-tile kernel)
+    if (e && atoi(e) == 0) return false;
+    return p.groups == 1 && p.stride == 1 && p.dil == 1 && p.K == 5 && p.pad == 2 && p.Lout == p.Lin &&
+           p.pad_mode == MS_PAD_ZERO && !p.in_act && p.Cout % TCO == 0 && p.Cin % TCI == 0 && p.Cout >= 256 &&
+           p.Cin >= 256 && p.Lin <= 64 && (long long)p.B * p.Cout * p.Lin * 4 < (1ll << 31) &&
+           (long long)p.B * p.Cin * p.Lin * 4 < (1ll << 31);
+}
+
+size_t msw5_ws(const ConvP& p) {
+    const int NO = (p.Lin + 7) / 8, nsteps = (p.B * NO + 3) / 4;
+    return (size_t)pick_nsplit(p, nsteps) * ((size_t)p.Cout * p.Cin * 5 + p.Cout) * sizeof(float);
+}
+
+const char* msw5_name(const ConvP&) { return "k_wgrad_k5_split"; }
+
+int msw5_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act, float* gw, float* gb,
+                    float beta, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!ws || ws_bytes < msw5_ws(p) || (((uintptr_t)ws) & 15)) return MS_ERR_WORKSPACE;
+    W5P q;
+    q.B = p.B; q.M = p.Cout; q.C = p.Cin; q.L = p.Lin; q.NO = (p.Lin + 7) / 8;
+    q.nsteps = (p.B * q.NO + 3) / 4;
+    const int ns = pick_nsplit(p, q.nsteps);
+    q.sps = (q.nsteps + ns - 1) / ns;
+    q.act = p.act; q.slope = p.slope;
+    q.stride = (size_t)p.Cout * p.Cin * 5 + p.Cout;
+    const int nz = (q.nsteps + q.sps - 1) / q.sps;
+    const dim3 grid(p.Cout / TCO, p.Cin / TCI, nz);
+    const bool vec = p.Lin % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)gy) & 15) == 0 &&
+                     (!y_act || (((uintptr_t)y_act) & 15) == 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_k5_split<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_k5_split<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG);
+        attr_set = true;
+    }
+    float* partial = (float*)ws;
+    if (vec) hipLaunchKernelGGL((k_wgrad_k5_split<true>), grid, dim3(256), 2 * IMG, s, q, x, gy, y_act, partial);
+    else hipLaunchKernelGGL((k_wgrad_k5_split<false>), grid, dim3(256), 2 * IMG, s, q, x, gy, y_act, partial);
+    MS_CHECK_LAUNCH();
+    return msm_wgrad_reduce(partial, q.stride, nz, (size_t)p.Cout * p.Cin * 5, p.Cout, gw, gb, beta, s);
+}

@@ -236,6 +236,12 @@ HOT_CONVS = [
     ("g3_og4_l128", 3, 1024, 128, 1024, 41, 4, 20, 1, 256, 1, False),
     ("g3_og4_l65", 2, 512, 65, 512, 41, 4, 20, 1, 128, 1, False),
     ("d_k5", 2, 1024, 17, 1024, 5, 1, 2, 1, 1, 1, False),
+    # split-bf16 k5 weight gradient (wgrad_k5.hip: >= 256 channels both sides, rows <= 64): octets from one / several
+    # batch rows per step, ragged last octet and last step, aligned and unaligned rows, no activation
+    ("w5_l33_b3", 3, 256, 33, 320, 5, 1, 2, 1, 1, 1, False),
+    ("w5_l12_noact", 5, 320, 12, 256, 5, 1, 2, 1, 1, 0, False),
+    ("w5_l7", 2, 256, 7, 256, 5, 1, 2, 1, 1, 1, False),
+    ("w5_l64_b9", 9, 256, 64, 256, 5, 1, 2, 1, 1, 1, False),
     # >= 1000 columns of an odd row length: rows padded to a multiple of 4 for the 16-byte kernels (api.hip pad4)
     ("d_k5_l17_padded", 61, 256, 17, 272, 5, 1, 2, 1, 1, 1, False),
     ("d_k5_l33_padded", 31, 256, 33, 256, 5, 1, 2, 1, 1, 0, False),
