@@ -378,6 +378,7 @@ const char* ms_convt1d_kernel_name(const ms_convt1d_desc* d, int which) {
         return msm_fwd_applicable(q) ? msm_fwd_name(q) : msk_conv1d_fwd_direct_name(q);
     }
     if (which == 2) {
+        if (mswt8_applicable(p)) return mswt8_name(p);
         if (msm_convt_bwd_applicable(p)) return msm_convt_bwd_weight_name(p);
         return msm_bwd_weight_applicable(p) ? msm_bwd_weight_name(p) : msk_conv1d_bwd_weight_direct_name(p);
     }
@@ -428,8 +429,11 @@ int ms_convt1d_bwd_weight(const ms_convt1d_desc* d, const float* x, const float*
     if (!make_convt(d, &p) || !x || !gy || !gw) return MS_ERR_INVALID_ARG;
     if (beta != 0.f && beta != 1.f) return MS_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
-    int rc;
-    if (msm_convt_bwd_applicable(p))
+    int rc = MS_ERR_UNSUPPORTED;
+    if (mswt8_applicable(p) && workspace && workspace_bytes >= mswt8_ws(p) + msk_channel_sum_ws(p.Cin) + 32)
+        rc = mswt8_bwd_weight(p, x, gy, y_act, gw, beta, workspace, workspace_bytes, s);
+    if (rc != MS_ERR_UNSUPPORTED) {
+    } else if (msm_convt_bwd_applicable(p))
         rc = msm_convt1d_bwd_weight(p, x, gy, y_act, gw, beta, workspace, workspace_bytes, s);
     else if (msm_bwd_weight_applicable(p))
         rc = msm_conv1d_bwd_weight(p, gy, y_act, p.act, x, p.in_act ? x : nullptr,
@@ -463,8 +467,11 @@ size_t ms_convt1d_workspace_bytes(const ms_convt1d_desc* d, int which) {
     }
     if (which == 2) {
         const size_t tail = msk_channel_sum_ws(p.Cin) + 32;   // bias-grad slice partials
-        if (msm_convt_bwd_applicable(p)) return msm_convt_bwd_weight_ws(p) + tail;
-        return (msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p)) + tail;
+        const size_t t8 = mswt8_applicable(p) ? mswt8_ws(p) : 0;
+        size_t n = msm_convt_bwd_applicable(p) ? msm_convt_bwd_weight_ws(p)
+                   : (msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p));
+        if (t8 > n) n = t8;
+        return n + tail;
     }
     return 0;
 }

@@ -50,6 +50,13 @@ const char* msw5_name(const ConvP& p);
 int msw5_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act, float* gw, float* gb,
                     float beta, void* ws, size_t ws_bytes, hipStream_t s);
 
+// split-bf16 weight gradient of the stride-8 / kernel-16 transposed conv (wgrad_convt.hip); MSYNTH_WGRADT8=0 disables
+bool mswt8_applicable(const ConvP& p);
+size_t mswt8_ws(const ConvP& p);
+const char* mswt8_name(const ConvP& p);
+int mswt8_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act, float* gw, float beta,
+                     void* ws, size_t ws_bytes, hipStream_t s);
+
 // row-tile weight gradient (wgrad_rows.hip)
 bool msw_bwd_weight_applicable(const ConvP& p);
 size_t msw_bwd_weight_ws(const ConvP& p);

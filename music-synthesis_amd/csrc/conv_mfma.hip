@@ -1306,6 +1306,8 @@ const char* row_kname(RowCfg c, int K, bool act, int CK, int L = 0, int R = 1, i
             Row2P h = q;
             h.B = B; h.M = M > 0 ? M : 64; h.CK = CK; h.CKs = CK; h.PX = R * SS; h.Lt = L >= bn ? bn : L;
             h.tiles_per_row = L >= bn ? (L + bn - 1) / bn : 1;
+            h.dil = K > 1 ? (SS - h.Lt) / (K - 1) : 1;        // SS = Lt + (K - 1) dil (rows3p_retile rebuilds it)
+            if (h.dil < 1) h.dil = 1;
             if (const int bmp = B > 0 ? rows3p_bm(h, bn, K, am, epi_s, 1, 1) : 0) {
                 snprintf(buf, sizeof(buf), "k_conv_rows3p<%s, %d, %d>", bmp == 128 ? "2, 2, 2" : (bmp == 64 ? "2, 1, 2" : "1, 1, 1"), K, am);
                 return buf;
