@@ -408,7 +408,7 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
                                                     const float* __restrict__ bias,
                                                     const float* __restrict__ res,
                                                     float* __restrict__ Y,
-                                                    float* __restrict__ Yact, int seq) {
+                                                    float* __restrict__ Yact) {
     constexpr int WGN = 4 / WGM, BM = WGM * TM * 32, BN = WGN * TN * 32;
     static_assert(BN == 128, "a group owns one 128-column tile");
     constexpr int KA = HS ? 2 : K;                             // weight taps per row
@@ -423,12 +423,7 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
     const int wm = gw / WGN, wn = gw % WGN;
     unsigned char* const Xg = smem3 + 2 * a_bytes + g * x_bytes;
     const int m0 = blockIdx.y * BM;
-    float* const Ybase = Y;
-    // `seq` tile pairs per workgroup, one after the other: the stores of pair i drain to HBM while the K loop of
-    // pair i+1 runs (with one pair per workgroup and one workgroup per CU, every CU computes, then every CU stores)
-    for (int it = 0; it < seq; ++it) {
-    const int ti = 2 * (blockIdx.x * seq + it) + g;
-    Y = Ybase;
+    const int ti = 2 * blockIdx.x + g;
     int b0, t0;
     if (p.R == 1) { b0 = ti / p.tiles_per_row; t0 = (ti - b0 * p.tiles_per_row) * BN; }
     else { b0 = ti * p.R; t0 = 0; }
@@ -711,7 +706,8 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
                 *reinterpret_cast<float4*>(Y + ((size_t)(b0 + r) * Cout + co) * ((size_t)p.L * S) +
                                            (size_t)(t0 + tc) * S + ph0) = v;
         }
-    } else {
+        return;
+    }
     float4 tv[NQ], rv[NQ];
     size_t go[NQ];
     bool ok[NQ];
@@ -734,9 +730,6 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
         if (res) { v.x += rv[q].x; v.y += rv[q].y; v.z += rv[q].z; v.w += rv[q].w; }
         *reinterpret_cast<float4*>(Y + go[q]) = v;
     }
-    }
-    __syncthreads();                 // the transposed tile is read out before the next pair's staging reuses LDS
-    }
 }
 
 template <int BM, int K>
@@ -748,8 +741,7 @@ size_t ldsp_bytes(const Row2P& p) {
 
 template <int WGM, int TM, int TN, int K, int AM, int HS = 0, bool INA = false>
 int launch_pair(const Row2P& p, const float* X, const float* Xact, const float* W, const float* bias,
-                const float* res, float* Y, float* Yact, dim3 grid, hipStream_t s, int seq = 1) {
-    if (seq > 1) grid.x = (grid.x + seq - 1) / seq;
+                const float* res, float* Y, float* Yact, dim3 grid, hipStream_t s) {
     const size_t by = ldsp_bytes<WGM * TM * 32, HS ? 2 : K>(p);
     const size_t lds = by + 512 * 8;
     if (lds > 158 * 1024) return MS_ERR_UNSUPPORTED;
@@ -762,7 +754,7 @@ int launch_pair(const Row2P& p, const float* X, const float* Xact, const float* 
     Row2P pp = p;
     pp.scratch_off = (int)by;
     hipLaunchKernelGGL((k_conv_rows3p<WGM, TM, TN, K, AM, HS, INA>), grid, dim3(512), lds, s, pp, X, Xact, W, bias, res,
-                       Y, Yact, seq);
+                       Y, Yact);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }
@@ -868,11 +860,7 @@ int msr3p_launch(int bm, int K, int act_mode, const Row2P& p, const float* X, co
                  const float* bias, const float* res, float* Y, float* Yact, unsigned gz, hipStream_t s) {
     const unsigned ntiles = p.R == 1 ? (unsigned)(p.B * p.tiles_per_row) : (unsigned)((p.B + p.R - 1) / p.R);
     const dim3 grid((ntiles + 1) / 2, (unsigned)((p.M + bm - 1) / bm), gz);
-    // two tile pairs per workgroup where that still leaves one workgroup per CU: the stores of the first pair drain
-    // while the second pair's K loop runs (C = 64 / 32 atoms: 42 -> 40 us, 40 -> 37 us); MSYNTH_R3P_SEQ=1 disables
-    static const int seq_max = getenv("MSYNTH_R3P_SEQ") ? atoi(getenv("MSYNTH_R3P_SEQ")) : 2;
-    const int seq = (seq_max > 1 && grid.x * grid.y * grid.z >= 256u * seq_max) ? seq_max : 1;
-#define MS3P(WGM_, TM_, TN_, K_, A_) return launch_pair<WGM_, TM_, TN_, K_, A_>(p, X, Xact, W, bias, res, Y, Yact, grid, s, seq)
+#define MS3P(WGM_, TM_, TN_, K_, A_) return launch_pair<WGM_, TM_, TN_, K_, A_>(p, X, Xact, W, bias, res, Y, Yact, grid, s)
     if (bm == 128) {
         if (K == 3 && act_mode == 0) MS3P(2, 2, 2, 3, 0);
         if (K == 3 && act_mode == 1) MS3P(2, 2, 2, 3, 1);
