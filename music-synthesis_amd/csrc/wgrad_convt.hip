@@ -11,7 +11,7 @@
 //     (8 bf16) apart -- gfx950's transposing LDS read (ds_read_b64_tr_b16: 16 lanes supply 4 row addresses x 4 column
 //     quads, receive column-major data) delivers it from a plain bf16 copy of the row, as in gconv_split.hip's weight
 //     gradient; no phase-split image.
-// Workgroup = 64 ci x 16 co (wave w owns 16 ci and all 16 co: 16 accumulator tiles), the (b, q) range is cut into
+// Workgroup = 128 ci x 16 co (8 waves; wave w owns 16 ci and all 16 co: 16 accumulator tiles), the (b, q) range is cut into
 // `nsplit` slabs (deterministic reduce: msm_wgrad_reduce).  Staging as in wgrad_k5.hip: global loads of step s+1 in
 // flight during the MFMAs of step s, two LDS images, one barrier per step.  The LeakyReLU in front of the transposed
 // conv (in_act) is applied to x on its way into LDS.  The bias gradient is a separate channel sum (api.hip).
@@ -50,7 +50,8 @@ struct W8P {
 };
 
 constexpr int TS = 8, TK = 16;                 // stride, taps
-constexpr int TCI = 64, TCO = 16;              // workgroup tile
+constexpr int TCI = 128, TCO = 16;             // workgroup tile: 8 waves x 16 ci, every wave all 16 co
+constexpr int NT = 4 * TCI;                    // threads: one (ci, octet) input item each
 constexpr int QS = 32;                         // input positions per step
 constexpr int A_PIECE = 4 * TCI * 16;          // [octet slot][ci][8 q] bf16
 constexpr int GSPAN = QS * TS + TK;            // 272 gradient samples per (co, step)
@@ -58,9 +59,9 @@ constexpr int GQ = GSPAN / 4;                  // 68 quads
 constexpr int GROW = GSPAN * 2 + 16;           // bytes per LDS gradient row (16-byte multiple)
 constexpr int B_PIECE = TCO * GROW;
 constexpr int IMG = 3 * (A_PIECE + B_PIECE);
-constexpr int NGI = (TCO * GQ + 255) / 256;    // gradient quads per thread and step
+constexpr int NGI = (TCO * GQ + NT - 1) / NT;  // gradient quads per thread and step
 
-__global__ __launch_bounds__(256, 2) void k_wgrad_convt8_split(W8P p, const float* __restrict__ x,
+__global__ __launch_bounds__(NT) void k_wgrad_convt8_split(W8P p, const float* __restrict__ x,
                                                               const float* __restrict__ gy,
                                                               const float* __restrict__ y_act,
                                                               float* __restrict__ partial) {
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_convt8_split(W8P p, const floa
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c0 = blockIdx.x * TCI, o0 = blockIdx.y * TCO, z = blockIdx.z;
     const int kind = y_act ? p.act : MS_ACT_NONE;
-    const int r64 = tid & 63, oc = tid >> 6;
+    const int r64 = tid % TCI, oc = tid / TCI;            // input item: channel r64 of octet slot oc
     const int Lg = p.L * TS;
     constexpr unsigned OOB = 0xF0000000u;
     const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x80000000u, 0x00020000);
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_convt8_split(W8P p, const floa
     int g_co[NGI], g_q[NGI];
 #pragma unroll
     for (int i = 0; i < NGI; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + NT * i;
         const int co = idx / GQ;
         g_co[i] = co < TCO ? co : -1;
         g_q[i] = idx - co * GQ;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_convt8_split(W8P p, const floa
 
 int pick_nsplit8(const ConvP& p, int nsteps) {
     const int tiles = (p.Cout / TCI) * (p.Cin / TCO);
-    int ns = (512 + tiles - 1) / tiles;
+    int ns = (256 + tiles - 1) / tiles;                     // one 8-wave workgroup per CU
     if (ns > nsteps / 2) ns = nsteps / 2;
     const size_t slab = (size_t)p.Cout * p.Cin * TK * sizeof(float);
     while (ns > 1 && (size_t)ns * slab > ((size_t)64 << 20)) --ns;
@@ -243,7 +244,7 @@ int mswt8_bwd_weight(const ConvP& p, const float* x, const float* gy, const floa
         attr_set = true;
     }
     float* partial = (float*)ws;
-    hipLaunchKernelGGL(k_wgrad_convt8_split, dim3(p.Cout / TCI, p.Cin / TCO, nz), dim3(256), 2 * IMG, s, q, x, gy,
+    hipLaunchKernelGGL(k_wgrad_convt8_split, dim3(p.Cout / TCI, p.Cin / TCO, nz), dim3(NT), 2 * IMG, s, q, x, gy,
                        y_act, partial);
     MS_CHECK_LAUNCH();
     return msm_wgrad_reduce(partial, q.stride, nz, q.stride, 0, gw, nullptr, beta, s);

@@ -323,7 +323,7 @@ def test_conv_hot_shapes_vs_oracle(case):
 HOT_CONVT = [("ct_512_256", 2, 512, 9, 256, 16, 8, 4),
              # input lengths that are multiples of 32: the split-bf16 stride-8 weight gradient (wgrad_convt.hip), one and
              # several steps per row, a ragged last slab
-             ("ct_w8_l32", 3, 128, 32, 48, 16, 8, 4), ("ct_w8_l96", 5, 64, 96, 16, 16, 8, 4), ("ct_256_128", 1, 256, 70, 128, 16, 8, 4),
+             ("ct_w8_l32", 3, 128, 32, 48, 16, 8, 4), ("ct_w8_l96", 5, 128, 96, 16, 16, 8, 4), ("ct_256_128", 1, 256, 70, 128, 16, 8, 4),
              ("ct_128_64", 2, 128, 130, 64, 4, 2, 1), ("ct_64_32", 1, 64, 1027, 32, 4, 2, 1),
              # lengths the pipelined kernels take (L % 4 == 0): one-chunk rows, chunk tails, batch tails
              ("ct_512_256_l32", 3, 512, 32, 256, 16, 8, 4), ("ct_256_128_l132", 1, 256, 132, 128, 16, 8, 4),
