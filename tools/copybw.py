@@ -1,3 +1,5 @@
+"""Practical HBM copy / read / write bandwidth of torch elementwise kernels at several sizes (the yardstick for the
+HBM-bound kernels: 33.5 MB in + 33.5 MB out copies in ~10 us on an MI355X)."""
 import torch
 def t(fn, n=50):
     for _ in range(5): fn()
