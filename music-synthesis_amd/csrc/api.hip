@@ -370,6 +370,8 @@ const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which) {
 const char* ms_convt1d_kernel_name(const ms_convt1d_desc* d, int which) {
     ConvP p;
     if (!make_convt(d, &p)) return "";
+    if (which == 0 && mst_convt1_applicable(p)) return mst_convt1_fwd_name();
+    if (which == 2 && mst_convt1_applicable(p)) return mst_convt1_wgrad_name();
     if (which == 0) return msm_convt_fwd_applicable(p) ? msm_convt_fwd_name(p) : msk_conv1d_bwd_data_direct_name(p);
     if (which == 1) {
         if (msm_convt_bwd_applicable(p)) return msm_convt_bwd_data_name(p);
@@ -396,6 +398,7 @@ int ms_convt1d_fwd(const ms_convt1d_desc* d, const float* x, const float* w, con
     ConvP p;
     if (!make_convt(d, &p) || !x || !w || !y) return MS_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (mst_convt1_applicable(p)) return mst_convt1_fwd(p, x, w, bias, y, s);      // one output channel: a stream
     if (msm_convt_fwd_applicable(p))
         return msm_convt1d_fwd(p, x, w, bias, y, workspace, workspace_bytes, s);
     ConvP q = p;     // direct path: the loader modifier kind rides in q.act, the epilogue gets p.act
@@ -430,7 +433,9 @@ int ms_convt1d_bwd_weight(const ms_convt1d_desc* d, const float* x, const float*
     if (beta != 0.f && beta != 1.f) return MS_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     int rc = MS_ERR_UNSUPPORTED;
-    if (mswt8_applicable(p) && workspace && workspace_bytes >= mswt8_ws(p) + msk_channel_sum_ws(p.Cin) + 32)
+    if (mst_convt1_applicable(p) && workspace && workspace_bytes >= mst_convt1_wgrad_ws(p) + msk_channel_sum_ws(p.Cin) + 32)
+        rc = mst_convt1_bwd_weight(p, x, gy, y_act, gw, beta, workspace, workspace_bytes, s);
+    else if (mswt8_applicable(p) && workspace && workspace_bytes >= mswt8_ws(p) + msk_channel_sum_ws(p.Cin) + 32)
         rc = mswt8_bwd_weight(p, x, gy, y_act, gw, beta, workspace, workspace_bytes, s);
     if (rc != MS_ERR_UNSUPPORTED) {
     } else if (msm_convt_bwd_applicable(p))
@@ -467,7 +472,8 @@ size_t ms_convt1d_workspace_bytes(const ms_convt1d_desc* d, int which) {
     }
     if (which == 2) {
         const size_t tail = msk_channel_sum_ws(p.Cin) + 32;   // bias-grad slice partials
-        const size_t t8 = mswt8_applicable(p) ? mswt8_ws(p) : 0;
+        size_t t8 = mswt8_applicable(p) ? mswt8_ws(p) : 0;
+        if (mst_convt1_applicable(p) && mst_convt1_wgrad_ws(p) > t8) t8 = mst_convt1_wgrad_ws(p);
         size_t n = msm_convt_bwd_applicable(p) ? msm_convt_bwd_weight_ws(p)
                    : (msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p));
         if (t8 > n) n = t8;

@@ -17,3 +17,13 @@ int mst_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, con
 int mst_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act,
                           float* gw, float* gb, float beta, void* ws, size_t ws_bytes,
                           hipStream_t s);
+
+// ConvTranspose1d with one output channel, stride 2 / kernel 4 / padding 1 (stage-1 generator's last layer): HBM-bound
+// streams.  p = mirrored conv (Cin_T = p.Cout, Cout_T = p.Cin = 1).
+bool mst_convt1_applicable(const ConvP& p);
+const char* mst_convt1_fwd_name();
+const char* mst_convt1_wgrad_name();
+int mst_convt1_fwd(const ConvP& p, const float* x, const float* w, const float* bias, float* y, hipStream_t s);
+size_t mst_convt1_wgrad_ws(const ConvP& p);
+int mst_convt1_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act, float* gw, float beta,
+                          void* ws, size_t ws_bytes, hipStream_t s);

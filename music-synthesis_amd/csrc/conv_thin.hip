@@ -10,6 +10,7 @@
 // K + 3 samples, the many-channel operand ("stream") as one 16-byte access per channel.
 #include "ms_common.h"
 #include "conv_thin.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -447,4 +448,157 @@ int mst_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const
     }
     MS_CHECK_LAUNCH();
     return msk_reduce_partials(partial, ps, nch, (size_t)p.Cout * p.Cin * p.K, p.Cout, gw, gb, beta, s);
+}
+
+// ---------------------------------------------------------------- ConvTranspose1d with ONE output channel
+// (stride 2, kernel 4, padding 1: the last layer of the stage-1 2-D generator as a transposed conv over lines,
+// reference featuregenerator/upscale.py:77-112).  HBM-bound streams: the forward reads C x L inputs per line and
+// writes 2 L outputs, the weight gradient reads the same inputs and reduces them to C x 4 numbers.
+//   y[2q]   = b + sum_ci w[ci][1] x[ci][q] + w[ci][3] x[ci][q-1]
+//   y[2q+1] = b + sum_ci w[ci][2] x[ci][q] + w[ci][0] x[ci][q+1]
+// p = mirrored conv: Cin_T = p.Cout, Cout_T = p.Cin = 1, Lin_T = p.Lout.
+namespace {
+
+// one thread: 4 consecutive input positions of one line -> 8 outputs; lanes run along the line (coalesced rows)
+template <bool INA>
+__global__ __launch_bounds__(256) void k_convt1_fwd(int B, int C, int L, int act, float slope,
+                                                   const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ y) {
+    const int nq = (L + 3) / 4;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)B * nq) return;
+    const int b = (int)(gid / nq), q0 = (int)(gid - (long long)b * nq) * 4;
+    const float* xb = x + (size_t)b * C * L;
+    float ev[4] = {0.f, 0.f, 0.f, 0.f}, od[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool full = q0 + 3 < L && (L % 4 == 0);
+    for (int ci = 0; ci < C; ++ci) {
+        const float* xr = xb + (size_t)ci * L;
+        float v[6];                                     // x[q0 - 1 .. q0 + 4]
+        if (full) {
+            const float4 c4 = *reinterpret_cast<const float4*>(xr + q0);
+            v[1] = c4.x; v[2] = c4.y; v[3] = c4.z; v[4] = c4.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[1 + e] = q0 + e < L ? xr[q0 + e] : 0.f;
+        }
+        v[0] = q0 > 0 ? xr[q0 - 1] : 0.f;
+        v[5] = q0 + 4 < L ? xr[q0 + 4] : 0.f;
+        if (INA) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+        }
+        const float w0 = w[ci * 4], w1 = w[ci * 4 + 1], w2 = w[ci * 4 + 2], w3 = w[ci * 4 + 3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ev[e] = fmaf(w1, v[1 + e], fmaf(w3, v[e], ev[e]));
+            od[e] = fmaf(w2, v[1 + e], fmaf(w0, v[2 + e], od[e]));
+        }
+    }
+    const float bv = bias ? bias[0] : 0.f;
+    float* yr = y + (size_t)b * 2 * L + 2 * q0;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o[2 * e] = ms_apply_act(ev[e] + bv, act, slope);
+        o[2 * e + 1] = ms_apply_act(od[e] + bv, act, slope);
+    }
+    if (full && (((uintptr_t)yr) & 15) == 0) {
+        *reinterpret_cast<float4*>(yr) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(yr + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (q0 + e / 2 < L) yr[e] = o[e];
+    }
+}
+
+// weight gradient: gw[ci][k] = sum_{b,q} x[ci][q] gp[2q + k - 1].  A workgroup owns a slice of lines; per line the
+// threads hold the four gradient samples around their positions and walk the channels; every channel's four sums are
+// reduced over the workgroup and accumulated in LDS; one slab [C][4] per workgroup (deterministic reduce after).
+template <bool INA>
+__global__ __launch_bounds__(256) void k_convt1_wgrad(int B, int C, int L, int act, float slope, int lines_per_wg,
+                                                     const float* __restrict__ x, const float* __restrict__ gy,
+                                                     const float* __restrict__ y_act, float* __restrict__ partial) {
+    extern __shared__ float accs[];                     // [C][4] sums of this workgroup, then 4 x [C][4] wave partials
+    float* wsum = accs + C * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < C * 4; i += 256) accs[i] = 0.f;
+    __syncthreads();
+    const int b_beg = blockIdx.x * lines_per_wg, b_end = min(B, b_beg + lines_per_wg);
+    const int kind = y_act ? act : MS_ACT_NONE;
+    for (int b = b_beg; b < b_end; ++b) {
+        const float* gr = gy + (size_t)b * 2 * L;
+        const float* ar = y_act ? y_act + (size_t)b * 2 * L : gr;
+        for (int q0 = 0; q0 < L; q0 += 256) {
+            const int q = q0 + tid;
+            float g[4];                                 // gp[2q - 1 .. 2q + 2]
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = 2 * q + k - 1;
+                g[k] = (q < L && t >= 0 && t < 2 * L) ? ms_act_grad(gr[t], ar[t], kind, slope) : 0.f;
+            }
+            for (int ci = 0; ci < C; ++ci) {
+                float v = q < L ? x[((size_t)b * C + ci) * L + q] : 0.f;
+                if (INA) v = v > 0.f ? v : v * slope;
+                float s4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float r = v * g[k];
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) r += __shfl_xor(r, o, 64);
+                    s4[k] = r;
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) wsum[(wv * C + ci) * 4 + k] = s4[k];
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < C * 4; i += 256)
+                accs[i] += (wsum[i] + wsum[C * 4 + i]) + (wsum[2 * C * 4 + i] + wsum[3 * C * 4 + i]);
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < C * 4; i += 256) partial[(size_t)blockIdx.x * C * 4 + i] = accs[i];
+}
+
+bool convt1_geom(const ConvP& p) {
+    return p.Cin == 1 && p.groups == 1 && p.stride == 2 && p.K == 4 && p.pad == 1 && p.dil == 1 &&
+           p.Lin == 2 * p.Lout && p.Cout >= 1 && p.Cout <= 512 && (long long)p.B * ((p.Lout + 3) / 4) < (1ll << 31);
+}
+int convt1_lines_per_wg(const ConvP& p) { return ms_ceil_div(p.B, 512); }
+
+}  // namespace
+
+bool mst_convt1_applicable(const ConvP& p) {
+    const char* e = getenv("MSYNTH_CONVT1");          // tuning / test switch (0: direct kernels)
+    if (e && atoi(e) == 0) return false;
+    return convt1_geom(p);
+}
+const char* mst_convt1_fwd_name() { return "k_convt1_fwd"; }
+const char* mst_convt1_wgrad_name() { return "k_convt1_wgrad"; }
+
+int mst_convt1_fwd(const ConvP& p, const float* x, const float* w, const float* bias, float* y, hipStream_t s) {
+    const long long n = (long long)p.B * ((p.Lout + 3) / 4);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (p.in_act) hipLaunchKernelGGL((k_convt1_fwd<true>), dim3(nb), dim3(256), 0, s, p.B, p.Cout, p.Lout, p.act, p.slope, x, w, bias, y);
+    else hipLaunchKernelGGL((k_convt1_fwd<false>), dim3(nb), dim3(256), 0, s, p.B, p.Cout, p.Lout, p.act, p.slope, x, w, bias, y);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+size_t mst_convt1_wgrad_ws(const ConvP& p) {
+    return (size_t)ms_ceil_div(p.B, convt1_lines_per_wg(p)) * p.Cout * 4 * sizeof(float);
+}
+
+int mst_convt1_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act, float* gw, float beta,
+                          void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!ws || ws_bytes < mst_convt1_wgrad_ws(p)) return MS_ERR_WORKSPACE;
+    const int lpw = convt1_lines_per_wg(p), nwg = ms_ceil_div(p.B, lpw);
+    const size_t lds = (size_t)5 * p.Cout * 4 * sizeof(float);
+    float* partial = (float*)ws;
+    if (p.in_act) hipLaunchKernelGGL((k_convt1_wgrad<true>), dim3(nwg), dim3(256), lds, s, p.B, p.Cout, p.Lout, p.act, p.slope, lpw, x, gy, y_act, partial);
+    else hipLaunchKernelGGL((k_convt1_wgrad<false>), dim3(nwg), dim3(256), lds, s, p.B, p.Cout, p.Lout, p.act, p.slope, lpw, x, gy, y_act, partial);
+    MS_CHECK_LAUNCH();
+    return msk_reduce_partials(partial, (size_t)p.Cout * 4, nwg, (size_t)p.Cout * 4, 0, gw, nullptr, beta, s);
 }

@@ -323,6 +323,9 @@ def test_conv_hot_shapes_vs_oracle(case):
 HOT_CONVT = [("ct_512_256", 2, 512, 9, 256, 16, 8, 4),
              # input lengths that are multiples of 32: the split-bf16 stride-8 weight gradient (wgrad_convt.hip), one and
              # several steps per row, a ragged last slab
+             # one output channel, stride 2 (stage-1 generator's last layer as lines): stream kernels, aligned / ragged rows
+             ("ct_thin_c96_l256", 5, 96, 256, 1, 4, 2, 1), ("ct_thin_c40_l131", 3, 40, 131, 1, 4, 2, 1),
+             ("ct_thin_c8_l600", 2, 8, 600, 1, 4, 2, 1),
              ("ct_w8_l32", 3, 128, 32, 48, 16, 8, 4), ("ct_w8_l96", 5, 128, 96, 16, 16, 8, 4), ("ct_256_128", 1, 256, 70, 128, 16, 8, 4),
              ("ct_128_64", 2, 128, 130, 64, 4, 2, 1), ("ct_64_32", 1, 64, 1027, 32, 4, 2, 1),
              # lengths the pipelined kernels take (L % 4 == 0): one-chunk rows, chunk tails, batch tails
