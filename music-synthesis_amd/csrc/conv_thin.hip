@@ -512,54 +512,59 @@ __global__ __launch_bounds__(256) void k_convt1_fwd(int B, int C, int L, int act
     }
 }
 
-// weight gradient: gw[ci][k] = sum_{b,q} x[ci][q] gp[2q + k - 1].  A workgroup owns a slice of lines; per line the
-// threads hold the four gradient samples around their positions and walk the channels; every channel's four sums are
-// reduced over the workgroup and accumulated in LDS; one slab [C][4] per workgroup (deterministic reduce after).
+// weight gradient: gw[ci][k] = sum_{b,q} x[ci][q] gp[2q + k - 1].  A workgroup owns a slice of lines.  Channels are
+// walked in groups of 8: a thread accumulates its positions of ALL the workgroup's lines into 8 x 4 registers and the
+// group is reduced over the workgroup once (reducing per line cost 24 shuffles per channel and line: slower than the
+// direct kernel it replaced).  One slab [C][4] per workgroup, deterministic reduce after.
 template <bool INA>
 __global__ __launch_bounds__(256) void k_convt1_wgrad(int B, int C, int L, int act, float slope, int lines_per_wg,
                                                      const float* __restrict__ x, const float* __restrict__ gy,
                                                      const float* __restrict__ y_act, float* __restrict__ partial) {
-    extern __shared__ float accs[];                     // [C][4] sums of this workgroup, then 4 x [C][4] wave partials
-    float* wsum = accs + C * 4;
+    constexpr int CG = 8;
+    __shared__ float wsum[4][CG * 4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int i = tid; i < C * 4; i += 256) accs[i] = 0.f;
-    __syncthreads();
     const int b_beg = blockIdx.x * lines_per_wg, b_end = min(B, b_beg + lines_per_wg);
     const int kind = y_act ? act : MS_ACT_NONE;
-    for (int b = b_beg; b < b_end; ++b) {
-        const float* gr = gy + (size_t)b * 2 * L;
-        const float* ar = y_act ? y_act + (size_t)b * 2 * L : gr;
-        for (int q0 = 0; q0 < L; q0 += 256) {
-            const int q = q0 + tid;
-            float g[4];                                 // gp[2q - 1 .. 2q + 2]
+    for (int cg = 0; cg < C; cg += CG) {
+        float acc[CG][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int t = 2 * q + k - 1;
-                g[k] = (q < L && t >= 0 && t < 2 * L) ? ms_act_grad(gr[t], ar[t], kind, slope) : 0.f;
-            }
-            for (int ci = 0; ci < C; ++ci) {
-                float v = q < L ? x[((size_t)b * C + ci) * L + q] : 0.f;
-                if (INA) v = v > 0.f ? v : v * slope;
-                float s4[4];
+        for (int c = 0; c < CG; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[c][k] = 0.f;
+        for (int b = b_beg; b < b_end; ++b) {
+            const float* gr = gy + (size_t)b * 2 * L;
+            const float* ar = y_act ? y_act + (size_t)b * 2 * L : gr;
+            for (int q = tid; q < L; q += 256) {
+                float g[4];                             // gp[2q - 1 .. 2q + 2]
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float r = v * g[k];
-#pragma unroll
-                    for (int o = 32; o >= 1; o >>= 1) r += __shfl_xor(r, o, 64);
-                    s4[k] = r;
+                    const int t = 2 * q + k - 1;
+                    g[k] = (t >= 0 && t < 2 * L) ? ms_act_grad(gr[t], ar[t], kind, slope) : 0.f;
                 }
-                if (lane == 0) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) wsum[(wv * C + ci) * 4 + k] = s4[k];
+                for (int c = 0; c < CG; ++c) {
+                    float v = cg + c < C ? x[((size_t)b * C + cg + c) * L + q] : 0.f;
+                    if (INA) v = v > 0.f ? v : v * slope;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[c][k] = fmaf(v, g[k], acc[c][k]);
                 }
             }
-            __syncthreads();
-            for (int i = tid; i < C * 4; i += 256)
-                accs[i] += (wsum[i] + wsum[C * 4 + i]) + (wsum[2 * C * 4 + i] + wsum[3 * C * 4 + i]);
-            __syncthreads();
         }
+#pragma unroll
+        for (int c = 0; c < CG; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float r = acc[c][k];
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) r += __shfl_xor(r, o, 64);
+                if (lane == 0) wsum[wv][c * 4 + k] = r;
+            }
+        __syncthreads();
+        if (tid < CG * 4 && cg + tid / 4 < C)
+            partial[(size_t)blockIdx.x * C * 4 + (size_t)cg * 4 + tid] =
+                (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
+        __syncthreads();
     }
-    for (int i = tid; i < C * 4; i += 256) partial[(size_t)blockIdx.x * C * 4 + i] = accs[i];
 }
 
 bool convt1_geom(const ConvP& p) {
@@ -595,10 +600,9 @@ int mst_convt1_bwd_weight(const ConvP& p, const float* x, const float* gy, const
                           void* ws, size_t ws_bytes, hipStream_t s) {
     if (!ws || ws_bytes < mst_convt1_wgrad_ws(p)) return MS_ERR_WORKSPACE;
     const int lpw = convt1_lines_per_wg(p), nwg = ms_ceil_div(p.B, lpw);
-    const size_t lds = (size_t)5 * p.Cout * 4 * sizeof(float);
     float* partial = (float*)ws;
-    if (p.in_act) hipLaunchKernelGGL((k_convt1_wgrad<true>), dim3(nwg), dim3(256), lds, s, p.B, p.Cout, p.Lout, p.act, p.slope, lpw, x, gy, y_act, partial);
-    else hipLaunchKernelGGL((k_convt1_wgrad<false>), dim3(nwg), dim3(256), lds, s, p.B, p.Cout, p.Lout, p.act, p.slope, lpw, x, gy, y_act, partial);
+    if (p.in_act) hipLaunchKernelGGL((k_convt1_wgrad<true>), dim3(nwg), dim3(256), 0, s, p.B, p.Cout, p.Lout, p.act, p.slope, lpw, x, gy, y_act, partial);
+    else hipLaunchKernelGGL((k_convt1_wgrad<false>), dim3(nwg), dim3(256), 0, s, p.B, p.Cout, p.Lout, p.act, p.slope, lpw, x, gy, y_act, partial);
     MS_CHECK_LAUNCH();
     return msk_reduce_partials(partial, (size_t)p.Cout * 4, nwg, (size_t)p.Cout * 4, 0, gw, nullptr, beta, s);
 }
