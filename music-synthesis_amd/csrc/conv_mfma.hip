@@ -1115,6 +1115,16 @@ RowCfg pick_row_cfg(int M, int B, int L, bool dense = false) {
     return ROW_64x128;
 }
 
+// tile shape of the transposed-conv forward: short rows (the stage-1 2-D transposed convs as lines: L = 16 .. 64,
+// thousands of lines) take the 128-column tiling with R = 128 / L rows per tile even for M < 512, so that the paired
+// split-bf16 kernel (which owns 128-column tiles) applies
+RowCfg convt_fwd_cfg(int M, int B, int L) {
+    const RowCfg c = pick_row_cfg(M, B, L);
+    if (c == ROW_64x64 && L < 128 && L % 4 == 0 && 128 % L == 0 && M % 64 == 0 && (long long)B * L >= 128 * 256)
+        return ROW_64x128;
+    return c;
+}
+
 void row_tile(RowCfg c, int* bm, int* bn) {
     switch (c) {
         case ROW_128x128: *bm = 128; *bn = 128; break;
@@ -1457,7 +1467,7 @@ bool msm_convt_fwd_applicable(const ConvP& p) {
     if (p.Cout % 8 || p.Cin < 32 || (p.Cin * S) % 32) return false;
     if ((long long)p.B * p.Lin >= (1LL << 31)) return false;
     RowP q;
-    return make_rowp(&q, pick_row_cfg(p.Cin * S, p.B, p.Lout), p.B, p.Cout, p.Lout, p.Cin * S, 3, 1, -1, 0, 0, 0, 0.f);
+    return make_rowp(&q, convt_fwd_cfg(p.Cin * S, p.B, p.Lout), p.B, p.Cout, p.Lout, p.Cin * S, 3, 1, -1, 0, 0, 0, 0.f);
 }
 size_t msm_fwd_ws(const ConvP& p) {
     if (!rows_ok(p, false)) return 0;
@@ -1479,7 +1489,7 @@ size_t msm_bwd_weight_ws(const ConvP& p) {
 }
 size_t msm_convt_fwd_ws(const ConvP& p) {
     RowP r;
-    const RowCfg cfg = pick_row_cfg(p.Cin * p.stride, p.B, p.Lout);
+    const RowCfg cfg = convt_fwd_cfg(p.Cin * p.stride, p.B, p.Lout);
     make_rowp(&r, cfg, p.B, p.Cout, p.Lout, p.Cin * p.stride, 3, 1, -1, 0, 0, 0, 0.f);
     return align16((size_t)p.Cin * p.stride * p.Cout * 3 * sizeof(float)) + rows_split_ws(cfg, r, row_cc(3));
 }
@@ -1509,7 +1519,7 @@ const char* msm_bwd_weight_name(const ConvP& p) {
 }
 const char* msm_convt_fwd_name(const ConvP& p) {
     static thread_local char buf[96];
-    const RowCfg c = pick_row_cfg(p.Cin * p.stride, p.B, p.Lout);
+    const RowCfg c = convt_fwd_cfg(p.Cin * p.stride, p.B, p.Lout);
     RowP r;
     make_rowp(&r, c, p.B, p.Cout, p.Lout, p.Cin * p.stride, 3, 1, -1, 0, 0, 0, 0.f);
     {   // the paired split-bf16 kernel, decided exactly as msm_convt1d_fwd does (dummy 16-byte aligned pointers)
@@ -1658,7 +1668,7 @@ int msm_convt1d_fwd(const ConvP& p, const float* x, const float* w, const float*
     unsigned nb = (unsigned)((total + 255) / 256);
     if (nb > 4096) nb = 4096;
     RowP r;
-    const RowCfg cfg = pick_row_cfg(CoutT * S, p.B, LinT);
+    const RowCfg cfg = convt_fwd_cfg(CoutT * S, p.B, LinT);
     make_rowp(&r, cfg, p.B, CinT, LinT, CoutT * S, 3, 1, -1, MS_PAD_ZERO, p.act, MS_ACT_NONE, p.slope);
     const size_t wbytes = align16(total * sizeof(float));
     const bool ia = p.in_act != 0;   // LeakyReLU in front of the transposed conv: applied to x on load
