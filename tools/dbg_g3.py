@@ -1,5 +1,4 @@
-"""k_gconv_split_fwd on the long layers under launch-shape knobs (MSYNTH_GW = target waves, MSYNTH_G3PIPE = min units
-per wave for the pipelined variant)."""
+"""k_gconv_split_fwd on the long layers under the launch-shape knob MSYNTH_GW (target waves per launch)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
@@ -17,10 +16,8 @@ for (B, Cin, Cout, groups, Lin) in ((64, 16, 64, 4, 8192), (32, 16, 64, 4, 8192)
     x = torch.randn(B, Cin, Lin, device="cuda"); w = torch.randn(Cout, 4, 41, device="cuda") * 0.05
     b = torch.randn(Cout, device="cuda")
     d, lo = P.conv_desc(x.shape, w.shape, stride=4, pad=20, groups=groups, act=1)
-    for pipe in ("3", "99"):
-        os.environ["MSYNTH_G3PIPE"] = pipe
-        row = []
-        for gw in ("512", "1024", "1536", "2048", "3072", "4096"):
-            os.environ["MSYNTH_GW"] = gw
-            row.append("%s:%5.1f" % (gw, timeit(lambda: P.conv1d_fwd(x, w, b, d, lo))))
-        print((B, Cin, Lin), "pipe>=" + pipe, " ".join(row), flush=True)
+    row = []
+    for gw in ("512", "1024", "1536", "2048", "3072", "4096"):
+        os.environ["MSYNTH_GW"] = gw
+        row.append("%s:%5.1f" % (gw, timeit(lambda: P.conv1d_fwd(x, w, b, d, lo))))
+    print((B, Cin, Lin), " ".join(row), flush=True)
