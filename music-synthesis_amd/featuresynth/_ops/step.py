@@ -40,7 +40,7 @@ def _slots(params):
     return G.GradSink(len(slots), slots, [True] * len(slots))
 
 
-def d_step(gen_params, disc_params, samples, features, scales=2, cut=None, debug=None):
+def d_step(gen_params, disc_params, samples, features, scales=2, cut=None, debug=None, loss_slot=None):
     """-> d_loss (0-d device tensor); discriminator gradients accumulate into its bucket."""
     fake, _ = G.gen_forward(features, gen_params, save=False)
     B = fake.shape[0]
@@ -49,6 +49,8 @@ def d_step(gen_params, disc_params, samples, features, scales=2, cut=None, debug
     both = torch.cat([fake, samples], 0)
     _, judges, ctx = G.melgan_forward(both, disc_params, scales)
     loss = F_.disc_loss_cat_fwd(judges, B)
+    if loss_slot is not None:          # data parallel: the value travels with the gradient slice behind the cut
+        loss_slot.copy_(loss)
     gjs = F_.disc_loss_cat_bwd(judges, B, _one(samples.device))
     if debug is not None:
         debug.update(fake=fake, judges=judges, disc_ctx=ctx, gjs=gjs)
@@ -56,7 +58,8 @@ def d_step(gen_params, disc_params, samples, features, scales=2, cut=None, debug
     return loss
 
 
-def g_step(gen_params, disc_params, samples, features, scales=2, weight=10.0, cut=None, debug=None):
+def g_step(gen_params, disc_params, samples, features, scales=2, weight=10.0, cut=None, debug=None,
+           loss_slot=None):
     """-> (g_loss, fake); generator gradients accumulate into its bucket."""
     dev = samples.device
     # the real path neither depends on the generator nor needs gradients: it runs on a forked stream
@@ -78,6 +81,8 @@ def g_step(gen_params, disc_params, samples, features, scales=2, weight=10.0, cu
     rf = [t for grp in r_feats for t in grp]
     ff = [t for grp in f_feats for t in grp]
     loss, fscale = F_.gen_loss_fwd(S, Lyr, weight, rf, ff, f_judges)
+    if loss_slot is not None:
+        loss_slot.copy_(loss)
     _, g_ff, g_fj = F_.gen_loss_bwd(S, fscale, rf, ff, f_judges, _one(dev), [False] * len(rf),
                                     [True] * len(ff), [True] * S)
     g_feats = [g_ff[Lyr * s:Lyr * s + Lyr] for s in range(S)]

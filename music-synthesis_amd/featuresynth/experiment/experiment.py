@@ -186,7 +186,8 @@ def _load_optim_state(opt, st):
             raise ValueError("checkpoint holds a torch.optim.Adam state, the experiment uses FlatAdam")
         if st["empty"]:
             return
-        opt.flatten()
+        if not opt._bucket_ok():          # an intact bucket stays where it is (captured hipGraphs hold its addresses)
+            opt.flatten()
         _, _, m, v, step, _ = opt._flat
         m.copy_(st["m"]); v.copy_(st["v"]); step.copy_(st["step"])
     else:

@@ -56,7 +56,11 @@ class FlatAdam(torch.optim.Optimizer):
             total += (p.numel() + 3) // 4 * 4          # keep every view 16-byte aligned
         old = self._flat
         fp = torch.zeros(total, dtype=torch.float32, device=dev)
-        fg = torch.zeros(total, dtype=torch.float32, device=dev)
+        # the gradient bucket carries 4 spare floats behind the last parameter: element [total] is the
+        # step's loss value, so that under data parallelism the rank-sum of the loss rides in the same
+        # all-reduce as the gradient slice it sits behind (train.py) -- no extra collective
+        self._grad_store = torch.zeros(total + 4, dtype=torch.float32, device=dev)
+        fg = self._grad_store[:total]
         if old is not None and old[0].numel() == total and old[0].device == dev:
             m, v, step = old[2], old[3], old[4]
         else:
@@ -85,6 +89,23 @@ class FlatAdam(torch.optim.Optimizer):
         if not self._bucket_ok():
             self.flatten()
         return self._flat[1]
+
+    @property
+    def grad_store(self):
+        """The gradient bucket plus its 4 trailing spare floats ([numel-4] = the loss slot)."""
+        self.flat_grads
+        return self._grad_store
+
+    @property
+    def loss_slot(self):
+        """0-d view of the spare float behind the gradient bucket (see flatten)."""
+        return self.grad_store[-4:-3].view(())
+
+    def bucket_version(self):
+        """Changes whenever the buckets are re-homed: captured hipGraphs bake the bucket addresses in, so
+        the trainers re-plan when this differs from the value they captured with."""
+        fp = self.flat_params
+        return (fp.data_ptr(), self._flat[1].data_ptr(), self._flat[2].data_ptr())
 
     def grad_views(self):
         """Per-parameter views of the gradient bucket (state_dict order)."""
@@ -154,7 +175,10 @@ class FlatAdam(torch.optim.Optimizer):
         flat = state_dict.pop("flat", None)
         super().load_state_dict(state_dict)
         if flat is not None:
-            self.flatten()
+            # keep the bucket where it is when it is intact: captured hipGraphs (train.py) hold its addresses;
+            # re-homing parameters and gradients here would leave them replaying on freed storage
+            if not self._bucket_ok():
+                self.flatten()
             _, _, m, v, step, offs = self._flat
             if [tuple(o) for o in offs] != [tuple(o) for o in flat["layout"]]:
                 raise ValueError("FlatAdam.load_state_dict: the checkpoint's bucket layout does not match "

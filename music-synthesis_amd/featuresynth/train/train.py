@@ -16,6 +16,7 @@ Two execution paths, same numbers:
 """
 import os
 import sys
+import warnings
 from datetime import datetime
 
 import numpy as np
@@ -56,6 +57,12 @@ class _GraphedStep:
         self.seen = {}
         self.graphs = {}
         self.disabled = False
+        self.capture_error = None     # the exception that demoted this step to eager execution, if any
+        self.segment = None           # index of the segment being issued (eager call or capture), else None
+
+    def in_final_segment(self):
+        """True unless a body is running in front of a cut that is still to come."""
+        return self.segment is None or self.segment == len(self.between)
 
     def _eager(self, samples, features):
         k = [0]
@@ -63,7 +70,12 @@ class _GraphedStep:
         def cut():
             self.between[k[0]]()
             k[0] += 1
-        out = self.body(samples, features, cut)
+            self.segment = k[0]
+        self.segment = 0
+        try:
+            out = self.body(samples, features, cut)
+        finally:
+            self.segment = None
         assert k[0] == len(self.between), "train step: body made %d cuts, %d expected" % (k[0], len(self.between))
         return out
 
@@ -73,8 +85,12 @@ class _GraphedStep:
         if not self.between:
             g = torch.cuda.CUDAGraph()
             # (thread-local error mode: other threads -- the RCCL watchdog polling its events -- stay legal)
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                out = self.body(s_in, f_in, None)
+            self.segment = 0
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    out = self.body(s_in, f_in, None)
+            finally:
+                self.segment = None
             return [g], out
         pool = torch.cuda.graph_pool_handle()
         stream = torch.cuda.Stream()
@@ -93,11 +109,14 @@ class _GraphedStep:
         def cut():
             end()
             begin()
+            self.segment += 1
         with torch.cuda.stream(stream):
             begin()
+            self.segment = 0
             try:
                 out = self.body(s_in, f_in, cut)
             finally:
+                self.segment = None
                 if cur[0] is not None:
                     end()
         torch.cuda.current_stream().wait_stream(stream)
@@ -119,11 +138,12 @@ class _GraphedStep:
                 graphs, out = self._capture(s_in, f_in)
                 entry = (graphs, s_in, f_in, out)
                 self.graphs[key] = entry
-            except Exception as e:  # perf-only fallback, reported loudly
-                self.disabled = True
+            except Exception as e:  # perf-only fallback, reported loudly: a warning once + an attribute
+                self.disabled = True            # that loggers can read (trainer.graph_status())
+                self.capture_error = e
                 torch.cuda.synchronize()
-                print("featuresynth: hipGraph capture failed (%s: %s); running the step eagerly"
-                      % (type(e).__name__, e), file=sys.stderr)
+                warnings.warn("featuresynth: hipGraph capture of the train step failed (%s: %s); this trainer "
+                              "runs eagerly from now on" % (type(e).__name__, e), RuntimeWarning, stacklevel=2)
                 return self._eager(samples, features)
         graphs, s_in, f_in, out = entry
         s_in.copy_(samples)
@@ -158,7 +178,7 @@ class _TrainerBase(object):
     def _stock_losses(self):
         raise NotImplementedError
 
-    def _fwd_bwd(self, samples, features, cut=None):
+    def _fwd_bwd(self, samples, features, cut=None, loss_slot=None):
         raise NotImplementedError
 
     def _direct_ok(self):
@@ -180,15 +200,39 @@ class _TrainerBase(object):
                 res['fake'] = out["fake"].cpu().numpy()
             return res
         torch.cuda.current_stream(device).synchronize()
-        res = {loss_key: float(out["loss"])}
+        loss = float(out["loss"])
+        if self._runner is not None and self._runner.between:     # data-parallel plan: the slot holds the rank SUM
+            loss /= _dist.world_size()
+        res = {loss_key: loss}
         if with_fake:
             res['fake'] = out["fake"].numpy().copy()   # (the pinned buffer is reused by the next step)
         return res
 
+    def graph_status(self):
+        """{'mode': 'graph' | 'eager' | 'eager (capture failed)' | 'unplanned', 'segments': [...], 'error': str | None}
+        -- what `training_loop` loggers can print: a failed hipGraph capture demotes the trainer to eager
+        execution for the life of the process (a RuntimeWarning is raised once when it happens)."""
+        r = self._runner
+        if r is None:
+            return {"mode": "unplanned", "segments": [], "error": None}
+        if r.disabled:
+            return {"mode": "eager (capture failed)", "segments": [],
+                    "error": "%s: %s" % (type(r.capture_error).__name__, r.capture_error)}
+        return {"mode": "graph" if r.graphs else "eager", "segments": [len(e[0]) for e in r.graphs.values()],
+                "error": None}
+
     def _to_host(self, out):
         """Device results -> pinned host buffers with asynchronous copies issued on the step's stream
         (inside the captured graph they become memcpy nodes): the caller then needs ONE stream
-        synchronisation instead of a blocking .item() plus a blocking pageable copy of `fake`."""
+        synchronisation instead of a blocking .item() plus a blocking pageable copy of `fake`.
+
+        Only in the FINAL segment of a multi-segment step: the host reads the pinned buffers (and the next
+        trainer call overwrites the static inputs) as soon as the stream has drained, which must mean the whole
+        step has -- a device-to-host copy node in an earlier segment of a pool-sharing capture sequence is the
+        one topology that crashed hipGraphLaunch on ROCm 7.2 ("graph faults")."""
+        if self._runner is not None and not self._runner.in_final_segment():
+            raise RuntimeError("train step: host copies belong to the last graph segment (segment %d of %d)"
+                               % (self._runner.segment, len(self._runner.between) + 1))
         if not hasattr(self, "_pins"):
             self._pins = {}
         host = {}
@@ -206,11 +250,22 @@ class _TrainerBase(object):
         ([off, end)); 0 when the step has no cut point (one all-reduce of the whole bucket)."""
         return 0
 
+    @staticmethod
+    def _bucket_in_module_order(opt, net):
+        """The cut points of graph.py are defined in MODULE parameter order: the sliced exchange is only
+        valid when the optimizer's bucket holds exactly list(net.parameters()), same objects, same order."""
+        ps = opt.param_groups[0]["params"]
+        ms = list(net.parameters())
+        return len(ps) == len(ms) and all(a is b for a, b in zip(ps, ms))
+
     def _native_step(self, samples, features):
         """world 1: ONE graph (zero_grad, forwards, backward, Adam).
         Data parallel: [graph: zero_grad + forwards + backward up to the cut] -> all-reduce of the early
         slice, asynchronous (RCCL) -> [graph: rest of the backward, overlapping it] -> all-reduce of the
-        late slice -> [graph: Adam with grad_scale = 1/world]."""
+        late slice -> [graph: Adam with grad_scale = 1/world + the copies to the host].
+        The loss value rides in the spare float behind the gradient bucket (FlatAdam.loss_slot), i.e. inside the
+        early slice's all-reduce: the value returned under data parallelism is the mean over ranks (what a
+        single process on the global batch prints, the reference's loggers: evaluate.py:164-165)."""
         opt = self._stepped_optim()
         flat = isinstance(opt, FlatAdam) and isinstance(self.g_optim, FlatAdam) and \
             isinstance(self.d_optim, FlatAdam)
@@ -223,14 +278,18 @@ class _TrainerBase(object):
                     if p.grad is not None:
                         _dist.allreduce_sum_(p.grad)
                         p.grad.div_(world)
+                out["loss"] = _dist.allreduce_mean_scalar(out["loss"])
             opt.step()
             return out
         opt.grad_scale = 1.0 / world
-        self.g_optim.flat_grads, self.d_optim.flat_grads      # (builds the buckets: _split_point reads their layout)
-        if self._runner is not None and self._runner_world != (world, force_dp):
-            self._runner = None                   # the process group appeared / went away: re-plan
+        # (builds the buckets: _split_point reads their layout.)  A captured graph holds the buckets' addresses: when
+        # an optimizer re-homes them (flatten() after .to(device), a checkpoint load into a fresh bucket) the plan is
+        # dropped and re-captured
+        plan = (world, force_dp, self.g_optim.bucket_version(), self.d_optim.bucket_version())
+        if self._runner is not None and self._runner_world != plan:
+            self._runner = None                   # the process group appeared / went away, or a bucket moved: re-plan
         if self._runner is None:
-            self._runner_world = (world, force_dp)
+            self._runner_world = plan
             if world == 1 and not force_dp:
                 def body(s, f, cut):
                     out = self._fwd_bwd(s, f)
@@ -239,34 +298,40 @@ class _TrainerBase(object):
                 self._runner = _GraphedStep(body)
             else:
                 direct = self._direct_ok()
+                off = self._split_point(opt) if direct else 0
                 pending = []
 
                 def start_early():
-                    off = self._split_point(opt) if direct else 0
-                    fg = opt.flat_grads
-                    pending.append(_dist.allreduce_sum_async(fg[off:] if off else fg, force=force_dp))
+                    # [off, end) + the loss slot; the whole store when the step has no cut point
+                    st = opt.grad_store
+                    pending.append(_dist.allreduce_sum_async(st[off:] if off else st, force=force_dp))
 
                 def finish():
-                    off = self._split_point(opt) if direct else 0
                     if off:
                         pending.append(_dist.allreduce_sum_async(opt.flat_grads[:off], force=force_dp))
                     for w in pending:
                         w.wait()
                     del pending[:]
 
-                if direct and self._split_point(opt):
+                def publish(out):
+                    out = dict(out)
+                    out["loss"] = opt.loss_slot       # summed over ranks by now; _result divides by world
+                    return self._to_host(out)
+
+                if off:
                     def body(s, f, cut):
-                        out = self._fwd_bwd(s, f, cut)     # calls cut() once, where the early slice is final
+                        # _fwd_bwd writes the loss into the slot and calls cut() once, where the early slice is final
+                        out = self._fwd_bwd(s, f, cut, loss_slot=opt.loss_slot)
                         cut()
                         opt.step()
-                        return self._to_host(out)
+                        return publish(out)
                     self._runner = _GraphedStep(body, [start_early, finish])
                 else:
                     def body(s, f, cut):
-                        out = self._fwd_bwd(s, f)
+                        out = self._fwd_bwd(s, f, loss_slot=opt.loss_slot)
                         cut()
                         opt.step()
-                        return self._to_host(out)
+                        return publish(out)
                     self._runner = _GraphedStep(body, [lambda: (start_early(), finish())])
         return self._runner(samples, features)
 
@@ -283,13 +348,16 @@ class GeneratorTrainer(_TrainerBase):
         return self.loss is _mel_gan_gen_loss and self.sub_loss is hinge_generator_loss
 
     def _split_point(self, opt):
-        return opt._flat[5][_graph.G_TAIL_PARAM][0] if opt._flat is not None else 0
+        if opt._flat is None or not self._bucket_in_module_order(opt, self.generator):
+            return 0
+        return opt._flat[5][_graph.G_TAIL_PARAM][0]
 
-    def _fwd_bwd(self, samples, features, cut=None):
+    def _fwd_bwd(self, samples, features, cut=None, loss_slot=None):
         zero_grad(self.g_optim, self.d_optim)
         if self._direct_ok():
             loss, fake = _step.g_step(list(self.generator.parameters()), list(self.discriminator.parameters()),
-                                      samples, features, self.discriminator.scales, cut=cut, debug=self.debug)
+                                      samples, features, self.discriminator.scales, cut=cut, debug=self.debug,
+                                      loss_slot=loss_slot)
             return {"loss": loss, "fake": fake}
         d_params = [p for p in self.discriminator.parameters() if p.requires_grad]
         for p in d_params:          # discriminator weight grads are never used by a G-step
@@ -310,6 +378,8 @@ class GeneratorTrainer(_TrainerBase):
         finally:
             for p in d_params:
                 p.requires_grad_(True)
+        if loss_slot is not None:
+            loss_slot.copy_(loss.detach())
         return {"loss": loss.detach(), "fake": fake.detach()}
 
     def train(self, samples, features):
@@ -343,13 +413,16 @@ class DiscriminatorTrainer(_TrainerBase):
         return self.loss is _mel_gan_disc_loss and self.sub_loss is hinge_discriminator_loss
 
     def _split_point(self, opt):
-        return opt._flat[5][_graph.D_HEAD_PARAM][0] if opt._flat is not None else 0
+        if opt._flat is None or not self._bucket_in_module_order(opt, self.discriminator):
+            return 0
+        return opt._flat[5][_graph.D_HEAD_PARAM][0]
 
-    def _fwd_bwd(self, samples, features, cut=None):
+    def _fwd_bwd(self, samples, features, cut=None, loss_slot=None):
         zero_grad(self.g_optim, self.d_optim)
         if self._direct_ok():
             loss = _step.d_step(list(self.generator.parameters()), list(self.discriminator.parameters()),
-                                samples, features, self.discriminator.scales, cut=cut, debug=self.debug)
+                                samples, features, self.discriminator.scales, cut=cut, debug=self.debug,
+                                loss_slot=loss_slot)
             return {"loss": loss}
         with torch.no_grad():       # generator grads of a D-step are discarded by the reference
             fake = self.generator(features)
@@ -357,7 +430,12 @@ class DiscriminatorTrainer(_TrainerBase):
         # so the judgements are the same and the shared weights' gradients are summed in-kernel
         B = fake.shape[0]
         both = torch.cat([fake, samples], 0)
-        _, scores = self.discriminator(both, features)
+        # a discriminator that consumes its conditioning (experiment/realmelgan.py:128-136,149-152) needs one
+        # conditioning row per row of the doubled batch
+        cond = features
+        if getattr(self.discriminator, "conditioning_channels", 0) > 0:
+            cond = torch.cat([features, features], 0)
+        _, scores = self.discriminator(both, cond)
         if self._stock_losses():
             loss = _F.MelGanDiscLossCatFn.apply(len(scores), B, *scores)   # no per-slice autograd nodes
         elif isinstance(scores, torch.Tensor):      # single-judgement discriminators (stage 1)
@@ -367,6 +445,8 @@ class DiscriminatorTrainer(_TrainerBase):
             r_score = [j[B:] for j in scores]
             loss = self.loss(r_score, f_score, gan_loss=self.sub_loss)
         loss.backward()
+        if loss_slot is not None:
+            loss_slot.copy_(loss.detach())
         return {"loss": loss.detach()}
 
     def train(self, samples, features):

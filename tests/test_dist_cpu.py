@@ -134,3 +134,45 @@ def test_single_process_helpers_are_noops():
     assert _dist.world_size() == 1 and _dist.rank() == 0 and not _dist.is_distributed()
     t = torch.ones(3)
     assert _dist.allreduce_sum_(t) is t and torch.equal(t, torch.ones(3))
+
+
+def test_host_copies_only_in_the_final_segment():
+    """Constraint recorded in DESIGN.md section 6 ("graph faults"): the device-to-host result copies of a
+    multi-segment train step belong to its LAST segment; _to_host refuses anything else (on an eager call and
+    under capture alike -- the guard sits in front of any device work)."""
+    from featuresynth.train.train import _GraphedStep, _TrainerBase
+    tr = _TrainerBase.__new__(_TrainerBase)
+
+    def bad_body(s, f, cut):
+        tr._to_host({})          # in front of a cut that is still to come
+        cut()
+        return {}
+
+    tr._runner = _GraphedStep(bad_body, [lambda: None])
+    x = torch.zeros(2, 1, 8)
+    with pytest.raises(RuntimeError, match="last graph segment"):
+        tr._runner(x, x)
+    assert tr._runner.segment is None
+
+    def good_body(s, f, cut):
+        cut()
+        return tr._to_host({})
+
+    tr._runner = _GraphedStep(good_body, [lambda: None])
+    assert tr._runner(x, x) == {}
+
+
+def test_split_point_needs_module_parameter_order():
+    """the sliced exchange's cut offset is only valid when the optimizer's bucket lists the module's
+    parameters in module order; any other optimizer gets a whole-bucket all-reduce (offset 0)."""
+    import featuresynth as fs
+    from featuresynth.train.train import _TrainerBase
+    d = fs.MelGanDiscriminator()
+    ps = list(d.parameters())
+
+    class Opt:
+        def __init__(self, params):
+            self.param_groups = [{"params": params}]
+    assert _TrainerBase._bucket_in_module_order(Opt(ps), d)
+    assert not _TrainerBase._bucket_in_module_order(Opt(ps[::-1]), d)
+    assert not _TrainerBase._bucket_in_module_order(Opt(ps[:-1]), d)

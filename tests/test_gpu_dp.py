@@ -32,19 +32,25 @@ def _nets():
     return g.cuda(), d.cuda()
 
 
-def _run_steps(samples, feats, ncalls):
+def _run_steps(samples, feats, ncalls, lr=1e-4, buckets=None):
+    """buckets (a list): receives, after every call, the stepped network's EFFECTIVE flat gradient -- the
+    (all-reduced) bucket times FlatAdam.grad_scale (1/world under data parallelism) -- as a numpy array."""
     import featuresynth as fs
     from featuresynth import loss as LS
     from featuresynth.train import DiscriminatorTrainer, GeneratorTrainer
     g, d = _nets()
-    go = fs.FlatAdam(g.parameters(), lr=1e-4, betas=(0.5, 0.9))
-    do = fs.FlatAdam(d.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    go = fs.FlatAdam(g.parameters(), lr=lr, betas=(0.5, 0.9))
+    do = fs.FlatAdam(d.parameters(), lr=lr, betas=(0.5, 0.9))
     dt = DiscriminatorTrainer(g, go, d, do, LS.mel_gan_disc_loss)
     gt = GeneratorTrainer(g, go, d, do, LS.mel_gan_gen_loss)
     s, f = torch.from_numpy(samples).cuda(), torch.from_numpy(feats).cuda()
     losses = []
     for i in range(ncalls):                     # same batch every call: calls 3+ replay the graphs
         losses.append(dt.train(s, f)["d_loss"] if i % 2 == 0 else gt.train(s, f)["g_loss"])
+        if buckets is not None:
+            opt = do if i % 2 == 0 else go
+            torch.cuda.synchronize()
+            buckets.append(opt.flat_grads.detach().cpu().numpy() * np.float32(opt.grad_scale))
     sd = {k: v.detach().cpu().numpy() for k, v in list(g.state_dict().items()) + list(d.state_dict().items())}
     return losses, sd, (dt, gt)
 
@@ -69,8 +75,36 @@ def _worker(rank, world, port, out_dir):
         assert tr._runner.graphs and not tr._runner.disabled, "graphs not captured under data parallelism"
         assert all(len(e[0]) == 3 for e in tr._runner.graphs.values()), "expected 3 graph segments per step"
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=np.array(losses), **sd)
+    # the exchange itself, with Adam out of the way: lr = 0 keeps the parameters where they are, so EVERY call
+    # (1-2 eager, 3-4 capture, 5-6 graph replay; split point active) differentiates the same function and its
+    # all-reduced bucket x 1/world must equal the global-batch gradient up to fp32 summation order
+    buckets = []
+    l0, sd0, (dt0, gt0) = _run_steps(synthetic_samples(B, T * 256, rank=rank),
+                                     synthetic_features(B, 80, T, rank=rank), 6, lr=0.0, buckets=buckets)
+    assert len(dt0._runner.between) == 2 and all(len(e[0]) == 3 for e in dt0._runner.graphs.values())
+    assert len(gt0._runner.between) == 2 and all(len(e[0]) == 3 for e in gt0._runner.graphs.values())
+    sums = np.array([[float(b.astype(np.float64).sum()), float((b.astype(np.float64) ** 2).sum())] for b in buckets])
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "buckets0.npz"), losses=np.array(l0), sums=sums,
+                 **{"b%d" % i: b for i, b in enumerate(buckets)})
+    else:
+        np.savez(os.path.join(out_dir, "buckets%d.npz" % rank), losses=np.array(l0), sums=sums)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
+
+
+GRAD_BUCKET_TOL = 1e-5      # fp32 summation order only
+
+
+_SD0 = {}
+
+
+def sd0_reference(k):
+    """Initial parameter k (the synthetic state dicts every _nets() call loads)."""
+    if not _SD0:
+        g, d = _nets()
+        _SD0.update({n: v.detach().cpu().numpy() for n, v in list(g.state_dict().items()) + list(d.state_dict().items())})
+    return _SD0[k]
 
 
 def test_two_ranks_match_global_batch(tmp_path):
@@ -88,7 +122,9 @@ def test_two_ranks_match_global_batch(tmp_path):
     samples = np.concatenate([synthetic_samples(B, T * 256, rank=r) for r in range(world)])
     feats = np.concatenate([synthetic_features(B, 80, T, rank=r) for r in range(world)])
     losses, sd, _ = _run_steps(samples, feats, 6)
-    mean_losses = 0.5 * (r0["losses"] + r1["losses"])
+    # the trainers return the mean over ranks (the loss slot rides in the gradient all-reduce): same bits everywhere
+    assert np.array_equal(r0["losses"], r1["losses"]), (r0["losses"], r1["losses"])
+    mean_losses = r0["losses"]
     assert abs(mean_losses[0] - losses[0]) <= 1e-5 * abs(losses[0])          # d_loss, same params
     for i, (a, b) in enumerate(zip(mean_losses[1:], losses[1:]), 1):
         # after Adam updates (DESIGN.md "Adam sensitivity"): d_loss ~ 6 stays tight, g_loss is a
@@ -103,9 +139,35 @@ def test_two_ranks_match_global_batch(tmp_path):
         assert d.max() <= 3 * 2.1e-4, (k, d.max())                           # 3 updates per net, +-lr each
         if k.endswith("weight"):
             assert rel_l2(r0[k], v) < 1e-2, k
+    # ---- the real gate: all-reduced flat gradient bucket x 1/world vs the global-batch bucket, no Adam in the way
+    # (the trajectory checks above are smoke checks only: DESIGN.md "Adam sensitivity")
+    b0, b1 = np.load(str(tmp_path / "buckets0.npz")), np.load(str(tmp_path / "buckets1.npz"))
+    assert np.array_equal(b0["sums"], b1["sums"]), "ranks hold different all-reduced buckets"
+    assert np.array_equal(b0["losses"], b1["losses"])
+    gb = []
+    gl, gsd, _ = _run_steps(samples, feats, 6, lr=0.0, buckets=gb)
+    for k, v in gsd.items():                                                 # lr = 0: parameters never moved
+        assert np.array_equal(v, sd0_reference(k)), k
+    errs = []
+    for i in range(6):
+        dp = b0["b%d" % i]
+        assert dp.shape == gb[i].shape
+        errs.append(rel_l2(dp, gb[i]))
+        # per-parameter-slice check as well: a wrong slice offset or a missing 1/world in ONE slice shows here
+        # even where that slice is a small part of the bucket's norm
+        half = dp.shape[0] // 2
+        for lo, hi in ((0, half), (half, dp.shape[0])):
+            assert rel_l2(dp[lo:hi], gb[i][lo:hi]) <= GRAD_BUCKET_TOL, (i, lo, hi, rel_l2(dp[lo:hi], gb[i][lo:hi]))
+        assert abs(b0["losses"][i] - gl[i]) <= 1e-5 * abs(gl[i]) + 1e-7, (i, b0["losses"][i], gl[i])
+    print("DP gradient bucket vs global batch, rel-L2 per call (D,G,D,G,D,G):", ["%.2e" % e for e in errs])
+    assert max(errs) <= GRAD_BUCKET_TOL, errs
+    # eager (calls 1-2), capture (3-4) and replay (5-6) of the data-parallel schedule agree bitwise
+    for i in (2, 4):
+        assert np.array_equal(b0["b%d" % i], b0["b0"]), i
+        assert np.array_equal(b0["b%d" % (i + 1)], b0["b1"]), i + 1
 
 
-def _single_rank_worker(rank, port, out_dir, comm):
+def _single_rank_worker(rank, port, out_dir, comm, B=2, T=4):
     """One rank, RCCL for real: the "nccl" process group of torch.distributed (ProcessGroupNCCL = RCCL on
     ROCm) or the C ABI's own communicator (ms_comm_init / ms_allreduce_f32), driving the data-parallel
     control flow (3 graph segments, two slice all-reduces) through MSYNTH_DP_FORCE=1."""
@@ -131,28 +193,39 @@ def _single_rank_worker(rank, port, out_dir, comm):
         from featuresynth._ops import lib as L
         c = _dist.abi_comm()
         assert L.load().ms_comm_world(c) == 1 and L.load().ms_comm_rank(c) == 0
-    B, T = 2, 4
-    losses, sd, (dt, gt) = _run_steps(synthetic_samples(B, T * 256), synthetic_features(B, 80, T), 6)
+    buckets = []
+    losses, sd, (dt, gt) = _run_steps(synthetic_samples(B, T * 256), synthetic_features(B, 80, T), 6, buckets=buckets)
     assert len(dt._runner.between) == 2 and len(gt._runner.between) == 2
-    assert all(len(e[0]) == 3 for e in dt._runner.graphs.values()) and not dt._runner.disabled
-    np.savez(os.path.join(out_dir, "dp_%s.npz" % comm), losses=np.array(losses), **sd)
+    for tr in (dt, gt):
+        assert all(len(e[0]) == 3 for e in tr._runner.graphs.values()) and not tr._runner.disabled
+        assert tr.graph_status()["mode"] == "graph" and tr.graph_status()["segments"] == [3]
+    np.savez(os.path.join(out_dir, "dp_%s.npz" % comm), losses=np.array(losses),
+             bucket_d=buckets[4], bucket_g=buckets[5], **sd)
     if comm == "abi":
         _dist.abi_comm_destroy()
     torch.distributed.destroy_process_group()
 
 
+@pytest.mark.parametrize("size", ["small", "full"])
 @pytest.mark.parametrize("comm", ["torch", "abi"])
-def test_single_rank_rccl_matches_plain_step(tmp_path, comm):
+def test_single_rank_rccl_matches_plain_step(tmp_path, comm, size):
     """World size 1 over RCCL: the sliced exchange is the identity, so the data-parallel schedule (head
-    phase -> cut -> tail phase, three graph segments) must reproduce the single-graph step bitwise."""
+    phase -> cut -> tail phase, three graph segments) must reproduce the single-graph step bitwise -- losses
+    (through the loss slot behind the gradient bucket), the gradient buckets of the replayed calls and every
+    parameter after D,G,D,G,D,G (calls 1-2 eager, 3-4 capture, 5-6 replay).
+    "full" = BASELINE config 3 / the per-GPU shard of config 4: B = 32, 8192-sample windows, where the split-K
+    plans, the [fake; real] B = 64 tiles and the G-step's cut behind the C = 256 stack's batched weight
+    gradients are the ones the bench runs."""
     import torch.multiprocessing as mp
     from featuresynth._synthetic import synthetic_features, synthetic_samples
-    mp.spawn(_single_rank_worker, args=(_free_port(), str(tmp_path), comm), nprocs=1, join=True)
+    B, T = (2, 4) if size == "small" else (32, 32)
+    mp.spawn(_single_rank_worker, args=(_free_port(), str(tmp_path), comm, B, T), nprocs=1, join=True)
     r = np.load(str(tmp_path / ("dp_%s.npz" % comm)))
-    B, T = 2, 4
-    losses, sd, (dt, _) = _run_steps(synthetic_samples(B, T * 256), synthetic_features(B, 80, T), 6)
+    buckets = []
+    losses, sd, (dt, _) = _run_steps(synthetic_samples(B, T * 256), synthetic_features(B, 80, T), 6, buckets=buckets)
     assert all(len(e[0]) == 1 for e in dt._runner.graphs.values())
     assert list(r["losses"]) == list(losses), (r["losses"], losses)
+    assert np.array_equal(r["bucket_d"], buckets[4]) and np.array_equal(r["bucket_g"], buckets[5])
     for k, v in sd.items():
         assert np.array_equal(r[k], v), k
 

@@ -556,3 +556,45 @@ def test_training_loop_checkpoint_resume(tmp_path, monkeypatch):
     assert abs(a - b) < 1e-6
     for (k, p), (_, q) in zip(exp.discriminator.state_dict().items(), exp2.discriminator.state_dict().items()):
         assert np.abs(host(p) - host(q)).max() < 1e-7, k
+
+
+def test_flat_adam_state_reload_keeps_captured_graphs_valid(monkeypatch):
+    """FlatAdam.load_state_dict after the first captured step.  The captured hipGraphs hold the
+    bucket addresses, so a reload must not re-home the buckets (and if one moves, the trainers re-plan):
+    3 calls, save + load both optimizer states and both modules, 3 more calls == 6 uninterrupted calls, bitwise."""
+    from featuresynth._synthetic import synthetic_features, synthetic_samples
+    B, T = 2, 4
+    batches = [(dev(synthetic_samples(B, T * 256, rank=i)), dev(synthetic_features(B, 80, T, rank=i))) for i in range(6)]
+
+    def run(reload_at):
+        g, d, _, _ = make_nets(dict(seed=7, bias_scale=0.02), dict(seed=8, bias_scale=0.02))
+        dt, gt, go, do = _trainers(g, d)
+        losses = []
+        for i, (s, f) in enumerate(batches):
+            if i == reload_at:
+                ptrs = (go.flat_params.data_ptr(), do.flat_params.data_ptr())
+                st = (go.state_dict(), do.state_dict(), {k: v.clone() for k, v in g.state_dict().items()},
+                      {k: v.clone() for k, v in d.state_dict().items()})
+                go.load_state_dict(st[0]); do.load_state_dict(st[1])
+                g.load_state_dict(st[2]); d.load_state_dict(st[3])
+                assert (go.flat_params.data_ptr(), do.flat_params.data_ptr()) == ptrs, "intact buckets must stay put"
+            losses.append(dt.train(s, f)["d_loss"] if i % 2 == 0 else gt.train(s, f)["g_loss"])
+        assert dt._runner.graphs and gt._runner.graphs and dt.graph_status()["mode"] == "graph"
+        return losses, {k: host(v) for k, v in list(g.state_dict().items()) + list(d.state_dict().items())}
+
+    l0, sd0 = run(None)
+    l1, sd1 = run(4)                 # both trainers have captured by call 4 (calls 3 and 4 capture); 5-6 replay
+    assert l0 == l1, (l0, l1)
+    for k in sd0:
+        assert np.array_equal(sd0[k], sd1[k]), k
+    # a bucket that DOES move (flatten() called by hand) makes the trainers drop their plan and re-capture
+    g, d, _, _ = make_nets(dict(seed=7, bias_scale=0.02), dict(seed=8, bias_scale=0.02))
+    dt, gt, go, do = _trainers(g, d)
+    for i in range(4):
+        s, f = batches[i]
+        (dt if i % 2 == 0 else gt).train(s, f)
+    old = dt._runner
+    do.flatten()
+    l_d = dt.train(*batches[4])["d_loss"]
+    assert dt._runner is not old, "the trainer must re-plan when the bucket moved"
+    assert abs(l_d - l0[4]) <= 1e-5 * abs(l0[4])

@@ -322,3 +322,59 @@ def test_discriminator_conditioning_branch_golden(golden):
         if "cond" in k or "layer_6" in k:
             s = z["cond/grad_sum/" + k]
             assert abs(float(np.linalg.norm(host(p.grad).astype(np.float64))) - s[0]) <= 1e-3 * s[0] + 1e-9, k
+
+
+def test_conditioned_discriminator_through_trainers():
+    """a discriminator that consumes its conditioning (conditioning_channels = 128) through
+    featuresynth.train.  The native D-step runs ONE pass over [fake; real] (batch 2B), so the conditioning must be
+    doubled with it; D-step and G-step gradients and losses are compared with the reference's order of operations
+    (train/train.py:26-42,63-74) spelled out over the same modules."""
+    from featuresynth import loss as LS
+    from featuresynth._synthetic import (module_param_shapes, synthetic_features, synthetic_samples,
+                                         synthetic_state_dict)
+    from featuresynth.experiment import realmelgan as R
+    from featuresynth.train import DiscriminatorTrainer, GeneratorTrainer
+    from featuresynth.util.modules import zero_grad
+    B, T = 2, 8
+
+    def nets():
+        g = R.Generator(128, 32, 3)
+        d = R.Discriminator(3, 16, 4, 4, conditioning_channels=128)
+        g.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(
+            module_param_shapes(g), seed=41, weight_scale=0.1, bias_scale=0.05).items()})
+        d.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(
+            module_param_shapes(d), seed=45, weight_scale=0.3, bias_scale=0.05).items()})
+        return g.cuda(), d.cuda()
+
+    samples, feats = dev(synthetic_samples(B, T * 256, rank=5)), dev(synthetic_features(B, 128, T, rank=5))
+    for kind in ("d", "g"):
+        # reference order of operations
+        g, d = nets()
+        go = torch.optim.Adam(g.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        do = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        zero_grad(go, do)
+        fake = g(feats)
+        f_feat, f_score = d(fake, feats)
+        r_feat, r_score = d(samples, feats)
+        if kind == "d":
+            ref_loss = LS.mel_gan_disc_loss(r_score, f_score, gan_loss=LS.hinge_discriminator_loss)
+        else:
+            ref_loss = R.mel_gan_gen_loss(r_feat, f_feat, r_score, f_score, gan_loss=LS.hinge_generator_loss)
+        ref_loss.backward()
+        ref = {k: host(p.grad) for k, p in (d if kind == "d" else g).named_parameters()}
+        # trainer (native path: batched [fake; real] pass in the D-step)
+        g2, d2 = nets()
+        go2 = torch.optim.Adam(g2.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        do2 = torch.optim.Adam(d2.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        if kind == "d":
+            r = DiscriminatorTrainer(g2, go2, d2, do2, LS.mel_gan_disc_loss).train(samples, feats)
+            assert abs(r["d_loss"] - ref_loss.item()) <= 1e-5 * abs(ref_loss.item())
+        else:
+            r = GeneratorTrainer(g2, go2, d2, do2, R.mel_gan_gen_loss).train(samples, feats)
+            assert abs(r["g_loss"] - ref_loss.item()) <= 1e-5 * abs(ref_loss.item())
+        worst = 0.0
+        for k, p in (d2 if kind == "d" else g2).named_parameters():
+            e = rel_l2(host(p.grad), ref[k])
+            worst = max(worst, e)
+            assert e < 1e-4, (kind, k, e)
+        print("conditioned discriminator, %s-step: worst grad rel-L2 vs reference order %.2e" % (kind, worst))
