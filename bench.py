@@ -16,8 +16,13 @@ contract, train.py:39-42,74).  value = world * B * 8192 * K / max-over-ranks(wal
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline      dominant kernel (by device time in an instrumented eager D+G pass): algorithmic
                 FLOPs per launch / mean launch duration measured with HIP events on the launch
-                stream, against the fp32 MFMA/vector peak (157.3 TFLOP/s) or HBM peak (8 TB/s)
-  step_roofline sum over launches of max(bytes/8 TB/s, flops/157.3 TFLOP/s) / measured time
+                stream (raw readings: nothing subtracted), against the ceiling of the pipe the kernel
+                runs on -- bf16 MFMA peak / 6 = 416.7 TFLOP/s for the split-bf16 kernels (six bf16
+                products per fp32 multiply), 157.3 for fp32-input MFMA, 8 TB/s for streams -- with the
+                fraction of the fp32 roofline (157.3) quoted beside it
+  step_roofline three fractions of the measured step: vs sum max(bytes/8 TB/s, flops/157.3 TFLOP/s)
+                (SURVEY 8(d)'s contract), vs sum max(bytes/8 TB/s, flops/416.7 TFLOP/s) (the pipe the
+                dense kernels now run on) and vs sum bytes/8 TB/s (pure memory-bound)
   cpu_baseline  the torch-functional CPU restatement of the reference graph (oracle/torch_graph.py)
                 timed on this host's cores on a bounded sample (N=1 runs only)
 """
@@ -269,17 +274,13 @@ def main():
         out_d = dt._fwd_bwd(s, f); d_optim.step()
         mark = len(L.PROFILE)
         out_g = gt._fwd_bwd(s, f); g_optim.step()
-        rec_raw, ev_ms = L.profile_end(calibrate=True)
+        rec, ev_ms = L.profile_end(calibrate=True)
         os.environ.pop("MSYNTH_STREAMS", None)
         del out_d, out_g
-        # the two event records of a measurement are stream commands themselves: an EMPTY pair reads
-        # ev_ms; that instrument offset is subtracted from every launch (raw figures are kept beside)
-        rec = [(name, cost, max(ms - ev_ms, 1e-4)) for name, cost, ms in rec_raw]
-        raw_ms = {}
-        for name, cost, ms in rec_raw:
-            kf = (cost.get("kernel") or name).split("<")[0]
-            raw_ms[kf] = raw_ms.get(kf, 0.0) + ms
-        log("[bench] empty event pair: %.2f us (subtracted from every launch)" % (ev_ms * 1e3))
+        # Raw event readings.  (r02 subtracted the reading of an EMPTY event pair, 4.6-4.9 us, from every launch;
+        # the rocprofv3 serial trace refuted that: traced durations sit 1-2 us BELOW the raw readings, not 5.  The
+        # empty-pair reading is still reported, as information about the instrument.)
+        log("[bench] empty event pair: %.2f us (reported only; launch times below are raw event readings)" % (ev_ms * 1e3))
         agg = {}
         for name, cost, ms in rec:
             k = cost.get("kernel") or name
@@ -314,28 +315,32 @@ def main():
         k, a = sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[0]
         avg_s = a["ms"] / a["n"] / 1e3
         fl, by = a["flops"] / a["n"], a["bytes"] / a["n"]
-        compute_bound = fl / F32_PEAK >= by / HBM_PEAK
+        split_pipe = k.startswith(("k_conv_rows3", "k_wgrad_rows3", "k_gconv_split", "k_wgrad_k5_split",
+                                   "k_wgrad_convt8_split"))
+        # ceiling of the pipe the kernel runs on: fp32 FLOPs executed on the bf16 matrix pipe with every fp32
+        # operand split exactly into three bf16 pieces and six partial products per multiply (conv_rows3.hip) can
+        # go no faster than bf16 peak / 6; the fp32-input MFMA kernels no faster than the fp32 peak
+        pipe_peak = BF16_PEAK / 6 if split_pipe else F32_PEAK
+        compute_bound = fl / pipe_peak >= by / HBM_PEAK
         if compute_bound:
-            roof = {"bound": "mfma", "achieved": fl / avg_s / 1e12, "peak": F32_PEAK / 1e12,
+            roof = {"bound": "mfma", "achieved": fl / avg_s / 1e12, "peak": pipe_peak / 1e12,
                     "unit": "TFLOP/s"}
         else:
             roof = {"bound": "hbm", "achieved": by / avg_s / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        if compute_bound and k.startswith("k_conv_rows3"):
-            # fp32 FLOPs executed on the bf16 matrix pipe: every fp32 operand split exactly into three bf16
-            # pieces, six partial products per multiply (conv_rows3.hip).  `peak` stays the fp32 roofline the
-            # workload is priced against; the pipe's own ceiling for this scheme is bf16 / 6.
-            roof["pipe"] = "bf16 MFMA, exact 3-way operand split, 6 products per fp32 multiply, fp32 accumulate"
-            roof["pipe_peak"] = BF16_PEAK / 6 / 1e12
-            roof["pipe_frac"] = roof["achieved"] / roof["pipe_peak"]
+        if compute_bound:
+            roof["pipe"] = ("bf16 MFMA, exact 3-way operand split, 6 products per fp32 multiply, fp32 accumulate: "
+                            "peak = 2500 / 6" if split_pipe else "fp32-input MFMA")
+            roof["fp32_peak"] = F32_PEAK / 1e12                  # SURVEY 8(d)'s fp32 roofline, for continuity
+            roof["frac_of_fp32_peak"] = roof["achieved"] / roof["fp32_peak"]
         roof["traffic"] = None
         # HBM bytes per launch of that kernel from the TCC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # in separate passes, gfx950 x2 fetch correction: tools/pmc_traffic.sh), quoted only when the file was
         # collected on THIS code (code_version stamp)
         ver = code_version()
         roof["code_version"] = ver
-        pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as fh:
                 pmc = json.load(fh)
@@ -347,12 +352,13 @@ def main():
                         nd += rec_["dispatches"]
                 if nd:
                     roof["traffic"] = tb / nd
-                    roof["traffic_source"] = "profiles/r02_pmc_traffic.json (%d dispatches, code %s)" % (nd, ver)
+                    roof["traffic_source"] = "profiles/r03_pmc_traffic.json (%d dispatches, code %s)" % (nd, ver)
             else:
-                roof["traffic_source"] = "profiles/r02_pmc_traffic.json is for code %s, benched code is %s: not quoted" % (
+                roof["traffic_source"] = "profiles/r03_pmc_traffic.json is for code %s, benched code is %s: not quoted" % (
                     pmc.get("code_version"), ver)
         roof.update({"kernel": k, "launches_per_DG_pair": a["n"], "avg_launch_us": avg_s * 1e6,
-                     "avg_launch_us_uncorrected": 1e3 * raw_ms.get(k, 0.0) / a["n"],
+                     "timing": "HIP events on the launch stream around every launch of an eager, stream-serialised "
+                               "D+G pass; raw readings (they sit 1-2 us above rocprofv3's kernel durations)",
                      "event_pair_overhead_us": ev_ms * 1e3,
                      "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
                      "share_of_kernel_time": a["ms"] / tot_ms,
@@ -363,10 +369,19 @@ def main():
         result["roofline"] = roof
         launches = W.d_step_launches(B, args.mels, T) + W.g_step_launches(B, args.mels, T)
         ideal = W.roofline_seconds(launches, HBM_PEAK, F32_PEAK)
+        ideal_pipe = W.roofline_seconds(launches, HBM_PEAK, BF16_PEAK / 6)
+        ideal_hbm = W.roofline_seconds(launches, HBM_PEAK, float("inf"))
         pair_s = 2 * elapsed / args.steps
         result["step_roofline"] = {
             "ideal_ms_per_DG_pair": ideal * 1e3, "measured_ms_per_DG_pair": pair_s * 1e3,
-            "frac": ideal / pair_s, "algorithmic_gflop_per_DG_pair": W.totals(launches)["flops"] / 1e9,
+            "frac": ideal / pair_s,
+            "frac_definition": "sum over launches of max(bytes / 8 TB/s, flops / 157.3 TFLOP/s) / measured (SURVEY 8(d))",
+            "ideal_ms_split_bf16_pipe": ideal_pipe * 1e3, "frac_split_bf16_pipe": ideal_pipe / pair_s,
+            "frac_split_bf16_pipe_definition": "sum max(bytes / 8 TB/s, flops / (2500 / 6 = 416.7 TFLOP/s)) / measured: "
+                                               "every FLOP priced on the pipe the dense kernels run on",
+            "ideal_ms_memory_bound": ideal_hbm * 1e3, "frac_memory_bound": ideal_hbm / pair_s,
+            "frac_memory_bound_definition": "sum bytes / 8 TB/s / measured (north_star's memory-bound roofline)",
+            "algorithmic_gflop_per_DG_pair": W.totals(launches)["flops"] / 1e9,
             "algorithmic_mb_per_DG_pair": W.totals(launches)["bytes"] / 1e6,
             "kernel_ms_per_DG_pair_eager": tot_ms}
 

@@ -114,12 +114,51 @@ size_t ms_conv1d_bwd_weight_multi_workspace_bytes(const ms_wgrad_multi_desc* d);
 int ms_conv1d_bwd_weight_multi(const ms_wgrad_multi_desc* d, void* workspace, size_t workspace_bytes,
                                ms_stream_t stream);
 
+/*
+ * Fused ResidualAtom forward (util/modules.py:350-388):
+ *     y = x + lrelu(conv1d(lrelu(conv1d(x, w0, b0, padding = dil, dilation = dil)), w1, b1, padding = 1))
+ * both convs k = 3, C -> C channels, zero padding, in ONE launch: the intermediate activation stays on chip.
+ * Same arithmetic as two ms_conv1d_fwd calls (the results agree bitwise with them).
+ *   ms_residual_atom_pack_multi  splits the fp32 weights of up to MS_ATOM_PACK_MAX atoms once into the kernel's
+ *                                fragment-ordered bf16 x 3 images (ms_residual_atom_image_bytes(C) bytes each, caller-
+ *                                owned, 16-byte aligned); call it again whenever the weights changed (once per step)
+ *   ms_residual_atom_fwd         t / y_act (both or neither): training additionally stores t = lrelu(conv_d + b0) and
+ *                                y_act = lrelu(conv1 + b1), the activations the backward pass of the atom needs
+ *   ms_residual_atom_supported   1 when the fused kernel takes this geometry (C in {32, 64, 128}, L % 4 == 0,
+ *                                dil <= 9), else 0: the caller then issues the two convs
+ * b0, b1 and image must be 16-byte aligned.
+ */
+typedef struct ms_atom_desc {
+    int32_t B, C, L, dil;
+    float slope;      /* LeakyReLU negative slope */
+} ms_atom_desc;
+#define MS_ATOM_PACK_MAX 16
+typedef struct ms_atom_pack_desc {
+    int32_t count;
+    int32_t reserved;
+    int32_t C[MS_ATOM_PACK_MAX];
+    const float* w0[MS_ATOM_PACK_MAX];     /* (C, C, 3): the dilated conv */
+    const float* w1[MS_ATOM_PACK_MAX];     /* (C, C, 3): the dilation-1 conv */
+    void* image[MS_ATOM_PACK_MAX];
+} ms_atom_pack_desc;
+size_t ms_residual_atom_image_bytes(int32_t C);
+int ms_residual_atom_supported(const ms_atom_desc* d);
+int ms_residual_atom_pack_multi(const ms_atom_pack_desc* d, ms_stream_t stream);
+int ms_residual_atom_fwd(const ms_atom_desc* d, const float* x, const void* image, const float* b0, const float* b1,
+                         float* y, float* t, float* y_act, ms_stream_t stream);
+
 /* which: 0 fwd, 1 bwd_data, 2 bwd_weight */
 size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which);
 
 /* Name of the device kernel the dispatch selects for this geometry (which: 0 fwd, 1 bwd_data,
  * 2 bwd_weight) -- lets a profiler line be matched to a layer.  Static string, never NULL. */
 const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which);
+
+/* Profiling aid: spelling (as rocprofv3 prints it, without the namespace) of the dense-family kernel instantiation the
+ * calling THREAD's most recent ms_* call dispatched, "" when that call's launcher does not note one (then
+ * ms_conv1d_kernel_name applies).  ms_last_kernel_clear() empties it.  Thread-local; not needed for normal operation. */
+const char* ms_last_kernel_name(void);
+void ms_last_kernel_clear(void);
 
 /* nn.ConvTranspose1d geometry.  w is (Cin, Cout, K).  Lout = (Lin-1)*stride - 2*pad + K */
 typedef struct ms_convt1d_desc {

@@ -1,10 +1,21 @@
 // extern "C" entry points for the convolution family: argument validation, geometry, and the
 // dispatch between the direct (vector FMA) kernels and the f32-MFMA implicit-GEMM kernels.
 #include "ms_common.h"
+#include <stdarg.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include "conv_mfma.h"
 #include "gconv_mfma.h"
 #include "conv_thin.h"
+
+static thread_local char g_last_kernel[160] = "";
+
+void ms_note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+    va_end(ap);
+}
 
 namespace {
 
@@ -56,6 +67,9 @@ bool make_convt(const ms_convt1d_desc* d, ConvP* p) {
 extern "C" {
 
 int ms_version(void) { return MSYNTH_VERSION; }
+
+const char* ms_last_kernel_name(void) { return g_last_kernel; }
+void ms_last_kernel_clear(void) { g_last_kernel[0] = 0; }
 
 const char* ms_status_string(int status) {
     switch (status) {

@@ -1,0 +1,473 @@
+// Fused ResidualAtom forward:  out = x + lrelu(conv1_k3(lrelu(conv_d_k3_dil(x) + b0)) + b1)  in ONE launch
+// (reference util/modules.py:350-388; 24 of the generator's 30 convs are the two halves of such an atom).
+//
+// Same arithmetic as the two row-tile launches it replaces (conv_rows3.hip): fp32 operands split exactly into
+// three bf16 pieces, six partial products per multiply on v_mfma_f32_32x32x16_bf16, fp32 accumulation, chunks of
+// 16 input channels, taps inside a chunk -- so the intermediate t and the output are bitwise what the unfused
+// pair computes from the same weights.  What changes is where the data lives:
+//
+//   * a workgroup (4 waves) owns NO = NTP - 4 output columns of one batch row for ALL C channels.  It stages the
+//     input window x[:, c0-1-d .. c0+NTP+d) ONCE (all channels: the whole contraction is LDS-resident, there is
+//     no K-loop staging and no barrier inside either GEMM), computes t on the NTP columns c0-1 .. c0+NTP-2
+//     (one halo column each side for the k3 / dil 1 conv that follows), writes lrelu(t) -- split into its bf16
+//     pieces straight from the accumulators -- over the dead x window, and runs the second GEMM from there.
+//     t never travels to HBM (training additionally stores t and u = lrelu(conv1 + b1) for the backward pass);
+//   * the weights are PRE-SPLIT once per step by k_atom_pack into fragment-linear images (one 1 KiB block per
+//     (32 output rows, 16-channel chunk, tap, piece) in exactly the order the MFMA A operand wants them) and
+//     stream from L2 straight into registers, one chunk ahead: no LDS traffic, no vector work for weights at all
+//     (in the unfused kernels every workgroup re-splits every weight it stages: ~45 % of their staging work).
+//   MFMA issue is then only interleaved with the B-fragment ds_reads; the vector work left is one split per
+//   input element (prologue) and one per t element (between the GEMMs), hidden by the second workgroup on the CU.
+//
+// LDS: [chunk][column][3 pieces x 16 channels bf16 | 16 pad] = 112 B per (column, chunk) as in conv_rows3.hip
+// (fragment reads and 8-byte staging stores conflict-free).  C = 64, d = 9: 4 x 150 x 112 = 67 KB -> 2 WGs / CU.
+#include "ms_common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XRS = 112;          // bytes per LDS column of one 16-channel chunk: 3 pieces x 32 + 16
+
+// (a, b) -> three packed bf16 pairs with a = h.lo + m.lo + l.lo exactly (conv_rows3.hip)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    const f32x2 v = {a, b};
+    const bf16x2 hi = __builtin_convertvector(v, bf16x2);
+    const f32x2 r1 = v - __builtin_convertvector(hi, f32x2);
+    const bf16x2 mi = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(mi, f32x2);
+    const bf16x2 lo = __builtin_convertvector(r2, bf16x2);
+    h = __builtin_bit_cast(unsigned, hi);
+    m = __builtin_bit_cast(unsigned, mi);
+    l = __builtin_bit_cast(unsigned, lo);
+}
+
+__device__ __forceinline__ void split_quad(const float (&e)[4], uint2 (&o)[3]) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_pair(e[0], e[1], h0, m0, l0);
+    split_pair(e[2], e[3], h1, m1, l1);
+    o[0] = make_uint2(h0, h1);
+    o[1] = make_uint2(m0, m1);
+    o[2] = make_uint2(l0, l1);
+}
+
+// ---- weight image ------------------------------------------------------------------------------------------
+// image[conv][ms][chunk][tap][piece][lane] (16 B each): lane's A fragment of v_mfma_f32_32x32x16_bf16 for output
+// rows ms*32 + (lane & 31), contraction channels chunk*16 + 8*(lane >> 5) + 0..7, tap `tap`.
+__host__ __device__ constexpr size_t atom_conv_image_u4(int C) { return (size_t)(C / 32) * (C / 16) * 9 * 64; }
+
+struct AtomPackJob {
+    const float* w0;
+    const float* w1;
+    u32x4* image;
+    int C;
+    int first_block;     // prefix sum of blocks over the jobs
+};
+constexpr int ATOM_PACK_MAX = 16;
+struct AtomPackTable {
+    int count;
+    AtomPackJob job[ATOM_PACK_MAX];
+};
+
+// one thread = one lane's 16-byte fragment of all three pieces of one (conv, ms, chunk, tap)
+__global__ __launch_bounds__(256) void k_atom_pack(AtomPackTable t) {
+    int j = 0;
+#pragma unroll 1
+    for (int i = 1; i < t.count; ++i)
+        if ((int)blockIdx.x >= t.job[i].first_block) j = i;
+    const AtomPackJob jb = t.job[j];
+    const int C = jb.C, MS = C / 32, NC = C / 16;
+    const int idx = ((int)blockIdx.x - jb.first_block) * 256 + threadIdx.x;      // over conv x ms x chunk x tap x lane
+    const int total = 2 * MS * NC * 3 * 64;
+    if (idx >= total) return;
+    const int lane = idx & 63;
+    int r = idx >> 6;
+    const int tap = r % 3; r /= 3;
+    const int chunk = r % NC; r /= NC;
+    const int ms = r % MS;
+    const int conv = r / MS;
+    const float* w = conv ? jb.w1 : jb.w0;
+    const int row = ms * 32 + (lane & 31), ci0 = chunk * 16 + 8 * (lane >> 5);
+    unsigned pc[3][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = w[((size_t)row * C + ci0 + 2 * q) * 3 + tap];
+        const float b = w[((size_t)row * C + ci0 + 2 * q + 1) * 3 + tap];
+        split_pair(a, b, pc[0][q], pc[1][q], pc[2][q]);
+    }
+    u32x4* dst = jb.image + (size_t)conv * atom_conv_image_u4(C) + ((size_t)((ms * NC + chunk) * 3 + tap) * 3) * 64 + lane;
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) dst[pp * 64] = u32x4{pc[pp][0], pc[pp][1], pc[pp][2], pc[pp][3]};
+}
+
+// ---- the fused kernel ---------------------------------------------------------------------------------------
+struct AtomP {
+    int B, C, L, dil, NO, tiles_per_row, NXA;      // NXA: allocated LDS columns per chunk (>= NTP + 2 dil + 3)
+    float slope;
+};
+
+template <int C, int NTP>
+struct AtomCfg {
+    static constexpr int MS = C / 32, WGM = MS < 4 ? MS : 4, TM = MS / WGM, WGN = 4 / WGM, TN = NTP / 32 / WGN, NC = C / 16;
+    static constexpr int NVMAX = (NTP + 18 + 3 + 3) / 4, NV16MAX = (NVMAX + 3) / 4;       // dilation <= 9
+    static constexpr int ROUNDS = (NC * NV16MAX * 16 + 255) / 256;
+    static_assert(MS >= 1 && TN >= 1 && TM * WGM == MS && TN * WGN * 32 == NTP, "tile shape");
+};
+
+// DBG (tools/probe_atom.py only; 0 in the product) -- timing probes, results are garbage: 1 = weight fragments loaded
+// once (no streaming), 2 = B fragments read once per GEMM (no LDS traffic in the K loop), 3 = no global stores,
+// 4 = no x window loads / staging, 5 = no MFMAs.
+//
+// Persistent workgroups: the grid is the number of workgroups the chip holds at once; each walks the tiles
+// blockIdx.x, + gridDim.x, ...  Per tile:   [x window(t) registers -> split -> LDS] [issue the x window loads of tile
+// t + 1 into registers] [GEMM 1] [t tile -> LDS (+ stores of t)] [GEMM 2] [stores of y (and u)] -- the next tile's loads
+// and this tile's stores travel under the two GEMMs, so HBM and the matrix pipe overlap inside ONE workgroup.
+template <int C, int NTP, bool SAVE, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void k_atom_fwd(AtomP p, const float* __restrict__ X, const u32x4* __restrict__ IMG,
+                                                 const float* __restrict__ b0, const float* __restrict__ b1,
+                                                 float* __restrict__ Y, float* __restrict__ T, float* __restrict__ U) {
+    typedef AtomCfg<C, NTP> Cfg;
+    constexpr int TM = Cfg::TM, WGN = Cfg::WGN, TN = Cfg::TN, NC = Cfg::NC, ROUNDS = Cfg::ROUNDS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_atom[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: everything derived from it is scalar
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int d = p.dil, L = p.L;
+    const int sh = (((-1 - d) % 4) + 4) % 4;         // tile starts are multiples of 4: the window start c0 - 1 - d sits sh
+                                                     // samples behind an aligned 16-byte vector, the same for every tile
+    const int NX = NTP + 2 * d;                      // x columns the first GEMM reads
+    constexpr int NXA = NTP + 22;                    // LDS columns per chunk (dilation <= 9: NTP + 2 d + 3 used)
+    constexpr int XCS = NXA * XRS;                   // chunk stride of the x window (compile-time: LDS offsets fold into the instructions)
+    constexpr int TCS = (NTP + 2) * XRS;             // chunk stride of the t tile (aliases the x window)
+    constexpr unsigned OOB = 0xF0000000u;
+    const int ntiles = p.B * p.tiles_per_row;
+
+    // Operands and results go through buffer descriptors: a lane that is out of the tensor carries an out-of-range
+    // byte offset -- loads return 0.0 (the zero padding), stores are dropped -- and the per-row / per-channel part of an
+    // address travels in the scalar offset: no 64-bit address arithmetic, no divergent branches in the epilogues.
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, 0x80000000u, 0x00020000);
+    const auto rsY = __builtin_amdgcn_make_buffer_rsrc(Y, 0, 0x80000000u, 0x00020000);
+    const auto rsT = __builtin_amdgcn_make_buffer_rsrc(SAVE ? T : Y, 0, 0x80000000u, 0x00020000);
+    const auto rsU = __builtin_amdgcn_make_buffer_rsrc(SAVE ? U : Y, 0, 0x80000000u, 0x00020000);
+
+    // ---- tile-invariant staging units.  Unit = 4 channels x one aligned 4-sample vector; 16 consecutive lanes = 4
+    // channel quads x 4 consecutive vectors (their 8-byte LDS stores fall into 16 different bank pairs).
+    const int NV = (NX + sh + 3) >> 2, NV16 = (NV + 3) >> 2;
+    int u_goff[ROUNDS], u_t[ROUNDS], u_lcol[ROUNDS], u_lbase[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int u = tid + 256 * r;
+        const int grp = u >> 4, chunk = grp / NV16, vg = grp - chunk * NV16;
+        const int cq = (u >> 2) & 3, v = vg * 4 + (u & 3);
+        const bool in = chunk < NC && v < NV;
+        u_t[r] = in ? 4 * v - sh - 1 - d : (1 << 28);              // global column of the vector, relative to c0
+        u_goff[r] = 4 * ((chunk * 16 + 4 * cq) * L + (4 * v - sh - 1 - d));   // byte offset relative to the tile base
+        u_lcol[r] = in ? 4 * v - sh : -1000;
+        u_lbase[r] = chunk * XCS + cq * 8;
+    }
+    f32x4 rx[ROUNDS][4];
+    auto load_x = [&](int tile) {
+        const int bb = tile / p.tiles_per_row, cc0 = (tile - bb * p.tiles_per_row) * p.NO;
+        const int base = 4 * bb * C * L;                            // (wave-uniform: scalar offset)
+#pragma unroll
+        for (int r = 0; r < (DBG == 4 ? 0 : ROUNDS); ++r) {
+            const int t = cc0 + u_t[r];                              // multiple of 4: all inside the row or all outside
+            // (the column base rides in the lane offset: the hardware range-checks THAT part, which must not go negative)
+            const unsigned goff = (t >= 0 && t < L) ? (unsigned)(u_goff[r] + 4 * cc0) : OOB;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+                rx[r][cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, goff, base + cc * 4 * L, 0));
+        }
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int r = 0; r < (DBG == 4 ? 0 : ROUNDS); ++r) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = u_lcol[r] + e;
+                if (i < 0 || i >= NXA) continue;
+                const float c4[4] = {rx[r][0][e], rx[r][1][e], rx[r][2][e], rx[r][3][e]};
+                uint2 o3[3];
+                split_quad(c4, o3);
+                unsigned char* dst = smem_atom + u_lbase[r] + i * XRS;
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(dst + pp * 32) = o3[pp];
+            }
+        }
+    };
+
+    // ---- A fragments: image -> registers, one chunk ahead (pinned in place: the machine scheduler would otherwise sink
+    // every load to its first use and serialise the L2 latency into the MFMA stream)
+    // (buffer loads: lane part = lane * 16 + the wave's row block, everything else is a literal scalar offset -- 64-bit
+    //  per-fragment pointers would be hoisted out of the tile loop and eat ~100 registers)
+    bf16x8 fa[2][TM][3][3];
+    const auto rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(IMG), 0, 0x80000000u, 0x00020000);
+    const int a_voff = lane * 16 + wm * TM * NC * 9 * 1024;
+    auto load_a = [&](int conv, int chunk, bf16x8 (&dst)[TM][3][3]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+                    dst[i][s][pp] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                        rsI, a_voff, (int)(conv * atom_conv_image_u4(C) * 16) + ((i * NC + chunk) * 9 + s * 3 + pp) * 1024, 0));
+    };
+
+    f32x16 acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    // one GEMM over the LDS-resident operand: B fragment of (chunk, tap s, column sub-tile j) = 16 bytes per piece at
+    // column (col0 + 32 j + l31 + s * step), channels 8h .. 8h + 7 of the chunk.  next: what the last chunk prefetches
+    // (0: conv 1's chunk 0 for the second GEMM, 1: conv 0's chunk 0 for the next tile, 2: nothing)
+    auto gemm = [&](int conv, int cs, int step, int next) {
+        const unsigned char* Bs = smem_atom + ((wn * TN) * 32 + l31) * XRS + h * 16;
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};      // piece pairs, smallest products first
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) {
+            if (DBG == 1) {
+                if (ch == 0 && conv == 0) load_a(conv, 1, fa[1]);
+            } else if (ch + 1 < NC) load_a(conv, ch + 1, fa[(ch + 1) & 1]);
+            else if (next == 0) load_a(1, 0, fa[(ch + 1) & 1]);
+            else if (next == 1) load_a(0, 0, fa[(ch + 1) & 1]);
+            bf16x8 fb[2][TN][3];
+            auto fragb = [&](int s, bf16x8 (&dst)[TN][3]) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pp = 0; pp < 3; ++pp)
+                        dst[j][pp] = *reinterpret_cast<const bf16x8*>(Bs + ch * cs + (j * 32 + s * step) * XRS + pp * 32);
+            };
+            if (DBG != 2 || ch == 0) fragb(0, fb[0]);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                if (s + 1 < 3 && (DBG != 2 || ch == 0)) fragb(s + 1, fb[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (DBG == 5) continue;
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ch & 1][i][s][PA[t]], fb[s & 1][j][PB[t]],
+                                                                                acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // per-lane parts of the result offsets (bytes): column n of sub-tile j, channel half h
+    int o_lane[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) o_lane[j] = 4 * ((wn * TN + j) * 32 + l31 + 4 * h * L);
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_x(tile);
+    load_a(0, 0, fa[0]);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / p.tiles_per_row, c0 = (tile - b * p.tiles_per_row) * p.NO;
+        const int base = 4 * (b * C * L + c0);                      // byte offset of (row b, channel 0, column c0)
+        int L4;                                                      // 4 L, opaque to the optimiser: the per-channel scalar offsets
+        asm volatile("s_mov_b32 %0, %1" : "=s"(L4) : "s"(4 * L));    // are then formed where they are used (2 scalar ops), not hoisted
+        store_x();                                                   // (waits for this tile's window)
+        zero_acc();
+        const int nxt = tile + gridDim.x;
+        if (nxt < ntiles) load_x(nxt);                              // travels under both GEMMs
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                             // x window staged
+        gemm(0, XCS, d, 0);                                          // t (pre-activation) on columns c0-1 .. c0+NTP-2
+
+        unsigned o_y[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = (wn * TN + j) * 32 + l31;
+            o_y[j] = (n < p.NO && c0 + n < L) ? (unsigned)o_lane[j] : OOB;
+        }
+
+        __syncthreads();                                             // every wave is done with the x window: t overwrites it
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = (wn * TN + j) * 32 + l31;           // t tile column <-> global column c0 - 1 + col
+                const int gc = c0 - 1 + col;
+                const bool inrow = gc >= 0 && gc < L;                // outside the row t is conv1's ZERO padding
+                const unsigned o_t = (SAVE && DBG != 3 && inrow && col >= 1 && col <= p.NO) ? (unsigned)(o_lane[j] - 4) : OOB;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int chs = (wm * TM + i) * 32 + 8 * g, ch0 = chs + 4 * h;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(b0 + ch0);
+                    float e[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v = acc[i][j][4 * g + q] + bv[q];
+                        e[q] = inrow ? (v > 0.f ? v : v * p.slope) : 0.f;
+                    }
+                    if (SAVE) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e[q]), rsT, o_t, base + (chs + q) * L4, 0);
+                    }
+                    uint2 o3[3];
+                    split_quad(e, o3);
+                    unsigned char* dst = smem_atom + (col * XRS + 8 * h) + ((chs >> 4) * TCS + (chs & 15) * 2);
+#pragma unroll
+                    for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(dst + pp * 32) = o3[pp];
+                }
+            }
+        zero_acc();
+        __syncthreads();                                             // t tile complete
+        gemm(1, TCS, 1, nxt < ntiles ? 1 : 2);                       // output column n reads t tile columns n, n+1, n+2
+
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const unsigned oy = DBG == 3 ? OOB : o_y[j];
+                float xr[16];                                        // the residual x values of this lane's outputs (L2-warm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    xr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rsX, o_y[j], base + ((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0));
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int chs = (wm * TM + i) * 32 + 8 * g, ch0 = chs + 4 * h;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(b1 + ch0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v = acc[i][j][4 * g + q] + bv[q];
+                        v = v > 0.f ? v : v * p.slope;
+                        if (SAVE) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsU, oy, base + (chs + q) * L4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + xr[4 * g + q]), rsY, oy,
+                                                              base + (chs + q) * L4, 0);
+                    }
+                }
+            }
+        __syncthreads();                                             // the t tile is dead: the next window may overwrite it
+    }
+}
+
+template <int C, int NTP>
+int launch_atom(const AtomP& p0, const float* x, const void* image, const float* b0, const float* b1, float* y, float* t,
+                float* u, hipStream_t s) {
+    AtomP p = p0;
+    p.NO = NTP - 4;
+    p.tiles_per_row = (p.L + p.NO - 1) / p.NO;
+    p.NXA = NTP + 22;
+    const size_t lds = (size_t)(C / 16) * p.NXA * XRS;
+    if (lds > 158 * 1024) return MS_ERR_UNSUPPORTED;
+    const bool save = t != nullptr;
+    const void* fn = save ? reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, true>)
+                          : reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, false>);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[save]) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        attr_set[save] = true;
+    }
+    static int wgs_per_cu[2] = {0, 0}, n_cu = 0;
+    if (!wgs_per_cu[save]) {
+        int nb = 0, dev = 0;
+        hipDeviceProp_t prop;
+        (void)hipGetDevice(&dev);
+        (void)hipGetDeviceProperties(&prop, dev);
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        // (LDS is the limit: sized for the largest window, dilation 9)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, (size_t)(C / 16) * (NTP + 22) * XRS) != hipSuccess || nb < 1) nb = 1;
+        wgs_per_cu[save] = nb;
+    }
+    const long long ntiles = (long long)p.B * p.tiles_per_row;
+    const long long slots = (long long)n_cu * wgs_per_cu[save];
+    const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
+    static const int dbg = getenv("MSYNTH_ATOM_DBG") ? atoi(getenv("MSYNTH_ATOM_DBG")) : 0;       // timing probes
+    if (dbg && save) {
+#define MS_ATOM_DBG(D_) if (dbg == D_) { \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, true, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); \
+            hipLaunchKernelGGL((k_atom_fwd<C, NTP, true, D_>), grid, dim3(256), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u); MS_CHECK_LAUNCH(); return MS_OK; }
+        MS_ATOM_DBG(1) MS_ATOM_DBG(2) MS_ATOM_DBG(3) MS_ATOM_DBG(4) MS_ATOM_DBG(5)
+#undef MS_ATOM_DBG
+    }
+    ms_note_kernel("k_atom_fwd<%d, %d, %s>", C, NTP, save ? "true" : "false");
+    if (save)
+        hipLaunchKernelGGL((k_atom_fwd<C, NTP, true>), grid, dim3(256), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u);
+    else
+        hipLaunchKernelGGL((k_atom_fwd<C, NTP, false>), grid, dim3(256), lds, s, p, x, (const u32x4*)image, b0, b1, y,
+                           nullptr, nullptr);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+bool atom_ok(const ms_atom_desc* d) {
+    if (!d || d->B <= 0 || d->L <= 0 || d->dil < 1 || d->dil > 9) return false;
+    if (d->C != 32 && d->C != 64 && d->C != 128) return false;
+    if (d->L % 4) return false;                                   // 16-byte aligned rows
+    if ((long long)d->B * d->C * d->L * 4 >= (1ll << 31)) return false;   // 32-bit buffer offsets
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ms_residual_atom_image_bytes(int32_t C) {
+    if (C <= 0 || C % 32) return 0;
+    return 2 * atom_conv_image_u4(C) * 16;
+}
+
+int ms_residual_atom_supported(const ms_atom_desc* d) {
+    const char* sw = getenv("MSYNTH_ATOM");                      // tuning / test switch (0: the two row-tile launches)
+    if (sw && atoi(sw) == 0) return 0;
+    return atom_ok(d) ? 1 : 0;
+}
+
+int ms_residual_atom_pack_multi(const ms_atom_pack_desc* d, ms_stream_t stream) {
+    if (!d || d->count <= 0 || d->count > MS_ATOM_PACK_MAX) return MS_ERR_INVALID_ARG;
+    AtomPackTable t;
+    t.count = d->count;
+    int blocks = 0;
+    for (int i = 0; i < d->count; ++i) {
+        const int C = d->C[i];
+        if (C <= 0 || C % 32 || !d->w0[i] || !d->w1[i] || !d->image[i] || (((uintptr_t)d->image[i]) & 15))
+            return MS_ERR_INVALID_ARG;
+        t.job[i].w0 = d->w0[i];
+        t.job[i].w1 = d->w1[i];
+        t.job[i].image = (u32x4*)d->image[i];
+        t.job[i].C = C;
+        t.job[i].first_block = blocks;
+        const int total = 2 * (C / 32) * (C / 16) * 3 * 64;
+        blocks += (total + 255) / 256;
+    }
+    hipLaunchKernelGGL(k_atom_pack, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_residual_atom_fwd(const ms_atom_desc* d, const float* x, const void* image, const float* b0, const float* b1,
+                         float* y, float* t, float* y_act, ms_stream_t stream) {
+    if (!atom_ok(d)) return d ? MS_ERR_UNSUPPORTED : MS_ERR_INVALID_ARG;
+    if (!x || !image || !b0 || !b1 || !y || ((t == nullptr) != (y_act == nullptr))) return MS_ERR_INVALID_ARG;
+    if ((((uintptr_t)image) & 15) || (((uintptr_t)b0) & 15) || (((uintptr_t)b1) & 15)) return MS_ERR_INVALID_ARG;
+    AtomP p;
+    p.B = d->B; p.C = d->C; p.L = d->L; p.dil = d->dil; p.slope = d->slope;
+    hipStream_t s = (hipStream_t)stream;
+    switch (d->C) {
+        case 32: return launch_atom<32, 128>(p, x, image, b0, b1, y, t, y_act, s);
+        case 64: return launch_atom<64, 128>(p, x, image, b0, b1, y, t, y_act, s);
+        case 128: return launch_atom<128, 64>(p, x, image, b0, b1, y, t, y_act, s);
+        default: return MS_ERR_UNSUPPORTED;
+    }
+}
+
+}  // extern "C"

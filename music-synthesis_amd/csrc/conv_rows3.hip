@@ -401,7 +401,10 @@ __global__ __launch_bounds__(256) void k_conv_rows3(Row2P p, const float* __rest
 // so a 32-row sub-tile multiplies two weight taps (A has K = 2) against the window columns offset by its half.
 // The epilogue scatters row (co, phase) / column q to y[co][q S + phase]: four consecutive samples per store.
 // INA: LeakyReLU applied to the input on its way into LDS (the activation in front of the transposed conv).
-template <int WGM, int TM, int TN, int K, int AM, int HS = 0, bool INA = false>
+// DBG (tools/dbg_r3p.py only; 0 in the product): 1 = staging without the operand split (raw bits stored),
+// 2 = no MFMAs, 3 = no staging at all (no loads, no LDS stores), 4 = no global loads inside the K loop, 5 = loads but no
+// split / LDS stores -- timing probes, results are garbage.
+template <int WGM, int TM, int TN, int K, int AM, int HS = 0, bool INA = false, int DBG = 0>
 __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __restrict__ X,
                                                     const float* __restrict__ Xact,
                                                     const float* __restrict__ W,
@@ -528,7 +531,11 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
                 for (int qq = 0; qq < 4; ++qq) e[qq] = rad[qq * K + (K - 1 - j)];   // taps flipped
             }
             uint2 o3[3];
-            split_quad(e, o3);
+            if (DBG == 1) {
+                o3[0] = make_uint2(__float_as_uint(e[0]), __float_as_uint(e[1]));
+                o3[1] = make_uint2(__float_as_uint(e[2]), __float_as_uint(e[3]));
+                o3[2] = o3[0];
+            } else split_quad(e, o3);
 #pragma unroll
             for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(base0 + j * jstep + pp * pstep) = o3[pp];
         }
@@ -547,18 +554,32 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
                 if (INA) c4[cc] = c4[cc] > 0.f ? c4[cc] : c4[cc] * p.slope;
             }
             uint2 o3[3];
-            split_quad(c4, o3);
+            if (DBG == 1) {
+                o3[0] = make_uint2(__float_as_uint(c4[0]), __float_as_uint(c4[1]));
+                o3[1] = make_uint2(__float_as_uint(c4[2]), __float_as_uint(c4[3]));
+                o3[2] = o3[0];
+            } else split_quad(c4, o3);
 #pragma unroll
             for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(base + pp * pstep) = o3[pp];
         }
     };
 
+    float dbg_sink = 0.f;
+    auto sink_regs = [&]() {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) dbg_sink += rx[cc][0] + rx[cc][1] + rx[cc][2] + rx[cc][3];
+        if (AM == 0) {
+#pragma unroll
+            for (int k4 = 0; k4 < KA; ++k4) dbg_sink += ra[k4][0] + ra[k4][1] + ra[k4][2] + ra[k4][3];
+        }
+    };
     const int cbeg = blockIdx.z * p.CKs;
     const int nchunks = ((cbeg + p.CKs < p.CK ? cbeg + p.CKs : p.CK) - cbeg) / CC3;
     Y += (size_t)blockIdx.z * p.zstride;
 
     const int arow = (wm * TM * 32 + (lane & 31)) * ARS + h * 16;
     auto compute = [&](const unsigned char* As) {
+        if (DBG == 2) return;
         const unsigned char* Xs = Xg + h * 16;
         if constexpr (HS != 0) {
             // two weight taps; sub-tile i reads the window columns (tap + its half): TM == 1: the wave's 32 rows
@@ -623,11 +644,11 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
 
     // prologue: everybody stages its half of A[0]; group 0 its X0[0]; group 1 then holds X1[0] and its half of
     // A[1] in registers for slot 0
-    load_a(cbeg, true);
-    if (g == 0) load_x(cbeg, true);
-    store_a(Abuf);
-    if (g == 0) store_x();
-    else { load_x(cbeg, true); load_a(cbeg + CC3, nchunks > 1); }
+    if (DBG != 3) load_a(cbeg, true);
+    if (g == 0 && DBG != 3) load_x(cbeg, true);
+    if (DBG != 3) store_a(Abuf);
+    if (g == 0 && DBG != 3) store_x();
+    else if (DBG != 3) { load_x(cbeg, true); load_a(cbeg + CC3, nchunks > 1); }
     __syncthreads();
 
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -635,22 +656,22 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
         unsigned char* An = Abuf + ((ch & 1) ^ 1) * a_bytes;
         // slot 2*ch
         if (g == 0) {
-            load_x(cbeg + (ch + 1) * CC3, ch + 1 < nchunks);     // staged in slot 2*ch + 1
-            load_a(cbeg + (ch + 1) * CC3, ch + 1 < nchunks);
+            if (DBG != 3 && DBG != 4) load_x(cbeg + (ch + 1) * CC3, ch + 1 < nchunks);     // staged in slot 2*ch + 1
+            if (DBG != 3 && DBG != 4) load_a(cbeg + (ch + 1) * CC3, ch + 1 < nchunks);
             compute(As);
         } else {
-            store_x();                                           // X1[ch]
-            store_a(An);                                         // its half of A[ch + 1]
+            if (DBG == 5) sink_regs(); else if (DBG != 3) store_x();                                           // X1[ch]
+            if (DBG != 3 && DBG != 5) store_a(An);                                         // its half of A[ch + 1]
         }
         __syncthreads();
         // slot 2*ch + 1
         if (g == 1) {
-            load_x(cbeg + (ch + 1) * CC3, ch + 1 < nchunks);     // staged in slot 2*ch + 2
-            load_a(cbeg + (ch + 2) * CC3, ch + 2 < nchunks);
+            if (DBG != 3 && DBG != 4) load_x(cbeg + (ch + 1) * CC3, ch + 1 < nchunks);     // staged in slot 2*ch + 2
+            if (DBG != 3 && DBG != 4) load_a(cbeg + (ch + 2) * CC3, ch + 2 < nchunks);
             compute(As);
         } else {
-            store_x();                                           // X0[ch + 1]
-            store_a(An);                                         // its half of A[ch + 1]
+            if (DBG == 5) sink_regs(); else if (DBG != 3) store_x();                                           // X0[ch + 1]
+            if (DBG != 3 && DBG != 5) store_a(An);                                         // its half of A[ch + 1]
         }
         __syncthreads();
     }
@@ -658,6 +679,7 @@ __global__ __launch_bounds__(512) void k_conv_rows3p(Row2P p, const float* __res
     // ---- epilogue: each group transposes its tile through its own LDS region (the K-loop buffers are dead)
     constexpr int TP = BN + 4;
     float* Ts = reinterpret_cast<float*>(smem3) + g * BM * TP;
+    if (DBG == 5 && dbg_sink == 1.2345e-30f) Y[0] = dbg_sink;       // (keeps the probe's loads alive)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int mb = wm * TM * 32 + i * 32 + 4 * h;
@@ -739,7 +761,7 @@ size_t ldsp_bytes(const Row2P& p) {
     return by < epi ? epi : by;
 }
 
-template <int WGM, int TM, int TN, int K, int AM, int HS = 0, bool INA = false>
+template <int WGM, int TM, int TN, int K, int AM, int HS = 0, bool INA = false, int DBG = 0>
 int launch_pair(const Row2P& p, const float* X, const float* Xact, const float* W, const float* bias,
                 const float* res, float* Y, float* Yact, dim3 grid, hipStream_t s) {
     const size_t by = ldsp_bytes<WGM * TM * 32, HS ? 2 : K>(p);
@@ -747,13 +769,14 @@ int launch_pair(const Row2P& p, const float* X, const float* Xact, const float* 
     if (lds > 158 * 1024) return MS_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rows3p<WGM, TM, TN, K, AM, HS, INA>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rows3p<WGM, TM, TN, K, AM, HS, INA, DBG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
         attr_set = true;
     }
     Row2P pp = p;
     pp.scratch_off = (int)by;
-    hipLaunchKernelGGL((k_conv_rows3p<WGM, TM, TN, K, AM, HS, INA>), grid, dim3(512), lds, s, pp, X, Xact, W, bias, res,
+    ms_note_kernel("k_conv_rows3p<%d, %d, %d, %d, %d, %d, %s>", WGM, TM, TN, K, AM, HS, INA ? "true" : "false");
+    hipLaunchKernelGGL((k_conv_rows3p<WGM, TM, TN, K, AM, HS, INA, DBG>), grid, dim3(512), lds, s, pp, X, Xact, W, bias, res,
                        Y, Yact);
     MS_CHECK_LAUNCH();
     return MS_OK;
@@ -782,6 +805,7 @@ int launch_inst(const Row2P& p, const float* X, const float* Xact, const float* 
     }
     Row2P pp = p;
     pp.scratch_off = (int)by;
+    ms_note_kernel("k_conv_rows3<%d, %d, %d, %d, %d, %d, %s>", WGM, WGN, TM, TN, K, AM, VEC ? "true" : "false");
     hipLaunchKernelGGL((k_conv_rows3<WGM, WGN, TM, TN, K, AM, VEC>), grid, dim3(256), lds, s, pp, X, Xact, W, bias,
                        res, Y, Yact);
     MS_CHECK_LAUNCH();
@@ -861,6 +885,14 @@ int msr3p_launch(int bm, int K, int act_mode, const Row2P& p, const float* X, co
     const unsigned ntiles = p.R == 1 ? (unsigned)(p.B * p.tiles_per_row) : (unsigned)((p.B + p.R - 1) / p.R);
     const dim3 grid((ntiles + 1) / 2, (unsigned)((p.M + bm - 1) / bm), gz);
 #define MS3P(WGM_, TM_, TN_, K_, A_) return launch_pair<WGM_, TM_, TN_, K_, A_>(p, X, Xact, W, bias, res, Y, Yact, grid, s)
+    if (bm == 128 && K == 3 && act_mode == 0) {
+        static const int dbg = getenv("MSYNTH_R3P_DBG") ? atoi(getenv("MSYNTH_R3P_DBG")) : 0;     // timing probes (tools/dbg_r3p.py)
+        if (dbg == 1) return launch_pair<2, 2, 2, 3, 0, 0, false, 1>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+        if (dbg == 2) return launch_pair<2, 2, 2, 3, 0, 0, false, 2>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+        if (dbg == 3) return launch_pair<2, 2, 2, 3, 0, 0, false, 3>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+        if (dbg == 4) return launch_pair<2, 2, 2, 3, 0, 0, false, 4>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+        if (dbg == 5) return launch_pair<2, 2, 2, 3, 0, 0, false, 5>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
+    }
     if (bm == 128) {
         if (K == 3 && act_mode == 0) MS3P(2, 2, 2, 3, 0);
         if (K == 3 && act_mode == 1) MS3P(2, 2, 2, 3, 1);

@@ -11,6 +11,11 @@
         if (hipGetLastError() != hipSuccess) return MS_ERR_LAUNCH; \
     } while (0)
 
+// Profiling aid: the launchers of the templated dense families note the instantiation they dispatched, in the
+// spelling rocprofv3 prints ("k_conv_rows3p<2, 2, 2, 3, 0, 0, false>"); ms_last_kernel_name() hands it to the
+// caller so that a profiler line can be matched to a layer without re-deriving the dispatch (thread-local).
+void ms_note_kernel(const char* fmt, ...);
+
 struct ConvP {  // kernel-side copy of ms_conv1d_desc (+ derived sizes)
     int B, Cin, Lin, Cout, Lout, K, stride, pad, dil, groups, Cg, Og, pad_mode, act;
     float slope;

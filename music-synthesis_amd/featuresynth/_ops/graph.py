@@ -95,12 +95,46 @@ class _WgradFork:
             self.keep.clear()
 
 
-def atom_forward(h, w0, b0, w1, b1, dil, save):
+def atom_fused_ok(x_shape, w0, b0, b1, dil):
+    """The fused one-launch atom (csrc/atom_fused.hip) takes this geometry and these (16-byte aligned) biases."""
+    B, C, Lg = x_shape
+    return (tuple(w0.shape) == (C, C, 3) and b0 is not None and b1 is not None and
+            b0.data_ptr() % 16 == 0 and b1.data_ptr() % 16 == 0 and P.atom_supported(B, C, Lg, dil))
+
+
+def atom_forward(h, w0, b0, w1, b1, dil, save, image=None):
+    """image: the atom's pre-split weight image (P.atom_pack) -> ONE fused launch, the intermediate stays on chip;
+    None -> the two row-tile conv launches.  Same results bitwise."""
     d0, lo = P.conv_desc(h.shape, w0.shape, pad=dil, dil=dil, act=L.ACT_LRELU)
+    d1, _ = P.conv_desc(h.shape, w1.shape, pad=1, act=L.ACT_LRELU)
+    if image is not None:
+        out, t, u = P.atom_fwd(h, image, b0, b1, dil, save)
+        return out, (d0, d1, h, t, u)
     t, _ = P.conv1d_fwd(h, w0, b0, d0, lo)
-    d1, lo = P.conv_desc(t.shape, w1.shape, pad=1, act=L.ACT_LRELU)
     out, u = P.conv1d_fwd(t, w1, b1, d1, lo, residual=h, want_y_act=save)
     return out, (d0, d1, h, t, u)
+
+
+def pack_atom_images(x_shape, params):
+    """Pre-splits the weights of every generator atom the fused kernel takes -- ONE launch per forward pass (the
+    images are only valid for the weights as they are now: they are rebuilt on every pass, 9 MB).
+    -> {parameter index of the atom's first weight: image}"""
+    B, _, Lg = x_shape
+    images, jobs = {}, []
+    i = 2
+    for stride, pad in G_UPSAMPLE:
+        K = params[i].shape[2]
+        Lg = (Lg - 1) * stride - 2 * pad + K
+        i += 2
+        for dil in DILATIONS:
+            w0, b0, w1, b1 = params[i], params[i + 1], params[i + 2], params[i + 3]
+            if atom_fused_ok((B, w0.shape[0], Lg), w0, b0, b1, dil):
+                images[i] = P.atom_image(w0.shape[0], w0.device)
+                jobs.append((w0, w1, images[i]))
+            i += 4
+    if jobs:
+        P.atom_pack(jobs)
+    return images
 
 
 def atom_backward(rec, w0, w1, g, sink, i, need_wgrad=True, need_gx=True, fork=None, batch=None):
@@ -152,6 +186,7 @@ def gen_forward(x, params, save):
                            (params[0].shape[1], tuple(x.shape)))
     i = 0
     tape = []
+    images = pack_atom_images(x.shape, params)
     w, b = params[i], params[i + 1]; i += 2
     d, lo = P.conv_desc(x.shape, w.shape, pad=3, pad_mode=L.PAD_REFLECT, act=L.ACT_LRELU)
     h, _ = P.conv1d_fwd(x, w, b, d, lo)
@@ -163,7 +198,8 @@ def gen_forward(x, params, save):
         h = P.convt1d_fwd(hin, w, b, dt, lo)
         tape.append(("convT", dt, hin, h))
         for dil in DILATIONS:
-            h, rec = atom_forward(h, params[i], params[i + 1], params[i + 2], params[i + 3], dil, save)
+            h, rec = atom_forward(h, params[i], params[i + 1], params[i + 2], params[i + 3], dil, save,
+                                  image=images.get(i))
             i += 4
             tape.append(("atom", rec))
     w, b = params[i], params[i + 1]

@@ -63,6 +63,18 @@ class WgradMultiDesc(ctypes.Structure):         # ms_wgrad_multi_desc
                 ("beta", _c_f * WGRAD_MULTI_MAX)]
 
 
+ATOM_PACK_MAX = 16
+
+
+class AtomDesc(ctypes.Structure):               # ms_atom_desc
+    _fields_ = [("B", _c_int), ("C", _c_int), ("L", _c_int), ("dil", _c_int), ("slope", _c_f)]
+
+
+class AtomPackDesc(ctypes.Structure):           # ms_atom_pack_desc
+    _fields_ = [("count", _c_int), ("reserved", _c_int), ("C", _c_int * ATOM_PACK_MAX),
+                ("w0", _vp * ATOM_PACK_MAX), ("w1", _vp * ATOM_PACK_MAX), ("image", _vp * ATOM_PACK_MAX)]
+
+
 WN_MULTI_MAX = 64
 
 
@@ -83,9 +95,15 @@ SIGNATURES = {
     "ms_conv1d_bwd_weight": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _c_f, _vp, _sz, _vp]),
     "ms_conv1d_bwd_weight_multi_workspace_bytes": (_sz, [ctypes.POINTER(WgradMultiDesc)]),
     "ms_conv1d_bwd_weight_multi": (_c_int, [ctypes.POINTER(WgradMultiDesc), _vp, _sz, _vp]),
+    "ms_residual_atom_image_bytes": (_sz, [_c_int]),
+    "ms_residual_atom_supported": (_c_int, [ctypes.POINTER(AtomDesc)]),
+    "ms_residual_atom_pack_multi": (_c_int, [ctypes.POINTER(AtomPackDesc), _vp]),
+    "ms_residual_atom_fwd": (_c_int, [ctypes.POINTER(AtomDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ms_conv1d_workspace_bytes": (_sz, [ctypes.POINTER(ConvDesc), _c_int]),
     "ms_conv1d_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvDesc), _c_int]),
     "ms_convt1d_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvTDesc), _c_int]),
+    "ms_last_kernel_name": (ctypes.c_char_p, []),
+    "ms_last_kernel_clear": (None, []),
     "ms_convt1d_out_len": (_c_int, [ctypes.POINTER(ConvTDesc)]),
     "ms_convt1d_fwd": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ms_convt1d_bwd_data": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -232,8 +250,14 @@ def call(name, cost_fn, *args):
         check(fn(*args), name)
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    lib = load()
+    lib.ms_last_kernel_clear()
     e0.record()
     rc = fn(*args)
     e1.record()
     check(rc, name)
-    PROFILE.append((name, cost_fn() if cost_fn else {}, e0, e1))
+    cost = cost_fn() if cost_fn else {}
+    noted = lib.ms_last_kernel_name().decode()
+    if noted:                   # the instantiation the launcher really dispatched (split-K aware)
+        cost["kernel"] = noted
+    PROFILE.append((name, cost, e0, e1))

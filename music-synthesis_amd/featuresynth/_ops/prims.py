@@ -141,6 +141,52 @@ def conv1d_bwd_weight_multi(jobs):
     return out
 
 
+# ---- fused ResidualAtom forward (csrc/atom_fused.hip)
+def atom_supported(B, C, Lg, dil):
+    return bool(L.load().ms_residual_atom_supported(L.AtomDesc(B, C, Lg, dil, SLOPE)))
+
+
+def atom_image(C, device):
+    """Caller-owned buffer for the pre-split weight image of one atom (both convs)."""
+    return torch.empty(int(L.load().ms_residual_atom_image_bytes(C)), dtype=torch.uint8, device=device)
+
+
+def atom_pack(jobs):
+    """jobs: list of (w0, w1, image): splits the fp32 weights of every atom into its image, one launch per 16."""
+    for lo in range(0, len(jobs), L.ATOM_PACK_MAX):
+        chunk = jobs[lo:lo + L.ATOM_PACK_MAX]
+        d = L.AtomPackDesc()
+        d.count = len(chunk)
+        n = 0
+        for k, (w0, w1, img) in enumerate(chunk):
+            L.require(w0, "atom weight"); L.require(w1, "atom weight")
+            C = w0.shape[0]
+            if tuple(w0.shape) != (C, C, 3) or tuple(w1.shape) != (C, C, 3):
+                raise RuntimeError("residual atom: weights must be (C, C, 3), got %s / %s" % (tuple(w0.shape), tuple(w1.shape)))
+            d.C[k], d.w0[k], d.w1[k], d.image[k] = C, w0.data_ptr(), w1.data_ptr(), img.data_ptr()
+            n += 2 * w0.numel()
+        L.call("ms_residual_atom_pack_multi", _scost(n, 1, 1.58), d, L.stream())
+
+
+def atom_fwd(x, image, b0, b1, dil, save):
+    """-> (y, t, u): y = x + lrelu(conv1(lrelu(conv_d(x) + b0)) + b1); t, u (the activations the backward pass needs)
+    only when save."""
+    L.require(x, "residual atom input"); L.require(b0, "bias"); L.require(b1, "bias")
+    B, C, Lg = x.shape
+    y = torch.empty_like(x)
+    t = torch.empty_like(x) if save else None
+    u = torch.empty_like(x) if save else None
+    d = L.AtomDesc(B, C, Lg, dil, SLOPE)
+
+    def cost():
+        c0 = W.conv_cost(B, C, Lg, C, 3, 1, dil, dil, 1, "fwd")
+        return {"flops": 2 * c0["flops"], "bytes": 4 * x.numel() * (2 + 2 * int(save)) + 4 * 2 * (3 * C * C + C),
+                "geom": (B, C, Lg, C, 3, 1, dil, 1)}
+    L.call("ms_residual_atom_fwd", cost, d, x.data_ptr(), image.data_ptr(), b0.data_ptr(), b1.data_ptr(),
+           y.data_ptr(), L.ptr(t), L.ptr(u), L.stream())
+    return y, t, u
+
+
 def convt_desc(x_shape, w_shape, stride, pad, act=L.ACT_NONE, in_act=L.ACT_NONE):
     B, Cin, Lin = x_shape
     Cin2, Cout, K = w_shape

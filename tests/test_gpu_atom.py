@@ -1,0 +1,129 @@
+"""Fused ResidualAtom forward (csrc/atom_fused.hip, one launch per atom) -- reference util/modules.py:350-388,384-388:
+x + lrelu(conv_k3_d1(lrelu(conv_k3_dil(x)))) -- against the CPU oracle and against the two row-tile launches it
+replaces (same arithmetic: bitwise), at the generator's channel counts, dilations 1 / 3 / 9, aligned and ragged tile
+counts, single and multiple batch rows, inference (no saved activations) and training mode."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2, stable_seed
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def _inputs(name, B, C, Lg):
+    rng = np.random.default_rng(stable_seed(name))
+    x = rng.standard_normal((B, C, Lg)).astype(np.float32)
+    sc = 1.0 / np.sqrt(3 * C)            # O(1) activations through both convs
+    w0 = (rng.standard_normal((C, C, 3)) * sc).astype(np.float32)
+    w1 = (rng.standard_normal((C, C, 3)) * sc).astype(np.float32)
+    b0 = (rng.standard_normal((C,)) * 0.1).astype(np.float32)
+    b1 = (rng.standard_normal((C,)) * 0.1).astype(np.float32)
+    return x, w0, b0, w1, b1
+
+
+# name, B, C, L, dil   (tile = 124 output columns for C = 32 / 64, 60 for C = 128)
+ATOM_CASES = [("c32_d1_one_tile", 1, 32, 124, 1), ("c32_d9_ragged", 2, 32, 1032, 9), ("c32_d3_short", 3, 32, 8, 3),
+              ("c64_d1", 1, 64, 516, 1), ("c64_d3_two_rows", 2, 64, 248, 3), ("c64_d9_tail4", 1, 64, 252, 9),
+              ("c128_d1", 1, 128, 300, 1), ("c128_d3", 2, 128, 64, 3), ("c128_d9_ragged", 1, 128, 188, 9),
+              # the generator's own row lengths (several batch rows): the two-launch path runs its split-bf16 kernels here
+              ("c32_l8192_d9", 3, 32, 8192, 9), ("c64_l4096_d3", 3, 64, 4096, 3), ("c128_l2048_d1", 3, 128, 2048, 1)]
+
+
+@pytest.mark.parametrize("case", ATOM_CASES, ids=[c[0] for c in ATOM_CASES])
+@pytest.mark.parametrize("save", [False, True], ids=["inference", "training"])
+def test_fused_atom_vs_oracle_and_unfused(case, save, monkeypatch):
+    from featuresynth._ops import graph as G
+    from featuresynth._ops import prims as P
+    from oracle import oracle as O
+    name, B, C, Lg, dil = case
+    x, w0, b0, w1, b1 = _inputs(name, B, C, Lg)
+    xt, w0t, b0t, w1t, b1t = (dev(a) for a in (x, w0, b0, w1, b1))
+    assert G.atom_fused_ok(xt.shape, w0t, b0t, b1t, dil), "the fused kernel must take the hot geometries"
+    img = P.atom_image(C, xt.device)
+    P.atom_pack([(w0t, w1t, img)])
+    y, rec = G.atom_forward(xt, w0t, b0t, w1t, b1t, dil, save, image=img)
+    # CPU oracle (double accumulation)
+    t_ref = O.conv1d_fwd(x, w0, b0, 1, dil, dil, 1, O.PAD_ZERO, 1)
+    u_ref = O.conv1d_fwd(t_ref, w1, b1, 1, 1, 1, 1, O.PAD_ZERO, 1)
+    assert rel_l2(host(y), x + u_ref) < 1e-5
+    # the two launches it replaces: small grids send them to split-K slices or to the fp32-MFMA kernels (another
+    # summation order / rounding sequence of the same accuracy): 1e-6 here, bitwise at the bench's shapes below
+    y2, rec2 = G.atom_forward(xt, w0t, b0t, w1t, b1t, dil, save, image=None)
+
+    def agree(a, b_, what):
+        assert rel_l2(host(a), host(b_)) < 1e-6, what
+    agree(y, y2, "y")
+    if save:
+        assert rec[3] is not None and rec[4] is not None
+        assert rel_l2(host(rec[3]), t_ref) < 1e-5 and rel_l2(host(rec[4]), u_ref) < 1e-5
+        agree(rec[3], rec2[3], "t"); agree(rec[4], rec2[4], "y_act")
+    else:
+        assert rec[3] is None and rec[4] is None
+    # MSYNTH_ATOM=0 switches the fused kernel off (tuning / test switch)
+    monkeypatch.setenv("MSYNTH_ATOM", "0")
+    assert not G.atom_fused_ok(xt.shape, w0t, b0t, b1t, dil)
+
+
+@pytest.mark.parametrize("C,Lg,dil", [(32, 8192, 9), (64, 4096, 3), (128, 2048, 1)])
+def test_fused_atom_bitwise_at_bench_shapes(C, Lg, dil):
+    """BASELINE config 3's shapes (B = 32): the two-launch path runs the paired split-bf16 kernel without split-K --
+    the same products accumulated in the same order -- so the fused kernel must reproduce it BITWISE: output and both
+    saved activations."""
+    from featuresynth._ops import graph as G
+    from featuresynth._ops import lib as L
+    from featuresynth._ops import prims as P
+    x, w0, b0, w1, b1 = _inputs("bench_%d" % C, 32, C, Lg)
+    xt, w0t, b0t, w1t, b1t = (dev(a) for a in (x, w0, b0, w1, b1))
+    img = P.atom_image(C, xt.device)
+    P.atom_pack([(w0t, w1t, img)])
+    y, rec = G.atom_forward(xt, w0t, b0t, w1t, b1t, dil, True, image=img)
+    y2, rec2 = G.atom_forward(xt, w0t, b0t, w1t, b1t, dil, True, image=None)
+    names = [L.load().ms_conv1d_kernel_name(rec2[k], 0).decode() for k in (0, 1)]
+    assert all(n.startswith("k_conv_rows3p") for n in names), names
+    assert torch.equal(rec[3], rec2[3]), "t: rel %.3e" % rel_l2(host(rec[3]), host(rec2[3]))
+    assert torch.equal(rec[4], rec2[4]) and torch.equal(y, y2)
+    y3, _ = G.atom_forward(xt, w0t, b0t, w1t, b1t, dil, False, image=img)
+    assert torch.equal(y3, y)
+
+
+def test_fused_atom_pack_is_per_call_and_multi():
+    """All 12 atoms of a generator are packed by ONE launch per forward pass, from the weights as they are at that
+    moment: a forward after an in-place weight change sees the new weights (no stale image)."""
+    import featuresynth as fs
+    from featuresynth._ops import lib as L
+    from featuresynth._synthetic import module_param_shapes, synthetic_state_dict
+    g = fs.MelGanGenerator(32, 80)
+    g.load_state_dict({k: torch.from_numpy(v) for k, v in
+                       synthetic_state_dict(module_param_shapes(g), seed=7, bias_scale=0.02).items()})
+    g.cuda()
+    feat = dev(np.random.default_rng(1).standard_normal((2, 80, 4)).astype(np.float32))
+    L.profile_begin()
+    with torch.no_grad():
+        y0 = g(feat)
+    rec = L.profile_end()
+    names = [r[0] for r in rec]
+    assert names.count("ms_residual_atom_pack_multi") == 1
+    # C = 256 (L = 32 here) stays on the two-launch path; C = 128 / 64 / 32 atoms are fused: 9 launches
+    assert names.count("ms_residual_atom_fwd") == 9, names
+    with torch.no_grad():
+        p = dict(g.named_parameters())["main.14.main.1.main.0.weight"]
+        p.data.mul_(1.5)                         # a `.data` write: no version counter would notice it
+        y1 = g(feat)
+    assert not torch.equal(y0, y1)
+    import os
+    os.environ["MSYNTH_ATOM"] = "0"
+    try:
+        with torch.no_grad():
+            y2 = g(feat)
+    finally:
+        del os.environ["MSYNTH_ATOM"]
+    assert float((y1 - y2).norm() / y2.norm()) < 1e-6    # (small grids: the two-launch path runs other kernels)
