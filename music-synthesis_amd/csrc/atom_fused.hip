@@ -112,11 +112,13 @@ struct AtomP {
     float slope;
 };
 
-template <int C, int NTP>
+// NW waves per workgroup (4, or 8 for C = 256): WGM of them along the channels (32 rows each x TM), WGN along the columns
+template <int C, int NTP, int NW>
 struct AtomCfg {
-    static constexpr int MS = C / 32, WGM = MS < 4 ? MS : 4, TM = MS / WGM, WGN = 4 / WGM, TN = NTP / 32 / WGN, NC = C / 16;
+    static constexpr int MS = C / 32, WGM = MS < NW ? MS : NW, TM = MS / WGM, WGN = NW / WGM, TN = NTP / 32 / WGN, NC = C / 16;
+    static constexpr int NT = 64 * NW;
     static constexpr int NVMAX = (NTP + 18 + 3 + 3) / 4, NV16MAX = (NVMAX + 3) / 4;       // dilation <= 9
-    static constexpr int ROUNDS = (NC * NV16MAX * 16 + 255) / 256;
+    static constexpr int ROUNDS = (NC * NV16MAX * 16 + NT - 1) / NT;
     static_assert(MS >= 1 && TN >= 1 && TM * WGM == MS && TN * WGN * 32 == NTP, "tile shape");
 };
 
@@ -128,12 +130,12 @@ struct AtomCfg {
 // blockIdx.x, + gridDim.x, ...  Per tile:   [x window(t) registers -> split -> LDS] [issue the x window loads of tile
 // t + 1 into registers] [GEMM 1] [t tile -> LDS (+ stores of t)] [GEMM 2] [stores of y (and u)] -- the next tile's loads
 // and this tile's stores travel under the two GEMMs, so HBM and the matrix pipe overlap inside ONE workgroup.
-template <int C, int NTP, bool SAVE, int DBG = 0>
-__global__ __launch_bounds__(256, 2) void k_atom_fwd(AtomP p, const float* __restrict__ X, const u32x4* __restrict__ IMG,
+template <int C, int NTP, int NW, bool SAVE, int DBG = 0>
+__global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* __restrict__ X, const u32x4* __restrict__ IMG,
                                                  const float* __restrict__ b0, const float* __restrict__ b1,
                                                  float* __restrict__ Y, float* __restrict__ T, float* __restrict__ U) {
-    typedef AtomCfg<C, NTP> Cfg;
-    constexpr int TM = Cfg::TM, WGN = Cfg::WGN, TN = Cfg::TN, NC = Cfg::NC, ROUNDS = Cfg::ROUNDS;
+    typedef AtomCfg<C, NTP, NW> Cfg;
+    constexpr int TM = Cfg::TM, WGN = Cfg::WGN, TN = Cfg::TN, NC = Cfg::NC, ROUNDS = Cfg::ROUNDS, NT = Cfg::NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_atom[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: everything derived from it is scalar
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void k_atom_fwd(AtomP p, const float* __res
     int u_goff[ROUNDS], u_t[ROUNDS], u_lcol[ROUNDS], u_lbase[ROUNDS];
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-        const int u = tid + 256 * r;
+        const int u = tid + NT * r;
         const int grp = u >> 4, chunk = grp / NV16, vg = grp - chunk * NV16;
         const int cq = (u >> 2) & 3, v = vg * 4 + (u & 3);
         const bool in = chunk < NC && v < NV;
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void k_atom_fwd(AtomP p, const float* __res
     }
 }
 
-template <int C, int NTP>
+template <int C, int NTP, int NW>
 int launch_atom(const AtomP& p0, const float* x, const void* image, const float* b0, const float* b1, float* y, float* t,
                 float* u, hipStream_t s) {
     AtomP p = p0;
@@ -370,40 +372,35 @@ int launch_atom(const AtomP& p0, const float* x, const void* image, const float*
     const size_t lds = (size_t)(C / 16) * p.NXA * XRS;
     if (lds > 158 * 1024) return MS_ERR_UNSUPPORTED;
     const bool save = t != nullptr;
-    const void* fn = save ? reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, true>)
-                          : reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, false>);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[save]) {
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-        attr_set[save] = true;
-    }
+    const void* fn = save ? reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, NW, true>)
+                          : reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, NW, false>);
     static int wgs_per_cu[2] = {0, 0}, n_cu = 0;
     if (!wgs_per_cu[save]) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
         int nb = 0, dev = 0;
         hipDeviceProp_t prop;
         (void)hipGetDevice(&dev);
         (void)hipGetDeviceProperties(&prop, dev);
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        // (LDS is the limit: sized for the largest window, dilation 9)
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, (size_t)(C / 16) * (NTP + 22) * XRS) != hipSuccess || nb < 1) nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * NW, lds) != hipSuccess || nb < 1) nb = 1;
         wgs_per_cu[save] = nb;
     }
     const long long ntiles = (long long)p.B * p.tiles_per_row;
     const long long slots = (long long)n_cu * wgs_per_cu[save];
     const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
     static const int dbg = getenv("MSYNTH_ATOM_DBG") ? atoi(getenv("MSYNTH_ATOM_DBG")) : 0;       // timing probes
-    if (dbg && save) {
+    if (dbg && save && NW == 4) {
 #define MS_ATOM_DBG(D_) if (dbg == D_) { \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, true, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); \
-            hipLaunchKernelGGL((k_atom_fwd<C, NTP, true, D_>), grid, dim3(256), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u); MS_CHECK_LAUNCH(); return MS_OK; }
-        MS_ATOM_DBG(1) MS_ATOM_DBG(2) MS_ATOM_DBG(3) MS_ATOM_DBG(4) MS_ATOM_DBG(5)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, 4, true, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); \
+            hipLaunchKernelGGL((k_atom_fwd<C, NTP, 4, true, D_>), grid, dim3(256), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u); MS_CHECK_LAUNCH(); return MS_OK; }
+        if (C == 64 || C == 32) { MS_ATOM_DBG(1) MS_ATOM_DBG(2) MS_ATOM_DBG(3) MS_ATOM_DBG(4) MS_ATOM_DBG(5) }
 #undef MS_ATOM_DBG
     }
-    ms_note_kernel("k_atom_fwd<%d, %d, %s>", C, NTP, save ? "true" : "false");
+    ms_note_kernel("k_atom_fwd<%d, %d, %d, %s>", C, NTP, NW, save ? "true" : "false");
     if (save)
-        hipLaunchKernelGGL((k_atom_fwd<C, NTP, true>), grid, dim3(256), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u);
+        hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, true>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u);
     else
-        hipLaunchKernelGGL((k_atom_fwd<C, NTP, false>), grid, dim3(256), lds, s, p, x, (const u32x4*)image, b0, b1, y,
+        hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, false>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y,
                            nullptr, nullptr);
     MS_CHECK_LAUNCH();
     return MS_OK;
@@ -411,7 +408,7 @@ int launch_atom(const AtomP& p0, const float* x, const void* image, const float*
 
 bool atom_ok(const ms_atom_desc* d) {
     if (!d || d->B <= 0 || d->L <= 0 || d->dil < 1 || d->dil > 9) return false;
-    if (d->C != 32 && d->C != 64 && d->C != 128) return false;
+    if (d->C != 32 && d->C != 64 && d->C != 128 && d->C != 256) return false;
     if (d->L % 4) return false;                                   // 16-byte aligned rows
     if ((long long)d->B * d->C * d->L * 4 >= (1ll << 31)) return false;   // 32-bit buffer offsets
     return true;
@@ -462,10 +459,20 @@ int ms_residual_atom_fwd(const ms_atom_desc* d, const float* x, const void* imag
     AtomP p;
     p.B = d->B; p.C = d->C; p.L = d->L; p.dil = d->dil; p.slope = d->slope;
     hipStream_t s = (hipStream_t)stream;
+    // tile width: the widest tile whose grid still spreads over the chip; narrow tiles when the whole problem is a few
+    // dozen tiles (B = 1 inference: latency, not throughput)
+    const long long cols = (long long)d->B * d->L;
     switch (d->C) {
-        case 32: return launch_atom<32, 128>(p, x, image, b0, b1, y, t, y_act, s);
-        case 64: return launch_atom<64, 128>(p, x, image, b0, b1, y, t, y_act, s);
-        case 128: return launch_atom<128, 64>(p, x, image, b0, b1, y, t, y_act, s);
+        case 32: return launch_atom<32, 128, 4>(p, x, image, b0, b1, y, t, y_act, s);
+        case 64:
+            if (cols < 124 * 128) return launch_atom<64, 64, 4>(p, x, image, b0, b1, y, t, y_act, s);
+            return launch_atom<64, 128, 4>(p, x, image, b0, b1, y, t, y_act, s);
+        case 128:
+            if (cols < 60 * 128) return launch_atom<128, 32, 4>(p, x, image, b0, b1, y, t, y_act, s);
+            return launch_atom<128, 64, 4>(p, x, image, b0, b1, y, t, y_act, s);
+        case 256:
+            if (cols < 60 * 64) return launch_atom<256, 32, 8>(p, x, image, b0, b1, y, t, y_act, s);
+            return launch_atom<256, 64, 8>(p, x, image, b0, b1, y, t, y_act, s);
         default: return MS_ERR_UNSUPPORTED;
     }
 }

@@ -18,7 +18,7 @@ def timeit(fn, n=30):
 torch.manual_seed(0)
 Bs = [int(v) for v in sys.argv[1:]] or [32, 1]
 for B in Bs:
-    for (C, Lg) in ((32, 8192), (64, 4096), (128, 2048)):
+    for (C, Lg) in ((32, 8192), (64, 4096), (128, 2048), (256, 256)):
         for dil in (1, 9):
             x = torch.randn(B, C, Lg, device="cuda")
             w0 = torch.randn(C, C, 3, device="cuda") * 0.05; w1 = torch.randn(C, C, 3, device="cuda") * 0.05
