@@ -140,12 +140,24 @@ typedef struct ms_atom_pack_desc {
     const float* w0[MS_ATOM_PACK_MAX];     /* (C, C, 3): the dilated conv */
     const float* w1[MS_ATOM_PACK_MAX];     /* (C, C, 3): the dilation-1 conv */
     void* image[MS_ATOM_PACK_MAX];
+    int32_t backward[MS_ATOM_PACK_MAX];    /* 0: image for ms_residual_atom_fwd; 1: for ms_residual_atom_bwd_data */
 } ms_atom_pack_desc;
 size_t ms_residual_atom_image_bytes(int32_t C);
 int ms_residual_atom_supported(const ms_atom_desc* d);
 int ms_residual_atom_pack_multi(const ms_atom_pack_desc* d, ms_stream_t stream);
 int ms_residual_atom_fwd(const ms_atom_desc* d, const float* x, const void* image, const float* b0, const float* b1,
                          float* y, float* t, float* y_act, ms_stream_t stream);
+/*
+ * Backward data of the atom in one launch (autograd of the op above w.r.t. x), from the two saved activations:
+ *     gt = conv1d_backward_input(gy * lrelu'(y_act), w1)                     (raw: the weight gradient of the dilated conv
+ *                                                                            applies lrelu'(t) itself, ms_conv1d_bwd_weight)
+ *     gx = gy + conv1d_backward_input(gt * lrelu'(t), w0)
+ * image_bwd: packed with backward[i] = 1.  Same arithmetic as the two ms_conv1d_bwd_data calls it replaces.
+ * ms_residual_atom_bwd_supported: 1 when the fused kernel takes (and pays for) this geometry.
+ */
+int ms_residual_atom_bwd_supported(const ms_atom_desc* d);
+int ms_residual_atom_bwd_data(const ms_atom_desc* d, const float* gy, const float* y_act, const float* t,
+                              const void* image_bwd, float* gt, float* gx, ms_stream_t stream);
 
 /* which: 0 fwd, 1 bwd_data, 2 bwd_weight */
 size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which);

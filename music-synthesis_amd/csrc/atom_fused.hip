@@ -68,6 +68,7 @@ struct AtomPackJob {
     u32x4* image;
     int C;
     int first_block;     // prefix sum of blocks over the jobs
+    int backward;        // 1: the images of the backward-data pass (rows = input channels, taps flipped, conv1 first)
 };
 constexpr int ATOM_PACK_MAX = 16;
 struct AtomPackTable {
@@ -92,13 +93,21 @@ __global__ __launch_bounds__(256) void k_atom_pack(AtomPackTable t) {
     const int chunk = r % NC; r /= NC;
     const int ms = r % MS;
     const int conv = r / MS;
-    const float* w = conv ? jb.w1 : jb.w0;
-    const int row = ms * 32 + (lane & 31), ci0 = chunk * 16 + 8 * (lane >> 5);
+    // forward: GEMM 0 = the dilated conv (w0), GEMM 1 = the dilation-1 conv (w1), A[row = co][k = ci][tap]
+    // backward data: GEMM 0 = conv1 transposed, GEMM 1 = the dilated conv transposed: A[row = ci][k = co][tap] = W[co][ci][2 - tap]
+    const float* w = (conv != jb.backward) ? jb.w1 : jb.w0;
+    const int row = ms * 32 + (lane & 31), k0 = chunk * 16 + 8 * (lane >> 5);
     unsigned pc[3][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float a = w[((size_t)row * C + ci0 + 2 * q) * 3 + tap];
-        const float b = w[((size_t)row * C + ci0 + 2 * q + 1) * 3 + tap];
+        float a, b;
+        if (!jb.backward) {
+            a = w[((size_t)row * C + k0 + 2 * q) * 3 + tap];
+            b = w[((size_t)row * C + k0 + 2 * q + 1) * 3 + tap];
+        } else {
+            a = w[((size_t)(k0 + 2 * q) * C + row) * 3 + (2 - tap)];
+            b = w[((size_t)(k0 + 2 * q + 1) * C + row) * 3 + (2 - tap)];
+        }
         split_pair(a, b, pc[0][q], pc[1][q], pc[2][q]);
     }
     u32x4* dst = jb.image + (size_t)conv * atom_conv_image_u4(C) + ((size_t)((ms * NC + chunk) * 3 + tap) * 3) * 64 + lane;
@@ -130,10 +139,18 @@ struct AtomCfg {
 // blockIdx.x, + gridDim.x, ...  Per tile:   [x window(t) registers -> split -> LDS] [issue the x window loads of tile
 // t + 1 into registers] [GEMM 1] [t tile -> LDS (+ stores of t)] [GEMM 2] [stores of y (and u)] -- the next tile's loads
 // and this tile's stores travel under the two GEMMs, so HBM and the matrix pipe overlap inside ONE workgroup.
-template <int C, int NTP, int NW, bool SAVE, int DBG = 0>
+// MODE 0: forward, inference (nothing saved);  1: forward, training (also stores t and u);
+// MODE 2: BACKWARD DATA of the atom.  With g = dL/dy:   gt = conv1^T(g * lrelu'(u)),   gx = g + conv_d^T(gt * lrelu'(t)).
+//   Same two-GEMM structure with the roles mirrored: X = g, the window is multiplied by the LeakyReLU derivative taken from
+//   u (U, read) on its way into LDS; GEMM 0 is the dilation-1 conv transposed (halo 1), its raw result gt is stored (T: the
+//   weight gradient of the dilated conv needs it) and, multiplied by the derivative from t (Tm, read), becomes the LDS operand
+//   of GEMM 1, the dilated conv transposed (halo d): a tile yields NO = NTP - 2 d output columns.
+template <int C, int NTP, int NW, int MODE, int DBG = 0>
 __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* __restrict__ X, const u32x4* __restrict__ IMG,
                                                  const float* __restrict__ b0, const float* __restrict__ b1,
-                                                 float* __restrict__ Y, float* __restrict__ T, float* __restrict__ U) {
+                                                 float* __restrict__ Y, float* __restrict__ T, float* __restrict__ U,
+                                                 const float* __restrict__ Tm) {
+    constexpr bool SAVE = MODE == 1, BWD = MODE == 2;
     typedef AtomCfg<C, NTP, NW> Cfg;
     constexpr int TM = Cfg::TM, WGN = Cfg::WGN, TN = Cfg::TN, NC = Cfg::NC, ROUNDS = Cfg::ROUNDS, NT = Cfg::NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_atom[];
@@ -141,12 +158,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: everything derived from it is scalar
     const int wm = wid / WGN, wn = wid % WGN;
     const int d = p.dil, L = p.L;
+    const int h1 = BWD ? 1 : d, h2 = BWD ? d : 1;    // halo (= tap step) of the first / second GEMM's conv
     const int sh = (((-1 - d) % 4) + 4) % 4;         // tile starts are multiples of 4: the window start c0 - 1 - d sits sh
                                                      // samples behind an aligned 16-byte vector, the same for every tile
-    const int NX = NTP + 2 * d;                      // x columns the first GEMM reads
+    const int NX = NTP + 2 * h1;                     // window columns the first GEMM reads
     constexpr int NXA = NTP + 22;                    // LDS columns per chunk (dilation <= 9: NTP + 2 d + 3 used)
     constexpr int XCS = NXA * XRS;                   // chunk stride of the x window (compile-time: LDS offsets fold into the instructions)
-    constexpr int TCS = (NTP + 2) * XRS;             // chunk stride of the t tile (aliases the x window)
+    constexpr int TCS = XCS;                         // the t tile aliases the window, same strides (it is read up to column NTP - 1 + 2 h2)
     constexpr unsigned OOB = 0xF0000000u;
     const int ntiles = p.B * p.tiles_per_row;
 
@@ -155,8 +173,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
     // address travels in the scalar offset: no 64-bit address arithmetic, no divergent branches in the epilogues.
     const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, 0x80000000u, 0x00020000);
     const auto rsY = __builtin_amdgcn_make_buffer_rsrc(Y, 0, 0x80000000u, 0x00020000);
-    const auto rsT = __builtin_amdgcn_make_buffer_rsrc(SAVE ? T : Y, 0, 0x80000000u, 0x00020000);
-    const auto rsU = __builtin_amdgcn_make_buffer_rsrc(SAVE ? U : Y, 0, 0x80000000u, 0x00020000);
+    // (t tile column `col` is global column c0 - h2 + col: the descriptors of the tensors addressed by t-tile columns start
+    //  h2 elements early, so that the lane part of an offset is 4 col >= 0 -- the part the hardware range-checks -- and the
+    //  scalar part stays non-negative; lanes left of the row are masked out before they could touch those h2 elements)
+    const auto rsT = __builtin_amdgcn_make_buffer_rsrc(MODE ? T - h2 : Y, 0, 0x80000000u, 0x00020000);
+    const auto rsU = __builtin_amdgcn_make_buffer_rsrc(MODE ? U : Y, 0, 0x80000000u, 0x00020000);
+    const auto rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BWD ? Tm - h2 : X), 0, 0x80000000u, 0x00020000);
 
     // ---- tile-invariant staging units.  Unit = 4 channels x one aligned 4-sample vector; 16 consecutive lanes = 4
     // channel quads x 4 consecutive vectors (their 8-byte LDS stores fall into 16 different bank pairs).
@@ -187,6 +209,21 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                 rx[r][cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, goff, base + cc * 4 * L, 0));
         }
     };
+    // backward: the window of u (this tile; not prefetched: it would double the registers held across the GEMMs) gives
+    // the LeakyReLU derivative the gradient window is multiplied by
+    f32x4 ru[BWD ? ROUNDS : 1][4];
+    auto load_u = [&](int tile) {
+        const int bb = tile / p.tiles_per_row, cc0 = (tile - bb * p.tiles_per_row) * p.NO;
+        const int base = 4 * bb * C * L;
+#pragma unroll
+        for (int r = 0; r < (BWD ? ROUNDS : 0); ++r) {
+            const int t = cc0 + u_t[r];
+            const unsigned goff = (t >= 0 && t < L) ? (unsigned)(u_goff[r] + 4 * cc0) : OOB;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+                ru[r][cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, goff, base + cc * 4 * L, 0));
+        }
+    };
     auto store_x = [&]() {
 #pragma unroll
         for (int r = 0; r < (DBG == 4 ? 0 : ROUNDS); ++r) {
@@ -194,7 +231,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
             for (int e = 0; e < 4; ++e) {
                 const int i = u_lcol[r] + e;
                 if (i < 0 || i >= NXA) continue;
-                const float c4[4] = {rx[r][0][e], rx[r][1][e], rx[r][2][e], rx[r][3][e]};
+                float c4[4] = {rx[r][0][e], rx[r][1][e], rx[r][2][e], rx[r][3][e]};
+                if (BWD) {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) c4[cc] = ru[r][cc][e] > 0.f ? c4[cc] : c4[cc] * p.slope;
+                }
                 uint2 o3[3];
                 split_quad(c4, o3);
                 unsigned char* dst = smem_atom + u_lbase[r] + i * XRS;
@@ -282,6 +323,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
     for (; tile < ntiles; tile += gridDim.x) {
         const int b = tile / p.tiles_per_row, c0 = (tile - b * p.tiles_per_row) * p.NO;
         const int base = 4 * (b * C * L + c0);                      // byte offset of (row b, channel 0, column c0)
+        if (BWD) load_u(tile);
         int L4;                                                      // 4 L, opaque to the optimiser: the per-channel scalar offsets
         asm volatile("s_mov_b32 %0, %1" : "=s"(L4) : "s"(4 * L));    // are then formed where they are used (2 scalar ops), not hoisted
         store_x();                                                   // (waits for this tile's window)
@@ -290,7 +332,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
         if (nxt < ntiles) load_x(nxt);                              // travels under both GEMMs
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                             // x window staged
-        gemm(0, XCS, d, 0);                                          // t (pre-activation) on columns c0-1 .. c0+NTP-2
+        gemm(0, XCS, h1, 0);                                         // t (pre-activation) on columns c0-h2 .. c0-h2+NTP-1
 
         unsigned o_y[TN];
 #pragma unroll
@@ -304,24 +346,42 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int col = (wn * TN + j) * 32 + l31;           // t tile column <-> global column c0 - 1 + col
-                const int gc = c0 - 1 + col;
-                const bool inrow = gc >= 0 && gc < L;                // outside the row t is conv1's ZERO padding
-                const unsigned o_t = (SAVE && DBG != 3 && inrow && col >= 1 && col <= p.NO) ? (unsigned)(o_lane[j] - 4) : OOB;
+                const int col = (wn * TN + j) * 32 + l31;           // t tile column <-> global column c0 - h2 + col
+                const int gc = c0 - h2 + col;
+                const bool inrow = gc >= 0 && gc < L;                // outside the row t is the second conv's ZERO padding
+                // the tile's own columns of t are stored (forward training: the saved activation; backward: the raw gt)
+                const unsigned o_t = (MODE != 0 && DBG != 3 && inrow && col >= h2 && col < h2 + p.NO) ? (unsigned)o_lane[j] : OOB;
+                float tm[BWD ? 16 : 1];                              // backward: t itself, for the derivative
+                if (BWD) {
+                    const unsigned o_m = inrow ? (unsigned)o_lane[j] : OOB;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        tm[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rsM, o_m, base + ((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0));
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int chs = (wm * TM + i) * 32 + 8 * g, ch0 = chs + 4 * h;
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(b0 + ch0);
                     float e[4];
+                    if (!BWD) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(b0 + ch0);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float v = acc[i][j][4 * g + q] + bv[q];
-                        e[q] = inrow ? (v > 0.f ? v : v * p.slope) : 0.f;
+                        for (int q = 0; q < 4; ++q) {
+                            const float v = acc[i][j][4 * g + q] + bv[q];
+                            e[q] = inrow ? (v > 0.f ? v : v * p.slope) : 0.f;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) e[q] = acc[i][j][4 * g + q];
                     }
-                    if (SAVE) {
+                    if (MODE != 0) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e[q]), rsT, o_t, base + (chs + q) * L4, 0);
+                    }
+                    if (BWD) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) e[q] = inrow ? (tm[4 * g + q] > 0.f ? e[q] : e[q] * p.slope) : 0.f;
                     }
                     uint2 o3[3];
                     split_quad(e, o3);
@@ -332,7 +392,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
             }
         zero_acc();
         __syncthreads();                                             // t tile complete
-        gemm(1, TCS, 1, nxt < ntiles ? 1 : 2);                       // output column n reads t tile columns n, n+1, n+2
+        gemm(1, TCS, h2, nxt < ntiles ? 1 : 2);                      // output column n reads t tile columns n, n + h2, n + 2 h2
 
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -347,11 +407,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int chs = (wm * TM + i) * 32 + 8 * g, ch0 = chs + 4 * h;
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(b1 + ch0);
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (!BWD) bv = *reinterpret_cast<const f32x4*>(b1 + ch0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float v = acc[i][j][4 * g + q] + bv[q];
-                        v = v > 0.f ? v : v * p.slope;
+                        if (!BWD) v = v > 0.f ? v : v * p.slope;
                         if (SAVE) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsU, oy, base + (chs + q) * L4, 0);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + xr[4 * g + q]), rsY, oy,
                                                               base + (chs + q) * L4, 0);
@@ -362,20 +423,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
     }
 }
 
-template <int C, int NTP, int NW>
-int launch_atom(const AtomP& p0, const float* x, const void* image, const float* b0, const float* b1, float* y, float* t,
-                float* u, hipStream_t s) {
-    AtomP p = p0;
-    p.NO = NTP - 4;
+template <int C, int NTP, int NW, int MODE>
+int launch_atom_mode(AtomP p, const float* x, const void* image, const float* b0, const float* b1, float* y, float* t,
+                     float* u, const float* tm, hipStream_t s) {
+    p.NO = MODE == 2 ? ((NTP - 2 * p.dil) & ~3) : NTP - 4;
+    if (p.NO < 4) return MS_ERR_UNSUPPORTED;
     p.tiles_per_row = (p.L + p.NO - 1) / p.NO;
     p.NXA = NTP + 22;
     const size_t lds = (size_t)(C / 16) * p.NXA * XRS;
     if (lds > 158 * 1024) return MS_ERR_UNSUPPORTED;
-    const bool save = t != nullptr;
-    const void* fn = save ? reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, NW, true>)
-                          : reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, NW, false>);
-    static int wgs_per_cu[2] = {0, 0}, n_cu = 0;
-    if (!wgs_per_cu[save]) {
+    const void* fn = reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, NW, MODE>);
+    static int wgs_per_cu = 0, n_cu = 0;
+    if (!wgs_per_cu) {
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
         int nb = 0, dev = 0;
         hipDeviceProp_t prop;
@@ -383,27 +442,54 @@ int launch_atom(const AtomP& p0, const float* x, const void* image, const float*
         (void)hipGetDeviceProperties(&prop, dev);
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * NW, lds) != hipSuccess || nb < 1) nb = 1;
-        wgs_per_cu[save] = nb;
+        wgs_per_cu = nb;
     }
     const long long ntiles = (long long)p.B * p.tiles_per_row;
-    const long long slots = (long long)n_cu * wgs_per_cu[save];
+    const long long slots = (long long)n_cu * wgs_per_cu;
     const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
     static const int dbg = getenv("MSYNTH_ATOM_DBG") ? atoi(getenv("MSYNTH_ATOM_DBG")) : 0;       // timing probes
-    if (dbg && save && NW == 4) {
+    if (dbg && MODE == 1 && NW == 4 && (C == 64 || C == 32)) {
 #define MS_ATOM_DBG(D_) if (dbg == D_) { \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, 4, true, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); \
-            hipLaunchKernelGGL((k_atom_fwd<C, NTP, 4, true, D_>), grid, dim3(256), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u); MS_CHECK_LAUNCH(); return MS_OK; }
-        if (C == 64 || C == 32) { MS_ATOM_DBG(1) MS_ATOM_DBG(2) MS_ATOM_DBG(3) MS_ATOM_DBG(4) MS_ATOM_DBG(5) }
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, NW, 1, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); \
+            hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, 1, D_>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u, tm); MS_CHECK_LAUNCH(); return MS_OK; }
+        MS_ATOM_DBG(1) MS_ATOM_DBG(2) MS_ATOM_DBG(3) MS_ATOM_DBG(4) MS_ATOM_DBG(5)
 #undef MS_ATOM_DBG
     }
-    ms_note_kernel("k_atom_fwd<%d, %d, %d, %s>", C, NTP, NW, save ? "true" : "false");
-    if (save)
-        hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, true>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u);
-    else
-        hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, false>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y,
-                           nullptr, nullptr);
+    ms_note_kernel("k_atom_fwd<%d, %d, %d, %d>", C, NTP, NW, MODE);
+    hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, MODE>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u, tm);
     MS_CHECK_LAUNCH();
     return MS_OK;
+}
+
+// mode 0 / 1: forward (t, u: the saved activations, both or neither);  mode 2: backward data (x = g, u and tm read, t = gt out)
+template <int C, int NTP, int NW>
+int launch_atom(int mode, const AtomP& p, const float* x, const void* image, const float* b0, const float* b1, float* y,
+                float* t, float* u, const float* tm, hipStream_t s) {
+    if (mode == 2) return launch_atom_mode<C, NTP, NW, 2>(p, x, image, b0, b1, y, t, u, tm, s);
+    if (mode == 1) return launch_atom_mode<C, NTP, NW, 1>(p, x, image, b0, b1, y, t, u, tm, s);
+    return launch_atom_mode<C, NTP, NW, 0>(p, x, image, b0, b1, y, t, u, tm, s);
+}
+
+int dispatch_atom(int mode, const ms_atom_desc* d, const float* x, const void* image, const float* b0, const float* b1,
+                  float* y, float* t, float* u, const float* tm, hipStream_t s) {
+    AtomP p;
+    p.B = d->B; p.C = d->C; p.L = d->L; p.dil = d->dil; p.slope = d->slope;
+    // tile width: the widest tile whose grid still spreads over the chip; narrow tiles when the whole problem is a few
+    // dozen tiles (B = 1 inference: latency, not throughput)
+    const long long cols = (long long)d->B * d->L;
+    switch (d->C) {
+        case 32: return launch_atom<32, 128, 4>(mode, p, x, image, b0, b1, y, t, u, tm, s);
+        case 64:
+            if (cols < 124 * 128) return launch_atom<64, 64, 4>(mode, p, x, image, b0, b1, y, t, u, tm, s);
+            return launch_atom<64, 128, 4>(mode, p, x, image, b0, b1, y, t, u, tm, s);
+        case 128:
+            if (cols < 60 * 128 && mode != 2) return launch_atom<128, 32, 4>(mode, p, x, image, b0, b1, y, t, u, tm, s);
+            return launch_atom<128, 64, 4>(mode, p, x, image, b0, b1, y, t, u, tm, s);
+        case 256:
+            if (cols < 60 * 64 && mode != 2) return launch_atom<256, 32, 8>(mode, p, x, image, b0, b1, y, t, u, tm, s);
+            return launch_atom<256, 64, 8>(mode, p, x, image, b0, b1, y, t, u, tm, s);
+        default: return MS_ERR_UNSUPPORTED;
+    }
 }
 
 bool atom_ok(const ms_atom_desc* d) {
@@ -443,6 +529,7 @@ int ms_residual_atom_pack_multi(const ms_atom_pack_desc* d, ms_stream_t stream) 
         t.job[i].image = (u32x4*)d->image[i];
         t.job[i].C = C;
         t.job[i].first_block = blocks;
+        t.job[i].backward = d->backward[i] ? 1 : 0;
         const int total = 2 * (C / 32) * (C / 16) * 3 * 64;
         blocks += (total + 255) / 256;
     }
@@ -456,25 +543,24 @@ int ms_residual_atom_fwd(const ms_atom_desc* d, const float* x, const void* imag
     if (!atom_ok(d)) return d ? MS_ERR_UNSUPPORTED : MS_ERR_INVALID_ARG;
     if (!x || !image || !b0 || !b1 || !y || ((t == nullptr) != (y_act == nullptr))) return MS_ERR_INVALID_ARG;
     if ((((uintptr_t)image) & 15) || (((uintptr_t)b0) & 15) || (((uintptr_t)b1) & 15)) return MS_ERR_INVALID_ARG;
-    AtomP p;
-    p.B = d->B; p.C = d->C; p.L = d->L; p.dil = d->dil; p.slope = d->slope;
-    hipStream_t s = (hipStream_t)stream;
-    // tile width: the widest tile whose grid still spreads over the chip; narrow tiles when the whole problem is a few
-    // dozen tiles (B = 1 inference: latency, not throughput)
-    const long long cols = (long long)d->B * d->L;
-    switch (d->C) {
-        case 32: return launch_atom<32, 128, 4>(p, x, image, b0, b1, y, t, y_act, s);
-        case 64:
-            if (cols < 124 * 128) return launch_atom<64, 64, 4>(p, x, image, b0, b1, y, t, y_act, s);
-            return launch_atom<64, 128, 4>(p, x, image, b0, b1, y, t, y_act, s);
-        case 128:
-            if (cols < 60 * 128) return launch_atom<128, 32, 4>(p, x, image, b0, b1, y, t, y_act, s);
-            return launch_atom<128, 64, 4>(p, x, image, b0, b1, y, t, y_act, s);
-        case 256:
-            if (cols < 60 * 64) return launch_atom<256, 32, 8>(p, x, image, b0, b1, y, t, y_act, s);
-            return launch_atom<256, 64, 8>(p, x, image, b0, b1, y, t, y_act, s);
-        default: return MS_ERR_UNSUPPORTED;
-    }
+    return dispatch_atom(t ? 1 : 0, d, x, image, b0, b1, y, t, y_act, nullptr, (hipStream_t)stream);
+}
+
+int ms_residual_atom_bwd_supported(const ms_atom_desc* d) {
+    if (!ms_residual_atom_supported(d)) return 0;
+    const char* sw = getenv("MSYNTH_ATOM_BWD");                  // tuning / test switch (0: the two backward-data launches)
+    if (sw && atoi(sw) == 0) return 0;
+    // a tile yields NTP - 2 dil output columns: with 64-column tiles (128 / 256 channels) dilation 9 would spend a third
+    // of the first GEMM on halo -- those atoms keep the two launches
+    if (d->C >= 128 && d->dil > 3) return 0;
+    return 1;
+}
+
+int ms_residual_atom_bwd_data(const ms_atom_desc* d, const float* gy, const float* y_act, const float* t,
+                              const void* image_bwd, float* gt, float* gx, ms_stream_t stream) {
+    if (!atom_ok(d)) return d ? MS_ERR_UNSUPPORTED : MS_ERR_INVALID_ARG;
+    if (!gy || !y_act || !t || !image_bwd || !gt || !gx || (((uintptr_t)image_bwd) & 15)) return MS_ERR_INVALID_ARG;
+    return dispatch_atom(2, d, gy, image_bwd, nullptr, nullptr, gx, gt, const_cast<float*>(y_act), t, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -115,9 +115,9 @@ def atom_forward(h, w0, b0, w1, b1, dil, save, image=None):
     return out, (d0, d1, h, t, u)
 
 
-def pack_atom_images(x_shape, params):
-    """Pre-splits the weights of every generator atom the fused kernel takes -- ONE launch per forward pass (the
-    images are only valid for the weights as they are now: they are rebuilt on every pass, 9 MB).
+def pack_atom_images(x_shape, params, backward=False):
+    """Pre-splits the weights of every generator atom the fused kernel takes -- ONE launch per forward (backward) pass
+    (the images are only valid for the weights as they are now: they are rebuilt on every pass, 9 MB).
     -> {parameter index of the atom's first weight: image}"""
     B, _, Lg = x_shape
     images, jobs = {}, []
@@ -128,21 +128,34 @@ def pack_atom_images(x_shape, params):
         i += 2
         for dil in DILATIONS:
             w0, b0, w1, b1 = params[i], params[i + 1], params[i + 2], params[i + 3]
-            if atom_fused_ok((B, w0.shape[0], Lg), w0, b0, b1, dil):
+            if atom_fused_ok((B, w0.shape[0], Lg), w0, b0, b1, dil) and \
+                    (not backward or P.atom_bwd_supported(B, w0.shape[0], Lg, dil)):
                 images[i] = P.atom_image(w0.shape[0], w0.device)
                 jobs.append((w0, w1, images[i]))
             i += 4
     if jobs:
-        P.atom_pack(jobs)
+        P.atom_pack(jobs, backward=backward)
     return images
 
 
-def atom_backward(rec, w0, w1, g, sink, i, need_wgrad=True, need_gx=True, fork=None, batch=None):
+def atom_backward(rec, w0, w1, g, sink, i, need_wgrad=True, need_gx=True, fork=None, batch=None, image_bwd=None):
     """g = d loss / d atom output; parameter grads go to sink slots i..i+3 (w0, b0, w1, b1).
     batch: list collecting the weight-grad jobs (slot, x, gy, y_act, desc, w_shape) instead of running them
-    (the caller issues a stack's six jobs as one launch, flush_wgrad_batch)."""
+    (the caller issues a stack's six jobs as one launch, flush_wgrad_batch).
+    image_bwd: the atom's backward weight image -> both backward-data convs in ONE fused launch (atom_fused.hip)."""
     d0, d1, h, t, u = rec
     run = fork.run if fork is not None else (lambda fn, *ts: fn())
+    if image_bwd is not None and need_gx:
+        gt, gx = P.atom_bwd_data(g, u, t, image_bwd, d0.dil)
+        if need_wgrad and batch is not None:
+            batch.append((i + 2, t, g, u, d1, w1.shape))
+            batch.append((i, h, gt, t, d0, w0.shape))
+        elif need_wgrad:
+            gw, gb, acc = sink.pair(i + 2)
+            run(lambda: sink.put(i + 2, *P.conv1d_bwd_weight(t, g, u, d1, w1.shape, gw, gb, acc)), t, g, u)
+            gw, gb, acc = sink.pair(i)
+            run(lambda: sink.put(i, *P.conv1d_bwd_weight(h, gt, t, d0, w0.shape, gw, gb, acc)), h, gt, t)
+        return gx
     if need_wgrad and batch is not None:
         batch.append((i + 2, t, g, u, d1, w1.shape))
     elif need_wgrad:
@@ -227,6 +240,8 @@ def gen_backward(tape, params, gy, sink=None, need_gx=False, cut=None):
     fork = _WgradFork(gy.device)
     batch = [] if os.environ.get("MSYNTH_WMULTI", "1") == "1" else None
     deferred = []
+    conv0 = tape[0]
+    images_bwd = pack_atom_images(conv0[2].shape, params, backward=True)
     for rec in reversed(tape):
         kind = rec[0]
         if kind != "atom" and batch:
@@ -239,7 +254,8 @@ def gen_backward(tape, params, gy, sink=None, need_gx=False, cut=None):
             g = P.conv1d_bwd_data(g, y, params[i], d)
         elif kind == "atom":
             i -= 4
-            g = atom_backward(rec[1], params[i], params[i + 2], g, sink, i, fork=fork, batch=batch)
+            g = atom_backward(rec[1], params[i], params[i + 2], g, sink, i, fork=fork, batch=batch,
+                              image_bwd=images_bwd.get(i))
         elif kind == "convT":
             _, dt, hin, h = rec
             i -= 2

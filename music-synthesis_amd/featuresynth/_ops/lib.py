@@ -72,7 +72,8 @@ class AtomDesc(ctypes.Structure):               # ms_atom_desc
 
 class AtomPackDesc(ctypes.Structure):           # ms_atom_pack_desc
     _fields_ = [("count", _c_int), ("reserved", _c_int), ("C", _c_int * ATOM_PACK_MAX),
-                ("w0", _vp * ATOM_PACK_MAX), ("w1", _vp * ATOM_PACK_MAX), ("image", _vp * ATOM_PACK_MAX)]
+                ("w0", _vp * ATOM_PACK_MAX), ("w1", _vp * ATOM_PACK_MAX), ("image", _vp * ATOM_PACK_MAX),
+                ("backward", _c_int * ATOM_PACK_MAX)]
 
 
 WN_MULTI_MAX = 64
@@ -99,6 +100,8 @@ SIGNATURES = {
     "ms_residual_atom_supported": (_c_int, [ctypes.POINTER(AtomDesc)]),
     "ms_residual_atom_pack_multi": (_c_int, [ctypes.POINTER(AtomPackDesc), _vp]),
     "ms_residual_atom_fwd": (_c_int, [ctypes.POINTER(AtomDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ms_residual_atom_bwd_supported": (_c_int, [ctypes.POINTER(AtomDesc)]),
+    "ms_residual_atom_bwd_data": (_c_int, [ctypes.POINTER(AtomDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ms_conv1d_workspace_bytes": (_sz, [ctypes.POINTER(ConvDesc), _c_int]),
     "ms_conv1d_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvDesc), _c_int]),
     "ms_convt1d_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvTDesc), _c_int]),

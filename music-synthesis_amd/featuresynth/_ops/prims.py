@@ -151,14 +151,20 @@ def atom_image(C, device):
     return torch.empty(int(L.load().ms_residual_atom_image_bytes(C)), dtype=torch.uint8, device=device)
 
 
-def atom_pack(jobs):
-    """jobs: list of (w0, w1, image): splits the fp32 weights of every atom into its image, one launch per 16."""
+def atom_bwd_supported(B, C, Lg, dil):
+    return bool(L.load().ms_residual_atom_bwd_supported(L.AtomDesc(B, C, Lg, dil, SLOPE)))
+
+
+def atom_pack(jobs, backward=False):
+    """jobs: list of (w0, w1, image): splits the fp32 weights of every atom into its image, one launch per 16.
+    backward: the images of the backward-data kernel (rows = input channels, taps flipped)."""
     for lo in range(0, len(jobs), L.ATOM_PACK_MAX):
         chunk = jobs[lo:lo + L.ATOM_PACK_MAX]
         d = L.AtomPackDesc()
         d.count = len(chunk)
         n = 0
         for k, (w0, w1, img) in enumerate(chunk):
+            d.backward[k] = 1 if backward else 0
             L.require(w0, "atom weight"); L.require(w1, "atom weight")
             C = w0.shape[0]
             if tuple(w0.shape) != (C, C, 3) or tuple(w1.shape) != (C, C, 3):
@@ -185,6 +191,22 @@ def atom_fwd(x, image, b0, b1, dil, save):
     L.call("ms_residual_atom_fwd", cost, d, x.data_ptr(), image.data_ptr(), b0.data_ptr(), b1.data_ptr(),
            y.data_ptr(), L.ptr(t), L.ptr(u), L.stream())
     return y, t, u
+
+
+def atom_bwd_data(g, u, t, image_bwd, dil):
+    """-> (gt, gx): gt = conv1^T(g * lrelu'(u)) (raw), gx = g + conv_d^T(gt * lrelu'(t)) -- the atom's backward data, one launch."""
+    for a, nm in ((g, "grad_output"), (u, "y_act"), (t, "t")):
+        L.require(a, "residual atom " + nm)
+    B, C, Lg = g.shape
+    gt, gx = torch.empty_like(g), torch.empty_like(g)
+    d = L.AtomDesc(B, C, Lg, dil, SLOPE)
+
+    def cost():
+        c0 = W.conv_cost(B, C, Lg, C, 3, 1, dil, dil, 1, "bwd_data")
+        return {"flops": 2 * c0["flops"], "bytes": 4 * g.numel() * 5 + 4 * 2 * 3 * C * C, "geom": (B, C, Lg, C, 3, 1, dil, 1)}
+    L.call("ms_residual_atom_bwd_data", cost, d, g.data_ptr(), u.data_ptr(), t.data_ptr(), image_bwd.data_ptr(),
+           gt.data_ptr(), gx.data_ptr(), L.stream())
+    return gt, gx
 
 
 def convt_desc(x_shape, w_shape, stride, pad, act=L.ACT_NONE, in_act=L.ACT_NONE):

@@ -130,3 +130,58 @@ def test_fused_atom_pack_is_per_call_and_multi():
     finally:
         del os.environ["MSYNTH_ATOM"]
     assert float((y1 - y2).norm() / y2.norm()) < 1e-6    # (small grids: the two-launch path runs other kernels)
+
+
+BWD_CASES = [c for c in ATOM_CASES if not (c[2] >= 128 and c[4] > 3)]      # (128 / 256 channels at dilation 9 keep two launches)
+
+
+@pytest.mark.parametrize("case", BWD_CASES, ids=[c[0] for c in BWD_CASES])
+def test_fused_atom_backward_vs_oracle_and_unfused(case):
+    """Backward data of the atom in one launch (ms_residual_atom_bwd_data): gt = conv1^T(g lrelu'(u)) stored raw,
+    gx = g + conv_d^T(gt lrelu'(t)) -- against the oracle's conv1d_bwd_data (masks from the device's own activations)
+    and against the two ms_conv1d_bwd_data launches it replaces."""
+    from featuresynth._ops import graph as G
+    from featuresynth._ops import prims as P
+    from oracle import oracle as O
+    name, B, C, Lg, dil = case
+    x, w0, b0, w1, b1 = _inputs(name, B, C, Lg)
+    xt, w0t, b0t, w1t, b1t = (dev(a) for a in (x, w0, b0, w1, b1))
+    assert P.atom_bwd_supported(B, C, Lg, dil)
+    y, rec = G.atom_forward(xt, w0t, b0t, w1t, b1t, dil, True, image=None)
+    d0, d1, _, t, u = rec
+    g = np.random.default_rng(stable_seed(name) + 1).standard_normal((B, C, Lg)).astype(np.float32)
+    gt_d = dev(g)
+    img = P.atom_image(C, xt.device)
+    P.atom_pack([(w0t, w1t, img)], backward=True)
+    gt, gx = P.atom_bwd_data(gt_d, u, t, img, dil)
+    # oracle
+    gp1 = O.act_bwd(host(u), g, 1)
+    gt_ref = O.conv1d_bwd_data(gp1, w1, x.shape, 1, 1, 1, 1, O.PAD_ZERO)
+    gp0 = O.act_bwd(host(t), gt_ref, 1)
+    gx_ref = O.conv1d_bwd_data(gp0, w0, x.shape, 1, dil, dil, 1, O.PAD_ZERO) + g
+    assert rel_l2(host(gt), gt_ref) < 1e-5 and rel_l2(host(gx), gx_ref) < 1e-5
+    # the two launches
+    gt2 = P.conv1d_bwd_data(gt_d, u, w1t, d1)
+    gx2 = P.conv1d_bwd_data(gt2, t, w0t, d0, gx_add=gt_d)
+    assert rel_l2(host(gt), host(gt2)) < 1e-6 and rel_l2(host(gx), host(gx2)) < 1e-6
+
+
+@pytest.mark.parametrize("C,Lg,dil", [(32, 8192, 9), (64, 4096, 3), (128, 2048, 1), (256, 256, 3)])
+def test_fused_atom_backward_bitwise_at_bench_shapes(C, Lg, dil):
+    from featuresynth._ops import graph as G
+    from featuresynth._ops import lib as L
+    from featuresynth._ops import prims as P
+    x, w0, b0, w1, b1 = _inputs("bench_%d" % C, 32, C, Lg)
+    xt, w0t, b0t, w1t, b1t = (dev(a) for a in (x, w0, b0, w1, b1))
+    y, rec = G.atom_forward(xt, w0t, b0t, w1t, b1t, dil, True, image=None)
+    d0, d1, _, t, u = rec
+    g = dev(np.random.default_rng(5).standard_normal((32, C, Lg)).astype(np.float32))
+    img = P.atom_image(C, xt.device)
+    P.atom_pack([(w0t, w1t, img)], backward=True)
+    gt, gx = P.atom_bwd_data(g, u, t, img, dil)
+    gt2 = P.conv1d_bwd_data(g, u, w1t, d1)
+    gx2 = P.conv1d_bwd_data(gt2, t, w0t, d0, gx_add=g)
+    names = [L.load().ms_conv1d_kernel_name(dd, 1).decode() for dd in (d0, d1)]
+    assert all(n.startswith("k_conv_rows3") for n in names), names
+    assert torch.equal(gt, gt2), "gt: rel %.3e (%s)" % (rel_l2(host(gt), host(gt2)), names)
+    assert torch.equal(gx, gx2), "gx: rel %.3e (%s)" % (rel_l2(host(gx), host(gx2)), names)
