@@ -315,7 +315,7 @@ def main():
         k, a = sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[0]
         avg_s = a["ms"] / a["n"] / 1e3
         fl, by = a["flops"] / a["n"], a["bytes"] / a["n"]
-        split_pipe = k.startswith(("k_conv_rows3", "k_wgrad_rows3", "k_gconv_split", "k_wgrad_k5_split",
+        split_pipe = k.startswith(("k_atom_fwd", "k_conv_rows3", "k_wgrad_rows3", "k_gconv_split", "k_wgrad_k5_split",
                                    "k_wgrad_convt8_split"))
         # ceiling of the pipe the kernel runs on: fp32 FLOPs executed on the bf16 matrix pipe with every fp32
         # operand split exactly into three bf16 pieces and six partial products per multiply (conv_rows3.hip) can

@@ -11,6 +11,17 @@ if op == "dwgrad":      # dense weight gradient: dwgrad B Cin L Cout K dil
     d, lo = P.conv_desc(x.shape, (Cout, Cin, K), pad=dil * (K - 1) // 2, dil=dil, act=1)
     for _ in range(5): P.conv1d_bwd_weight(x, gy, ya, d, (Cout, Cin, K))
     torch.cuda.synchronize(); sys.exit(0)
+if op == "atom":      # fused residual atom, training forward + backward data: atom B C L dil
+    from featuresynth._ops import graph as G
+    B, C, Lg, dil = map(int, sys.argv[2:6])
+    x = torch.randn(B, C, Lg, device="cuda"); w0 = torch.randn(C, C, 3, device="cuda") * 0.05; w1 = torch.randn(C, C, 3, device="cuda") * 0.05
+    b0 = torch.randn(C, device="cuda") * 0.1; b1 = torch.randn(C, device="cuda") * 0.1; g = torch.randn_like(x)
+    img = P.atom_image(C, x.device); P.atom_pack([(w0, w1, img)])
+    imgb = P.atom_image(C, x.device); P.atom_pack([(w0, w1, imgb)], backward=True)
+    for _ in range(5):
+        y, rec = G.atom_forward(x, w0, b0, w1, b1, dil, True, image=img)
+        if P.atom_bwd_supported(B, C, Lg, dil): P.atom_bwd_data(g, rec[4], rec[3], imgb, dil)
+    torch.cuda.synchronize(); sys.exit(0)
 if op == "dfwd":      # dense forward: dfwd B C L K dil
     B, C, Lg, K, dil = map(int, sys.argv[2:7])
     x = torch.randn(B, C, Lg, device="cuda"); w = torch.randn(C, C, K, device="cuda") * 0.02; b = torch.randn(C, device="cuda")

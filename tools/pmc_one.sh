@@ -18,9 +18,9 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_$tag/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[r["Kernel_Name"][:110]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in agg.items():
-    if not any(t in k for t in ("gconv", "reduce", "wgrad", "rows")): continue
+    if not any(t in k for t in ("gconv", "reduce", "wgrad", "rows", "atom")): continue
     print(k)
     for c, v in sorted(cs.items()):
         print("   %-34s n=%d  mean %.4g" % (c, len(v), sum(v) / len(v)))
