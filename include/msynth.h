@@ -159,6 +159,26 @@ int ms_residual_atom_bwd_supported(const ms_atom_desc* d);
 int ms_residual_atom_bwd_data(const ms_atom_desc* d, const float* gy, const float* y_act, const float* t,
                               const void* image_bwd, float* gt, float* gx, ms_stream_t stream);
 
+/*
+ * Dense k = 5 / stride 1 / padding 2 conv on short rows (L <= 64) with PRE-SPLIT weight images: the discriminator's
+ * 1024 -> 1024 layer (discriminator/full.py:19) at its three scales, forward and backward data (csrc/conv5_img.hip).
+ * Same operation and accuracy as ms_conv1d_fwd / ms_conv1d_bwd_data on that geometry (other summation order: ~1e-7).
+ *   ms_conv1d_img_bytes            bytes of one image (forward and backward images have the same size); 0 = this geometry is
+ *                                  not taken (the caller uses ms_conv1d_fwd / ms_conv1d_bwd_data)
+ *   ms_conv1d_img_pack             w (Cout, Cin, 5) -> image (caller-owned, 16-byte aligned); backward = 1: the image of the
+ *                                  backward-data pass.  Once per weight update; one image serves every batch size / row length
+ *   ms_conv1d_img_fwd              y = act(conv1d(x, w) + bias)
+ *   ms_conv1d_img_bwd_data         gx = gx_add + conv1d_backward_input(gy * act'(y_act), w)    (y_act, gx_add may be NULL)
+ *   ms_conv1d_img_workspace_bytes  which: 0 fwd, 1 bwd_data (split-K slabs)
+ */
+size_t ms_conv1d_img_bytes(const ms_conv1d_desc* d);
+size_t ms_conv1d_img_workspace_bytes(const ms_conv1d_desc* d, int which);
+int ms_conv1d_img_pack(const ms_conv1d_desc* d, const float* w, int backward, void* image, ms_stream_t stream);
+int ms_conv1d_img_fwd(const ms_conv1d_desc* d, const float* x, const void* image, const float* bias, float* y,
+                      void* workspace, size_t workspace_bytes, ms_stream_t stream);
+int ms_conv1d_img_bwd_data(const ms_conv1d_desc* d, const float* gy, const float* y_act, const void* image_bwd,
+                           const float* gx_add, float* gx, void* workspace, size_t workspace_bytes, ms_stream_t stream);
+
 /* which: 0 fwd, 1 bwd_data, 2 bwd_weight */
 size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which);
 

@@ -1,0 +1,423 @@
+// Dense k5 / stride-1 / pad-2 conv on short rows with PRE-SPLIT weight images: the discriminator's 1024 -> 1024 layer
+// (reference discriminator/full.py:19; rows of 32 / 17 / 9 samples at the three scales), forward and backward data.
+//
+// It is 70 % of the discriminator's FLOPs and ran on the generic split-bf16 row kernels (conv_rows3.hip) at 95-220 TFLOP/s:
+// there every workgroup stages and SPLITS its 64 x 16 x 5 weight slab per chunk (5120 elements against 4224 activation
+// elements: more than half of the staging work, PMC: 7445 vector instructions per 1920 MFMAs per wave) and keeps it in
+// LDS twice (63 KB: one workgroup per CU).  Here, as in atom_fused.hip:
+//   * the weights are split ONCE per step (k_conv5_pack) into fragment-ordered images -- one 1 KiB block per (32 rows,
+//     16-channel chunk, tap, piece) = the A operand of one v_mfma_f32_32x32x16_bf16 -- and stream from L2 straight into
+//     registers, a whole chunk (15 blocks) ahead: no LDS, no vector work for weights;
+//   * LDS holds only the activation tile, double-buffered (2 x <= 39 KB: two workgroups per CU); all 8 waves run MFMAs
+//     all the time (2 x 4 waves of 32 rows x 64 columns); the activation chunk c+1 is split and stored while chunk c is
+//     multiplied, one barrier per chunk;
+//   * a tile is 64 rows x R whole batch rows (R = 256 / L: 8 / 15 / 26 rows), each row with its own 2-column zero halo in
+//     LDS, so rows of any length need no padding pass (api.hip pad4) and no dword loader;
+//   * split-K over channel slices fills the chip (tiles x slices ~ 512 workgroups); slices write raw slabs, a small finish
+//     kernel sums them in slice order (deterministic) and applies bias + LeakyReLU / the gradient add.
+// Arithmetic: the same exact 3-piece split and six products per multiply as conv_rows3.hip, fp32 accumulation; the
+// accumulation order differs from the row kernels' (other chunk / slice grouping): results agree to ~1e-7, not bitwise.
+#include "ms_common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XRS = 112;                 // bytes per LDS column of a 16-channel chunk: 3 pieces x 32 + 16
+constexpr int K5 = 5;
+constexpr int PX_MAX = 350;              // LDS columns per buffer (39.2 KB; two buffers, two workgroups per CU)
+constexpr unsigned OOB = 0xF0000000u;
+
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    const f32x2 v = {a, b};
+    const bf16x2 hi = __builtin_convertvector(v, bf16x2);
+    const f32x2 r1 = v - __builtin_convertvector(hi, f32x2);
+    const bf16x2 mi = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(mi, f32x2);
+    const bf16x2 lo = __builtin_convertvector(r2, bf16x2);
+    h = __builtin_bit_cast(unsigned, hi);
+    m = __builtin_bit_cast(unsigned, mi);
+    l = __builtin_bit_cast(unsigned, lo);
+}
+
+__device__ __forceinline__ void split_quad(const float (&e)[4], uint2 (&o)[3]) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_pair(e[0], e[1], h0, m0, l0);
+    split_pair(e[2], e[3], h1, m1, l1);
+    o[0] = make_uint2(h0, h1);
+    o[1] = make_uint2(m0, m1);
+    o[2] = make_uint2(l0, l1);
+}
+
+// image[ms][chunk][tap][piece][lane] (16 B): rows ms*32 + (lane & 31), contraction channels chunk*16 + 8*(lane >> 5) + 0..7
+//   forward:        A[row = co][k = ci][tap] = W[co][ci][tap]
+//   backward data:  A[row = ci][k = co][tap] = W[co][ci][4 - tap]
+__global__ __launch_bounds__(256) void k_conv5_pack(const float* __restrict__ W, u32x4* __restrict__ img, int M, int CK,
+                                                   int backward) {
+    const int NC = CK / 16;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over ms x chunk x tap x lane
+    const size_t total = (size_t)(M / 32) * NC * K5 * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    size_t r = idx >> 6;
+    const int tap = (int)(r % K5); r /= K5;
+    const int chunk = (int)(r % NC);
+    const int ms = (int)(r / NC);
+    const int row = ms * 32 + (lane & 31), k0 = chunk * 16 + 8 * (lane >> 5);
+    unsigned pc[3][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float a, b;
+        if (!backward) {          // W is (Cout = M, Cin = CK, 5)
+            a = W[((size_t)row * CK + k0 + 2 * q) * K5 + tap];
+            b = W[((size_t)row * CK + k0 + 2 * q + 1) * K5 + tap];
+        } else {                  // W is (Cout = CK, Cin = M, 5)
+            a = W[((size_t)(k0 + 2 * q) * M + row) * K5 + (K5 - 1 - tap)];
+            b = W[((size_t)(k0 + 2 * q + 1) * M + row) * K5 + (K5 - 1 - tap)];
+        }
+        split_pair(a, b, pc[0][q], pc[1][q], pc[2][q]);
+    }
+    u32x4* dst = img + ((size_t)((ms * NC + chunk) * K5 + tap) * 3) * 64 + lane;
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) dst[pp * 64] = u32x4{pc[pp][0], pc[pp][1], pc[pp][2], pc[pp][3]};
+}
+
+struct C5P {
+    int B, M, CK, L;          // GEMM rows (output channels of this pass), contraction channels, row length
+    int R, SS, PX;            // batch rows per tile, LDS columns per row (L + 4), LDS columns per buffer (R * SS)
+    int NV, NVG;              // 4-sample vectors per row, groups of 4 vectors
+    int cks, nsplit;          // channels per split-K slice (multiple of 16), slices
+    int act;                  // fused epilogue when nsplit == 1: bias + act (forward) / + add (backward data)
+    float slope;
+    long long zstride;        // floats per slab
+};
+
+// MODE 0: forward (X = x); MODE 1: backward data (X = gy, multiplied on load by act'(Xact) when Xact != nullptr)
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k_conv5_img(C5P p, const float* __restrict__ X, const float* __restrict__ Xact,
+                                                     const u32x4* __restrict__ IMG, const float* __restrict__ bias,
+                                                     const float* __restrict__ add, float* __restrict__ Y,
+                                                     float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem5[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;                   // 2 x 4 waves: 32 rows x 64 columns each
+    const int L = p.L, b0 = blockIdx.x * p.R, m0 = blockIdx.y * 64;
+    const int cbeg = blockIdx.z * p.cks;
+    const int cend = cbeg + p.cks < p.CK ? cbeg + p.cks : p.CK;
+    const int nchunks = (cend - cbeg) / 16;
+    const int buf_bytes = p.PX * XRS;
+    const bool masked = MODE == 1 && Xact != nullptr;
+
+    // (true sizes: a 4-sample vector that starts inside the last row may reach past the tensor -- those dwords read 0.0)
+    const unsigned x_bytes = 4u * (unsigned)(p.B * p.CK * L);
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, x_bytes, 0x00020000);
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(masked ? Xact : X), 0, x_bytes, 0x00020000);
+    const auto rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(IMG), 0, 0x80000000u, 0x00020000);
+
+    // ---- staging units (two rounds of 512): unit = (batch row r, channel quad cq, 4-sample vector v); 16 consecutive
+    // lanes = 4 quads x 4 consecutive vectors.  Rows are contiguous runs of L floats, 4-byte aligned (any L).
+    unsigned u_goff[2];
+    int u_l[2], u_lbase[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int u = tid + 512 * k;
+        const int g16 = u >> 4, r = g16 / p.NVG, vg = g16 - r * p.NVG;
+        const int cq = (u >> 2) & 3, v = vg * 4 + (u & 3);
+        const bool ok = r < p.R && v < p.NV && b0 + r < p.B;
+        u_goff[k] = ok ? 4u * (unsigned)((((b0 + r) * p.CK) + 4 * cq) * L + 4 * v) : OOB;       // + (c0 + cc) * L * 4 (scalar)
+        u_l[k] = ok ? 4 * v : (1 << 20);
+        u_lbase[k] = (r * p.SS + 2 + 4 * v) * XRS + cq * 8;
+    }
+    f32x4 rx[2][4], rxa[MODE == 1 ? 2 : 1][4];
+    auto load_x = [&](int c0, bool live) {
+        const int so = live ? 4 * c0 * L : 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                rx[k][cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, u_goff[k], so + cc * 4 * L, 0));
+                if (MODE == 1)
+                    rxa[k][cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, u_goff[k], so + cc * 4 * L, 0));
+            }
+    };
+    auto store_x = [&](unsigned char* buf) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (u_l[k] + e >= L) continue;                        // behind the row: the halo stays zero
+                float c4[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    c4[cc] = rx[k][cc][e];
+                    if (masked) c4[cc] = rxa[k][cc][e] > 0.f ? c4[cc] : c4[cc] * p.slope;
+                }
+                uint2 o3[3];
+                split_quad(c4, o3);
+                unsigned char* dst = buf + u_lbase[k] + e * XRS;
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(dst + pp * 32) = o3[pp];
+            }
+    };
+
+    // ---- A fragments: one chunk (5 taps x 3 pieces) in registers, refilled tap by tap for the next chunk
+    bf16x8 fa[K5][3];
+    const int NC = p.CK / 16;
+    const int a_voff = lane * 16;
+    const int a_row = ((blockIdx.y * 2 + wm) * NC) * (K5 * 3 * 1024);          // byte offset of (ms, chunk 0)
+    auto load_a_tap = [&](int chunk_abs, int t) {
+        const int so = a_row + chunk_abs * (K5 * 3 * 1024) + t * 3 * 1024;
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+            fa[t][pp] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsI, a_voff, so + pp * 1024, 0));
+    };
+
+    // ---- B fragment bases: MFMA column n = wn*64 + j*32 + l31 -> (row r, sample l)
+    int bbase[2];
+    unsigned o_lane[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = wn * 64 + j * 32 + l31;
+        const int r = n / L, l = n - r * L;
+        const bool ok = r < p.R && b0 + r < p.B;
+        bbase[j] = ok ? (r * p.SS + l) * XRS + h * 16 : h * 16;
+        o_lane[j] = ok ? 4u * (unsigned)((r * p.M + 4 * h) * L + l) : OOB;        // + ((b0*M + m) * L) * 4 (scalar)
+    }
+
+    // ---- zero both LDS buffers (the halos are never written), stage chunk 0, prefetch chunk 1
+    {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int i = tid * 16; i < 2 * buf_bytes; i += 512 * 16) *reinterpret_cast<u32x4*>(smem5 + i) = z;
+    }
+    load_x(cbeg, true);
+#pragma unroll
+    for (int t = 0; t < K5; ++t) load_a_tap(cbeg / 16, t);
+    __syncthreads();
+    store_x(smem5);
+    load_x(cbeg + 16, nchunks > 1);
+    __syncthreads();
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll 1
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const unsigned char* Xs = smem5 + (ch & 1) * buf_bytes;
+        unsigned char* Xn = smem5 + ((ch & 1) ^ 1) * buf_bytes;
+        const bool more = ch + 1 < nchunks;
+        const int a_next = (cbeg / 16) + (more ? ch + 1 : ch);
+        bf16x8 fb[2][2][3];
+        auto fragb = [&](int t, bf16x8 (&dst)[2][3]) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+                    dst[j][pp] = *reinterpret_cast<const bf16x8*>(Xs + bbase[j] + t * XRS + pp * 32);
+        };
+        fragb(0, fb[0]);
+#pragma unroll
+        for (int t = 0; t < K5; ++t) {
+            if (t + 1 < K5) fragb(t + 1, fb[(t + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 6; ++s)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][PA[s]], fb[t & 1][j][PB[s]], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a_tap(a_next, t);                                     // this tap's registers are free: the next chunk's tap
+            if (t == 1 && more) store_x(Xn);                           // chunk ch+1: registers -> the other buffer
+            if (t == 2) load_x(cbeg + (ch + 2) * 16, ch + 2 < nchunks);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: dword stores straight from the accumulators (32 lanes = 32 consecutive samples of one or two rows)
+    int L4;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(L4) : "s"(4 * L));
+    const bool fused = p.nsplit == 1;
+    float* out = fused ? Y : slabs + (size_t)blockIdx.z * p.zstride;
+    const auto rsO = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0x80000000u, 0x00020000);
+    const auto rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(add ? add : X), 0, 0x80000000u, 0x00020000);
+    const int base = b0 * p.M * L4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int chs = m0 + wm * 32 + 8 * g;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (fused && MODE == 0 && bias) bv = *reinterpret_cast<const f32x4*>(bias + chs + 4 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = acc[j][4 * g + q];
+                if (fused) {
+                    if (MODE == 0) {
+                        v += bv[q];
+                        if (p.act == MS_ACT_LRELU) v = v > 0.f ? v : v * p.slope;
+                    } else if (add) {
+                        v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, o_lane[j], base + (chs + q) * L4, 0));
+                    }
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, o_lane[j], base + (chs + q) * L4, 0);
+            }
+        }
+}
+
+// y = act(sum_z slab_z + bias[channel]) (+ add), slabs summed in slice order
+__global__ __launch_bounds__(256) void k_conv5_finish(const float* __restrict__ slabs, int ns, long long zstride,
+                                                     const float* __restrict__ bias, int M, int L, int act, float slope,
+                                                     const float* __restrict__ add, float* __restrict__ Y, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        float v = slabs[i];
+        for (int z = 1; z < ns; ++z) v += slabs[(long long)z * zstride + i];
+        if (bias) v += bias[(i / L) % M];
+        if (act == MS_ACT_LRELU) v = v > 0.f ? v : v * slope;
+        if (add) v += add[i];
+        Y[i] = v;
+    }
+}
+
+bool c5_geometry(const ConvP& c, bool backward, C5P* p) {
+    if (c.K != 5 || c.stride != 1 || c.dil != 1 || c.pad != 2 || c.groups != 1 || c.pad_mode != MS_PAD_ZERO || c.in_act) return false;
+    if (c.Lout != c.Lin || c.Lin < 1 || c.Lin > 64) return false;
+    if (c.act != MS_ACT_NONE && c.act != MS_ACT_LRELU) return false;
+    const int M = backward ? c.Cin : c.Cout, CK = backward ? c.Cout : c.Cin;
+    if (M % 64 || CK % 16 || M < 256 || CK < 256) return false;
+    if ((long long)c.B * M * c.Lin * 4 >= (1ll << 31) || (long long)c.B * CK * c.Lin * 4 >= (1ll << 31)) return false;
+    if ((long long)(M / 32) * (CK / 16) * (K5 * 3 * 1024) >= (1ll << 31)) return false;
+    p->B = c.B; p->M = M; p->CK = CK; p->L = c.Lin;
+    p->SS = c.Lin + 4;
+    int R = 256 / c.Lin;
+    if (R * p->SS > PX_MAX) R = PX_MAX / p->SS;
+    if (R < 1) return false;
+    p->R = R;
+    p->PX = R * p->SS;
+    p->NV = (c.Lin + 3) / 4;
+    p->NVG = (p->NV + 3) / 4;
+    if (R * p->NVG * 16 > 1024) return false;              // two staging rounds of 512 units
+    p->act = c.act; p->slope = c.slope;
+    // split-K: tiles x slices ~ the 512 resident workgroups, at least 8 chunks per slice, at most 8 slices / 64 MiB of slabs
+    const int tiles = (M / 64) * ((c.B + R - 1) / R);
+    const int nchunks = CK / 16;
+    int ns = 512 / tiles;
+    if (ns < 1) ns = 1;
+    if (ns > 8) ns = 8;
+    while (ns > 1 && nchunks / ns < 8) --ns;
+    p->zstride = (long long)c.B * M * c.Lin;
+    while (ns > 1 && (size_t)ns * p->zstride * 4 > ((size_t)64 << 20)) --ns;
+    int cks = ((nchunks + ns - 1) / ns) * 16;
+    p->cks = cks;
+    p->nsplit = (CK + cks - 1) / cks;
+    return true;
+}
+
+bool c5_enabled() {
+    const char* sw = getenv("MSYNTH_CONV5IMG");               // tuning / test switch (0: the generic row kernels)
+    return !(sw && atoi(sw) == 0);
+}
+
+template <int MODE>
+int c5_launch(const C5P& p, const float* X, const float* Xact, const void* image, const float* bias, const float* add, float* Y,
+              void* ws, size_t ws_bytes, hipStream_t s) {
+    float* slabs = nullptr;
+    if (p.nsplit > 1) {
+        const size_t need = (size_t)p.nsplit * p.zstride * sizeof(float);
+        if (!ws || ws_bytes < need || (((uintptr_t)ws) & 15)) return MS_ERR_WORKSPACE;
+        slabs = (float*)ws;
+    }
+    const size_t lds = (size_t)2 * p.PX * XRS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_img<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * PX_MAX * XRS);
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)((p.B + p.R - 1) / p.R), (unsigned)(p.M / 64), (unsigned)p.nsplit);
+    ms_note_kernel("k_conv5_img<%d>", MODE);
+    hipLaunchKernelGGL((k_conv5_img<MODE>), grid, dim3(512), lds, s, p, X, Xact, (const u32x4*)image, bias, add, Y, slabs);
+    MS_CHECK_LAUNCH();
+    if (p.nsplit > 1) {
+        const long long total = p.zstride;
+        unsigned nb = (unsigned)((total + 255) / 256);
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(k_conv5_finish, dim3(nb), dim3(256), 0, s, slabs, p.nsplit, p.zstride, MODE == 0 ? bias : nullptr, p.M,
+                           p.L, MODE == 0 ? p.act : MS_ACT_NONE, p.slope, MODE == 1 ? add : nullptr, Y, total);
+        MS_CHECK_LAUNCH();
+    }
+    return MS_OK;
+}
+
+bool to_convp(const ms_conv1d_desc* d, ConvP* p) {
+    if (!d || d->B <= 0 || d->Cin <= 0 || d->Lin <= 0 || d->Cout <= 0 || d->K <= 0 || d->stride <= 0 || d->pad < 0 || d->dil <= 0 ||
+        d->groups <= 0)
+        return false;
+    p->B = d->B; p->Cin = d->Cin; p->Lin = d->Lin; p->Cout = d->Cout; p->K = d->K; p->stride = d->stride; p->pad = d->pad;
+    p->dil = d->dil; p->groups = d->groups; p->Cg = d->Cin / d->groups; p->Og = d->Cout / d->groups;
+    p->Lout = (d->Lin + 2 * d->pad - d->dil * (d->K - 1) - 1) / d->stride + 1;
+    p->pad_mode = d->pad_mode; p->act = d->act; p->slope = d->slope; p->in_act = d->in_act;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ms_conv1d_img_bytes(const ms_conv1d_desc* d) {
+    ConvP c;
+    C5P p;
+    if (!to_convp(d, &c) || !c5_enabled() || !c5_geometry(c, false, &p)) return 0;
+    return (size_t)(p.M / 32) * (p.CK / 16) * K5 * 3 * 1024;
+}
+
+size_t ms_conv1d_img_workspace_bytes(const ms_conv1d_desc* d, int which) {
+    ConvP c;
+    C5P p;
+    if (!to_convp(d, &c) || !c5_geometry(c, which == 1, &p)) return 0;
+    return p.nsplit > 1 ? (size_t)p.nsplit * p.zstride * sizeof(float) : 0;
+}
+
+int ms_conv1d_img_pack(const ms_conv1d_desc* d, const float* w, int backward, void* image, ms_stream_t stream) {
+    ConvP c;
+    C5P p;
+    if (!to_convp(d, &c) || !w || !image || (((uintptr_t)image) & 15)) return MS_ERR_INVALID_ARG;
+    if (!c5_geometry(c, backward != 0, &p)) return MS_ERR_UNSUPPORTED;
+    const size_t total = (size_t)(p.M / 32) * (p.CK / 16) * K5 * 64;
+    hipLaunchKernelGGL(k_conv5_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (u32x4*)image, p.M,
+                       p.CK, backward ? 1 : 0);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+int ms_conv1d_img_fwd(const ms_conv1d_desc* d, const float* x, const void* image, const float* bias, float* y, void* workspace,
+                      size_t workspace_bytes, ms_stream_t stream) {
+    ConvP c;
+    C5P p;
+    if (!to_convp(d, &c) || !x || !image || !y || (((uintptr_t)image) & 15) || (bias && (((uintptr_t)bias) & 15)))
+        return MS_ERR_INVALID_ARG;
+    if (!c5_geometry(c, false, &p)) return MS_ERR_UNSUPPORTED;
+    return c5_launch<0>(p, x, nullptr, image, bias, nullptr, y, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ms_conv1d_img_bwd_data(const ms_conv1d_desc* d, const float* gy, const float* y_act, const void* image_bwd,
+                           const float* gx_add, float* gx, void* workspace, size_t workspace_bytes, ms_stream_t stream) {
+    ConvP c;
+    C5P p;
+    if (!to_convp(d, &c) || !gy || !image_bwd || !gx || (((uintptr_t)image_bwd) & 15)) return MS_ERR_INVALID_ARG;
+    if (!c5_geometry(c, true, &p)) return MS_ERR_UNSUPPORTED;
+    if (c.act == MS_ACT_NONE) y_act = nullptr;
+    return c5_launch<1>(p, gy, y_act, image_bwd, nullptr, gx_add, gx, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -290,7 +290,21 @@ def gen_backward(tape, params, gy, sink=None, need_gx=False, cut=None):
 
 
 
-def disc_forward(x, params):
+def pack_k5_image(x_shape, params, backward=False):
+    """Weight image of the discriminator's 1024 -> 1024 k5 conv (main.5) for the image kernel (csrc/conv5_img.hip), or
+    None when that kernel does not take the layer.  One image serves the three scales and every batch size; it is only
+    valid for the weights as they are now (rebuilt once per pass)."""
+    w = params[10]
+    B = x_shape[0]
+    if tuple(w.shape[1:]) != (w.shape[0], 5) or params[11].data_ptr() % 16:
+        return None
+    d = L.ConvDesc(B, w.shape[1], 32, w.shape[0], 5, 1, 2, 1, 1, L.PAD_ZERO, L.ACT_LRELU, P.SLOPE, L.ACT_NONE)
+    if not P.conv_img_bytes(d):
+        return None
+    return P.conv_img_pack(d, w, backward=backward)
+
+
+def disc_forward(x, params, k5_image=None):
     """One FullDiscriminator pass -> (features[6], judgement, tape)."""
     if len(params) != D_NPARAMS:
         raise RuntimeError("discriminator expects %d parameter tensors, got %d" % (D_NPARAMS, len(params)))
@@ -303,7 +317,10 @@ def disc_forward(x, params):
         w, b = params[2 * li], params[2 * li + 1]
         d, lo = P.conv_desc(h.shape, w.shape, stride=stride, pad=pad, groups=groups, act=L.ACT_LRELU)
         hin = h
-        h, _ = P.conv1d_fwd(hin, w, b, d, lo)
+        if li == 5 and k5_image is not None and P.conv_img_bytes(d):
+            h = P.conv1d_img_fwd(hin, k5_image, b, d, lo)
+        else:
+            h, _ = P.conv1d_fwd(hin, w, b, d, lo)
         tape.append((d, hin, h))
         feats.append(h)
     w, b = params[12], params[13]
@@ -316,7 +333,8 @@ def disc_forward(x, params):
 D_HEAD_PARAM = 10      # first parameter of the discriminator's "head" (main.5 = the 1024 -> 1024 k5 conv, then judge)
 
 
-def disc_backward(tape, params, g_feats, g_judge, sink, need_gx=True, need_wgrad=True, phase=None, g_in=None):
+def disc_backward(tape, params, g_feats, g_judge, sink, need_gx=True, need_wgrad=True, phase=None, g_in=None,
+                  k5_image_bwd=None):
     """g_feats: list of 6 (entries may be None) or None; g_judge may be None (treated as zero).
     Parameter grads go to `sink` (GradSink of 14); returns d loss / d x (or None).
 
@@ -351,7 +369,9 @@ def disc_backward(tape, params, g_feats, g_judge, sink, need_gx=True, need_wgrad
         if need_wgrad:
             gw, gb, acc = sink.pair(2 * li)
             sink.put(2 * li, *P.conv1d_bwd_weight(hin, g, h, d, params[2 * li].shape, gw, gb, acc))
-        if li > 0:
+        if li == 5 and k5_image_bwd is not None and P.conv_img_bytes(d):
+            g = P.conv1d_img_bwd_data(g, h, k5_image_bwd, d, gx_add=prev)
+        elif li > 0:
             g = P.conv1d_bwd_data(g, h, params[2 * li], d, gx_add=prev)
         elif need_gx:
             g = P.conv1d_bwd_data(g, h, params[0], d)
@@ -386,7 +406,7 @@ def _concurrent_scales():
     return os.environ.get("MSYNTH_STREAMS", "1") != "0"
 
 
-def melgan_forward(x, params, scales=2):
+def melgan_forward(x, params, scales=2, k5_image=None):
     """MelGanDiscriminator: the shared discriminator on x, pool(x), pool(pool(x)).
 
     The three scale passes are independent; the pooled scales are tiny (their 1024-channel layers
@@ -397,6 +417,8 @@ def melgan_forward(x, params, scales=2):
     for s in range(scales):
         xs.append(P.avg_pool_fwd(xs[-1]))
     res = [None] * (scales + 1)
+    if k5_image is None:
+        k5_image = pack_k5_image(x.shape, params)          # (on the caller's stream, ahead of the forks)
     if scales > 0 and _may_fork(x.device):   # forks are kept one level deep
         main = torch.cuda.current_stream(x.device)
         side = _side_streams(x.device, scales)
@@ -406,19 +428,19 @@ def melgan_forward(x, params, scales=2):
         fork_ev = torch.cuda.Event()
         fork_ev.record(main)
         if first:
-            res[0] = disc_forward(xs[0], params)
+            res[0] = disc_forward(xs[0], params, k5_image)
         for s in range(1, scales + 1):
             st = side[s - 1]
             st.wait_event(fork_ev)
             with forked(st):
-                res[s] = disc_forward(xs[s], params)
+                res[s] = disc_forward(xs[s], params, k5_image)
         if not first:
-            res[0] = disc_forward(xs[0], params)
+            res[0] = disc_forward(xs[0], params, k5_image)
         for st in side:
             main.wait_stream(st)
     else:
         for s in range(scales + 1):
-            res[s] = disc_forward(xs[s], params)
+            res[s] = disc_forward(xs[s], params, k5_image)
     feats = [r[0] for r in res]
     judges = [r[1] for r in res]
     tapes = [r[2] for r in res]
@@ -470,12 +492,14 @@ def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, nee
     # bucket of the same layout, folded in afterwards with ONE add (per phase) instead of one per parameter
     flat_main, offs, total = (_flat_view(sink, params) if (need_wgrad and fork) else (None, None, 0))
 
+    k5_bwd = pack_k5_image(xs[0].shape, params, backward=True)      # (ahead of the forks: all scales read it)
+
     def run_scale(s, ph, dest):
         has, gf, gj = grads[s]
         if not has:
             return
         out = disc_backward(tapes[s], params, gf, gj, dest, need_gx=need_gx, need_wgrad=need_wgrad,
-                            phase=ph, g_in=mid[s])
+                            phase=ph, g_in=mid[s], k5_image_bwd=k5_bwd)
         if ph == "head":
             mid[s] = out
         else:

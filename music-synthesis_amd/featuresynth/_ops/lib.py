@@ -102,6 +102,11 @@ SIGNATURES = {
     "ms_residual_atom_fwd": (_c_int, [ctypes.POINTER(AtomDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ms_residual_atom_bwd_supported": (_c_int, [ctypes.POINTER(AtomDesc)]),
     "ms_residual_atom_bwd_data": (_c_int, [ctypes.POINTER(AtomDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ms_conv1d_img_bytes": (_sz, [ctypes.POINTER(ConvDesc)]),
+    "ms_conv1d_img_workspace_bytes": (_sz, [ctypes.POINTER(ConvDesc), _c_int]),
+    "ms_conv1d_img_pack": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _c_int, _vp, _vp]),
+    "ms_conv1d_img_fwd": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ms_conv1d_img_bwd_data": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ms_conv1d_workspace_bytes": (_sz, [ctypes.POINTER(ConvDesc), _c_int]),
     "ms_conv1d_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvDesc), _c_int]),
     "ms_convt1d_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvTDesc), _c_int]),

@@ -141,6 +141,48 @@ def conv1d_bwd_weight_multi(jobs):
     return out
 
 
+# ---- dense k5 conv on short rows with pre-split weight images (csrc/conv5_img.hip)
+def conv_img_bytes(d):
+    """Bytes of the weight image the image kernel wants for this conv geometry; 0 = not taken."""
+    return int(L.load().ms_conv1d_img_bytes(d))
+
+
+def conv_img_pack(d, w, backward=False):
+    """-> image tensor (uint8) of w for the forward (backward-data) pass of every conv with d's channels / taps."""
+    L.require(w, "conv1d weight")
+    img = torch.empty(conv_img_bytes(d), dtype=torch.uint8, device=w.device)
+    L.call("ms_conv1d_img_pack", _scost(w.numel(), 1, 1.5), d, w.data_ptr(), 1 if backward else 0, img.data_ptr(), L.stream())
+    return img
+
+
+def conv1d_img_fwd(x, image, b, d, lout):
+    L.require(x, "conv1d input")
+    y = torch.empty((d.B, d.Cout, lout), dtype=torch.float32, device=x.device)
+    nws = L.load().ms_conv1d_img_workspace_bytes(d, 0)
+    ws = L.workspace(nws, x.device)
+
+    def cost():
+        return dict(W.conv_cost(d.B, d.Cin, d.Lin, d.Cout, d.K, d.stride, d.pad, d.dil, d.groups, "fwd"),
+                    geom=(d.B, d.Cin, d.Lin, d.Cout, d.K, d.stride, d.dil, d.groups))
+    L.call("ms_conv1d_img_fwd", cost, d, x.data_ptr(), image.data_ptr(), L.ptr(b), y.data_ptr(), L.ptr(ws), nws, L.stream())
+    return y
+
+
+def conv1d_img_bwd_data(gy, y_act, image_bwd, d, gx_add=None):
+    L.require(gy, "conv1d grad_output")
+    gx = torch.empty((d.B, d.Cin, d.Lin), dtype=torch.float32, device=gy.device)
+    nws = L.load().ms_conv1d_img_workspace_bytes(d, 1)
+    ws = L.workspace(nws, gy.device)
+
+    def cost():
+        return dict(W.conv_cost(d.B, d.Cin, d.Lin, d.Cout, d.K, d.stride, d.pad, d.dil, d.groups, "bwd_data",
+                                act_read=y_act is not None, extra_reads=int(gx_add is not None)),
+                    geom=(d.B, d.Cin, d.Lin, d.Cout, d.K, d.stride, d.dil, d.groups))
+    L.call("ms_conv1d_img_bwd_data", cost, d, gy.data_ptr(), L.ptr(y_act), image_bwd.data_ptr(), L.ptr(gx_add), gx.data_ptr(),
+           L.ptr(ws), nws, L.stream())
+    return gx
+
+
 # ---- fused ResidualAtom forward (csrc/atom_fused.hip)
 def atom_supported(B, C, Lg, dil):
     return bool(L.load().ms_residual_atom_supported(L.AtomDesc(B, C, Lg, dil, SLOPE)))

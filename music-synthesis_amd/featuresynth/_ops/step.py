@@ -67,14 +67,15 @@ def g_step(gen_params, disc_params, samples, features, scales=2, weight=10.0, cu
     main = torch.cuda.current_stream(dev)
     side = G.aux_stream(dev)
     fork_real = G._may_fork(dev)
+    k5 = G.pack_k5_image(samples.shape, disc_params)       # one weight image for both discriminator passes
     if fork_real:
         side.wait_stream(main)
         with G.forked(side):
-            r_feats, r_judges, _ = G.melgan_forward(samples, disc_params, scales)
+            r_feats, r_judges, _ = G.melgan_forward(samples, disc_params, scales, k5_image=k5)
     else:
-        r_feats, r_judges, _ = G.melgan_forward(samples, disc_params, scales)
+        r_feats, r_judges, _ = G.melgan_forward(samples, disc_params, scales, k5_image=k5)
     fake, tape = G.gen_forward(features, gen_params, save=True)
-    f_feats, f_judges, ctx = G.melgan_forward(fake, disc_params, scales)
+    f_feats, f_judges, ctx = G.melgan_forward(fake, disc_params, scales, k5_image=k5)
     if fork_real:
         main.wait_stream(side)
     S, Lyr = len(f_feats), len(f_feats[0])
