@@ -43,6 +43,7 @@ class GradSink:
 
 
 _FORK_DEPTH = 0     # > 0 while work is being issued on a forked stream (forks stay one level deep)
+_FORKED_SINCE_JOIN = set()     # side streams work was issued on since the last join_side_streams()
 
 
 @contextlib.contextmanager
@@ -53,6 +54,7 @@ def forked(stream):
     ("Streams inside the graph")."""
     global _FORK_DEPTH
     _FORK_DEPTH += 1
+    _FORKED_SINCE_JOIN.add(stream)
     try:
         with torch.cuda.stream(stream):
             yield
@@ -396,6 +398,18 @@ def _side_streams(device, n):
     if key not in _SIDE_STREAMS:   # created on the first (eager) call, never during graph capture
         _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
     return _SIDE_STREAMS[key]
+
+
+def join_side_streams(device):
+    """The caller's stream waits for every side stream of this device.  The autograd engine runs a node's backward on the
+    stream its forward ran on and syncs only what it accumulates itself: a Function that wrote parameter gradients straight
+    into FlatAdam slots from a forked stream (bias gradients of convs issued under `forked`) is invisible to it, so the
+    trainers join explicitly between loss.backward() and optimizer.step()."""
+    main = torch.cuda.current_stream(device)
+    for st in list(_FORKED_SINCE_JOIN):         # (only streams forked since the last join: under capture, streams of this capture)
+        if st.device == device and st != main:
+            main.wait_stream(st)
+        _FORKED_SINCE_JOIN.discard(st)
 
 
 def _on_aux(device):

@@ -45,11 +45,21 @@ def conv_desc(x_shape, w_shape, stride=1, pad=0, dil=1, groups=1, pad_mode=L.PAD
     return d, lout
 
 
-def conv1d_fwd(x, w, b, d, lout, residual=None, want_y_act=False):
+def _out(out, shape, device, what):
+    """Caller-provided output (e.g. one half of a batch-concatenated buffer) or a fresh tensor."""
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    L.require(out, what)
+    if tuple(out.shape) != tuple(shape):
+        raise RuntimeError("%s: output buffer %s != %s" % (what, tuple(out.shape), tuple(shape)))
+    return out
+
+
+def conv1d_fwd(x, w, b, d, lout, residual=None, want_y_act=False, out=None):
     L.require(x, "conv1d input"); L.require(w, "conv1d weight")
     if b is not None:
         L.require(b, "conv1d bias")
-    y = torch.empty((d.B, d.Cout, lout), dtype=torch.float32, device=x.device)
+    y = _out(out, (d.B, d.Cout, lout), x.device, "conv1d output")
     y_act = None
     if residual is not None:
         L.require(residual, "conv1d residual")
@@ -155,9 +165,9 @@ def conv_img_pack(d, w, backward=False):
     return img
 
 
-def conv1d_img_fwd(x, image, b, d, lout):
+def conv1d_img_fwd(x, image, b, d, lout, out=None):
     L.require(x, "conv1d input")
-    y = torch.empty((d.B, d.Cout, lout), dtype=torch.float32, device=x.device)
+    y = _out(out, (d.B, d.Cout, lout), x.device, "conv1d output")
     nws = L.load().ms_conv1d_img_workspace_bytes(d, 0)
     ws = L.workspace(nws, x.device)
 
@@ -306,10 +316,10 @@ def pool_out_len(lin):
     return (lin + 4 - 4) // 2 + 1
 
 
-def avg_pool_fwd(x):
+def avg_pool_fwd(x, out=None):
     L.require(x, "avg_pool1d input")
     B, C, Lin = x.shape
-    y = torch.empty((B, C, pool_out_len(Lin)), dtype=torch.float32, device=x.device)
+    y = _out(out, (B, C, pool_out_len(Lin)), x.device, "avg_pool1d output")
     L.call("ms_avg_pool1d_4_2_2_fwd", _scost(x.numel(), 1, 0.5), x.data_ptr(), y.data_ptr(), B * C, Lin,
            L.stream())
     return y

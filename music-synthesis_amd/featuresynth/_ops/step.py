@@ -45,7 +45,9 @@ def d_step(gen_params, disc_params, samples, features, scales=2, cut=None, debug
     fake, _ = G.gen_forward(features, gen_params, save=False)
     B = fake.shape[0]
     # one discriminator pass over [fake; real]: samples are independent (no batch coupling), so the
-    # judgements are the same and the shared weights' gradients are summed in-kernel
+    # judgements are the same and the shared weights' gradients are summed in-kernel.  (r03 tried the real half of the
+    # forward on the aux stream under the generator, both halves writing into shared full-batch buffers: 3.71 vs 3.66 ms
+    # per step -- the half-batch passes cost more than the overlap returns; dropped.)
     both = torch.cat([fake, samples], 0)
     _, judges, ctx = G.melgan_forward(both, disc_params, scales)
     loss = F_.disc_loss_cat_fwd(judges, B)

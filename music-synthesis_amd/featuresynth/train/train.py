@@ -375,6 +375,7 @@ class GeneratorTrainer(_TrainerBase):
             main.wait_stream(side)
             loss = self.loss(r_features, f_features, r_score, f_score, gan_loss=self.sub_loss)
             loss.backward()
+            _graph.join_side_streams(samples.device)      # (modules that fork streams inside their forward: realmelgan)
         finally:
             for p in d_params:
                 p.requires_grad_(True)
@@ -445,6 +446,7 @@ class DiscriminatorTrainer(_TrainerBase):
             r_score = [j[B:] for j in scores]
             loss = self.loss(r_score, f_score, gan_loss=self.sub_loss)
         loss.backward()
+        _graph.join_side_streams(samples.device)
         if loss_slot is not None:
             loss_slot.copy_(loss.detach())
         return {"loss": loss.detach()}

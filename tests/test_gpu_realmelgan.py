@@ -378,3 +378,43 @@ def test_conditioned_discriminator_through_trainers():
             worst = max(worst, e)
             assert e < 1e-4, (kind, k, e)
         print("conditioned discriminator, %s-step: worst grad rel-L2 vs reference order %.2e" % (kind, worst))
+
+
+def test_realmelgan_forked_replay_gradients_bitwise(monkeypatch):
+    """the three discriminators on forked HIP streams under hipGraph replay.  The divergence of
+    r01 / r02 was the autograd engine accumulating a gradient with TWO producers on different streams (a feature map:
+    next layer's backward on the forked stream + the feature-matching loss on the caller's; a pooled input: first layer +
+    pooling chain) -- only G-steps were affected, D-steps (single-producer hand-offs only) were exact.  With the hand-off
+    nodes (functional.HandoffFn) every accumulation is between gradients of one stream: with lr = 0 (parameters fixed)
+    the gradients of every call -- eager, capture, replay -- must equal the unforked eager run's bitwise."""
+    import featuresynth as fs
+    from featuresynth import loss as LS
+    from featuresynth._synthetic import synthetic_features, synthetic_samples
+    from featuresynth.experiment import realmelgan as R
+    from featuresynth.train import DiscriminatorTrainer, GeneratorTrainer
+    s, f = dev(synthetic_samples(2, 1024, rank=1)), dev(synthetic_features(2, 128, 4, rank=1))
+
+    def run(graph, fork):
+        monkeypatch.setenv("MSYNTH_GRAPH", graph)
+        monkeypatch.setenv("MSYNTH_REAL_FORK", fork)
+        g, d, _, _ = _nets()
+        go = fs.FlatAdam(g.parameters(), lr=0.0, betas=(0.5, 0.9))
+        do = fs.FlatAdam(d.parameters(), lr=0.0, betas=(0.5, 0.9))
+        dt = DiscriminatorTrainer(g, go, d, do, LS.mel_gan_disc_loss)
+        gt = GeneratorTrainer(g, go, d, do, R.mel_gan_gen_loss)
+        out = []
+        for i in range(6):
+            r = dt.train(s, f) if i % 2 == 0 else gt.train(s, f)
+            torch.cuda.synchronize()
+            opt = do if i % 2 == 0 else go
+            out.append((r.get("d_loss", r.get("g_loss")), host(opt.flat_grads).copy()))
+        if graph == "1":
+            assert dt._runner.graphs and gt._runner.graphs and not gt._runner.disabled
+        return out
+
+    ref = run("0", "0")
+    for graph, fork in (("0", "1"), ("1", "1")):
+        got = run(graph, fork)
+        for i in range(6):
+            assert got[i][0] == ref[i][0], (graph, fork, i, got[i][0], ref[i][0])
+            assert np.array_equal(got[i][1], ref[i][1]), (graph, fork, i, float(np.abs(got[i][1] - ref[i][1]).max()))
