@@ -306,6 +306,25 @@ def pack_k5_image(x_shape, params, backward=False):
     return P.conv_img_pack(d, w, backward=backward)
 
 
+def pack_k5_images_aside(x_shape, params, device):
+    """Both weight images of the k5 layer (forward, backward data), packed on the aux stream so that they travel beside
+    whatever the caller issues next (the generator forward): -> (fwd, bwd, event to wait for before the first use), or
+    (None, None, None) when the image kernel does not take the layer / streams are serialised."""
+    if not _may_fork(device):
+        return pack_k5_image(x_shape, params), pack_k5_image(x_shape, params, backward=True), None
+    main, aux = torch.cuda.current_stream(device), aux_stream(device)
+    aux.wait_stream(main)
+    with forked(aux):
+        f = pack_k5_image(x_shape, params)
+        b = pack_k5_image(x_shape, params, backward=True)
+        ev = torch.cuda.Event()
+        ev.record(aux)
+    for t in (f, b):
+        if t is not None:
+            t.record_stream(main)       # (allocated on aux, read on the caller's stream and its forks)
+    return f, b, ev
+
+
 def disc_forward(x, params, k5_image=None):
     """One FullDiscriminator pass -> (features[6], judgement, tape)."""
     if len(params) != D_NPARAMS:
@@ -487,7 +506,7 @@ def _flat_view(sink, params):
     return base.as_strided((total,), (1,)), offs, total
 
 
-def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, need_wgrad=True, cut=None):
+def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, need_wgrad=True, cut=None, k5_image_bwd=None):
     """cut: optional callback.  When given, every scale's head (judge + k5 layer, disc_backward phase
     "head") runs first, all streams join, cut() is called -- at that point sink slots D_HEAD_PARAM.. are
     final -- and the tails follow.  Without it each scale runs head and tail back to back."""
@@ -506,7 +525,8 @@ def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, nee
     # bucket of the same layout, folded in afterwards with ONE add (per phase) instead of one per parameter
     flat_main, offs, total = (_flat_view(sink, params) if (need_wgrad and fork) else (None, None, 0))
 
-    k5_bwd = pack_k5_image(xs[0].shape, params, backward=True)      # (ahead of the forks: all scales read it)
+    # (ahead of the forks: all scales read it; the hand-scheduled step packs it at its start, off the critical path)
+    k5_bwd = k5_image_bwd if k5_image_bwd is not None else pack_k5_image(xs[0].shape, params, backward=True)
 
     def run_scale(s, ph, dest):
         has, gf, gj = grads[s]

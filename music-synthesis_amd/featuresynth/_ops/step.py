@@ -42,21 +42,26 @@ def _slots(params):
 
 def d_step(gen_params, disc_params, samples, features, scales=2, cut=None, debug=None, loss_slot=None):
     """-> d_loss (0-d device tensor); discriminator gradients accumulate into its bucket."""
+    dev = samples.device
+    k5f, k5b, k5ev = G.pack_k5_images_aside(samples.shape, disc_params, dev)     # beside the generator forward
     fake, _ = G.gen_forward(features, gen_params, save=False)
     B = fake.shape[0]
+    if k5ev is not None:
+        torch.cuda.current_stream(dev).wait_event(k5ev)
     # one discriminator pass over [fake; real]: samples are independent (no batch coupling), so the
     # judgements are the same and the shared weights' gradients are summed in-kernel.  (r03 tried the real half of the
     # forward on the aux stream under the generator, both halves writing into shared full-batch buffers: 3.71 vs 3.66 ms
     # per step -- the half-batch passes cost more than the overlap returns; dropped.)
     both = torch.cat([fake, samples], 0)
-    _, judges, ctx = G.melgan_forward(both, disc_params, scales)
+    _, judges, ctx = G.melgan_forward(both, disc_params, scales, k5_image=k5f)
     loss = F_.disc_loss_cat_fwd(judges, B)
     if loss_slot is not None:          # data parallel: the value travels with the gradient slice behind the cut
         loss_slot.copy_(loss)
     gjs = F_.disc_loss_cat_bwd(judges, B, _one(samples.device))
     if debug is not None:
         debug.update(fake=fake, judges=judges, disc_ctx=ctx, gjs=gjs)
-    G.melgan_backward(ctx, disc_params, None, gjs, _slots(disc_params), need_gx=False, need_wgrad=True, cut=cut)
+    G.melgan_backward(ctx, disc_params, None, gjs, _slots(disc_params), need_gx=False, need_wgrad=True, cut=cut,
+                      k5_image_bwd=k5b)
     return loss
 
 
@@ -69,7 +74,9 @@ def g_step(gen_params, disc_params, samples, features, scales=2, weight=10.0, cu
     main = torch.cuda.current_stream(dev)
     side = G.aux_stream(dev)
     fork_real = G._may_fork(dev)
-    k5 = G.pack_k5_image(samples.shape, disc_params)       # one weight image for both discriminator passes
+    # one pair of weight images for both discriminator passes and the backward, packed on the aux stream (where the
+    # real pass follows them) beside the generator forward
+    k5, k5b, k5ev = G.pack_k5_images_aside(samples.shape, disc_params, dev)
     if fork_real:
         side.wait_stream(main)
         with G.forked(side):
@@ -77,6 +84,8 @@ def g_step(gen_params, disc_params, samples, features, scales=2, weight=10.0, cu
     else:
         r_feats, r_judges, _ = G.melgan_forward(samples, disc_params, scales, k5_image=k5)
     fake, tape = G.gen_forward(features, gen_params, save=True)
+    if k5ev is not None:
+        main.wait_event(k5ev)
     f_feats, f_judges, ctx = G.melgan_forward(fake, disc_params, scales, k5_image=k5)
     if fork_real:
         main.wait_stream(side)
@@ -89,7 +98,7 @@ def g_step(gen_params, disc_params, samples, features, scales=2, weight=10.0, cu
     _, g_ff, g_fj = F_.gen_loss_bwd(S, fscale, rf, ff, f_judges, _one(dev), [False] * len(rf),
                                     [True] * len(ff), [True] * S)
     g_feats = [g_ff[Lyr * s:Lyr * s + Lyr] for s in range(S)]
-    gx, _ = G.melgan_backward(ctx, disc_params, g_feats, g_fj, None, need_gx=True, need_wgrad=False)
+    gx, _ = G.melgan_backward(ctx, disc_params, g_feats, g_fj, None, need_gx=True, need_wgrad=False, k5_image_bwd=k5b)
     if debug is not None:
         debug.update(fake=fake, gen_tape=tape, disc_ctx=ctx, r_feats=r_feats, f_feats=f_feats,
                      f_judges=f_judges, g_fake=gx)
