@@ -293,10 +293,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                     for (int pp = 0; pp < 3; ++pp)
                         dst[j][pp] = *reinterpret_cast<const bf16x8*>(Bs + ch * cs + (j * 32 + s * step) * XRS + pp * 32);
             };
-            if (DBG != 2 || ch == 0) fragb(0, fb[0]);
+            // (C = 32: one fragment buffer -- the twelve registers of the second one are what keeps three waves per SIMD, and
+            //  with three waves the other two cover the ds_read latency)
+            constexpr bool FB2 = C != 32;
+            if (FB2 && (DBG != 2 || ch == 0)) fragb(0, fb[0]);
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
-                if (s + 1 < 3 && (DBG != 2 || ch == 0)) fragb(s + 1, fb[(s + 1) & 1]);
+                if (FB2 && s + 1 < 3 && (DBG != 2 || ch == 0)) fragb(s + 1, fb[(s + 1) & 1]);
+                if (!FB2 && (DBG != 2 || (ch == 0 && s == 0))) fragb(s, fb[s & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (DBG == 5) continue;
 #pragma unroll
@@ -320,12 +324,36 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
     int tile = blockIdx.x;
     if (tile < ntiles) load_x(tile);
     load_a(0, 0, fa[0]);
+    // biases: once per workgroup into LDS behind the window (an epilogue then waits ~100 cycles for a ds_read, not for L2)
+    float* sbias = reinterpret_cast<float*>(smem_atom + NC * XCS);
+    if (!BWD) {
+        for (int i = tid; i < 2 * C; i += NT) sbias[i] = i < C ? b0[i] : b1[i - C];
+    }
+    // PRE: the per-tile dependent loads of the epilogues (the residual; backward: t for the derivative) are issued a GEMM
+    // ahead of their use where the registers allow (<= 64 channels): with 2-3 workgroups per CU every memory round trip a
+    // tile waits for is throughput lost
+    constexpr bool PRE = C <= 64;
     for (; tile < ntiles; tile += gridDim.x) {
         const int b = tile / p.tiles_per_row, c0 = (tile - b * p.tiles_per_row) * p.NO;
         const int base = 4 * (b * C * L + c0);                      // byte offset of (row b, channel 0, column c0)
         if (BWD) load_u(tile);
         int L4;                                                      // 4 L, opaque to the optimiser: the per-channel scalar offsets
         asm volatile("s_mov_b32 %0, %1" : "=s"(L4) : "s"(4 * L));    // are then formed where they are used (2 scalar ops), not hoisted
+        constexpr bool PRE_T = BWD && C == 64;          // (C = 32: measured slower with the derivative operand hoisted)
+        float tmp[PRE_T ? TM : 1][PRE_T ? TN : 1][16];
+        if (PRE_T) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int gc = c0 - h2 + (wn * TN + j) * 32 + l31;
+                    const unsigned o_m = (gc >= 0 && gc < L) ? (unsigned)o_lane[j] : OOB;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        tmp[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rsM, o_m, base + ((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0));
+                }
+        }
         store_x();                                                   // (waits for this tile's window)
         zero_acc();
         const int nxt = tile + gridDim.x;
@@ -352,7 +380,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                 // the tile's own columns of t are stored (forward training: the saved activation; backward: the raw gt)
                 const unsigned o_t = (MODE != 0 && DBG != 3 && inrow && col >= h2 && col < h2 + p.NO) ? (unsigned)o_lane[j] : OOB;
                 float tm[BWD ? 16 : 1];                              // backward: t itself, for the derivative
-                if (BWD) {
+                if (PRE_T) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tm[r] = tmp[i][j][r];
+                } else if (BWD) {
                     const unsigned o_m = inrow ? (unsigned)o_lane[j] : OOB;
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -364,7 +395,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                     const int chs = (wm * TM + i) * 32 + 8 * g, ch0 = chs + 4 * h;
                     float e[4];
                     if (!BWD) {
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(b0 + ch0);
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + ch0);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float v = acc[i][j][4 * g + q] + bv[q];
@@ -390,7 +421,19 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                     for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(dst + pp * 32) = o3[pp];
                 }
             }
+        float xrp[PRE ? TM : 1][PRE ? TN : 1][16];                  // the residual x values of this lane's outputs (L2-warm)
+        if (PRE) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        xrp[i][j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rsX, o_y[j], base + ((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0));
+        }
         zero_acc();
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                             // t tile complete
         gemm(1, TCS, h2, nxt < ntiles ? 1 : 2);                      // output column n reads t tile columns n, n + h2, n + 2 h2
 
@@ -399,16 +442,21 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const unsigned oy = DBG == 3 ? OOB : o_y[j];
-                float xr[16];                                        // the residual x values of this lane's outputs (L2-warm)
+                float xr[16];
+                if (PRE) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    xr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rsX, o_y[j], base + ((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0));
+                    for (int r = 0; r < 16; ++r) xr[r] = xrp[i][j][r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        xr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rsX, o_y[j], base + ((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0));
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int chs = (wm * TM + i) * 32 + 8 * g, ch0 = chs + 4 * h;
                     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                    if (!BWD) bv = *reinterpret_cast<const f32x4*>(b1 + ch0);
+                    if (!BWD) bv = *reinterpret_cast<const f32x4*>(sbias + C + ch0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float v = acc[i][j][4 * g + q] + bv[q];
@@ -430,7 +478,7 @@ int launch_atom_mode(AtomP p, const float* x, const void* image, const float* b0
     if (p.NO < 4) return MS_ERR_UNSUPPORTED;
     p.tiles_per_row = (p.L + p.NO - 1) / p.NO;
     p.NXA = NTP + 22;
-    const size_t lds = (size_t)(C / 16) * p.NXA * XRS;
+    const size_t lds = (size_t)(C / 16) * p.NXA * XRS + 2 * C * sizeof(float);       // window + both biases
     if (lds > 158 * 1024) return MS_ERR_UNSUPPORTED;
     const void* fn = reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, NW, MODE>);
     static int wgs_per_cu = 0, n_cu = 0;

@@ -100,9 +100,14 @@ class ResidualAtomFn(Function):
 
     @staticmethod
     def forward(ctx, x, w0, b0, w1, b1, dil):
-        out, rec = G.atom_forward(x, w0, b0, w1, b1, dil, save=True)
+        image = None
+        if x.is_cuda and G.atom_fused_ok(x.shape, w0, b0, b1, dil):      # one fused launch (csrc/atom_fused.hip)
+            image = P.atom_image(w0.shape[0], x.device)
+            P.atom_pack([(w0, w1, image)])
+        out, rec = G.atom_forward(x, w0, b0, w1, b1, dil, save=True, image=image)
         ctx.rec = rec
         ctx.w = (w0, w1)
+        ctx.dil = dil
         return out
 
     @staticmethod
@@ -110,8 +115,14 @@ class ResidualAtomFn(Function):
         g = _c(g)
         sink = G.GradSink(4)
         need_w = any(ctx.needs_input_grad[1:5])
-        gx = G.atom_backward(ctx.rec, ctx.w[0], ctx.w[1], g, sink, 0, need_wgrad=need_w,
-                             need_gx=ctx.needs_input_grad[0])
+        w0, w1 = ctx.w
+        image_bwd = None
+        if ctx.needs_input_grad[0] and G.atom_fused_ok(g.shape, w0, w0, w0, ctx.dil) and \
+                P.atom_bwd_supported(g.shape[0], g.shape[1], g.shape[2], ctx.dil):
+            image_bwd = P.atom_image(w0.shape[0], g.device)
+            P.atom_pack([(w0, w1, image_bwd)], backward=True)
+        gx = G.atom_backward(ctx.rec, w0, w1, g, sink, 0, need_wgrad=need_w,
+                             need_gx=ctx.needs_input_grad[0], image_bwd=image_bwd)
         return (gx,) + tuple(sink.t) + (None,)
 
 
