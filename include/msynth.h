@@ -214,6 +214,17 @@ int ms_convt1d_bwd_weight(const ms_convt1d_desc* d, const float* x, const float*
                           const float* y_act, float* gw, float* gb, float beta, void* workspace,
                           size_t workspace_bytes, ms_stream_t stream);
 size_t ms_convt1d_workspace_bytes(const ms_convt1d_desc* d, int which);
+/*
+ * The generator's four upsampling layers (generator/full.py:27-40: 512->256 and 256->128 with k16 / s8 / p4, 128->64 and
+ * 64->32 with k4 / s2 / p1) forward on pre-split weight images (csrc/convt_img.hip): same operation as ms_convt1d_fwd.
+ *   ms_convt1d_img_bytes   bytes of the image; 0 = geometry not taken (use ms_convt1d_fwd)
+ *   ms_convt1d_img_pack    w (Cin, Cout, K) -> image (caller-owned, 16-byte aligned); once per weight update
+ *   ms_convt1d_img_fwd     y = act(conv_transpose1d(x, w) + bias)
+ */
+size_t ms_convt1d_img_bytes(const ms_convt1d_desc* d);
+int ms_convt1d_img_pack(const ms_convt1d_desc* d, const float* w, void* image, ms_stream_t stream);
+int ms_convt1d_img_fwd(const ms_convt1d_desc* d, const float* x, const void* image, const float* bias, float* y,
+                       ms_stream_t stream);
 const char* ms_convt1d_kernel_name(const ms_convt1d_desc* d, int which);
 
 /*

@@ -276,12 +276,29 @@ def convt_desc(x_shape, w_shape, stride, pad, act=L.ACT_NONE, in_act=L.ACT_NONE)
 
 def convt1d_fwd(x, w, b, d, lout):
     L.require(x, "conv_transpose1d input"); L.require(w, "conv_transpose1d weight")
+    if convt_img_bytes(d):
+        return convt1d_img_fwd(x, w, b, d, lout)
     y = torch.empty((d.B, d.Cout, lout), dtype=torch.float32, device=x.device)
     lib = L.load()
     nws = lib.ms_convt1d_workspace_bytes(d, 0)
     ws = L.workspace(nws, x.device)
     L.call("ms_convt1d_fwd", _tcost(d, "bwd_data", 0), d, x.data_ptr(), w.data_ptr(), L.ptr(b),
            y.data_ptr(), L.ptr(ws), nws, L.stream())
+    return y
+
+
+def convt_img_bytes(d):
+    """Bytes of the weight image the transposed-conv image kernel wants (csrc/convt_img.hip); 0 = geometry not taken."""
+    return int(L.load().ms_convt1d_img_bytes(d))
+
+
+def convt1d_img_fwd(x, w, b, d, lout):
+    """ConvTranspose1d forward on a pre-split weight image (packed here: one small launch per call)."""
+    L.require(x, "conv_transpose1d input"); L.require(w, "conv_transpose1d weight")
+    img = torch.empty(convt_img_bytes(d), dtype=torch.uint8, device=x.device)
+    L.call("ms_convt1d_img_pack", _scost(w.numel(), 1, 0.75), d, w.data_ptr(), img.data_ptr(), L.stream())
+    y = torch.empty((d.B, d.Cout, lout), dtype=torch.float32, device=x.device)
+    L.call("ms_convt1d_img_fwd", _tcost(d, "bwd_data", 0), d, x.data_ptr(), img.data_ptr(), L.ptr(b), y.data_ptr(), L.stream())
     return y
 
 
