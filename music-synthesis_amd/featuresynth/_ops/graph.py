@@ -140,6 +140,32 @@ def pack_atom_images(x_shape, params, backward=False):
     return images
 
 
+def pack_atom_images_aside(x_shape, params, device, with_backward=False):
+    """pack_atom_images on a side stream of its own, beside what the caller issues next (the first conv and the first
+    transposed conv): -> (forward images, backward images or None, event to wait for before the first atom -- None when
+    the packs ran on the caller's stream).  with_backward: the backward pass of the same step multiplies by the same
+    weights, its images are packed here too (they are off the critical path for good)."""
+    # (a fork + join costs ~15 us of dependency latency inside a replayed graph: only where the pass is long enough to hide a
+    #  pack launch behind -- measured at B = 1: 275 us on one stream, 311 us forked)
+    if not _may_fork(device) or x_shape[0] * x_shape[2] < 256 or os.environ.get("MSYNTH_PACKASIDE", "1") == "0":
+        return pack_atom_images(x_shape, params), (pack_atom_images(x_shape, params, True) if with_backward else None), None
+    main = torch.cuda.current_stream(device)
+    key = (device.index, "pack")
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    side = _SIDE_STREAMS[key]
+    side.wait_stream(main)
+    with forked(side):
+        images = pack_atom_images(x_shape, params)
+        images_bwd = pack_atom_images(x_shape, params, True) if with_backward else None
+        ev = torch.cuda.Event()
+        ev.record(side)
+    for group in (images, images_bwd or {}):
+        for t in group.values():
+            t.record_stream(main)       # (allocated on the side stream, read on the caller's)
+    return images, images_bwd, ev
+
+
 def atom_backward(rec, w0, w1, g, sink, i, need_wgrad=True, need_gx=True, fork=None, batch=None, image_bwd=None):
     """g = d loss / d atom output; parameter grads go to sink slots i..i+3 (w0, b0, w1, b1).
     batch: list collecting the weight-grad jobs (slot, x, gy, y_act, desc, w_shape) instead of running them
@@ -201,7 +227,7 @@ def gen_forward(x, params, save):
                            (params[0].shape[1], tuple(x.shape)))
     i = 0
     tape = []
-    images = pack_atom_images(x.shape, params)
+    images, images_bwd, packed = pack_atom_images_aside(x.shape, params, x.device, with_backward=save)
     w, b = params[i], params[i + 1]; i += 2
     d, lo = P.conv_desc(x.shape, w.shape, pad=3, pad_mode=L.PAD_REFLECT, act=L.ACT_LRELU)
     h, _ = P.conv1d_fwd(x, w, b, d, lo)
@@ -212,6 +238,9 @@ def gen_forward(x, params, save):
         hin = h
         h = P.convt1d_fwd(hin, w, b, dt, lo)
         tape.append(("convT", dt, hin, h))
+        if packed is not None:
+            torch.cuda.current_stream(x.device).wait_event(packed)
+            packed = None
         for dil in DILATIONS:
             h, rec = atom_forward(h, params[i], params[i + 1], params[i + 2], params[i + 3], dil, save,
                                   image=images.get(i))
@@ -221,6 +250,8 @@ def gen_forward(x, params, save):
     d, lo = P.conv_desc(h.shape, w.shape, pad=3, act=L.ACT_TANH)
     y, _ = P.conv1d_fwd(h, w, b, d, lo)
     tape.append(("last", d, h, y))
+    if images_bwd is not None:
+        tape.append(("images_bwd", images_bwd))      # (gen_backward: no pack launch in front of the backward chain)
     return y, (tape if save else None)
 
 
@@ -243,9 +274,12 @@ def gen_backward(tape, params, gy, sink=None, need_gx=False, cut=None):
     batch = [] if os.environ.get("MSYNTH_WMULTI", "1") == "1" else None
     deferred = []
     conv0 = tape[0]
-    images_bwd = pack_atom_images(conv0[2].shape, params, backward=True)
+    stash = [rec for rec in tape if rec[0] == "images_bwd"]
+    images_bwd = stash[0][1] if stash else pack_atom_images(conv0[2].shape, params, backward=True)
     for rec in reversed(tape):
         kind = rec[0]
+        if kind == "images_bwd":
+            continue
         if kind != "atom" and batch:
             flush_wgrad_batch(batch, sink, fork)     # the stack's six weight gradients: one launch
         if kind == "last":

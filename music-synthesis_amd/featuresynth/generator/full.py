@@ -7,9 +7,11 @@ four [ConvTranspose1d + LeakyReLU + ResidualStack] stages (512->256 k16 s8 p4, 2
 128->64 k4 s2 p1, 64->32 k4 s2 p1); Conv1d(32, 1, 7, padding=3) + Tanh.  Pads and activations are
 fused into the convolution kernels, so their Sequential slots hold `Fused` placeholders.
 """
+import torch
 from torch import nn
 
 from .._ops import functional as F_
+from .._ops import graph as G_
 from ..util.modules import Fused, HipConv1d, HipConvTranspose1d, ResidualStack
 
 
@@ -41,6 +43,10 @@ class MelGanGenerator(nn.Module):
     def forward(self, x):
         # one autograd node for the whole stack; iterating self.main layer by layer (as the
         # reference's forward does, full.py:47-50) gives the same values through per-layer nodes
+        if not torch.is_grad_enabled():
+            # inference (evaluate.py:133, BASELINE config 2): nothing is saved for a backward pass -- the fused atoms run in
+            # their inference mode (no stores of the two intermediate activations)
+            return G_.gen_forward(x, list(self.parameters()), False)[0]
         return F_.GeneratorFn.apply(x, *self.parameters())
 
     def forward_layerwise(self, x):
