@@ -289,6 +289,29 @@ int ms_add_act(const float* a, const float* b, float* out, int64_t n, int32_t ac
                ms_stream_t stream);
 
 /*
+ * Line movement of the stage-1 generator's ConvTranspose2d layers (reference featuregenerator/upscale.py:85-99; the host
+ * side is util/modules.py:HipConvTranspose2d).  Activations are lines (B, H, C, W); output row sH*q + phase of the 2-D
+ * transposed conv is a 1-D transposed conv over the channels of the `taps` input rows q + dy[phase][tap]:
+ *   ms_lines_stack       out (phases, B*H, taps*C, W): out[ph][(b,q)][j*C + c][w] = x[b][q + dy[ph][j]][c][w], 0 outside
+ *   ms_lines_fold        gx (B, H, C, W) = its transpose applied to gstack (phases, B*H, taps*C, W); terms are summed
+ *                        phase-major, then by tap (deterministic)
+ *   ms_lines_interleave  inverse = 0: src (phases, rows, n) -> dst (rows, phases, n)  (phase outputs -> image row order)
+ *                        inverse = 1: src (rows, phases, n) -> dst (phases, rows, n)
+ * 16-byte aligned buffers, C*W and n multiples of 4.
+ */
+#define MS_LINES_MAX_PHASES 2
+#define MS_LINES_MAX_TAPS 3
+typedef struct ms_lines_desc {
+    int32_t B, H, C, W;
+    int32_t phases, taps;
+    int32_t dy[MS_LINES_MAX_PHASES * MS_LINES_MAX_TAPS];   /* dy[phase * MS_LINES_MAX_TAPS + tap] */
+} ms_lines_desc;
+int ms_lines_stack(const ms_lines_desc* d, const float* x, float* out, ms_stream_t stream);
+int ms_lines_fold(const ms_lines_desc* d, const float* gstack, float* gx, ms_stream_t stream);
+int ms_lines_interleave(const float* src, float* dst, int64_t rows, int32_t phases, int64_t n, int32_t inverse,
+                        ms_stream_t stream);
+
+/*
  * Losses (loss/loss.py).  Every *_fwd writes ONE float to `out` (device); every *_bwd reads
  * the upstream scalar gradient from the device pointer `gout` (so no host sync is needed) and
  * multiplies it by the host constant `scale`.

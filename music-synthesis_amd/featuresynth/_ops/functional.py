@@ -95,6 +95,68 @@ class ConvTranspose1dFn(Function):
         return gx, gw, (gb if ctx.has_bias else None), None, None, None
 
 
+class ConvTranspose2dLinesFn(Function):
+    """ConvTranspose2d of the stage-1 generator on lines (util/modules.py:HipConvTranspose2d; reference
+    featuregenerator/upscale.py:85-99): (B, H, Cin, W) -> (B, sH*H, Cout, 2W).  Output row sH*q + phase is a 1-D transposed
+    conv (k4, s2, p1) over the channels of the input rows q + dy; the rows are stacked by ONE stream kernel for all phases
+    (csrc/lines.hip), every phase is one transposed-conv launch writing its slab of a (phases, B*H, Cout, 2W) buffer, one
+    stream kernel puts the slabs into image row order.  Backward: split the gradient rows by phase, the transposed conv's
+    backward kernels per phase, one fold kernel sums the overlapping input rows.
+    phases: ((dy, ...), (ky, ...)) per output-row phase: input-row offsets and the kernel rows they go through."""
+
+    @staticmethod
+    def forward(ctx, xl, weight, bias, phases, act):
+        B, H, C, W = xl.shape
+        Cout = weight.shape[1]
+        nph = len(phases)
+        ld = P.lines_desc(xl.shape, [list(dy) for dy, _ in phases])
+        stack = P.lines_stack(xl, ld)                                              # (nph, B*H, nt*C, W)
+        ws = [torch.cat([weight[:, :, k, :] for k in ky], dim=0).contiguous() for _, ky in phases]    # (nt*C, Cout, 4): weights only
+        slabs = torch.empty((nph, B * H, Cout, 2 * W), dtype=torch.float32, device=xl.device)
+        descs = []
+        for ph in range(nph):
+            d, lo = P.convt_desc(stack[ph].shape, ws[ph].shape, 2, 1, act)
+            P.convt1d_fwd(stack[ph], ws[ph], bias, d, lo, out=slabs[ph])
+            descs.append(d)
+        if nph == 1:
+            y = slabs.reshape(B, H, Cout, 2 * W)
+        else:
+            y = P.lines_interleave(slabs, B * H, nph, Cout * 2 * W).reshape(B, nph * H, Cout, 2 * W)
+        ctx.ld, ctx.descs, ctx.phases = ld, descs, phases
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(stack, weight, slabs, *ws)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        stack, weight, slabs = ctx.saved_tensors[:3]
+        ws = ctx.saved_tensors[3:]
+        ld, descs, phases = ctx.ld, ctx.descs, ctx.phases
+        nph = len(phases)
+        C = ld.C
+        rows, n = ld.B * ld.H, slabs.shape[2] * slabs.shape[3]
+        gy = _c(gy)
+        gs = gy.reshape(slabs.shape) if nph == 1 else P.lines_interleave(gy, rows, nph, n, inverse=True).reshape(slabs.shape)
+        gx = gw = gb = None
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        if need_w:
+            gw = torch.zeros_like(weight)
+        gstack = torch.empty_like(stack) if ctx.needs_input_grad[0] else None
+        for ph, (_, ky) in enumerate(phases):
+            d = descs[ph]
+            ya = slabs[ph] if d.act != L.ACT_NONE else None
+            if need_w:
+                gwp, gbp = P.convt1d_bwd_weight(stack[ph], gs[ph], ya, d, ws[ph].shape)
+                for j, k in enumerate(ky):                      # (weights only: kernel row k of the 2-D weight)
+                    gw[:, :, k, :] += gwp[j * C:(j + 1) * C]
+                gb = gbp if gb is None else gb + gbp
+            if gstack is not None:
+                P.convt1d_bwd_data(gs[ph], ya, ws[ph], d, out=gstack[ph])
+        if gstack is not None:
+            gx = P.lines_fold(gstack, ld)
+        return gx, gw, (gb if ctx.has_bias else None), None, None
+
+
 class ResidualAtomFn(Function):
     """x + lrelu(conv_k3(lrelu(conv_k3_dilated(x))))   (util/modules.py:384-388)"""
 

@@ -76,6 +76,14 @@ class AtomPackDesc(ctypes.Structure):           # ms_atom_pack_desc
                 ("backward", _c_int * ATOM_PACK_MAX)]
 
 
+LINES_MAX_PHASES, LINES_MAX_TAPS = 2, 3
+
+
+class LinesDesc(ctypes.Structure):              # ms_lines_desc
+    _fields_ = [("B", _c_int), ("H", _c_int), ("C", _c_int), ("W", _c_int), ("phases", _c_int), ("taps", _c_int),
+                ("dy", _c_int * (LINES_MAX_PHASES * LINES_MAX_TAPS))]
+
+
 WN_MULTI_MAX = 64
 
 
@@ -132,6 +140,9 @@ SIGNATURES = {
     "ms_judge_loss_multi_bwd": (_c_int, [ctypes.POINTER(JudgeMultiDesc), _vp, _c_f, _vp]),
     "ms_weight_norm_multi_fwd": (_c_int, [ctypes.POINTER(WnMultiDesc), _vp]),
     "ms_weight_norm_multi_bwd": (_c_int, [ctypes.POINTER(WnMultiDesc), _c_f, _vp]),
+    "ms_lines_stack": (_c_int, [ctypes.POINTER(LinesDesc), _vp, _vp, _vp]),
+    "ms_lines_fold": (_c_int, [ctypes.POINTER(LinesDesc), _vp, _vp, _vp]),
+    "ms_lines_interleave": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_i64, _c_int, _vp]),
     "ms_act_bwd": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _c_f, _vp]),
     "ms_add": (_c_int, [_vp, _vp, _vp, _c_i64, _vp]),
     "ms_add_act": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _c_f, _vp]),

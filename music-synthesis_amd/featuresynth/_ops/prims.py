@@ -274,11 +274,11 @@ def convt_desc(x_shape, w_shape, stride, pad, act=L.ACT_NONE, in_act=L.ACT_NONE)
     return d, lout
 
 
-def convt1d_fwd(x, w, b, d, lout):
+def convt1d_fwd(x, w, b, d, lout, out=None):
     L.require(x, "conv_transpose1d input"); L.require(w, "conv_transpose1d weight")
     if convt_img_bytes(d):
-        return convt1d_img_fwd(x, w, b, d, lout)
-    y = torch.empty((d.B, d.Cout, lout), dtype=torch.float32, device=x.device)
+        return convt1d_img_fwd(x, w, b, d, lout, out=out)
+    y = _out(out, (d.B, d.Cout, lout), x.device, "conv_transpose1d output")
     lib = L.load()
     nws = lib.ms_convt1d_workspace_bytes(d, 0)
     ws = L.workspace(nws, x.device)
@@ -292,19 +292,19 @@ def convt_img_bytes(d):
     return int(L.load().ms_convt1d_img_bytes(d))
 
 
-def convt1d_img_fwd(x, w, b, d, lout):
+def convt1d_img_fwd(x, w, b, d, lout, out=None):
     """ConvTranspose1d forward on a pre-split weight image (packed here: one small launch per call)."""
     L.require(x, "conv_transpose1d input"); L.require(w, "conv_transpose1d weight")
     img = torch.empty(convt_img_bytes(d), dtype=torch.uint8, device=x.device)
     L.call("ms_convt1d_img_pack", _scost(w.numel(), 1, 0.75), d, w.data_ptr(), img.data_ptr(), L.stream())
-    y = torch.empty((d.B, d.Cout, lout), dtype=torch.float32, device=x.device)
+    y = _out(out, (d.B, d.Cout, lout), x.device, "conv_transpose1d output")
     L.call("ms_convt1d_img_fwd", _tcost(d, "bwd_data", 0), d, x.data_ptr(), img.data_ptr(), L.ptr(b), y.data_ptr(), L.stream())
     return y
 
 
-def convt1d_bwd_data(gy, y_act, w, d):
+def convt1d_bwd_data(gy, y_act, w, d, out=None):
     L.require(gy, "conv_transpose1d grad_output")
-    gx = torch.empty((d.B, d.Cin, d.Lin), dtype=torch.float32, device=gy.device)
+    gx = _out(out, (d.B, d.Cin, d.Lin), gy.device, "conv_transpose1d grad_input")
     lib = L.load()
     nws = lib.ms_convt1d_workspace_bytes(d, 1)
     ws = L.workspace(nws, gy.device)
@@ -468,6 +468,48 @@ def act_bwd(y_act, gy, act):
     L.call("ms_act_bwd", _scost(gy.numel(), 2, 1), y_act.data_ptr(), gy.data_ptr(), out.data_ptr(),
            gy.numel(), act, SLOPE, L.stream())
     return out
+
+
+def lines_desc(x_shape, phases):
+    """x_shape (B, H, C, W); phases: [[dy, ...], ...] -- the input-row offsets of every output-row phase (csrc/lines.hip)."""
+    B, H, C, W = x_shape
+    d = L.LinesDesc()
+    d.B, d.H, d.C, d.W = B, H, C, W
+    d.phases, d.taps = len(phases), len(phases[0])
+    if d.phases > L.LINES_MAX_PHASES or d.taps > L.LINES_MAX_TAPS or any(len(t) != d.taps for t in phases):
+        raise RuntimeError("lines: %d phases x %s taps not supported" % (len(phases), [len(t) for t in phases]))
+    for ph, taps in enumerate(phases):
+        for j, dy in enumerate(taps):
+            d.dy[ph * L.LINES_MAX_TAPS + j] = dy
+    return d
+
+
+def lines_stack(x, d):
+    """(B, H, C, W) lines -> (phases, B*H, taps*C, W): the channel-stacked input rows of every output-row phase, one pass."""
+    L.require(x, "lines_stack input")
+    out = torch.empty((d.phases, d.B * d.H, d.taps * d.C, d.W), dtype=torch.float32, device=x.device)
+    L.call("ms_lines_stack", _scost(x.numel(), 1, d.phases * d.taps, 0), d, x.data_ptr(), out.data_ptr(), L.stream())
+    return out
+
+
+def lines_fold(gstack, d):
+    """Transpose of lines_stack: (phases, B*H, taps*C, W) -> (B, H, C, W), overlapping rows summed."""
+    L.require(gstack, "lines_fold input")
+    gx = torch.empty((d.B, d.H, d.C, d.W), dtype=torch.float32, device=gstack.device)
+    L.call("ms_lines_fold", _scost(gx.numel(), d.phases * d.taps, 1, d.phases * d.taps), d, gstack.data_ptr(), gx.data_ptr(),
+           L.stream())
+    return gx
+
+
+def lines_interleave(src, rows, phases, n, inverse=False):
+    """(phases, rows, n) -> (rows, phases, n), or back with inverse (flat buffers; returns a flat tensor)."""
+    L.require(src, "lines_interleave input")
+    if src.numel() != rows * phases * n:
+        raise RuntimeError("lines_interleave: %d elements, expected %d x %d x %d" % (src.numel(), phases, rows, n))
+    dst = torch.empty(src.numel(), dtype=torch.float32, device=src.device)
+    L.call("ms_lines_interleave", _scost(src.numel(), 1, 1, 0), src.data_ptr(), dst.data_ptr(), rows, phases, n,
+           1 if inverse else 0, L.stream())
+    return dst
 
 
 def add(a, b):

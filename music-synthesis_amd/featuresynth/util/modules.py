@@ -150,19 +150,11 @@ class HipConvTranspose2d(nn.Module):
         return [(0, [(1, 0), (0, 1), (-1, 2)])]
 
     def forward_lines(self, xl):
-        """xl: (B, H, Cin, W) lines -> (B, sH*H, Cout, 2W) lines."""
-        B, H, C, W = xl.shape
+        """xl: (B, H, Cin, W) lines -> (B, sH*H, Cout, 2W) lines.  Kernels only: the row stacking, the phase interleave and
+        their backward are stream kernels (csrc/lines.hip) inside one autograd node."""
         act = {None: L.ACT_NONE, "lrelu": L.ACT_LRELU, "tanh": L.ACT_TANH}[self.activation]
-        xp = torch.nn.functional.pad(xl, (0, 0, 0, 0, 1, 1))          # one zero line above and below
-        outs = []
-        for _, taps in self._phases():
-            lines = torch.cat([xp[:, 1 + dy:1 + dy + H] for dy, _ in taps], dim=2).reshape(B * H, len(taps) * C, W)
-            w = torch.cat([self.weight[:, :, ky, :] for _, ky in taps], dim=0).contiguous()
-            y = F_.ConvTranspose1dFn.apply(lines.contiguous(), w, self.bias, 2, 1, act)
-            outs.append(y.reshape(B, H, 1, self.out_channels, 2 * W))
-        if len(outs) == 1:
-            return outs[0].reshape(B, H, self.out_channels, 2 * W)
-        return torch.cat(outs, dim=2).reshape(B, 2 * H, self.out_channels, 2 * W)
+        phases = tuple((tuple(dy for dy, _ in taps), tuple(ky for _, ky in taps)) for _, taps in self._phases())
+        return F_.ConvTranspose2dLinesFn.apply(xl, self.weight, self.bias, phases, act)
 
     def forward(self, x):
         """x: (B, Cin, H, W) as nn.ConvTranspose2d."""
