@@ -239,8 +239,101 @@ def test_realmelgan_train_steps_golden(golden):
         for k, p in net.named_parameters():
             e = rel_l2(strided_sample(host(p.grad)), z["step/%sgrad_smp/%s" % (kind, k)])
             worst = max(worst, e)
-            assert e < 1e-2, (kind, k, e)      # deep LeakyReLU-mask flips, see oracle test
+            assert e < 1e-2, (kind, k, e)      # deep LeakyReLU-mask flips (the tight gate: the flip-aware test below)
         print("RealMelGan %s-step worst grad rel-L2 %.2e" % (kind, worst))
+
+
+def _hooked(net, classes):
+    """Forward hooks on every submodule of the given classes: {module name: [outputs, one per call]}."""
+    outs, handles = {}, []
+    for name, m in net.named_modules():
+        if isinstance(m, classes):
+            handles.append(m.register_forward_hook(
+                lambda mod, inp, out, name=name: outs.setdefault(name, []).append(out.detach() if not out.requires_grad else out)))
+    return outs, handles
+
+
+def test_realmelgan_train_steps_vs_flip_aware_oracle():
+    """The D-step and the G-step of the weight-normed variant against the float64 restatement (oracle/torch_graph_real.py)
+    with every LeakyReLU branch taken from the DEVICE's activations (forward hooks on the product modules): what is left
+    is the kernels' rounding, so every parameter gradient is held to 1e-4 rel-L2 (median 1e-5; the headline model's gate in
+    test_gpu_networks.py::test_train_steps_vs_oracle is 1e-3 / 1e-4); the fp32 reference fixtures above can only be met to
+    1e-2 because rounding-level pre-activations take the other branch there."""
+    from featuresynth import loss as LS
+    from featuresynth._synthetic import synthetic_features, synthetic_samples
+    from featuresynth.experiment import realmelgan as R
+    from featuresynth.train import DiscriminatorTrainer, GeneratorTrainer
+    from featuresynth.util.modules import Fused
+    from oracle import torch_graph_real as RG
+    B, T = 2, 8
+    samples, feats = synthetic_samples(B, T * 256, rank=3), synthetic_features(B, 128, T, rank=3)
+    s64, f64 = torch.from_numpy(samples).double(), torch.from_numpy(feats).double()
+    for kind in ("d", "g"):
+        g, d, gsd, dsd = _nets()
+        go = torch.optim.Adam(g.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        do = torch.optim.Adam(d.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        g_outs, h1 = _hooked(g, (R.WNConv1d, R.WNConvTranspose1d, R.ResnetBlock))
+        d_outs, h2 = _hooked(d, (torch.nn.Sequential,))
+        if kind == "d":
+            r = DiscriminatorTrainer(g, go, d, do, LS.mel_gan_disc_loss).train(dev(samples), dev(feats))
+            loss_dev, net = r["d_loss"], d
+        else:
+            r = GeneratorTrainer(g, go, d, do, R.mel_gan_gen_loss).train(dev(samples), dev(feats))
+            loss_dev, net = r["g_loss"], g
+        for h in h1 + h2:
+            h.remove()
+
+        def d_masks(rows):
+            m = {}
+            for name, calls in d_outs.items():
+                if ".layer_" not in name:
+                    continue
+                live = [o for o in calls if o.requires_grad]        # (the G-step's real pass runs under no_grad)
+                assert len(live) == 1, (name, len(calls))
+                m[name] = (live[0].detach()[rows] > 0).cpu()
+            assert len(m) == 18
+            return m
+
+        gp = RG.to_params(gsd, requires_grad=kind == "g", dtype=torch.float64)
+        dp = RG.to_params(dsd, requires_grad=kind == "d", dtype=torch.float64)
+        if kind == "d":
+            with torch.no_grad():
+                fake = RG.generator(gp, f64)
+            _, fj = RG.discriminator(dp, fake, masks=d_masks(slice(0, B)))
+            _, rj = RG.discriminator(dp, s64, masks=d_masks(slice(B, 2 * B)))
+            loss = RG.disc_loss(rj, fj)
+            params = dp
+        else:
+            gm, prev = {}, None
+            for idx, m in g.model.named_children():
+                name = "model." + idx
+                if isinstance(m, Fused):
+                    continue
+                if prev is not None:
+                    gm["pre." + name] = (g_outs[prev][-1].detach() > 0).cpu()
+                if isinstance(m, R.ResnetBlock):
+                    gm["mid." + name] = (g_outs[name + ".block.2"][-1].detach() > 0).cpu()
+                prev = name
+            assert len(gm) == 4 + 12 + 12 + 1
+            fake = RG.generator(gp, f64, masks=gm)
+            ff, fj = RG.discriminator(dp, fake, masks=d_masks(slice(0, B)))
+            with torch.no_grad():
+                rf, rj = RG.discriminator(dp, s64)
+            loss = RG.gen_loss(rf, ff, fj)
+            params = gp
+            assert rel_l2(r["fake"], fake.detach().numpy()) < 1e-5
+        loss.backward()
+        loss = float(loss.detach())
+        assert abs(loss_dev - loss) <= 1e-5 * max(1.0, abs(loss)), (kind, loss_dev, loss)
+        errs = {}
+        for k, p in net.named_parameters():
+            ref = params[k].grad.numpy()
+            errs[k] = rel_l2(host(p.grad), ref) if np.linalg.norm(ref) > 1e-12 else float(np.abs(host(p.grad)).max())
+        worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+        med = float(np.median(list(errs.values())))
+        print("RealMelGan %s-step vs flip-aware float64 oracle: worst %s, median %.2e" % (kind, worst, med))
+        assert worst[0][1] < 1e-4, (kind, worst)      # measured: 4.6e-6 (D-step), 8.2e-7 (G-step)
+        assert med < 1e-5, (kind, worst, med)
 
 
 def test_realmelgan_native_graph_path(monkeypatch):
