@@ -225,6 +225,20 @@ size_t ms_convt1d_img_bytes(const ms_convt1d_desc* d);
 int ms_convt1d_img_pack(const ms_convt1d_desc* d, const float* w, void* image, ms_stream_t stream);
 int ms_convt1d_img_fwd(const ms_convt1d_desc* d, const float* x, const void* image, const float* bias, float* y,
                        ms_stream_t stream);
+/*
+ * Transposed-conv BACKWARD DATA on pre-split weight images (csrc/convt_bwd_img.hip): same operation as ms_convt1d_bwd_data for
+ * kernel 2S / stride S / padding S/2 (S = 2, 8) on rows of 4 .. 256 input positions (a power of two) -- the generator's two
+ * stride-8 layers (generator/full.py:27-32) and the stage-1 generator's line convolutions (featuregenerator/upscale.py:85-97).
+ *   ms_convt1d_bwd_img_bytes            bytes of the image; 0 = geometry not taken (use ms_convt1d_bwd_data)
+ *   ms_convt1d_bwd_img_workspace_bytes  split-K slabs (16-byte aligned workspace)
+ *   ms_convt1d_bwd_img_pack             w (Cin, Cout, K) -> image (caller-owned, 16-byte aligned); once per weight update
+ *   ms_convt1d_bwd_img_data             gx = conv(gy * act'(y_act), w) with the mirrored geometry
+ */
+size_t ms_convt1d_bwd_img_bytes(const ms_convt1d_desc* d);
+size_t ms_convt1d_bwd_img_workspace_bytes(const ms_convt1d_desc* d);
+int ms_convt1d_bwd_img_pack(const ms_convt1d_desc* d, const float* w, void* image, ms_stream_t stream);
+int ms_convt1d_bwd_img_data(const ms_convt1d_desc* d, const float* gy, const float* y_act, const void* image, float* gx,
+                            void* workspace, size_t workspace_bytes, ms_stream_t stream);
 const char* ms_convt1d_kernel_name(const ms_convt1d_desc* d, int which);
 
 /*

@@ -128,6 +128,10 @@ SIGNATURES = {
     "ms_convt1d_img_bytes": (_sz, [ctypes.POINTER(ConvTDesc)]),
     "ms_convt1d_img_pack": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp]),
     "ms_convt1d_img_fwd": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp, _vp, _vp]),
+    "ms_convt1d_bwd_img_bytes": (_sz, [ctypes.POINTER(ConvTDesc)]),
+    "ms_convt1d_bwd_img_workspace_bytes": (_sz, [ctypes.POINTER(ConvTDesc)]),
+    "ms_convt1d_bwd_img_pack": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp]),
+    "ms_convt1d_bwd_img_data": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ms_avg_pool1d_4_2_2_fwd": (_c_int, [_vp, _vp, _c_i64, _c_int, _vp]),
     "ms_avg_pool1d_4_2_2_bwd": (_c_int, [_vp, _vp, _vp, _c_i64, _c_int, _vp]),
     "ms_avg_pool1d_4_2_1_fwd": (_c_int, [_vp, _vp, _c_i64, _c_int, _vp]),

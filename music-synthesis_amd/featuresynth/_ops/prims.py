@@ -302,10 +302,25 @@ def convt1d_img_fwd(x, w, b, d, lout, out=None):
     return y
 
 
+def convt_bwd_img_bytes(d):
+    """Bytes of the weight image the transposed-conv backward-data image kernel wants (csrc/convt_bwd_img.hip); 0 = not taken."""
+    return int(L.load().ms_convt1d_bwd_img_bytes(d))
+
+
 def convt1d_bwd_data(gy, y_act, w, d, out=None):
     L.require(gy, "conv_transpose1d grad_output")
     gx = _out(out, (d.B, d.Cin, d.Lin), gy.device, "conv_transpose1d grad_input")
     lib = L.load()
+    nimg = convt_bwd_img_bytes(d)
+    if nimg:
+        L.require(w, "conv_transpose1d weight")
+        img = torch.empty(nimg, dtype=torch.uint8, device=gy.device)
+        L.call("ms_convt1d_bwd_img_pack", _scost(w.numel(), 1, 1.5, 0), d, w.data_ptr(), img.data_ptr(), L.stream())
+        nws = lib.ms_convt1d_bwd_img_workspace_bytes(d)
+        ws = L.workspace(nws, gy.device)
+        L.call("ms_convt1d_bwd_img_data", _tcost(d, "fwd", 1, extra_reads=int(y_act is not None)),
+               d, gy.data_ptr(), L.ptr(y_act), img.data_ptr(), gx.data_ptr(), L.ptr(ws), nws, L.stream())
+        return gx
     nws = lib.ms_convt1d_workspace_bytes(d, 1)
     ws = L.workspace(nws, gy.device)
     L.call("ms_convt1d_bwd_data", _tcost(d, "fwd", 1, extra_reads=int(y_act is not None)),

@@ -174,6 +174,83 @@ def g_step_launches(B, mels=80, T=32):
     return out
 
 
+# ---- stage 1 (SURVEY.md 8(f) row 2 / BASELINE configs[4]): featuregenerator/upscale.py:85-99, featurediscriminator/upscale.py:7-27
+S1_G = ((1024, 512, 4, 2), (512, 256, 4, 2), (256, 128, 4, 2), (128, 128, 4, 2), (128, 64, 4, 2), (64, 32, 3, 1),
+        (32, 1, 3, 1))          # (Cin, Cout, kH, sH) of the ConvTranspose2d stack; kW = 4, sW = 2, padding (1, 1); from 4 x 4
+S1_D_DIL = (1, 3, 9, 27, 81, 1, 1)
+S1_NPARAM_G, S1_NPARAM_D = 13542881, 1278209
+
+
+def convt2d_cost(B, Cin, H, W, Cout, kH, sH, which, act_read=True):
+    """ConvTranspose2d k(kH, 4) s(sH, 2) p(1, 1): every output pixel meets (kH / sH) x 2 taps of every input channel."""
+    nin, nout, nw = B * Cin * H * W, B * Cout * (H * sH) * (2 * W), Cin * Cout * kH * 4 + Cout
+    macs = B * H * W * Cin * Cout * kH * 4
+    if which == "fwd":
+        elems = nin + nout + nw
+    elif which == "bwd_data":
+        elems = nout + (nout if act_read else 0) + nin + nw
+    else:
+        elems = nin + nout + (nout if act_read else 0) + nw
+    return {"flops": 2 * macs, "bytes": F32 * elems}
+
+
+def stage1_generator_launches(B, mode, noise_dim=128):
+    """mode: 'fwd' | 'bwd' (weight gradients of every layer, data gradients down to the Linear's output)."""
+    out = []
+    lin = {"flops": 2 * B * noise_dim * 16384, "bytes": F32 * (B * noise_dim + B * 16384 + noise_dim * 16384 + 16384)}
+    H = W = 4
+    geo = []
+    for cin, cout, kh, sh in S1_G:
+        geo.append((cin, H, W, cout, kh, sh))
+        H, W = H * sh, 2 * W
+    if mode == "fwd":
+        out.append(("s1g.linear.fwd", lin))
+        for i, (cin, h, w, cout, kh, sh) in enumerate(geo):
+            out.append(("s1g.convT2d%d.fwd" % i, convt2d_cost(B, cin, h, w, cout, kh, sh, "fwd")))
+    else:
+        for i, (cin, h, w, cout, kh, sh) in reversed(list(enumerate(geo))):
+            last = i == len(geo) - 1                     # no activation behind the last layer
+            out.append(("s1g.convT2d%d.bwd_weight" % i, convt2d_cost(B, cin, h, w, cout, kh, sh, "bwd_weight", not last)))
+            out.append(("s1g.convT2d%d.bwd_data" % i, convt2d_cost(B, cin, h, w, cout, kh, sh, "bwd_data", not last)))
+        out.append(("s1g.linear.bwd_weight", lin))
+    return out
+
+
+def stage1_discriminator_launches(B, mode, T=512, feat=128, ch=256):
+    """mode: 'fwd' | 'bwd_data' | 'bwd_weight'.  Residual layers read the skip once more (act(z + x))."""
+    out = []
+    for i, d in enumerate(S1_D_DIL):
+        cin = feat if i == 0 else ch
+        c = dict(B=B, Cin=cin, Lin=T, Cout=ch, K=3, stride=1, pad=d, dil=d, groups=1)
+        if mode == "fwd":
+            out.append(("s1d.conv%d.fwd" % i, conv_cost(which="fwd", extra_reads=int(i > 0), **c)))
+        elif mode == "bwd_weight":
+            out.append(("s1d.conv%d.bwd_weight" % i, conv_cost(which="bwd_weight", act_read=True, **c)))
+        else:
+            out.append(("s1d.conv%d.bwd_data" % i, conv_cost(which="bwd_data", act_read=True, extra_reads=int(i > 0), **c)))
+    j = dict(B=B, Cin=ch, Lin=T, Cout=1, K=1, stride=1, pad=0, dil=1, groups=1)
+    out.append(("s1d.judge.%s" % mode, conv_cost(which=mode, **j)))
+    return out
+
+
+def stage1_d_step_launches(B):
+    out = stage1_generator_launches(B, "fwd")
+    out += stage1_discriminator_launches(2 * B, "fwd")                  # one pass over [fake; real]
+    out += stage1_discriminator_launches(2 * B, "bwd_weight")
+    out += [l for l in stage1_discriminator_launches(2 * B, "bwd_data") if not l[0].startswith("s1d.conv0.")]
+    out.append(("adam.s1D", {"flops": 12 * S1_NPARAM_D, "bytes": 7 * F32 * S1_NPARAM_D}))
+    return out
+
+
+def stage1_g_step_launches(B):
+    out = stage1_generator_launches(B, "fwd")
+    out += stage1_discriminator_launches(B, "fwd")                      # least-squares generator loss: the fake pass only
+    out += stage1_discriminator_launches(B, "bwd_data")
+    out += stage1_generator_launches(B, "bwd")
+    out.append(("adam.s1G", {"flops": 12 * S1_NPARAM_G, "bytes": 7 * F32 * S1_NPARAM_G}))
+    return out
+
+
 def totals(launches):
     return {"flops": sum(c["flops"] for _, c in launches), "bytes": sum(c["bytes"] for _, c in launches)}
 
