@@ -22,6 +22,21 @@ if op == "atom":      # fused residual atom, training forward + backward data: a
         y, rec = G.atom_forward(x, w0, b0, w1, b1, dil, True, image=img)
         if P.atom_bwd_supported(B, C, Lg, dil): P.atom_bwd_data(g, rec[4], rec[3], imgb, dil)
     torch.cuda.synchronize(); sys.exit(0)
+if op == "k5img":     # the k5 layer on weight images (conv5_img.hip), forward + backward data: k5img B C L
+    B, C, Lg = map(int, sys.argv[2:5])
+    x = torch.randn(B, C, Lg, device="cuda"); w = torch.randn(C, C, 5, device="cuda") * 0.02; b = torch.randn(C, device="cuda")
+    d, lo = P.conv_desc(x.shape, w.shape, pad=2, act=1)
+    img, imgb = P.conv_img_pack(d, w), P.conv_img_pack(d, w, backward=True)
+    y = P.conv1d_img_fwd(x, img, b, d, lo); gy = torch.randn_like(y)
+    for _ in range(5):
+        P.conv1d_img_fwd(x, img, b, d, lo); P.conv1d_img_bwd_data(gy, y, imgb, d)
+    torch.cuda.synchronize(); sys.exit(0)
+if op == "ctbwd":     # transposed-conv backward data on weight images (convt_bwd_img.hip): ctbwd B Cin Lin Cout S
+    B, Cin, Lin, Cout, S = map(int, sys.argv[2:7])
+    w = torch.randn(Cin, Cout, 2 * S, device="cuda") * 0.05; gy = torch.randn(B, Cout, Lin * S, device="cuda"); y = torch.randn_like(gy)
+    d, _ = P.convt_desc((B, Cin, Lin), w.shape, S, S // 2, act=1)
+    for _ in range(5): P.convt1d_bwd_data(gy, y, w, d)
+    torch.cuda.synchronize(); sys.exit(0)
 if op == "dfwd":      # dense forward: dfwd B C L K dil
     B, C, Lg, K, dil = map(int, sys.argv[2:7])
     x = torch.randn(B, C, Lg, device="cuda"); w = torch.randn(C, C, K, device="cuda") * 0.02; b = torch.randn(C, device="cuda")
