@@ -395,6 +395,7 @@ const char* ms_convt1d_kernel_name(const ms_convt1d_desc* d, int which) {
     }
     if (which == 2) {
         if (mswt8_applicable(p)) return mswt8_name(p);
+        if (mswt2s_applicable(p)) return mswt2s_name(p);
         if (msm_convt_bwd_applicable(p)) return msm_convt_bwd_weight_name(p);
         return msm_bwd_weight_applicable(p) ? msm_bwd_weight_name(p) : msk_conv1d_bwd_weight_direct_name(p);
     }
@@ -451,6 +452,8 @@ int ms_convt1d_bwd_weight(const ms_convt1d_desc* d, const float* x, const float*
         rc = mst_convt1_bwd_weight(p, x, gy, y_act, gw, beta, workspace, workspace_bytes, s);
     else if (mswt8_applicable(p) && workspace && workspace_bytes >= mswt8_ws(p) + msk_channel_sum_ws(p.Cin) + 32)
         rc = mswt8_bwd_weight(p, x, gy, y_act, gw, beta, workspace, workspace_bytes, s);
+    else if (mswt2s_applicable(p) && workspace && workspace_bytes >= mswt2s_ws(p) + msk_channel_sum_ws(p.Cin) + 32)
+        rc = mswt2s_bwd_weight(p, x, gy, y_act, gw, beta, workspace, workspace_bytes, s);
     if (rc != MS_ERR_UNSUPPORTED) {
     } else if (msm_convt_bwd_applicable(p))
         rc = msm_convt1d_bwd_weight(p, x, gy, y_act, gw, beta, workspace, workspace_bytes, s);
@@ -488,6 +491,7 @@ size_t ms_convt1d_workspace_bytes(const ms_convt1d_desc* d, int which) {
         const size_t tail = msk_channel_sum_ws(p.Cin) + 32;   // bias-grad slice partials
         size_t t8 = mswt8_applicable(p) ? mswt8_ws(p) : 0;
         if (mst_convt1_applicable(p) && mst_convt1_wgrad_ws(p) > t8) t8 = mst_convt1_wgrad_ws(p);
+        if (mswt2s_applicable(p) && mswt2s_ws(p) > t8) t8 = mswt2s_ws(p);
         size_t n = msm_convt_bwd_applicable(p) ? msm_convt_bwd_weight_ws(p)
                    : (msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p));
         if (t8 > n) n = t8;

@@ -57,6 +57,14 @@ const char* mswt8_name(const ConvP& p);
 int mswt8_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act, float* gw, float beta,
                      void* ws, size_t ws_bytes, hipStream_t s);
 
+// split-bf16 weight gradient of the stride-2 / kernel-4 transposed conv on rows of 4 .. 32 positions (wgrad_convt2s.hip);
+// MSYNTH_WGRADT2S=0 disables
+bool mswt2s_applicable(const ConvP& p);
+size_t mswt2s_ws(const ConvP& p);
+const char* mswt2s_name(const ConvP& p);
+int mswt2s_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act, float* gw, float beta,
+                      void* ws, size_t ws_bytes, hipStream_t s);
+
 // row-tile weight gradient (wgrad_rows.hip)
 bool msw_bwd_weight_applicable(const ConvP& p);
 size_t msw_bwd_weight_ws(const ConvP& p);
