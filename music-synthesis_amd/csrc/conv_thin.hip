@@ -567,6 +567,75 @@ __global__ __launch_bounds__(256) void k_convt1_wgrad(int B, int C, int L, int a
     }
 }
 
+// The same with 16-byte loads (L % 4 == 0): a thread owns FOUR consecutive positions q .. q + 3 of a line (one float4 of x per
+// channel, gradient samples 2 q - 1 .. 2 q + 8), a workgroup walks its lines 256 / (L / 4) at a time -- four times the bytes in
+// flight per wave of the dword form above, which ran at 1.2 TB/s (341 us for the stage-1 generator's last layer: 403 MB).
+template <bool INA>
+__global__ __launch_bounds__(256) void k_convt1_wgrad_v4(int B, int C, int L, int act, float slope, int lines_per_wg,
+                                                        const float* __restrict__ x, const float* __restrict__ gy,
+                                                        const float* __restrict__ y_act, float* __restrict__ partial) {
+    constexpr int CG = 8;
+    __shared__ float wsum[4][CG * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b_beg = blockIdx.x * lines_per_wg, b_end = min(B, b_beg + lines_per_wg);
+    const int kind = y_act ? act : MS_ACT_NONE;
+    const int L4 = L / 4;                               // vectors per line
+    const int lines_par = 256 / L4 > 0 ? 256 / L4 : 1;  // lines a pass of the workgroup covers (L4 <= 256)
+    const int my_line = tid / L4, my_v = tid - my_line * L4;
+    const bool active = my_line < lines_par;
+    for (int cg = 0; cg < C; cg += CG) {
+        float acc[CG][4];
+#pragma unroll
+        for (int c = 0; c < CG; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[c][k] = 0.f;
+        for (int b0 = b_beg; b0 < b_end; b0 += lines_par) {
+            const int b = b0 + my_line;
+            if (!active || b >= b_end) continue;
+            const int q = 4 * my_v;
+            const float* gr = gy + (size_t)b * 2 * L + 2 * q;
+            const float* ar = y_act ? y_act + (size_t)b * 2 * L + 2 * q : gr;
+            float g[10];                                // gp[2q - 1 .. 2q + 8]
+            const float4 g0 = *reinterpret_cast<const float4*>(gr), g1 = *reinterpret_cast<const float4*>(gr + 4);
+            const float4 a0 = *reinterpret_cast<const float4*>(ar), a1 = *reinterpret_cast<const float4*>(ar + 4);
+            g[1] = ms_act_grad(g0.x, a0.x, kind, slope); g[2] = ms_act_grad(g0.y, a0.y, kind, slope);
+            g[3] = ms_act_grad(g0.z, a0.z, kind, slope); g[4] = ms_act_grad(g0.w, a0.w, kind, slope);
+            g[5] = ms_act_grad(g1.x, a1.x, kind, slope); g[6] = ms_act_grad(g1.y, a1.y, kind, slope);
+            g[7] = ms_act_grad(g1.z, a1.z, kind, slope); g[8] = ms_act_grad(g1.w, a1.w, kind, slope);
+            g[0] = q > 0 ? ms_act_grad(gr[-1], ar[-1], kind, slope) : 0.f;
+            g[9] = q + 4 < L ? ms_act_grad(gr[8], ar[8], kind, slope) : 0.f;
+            float4 xv[CG];
+#pragma unroll
+            for (int c = 0; c < CG; ++c)
+                xv[c] = cg + c < C ? *reinterpret_cast<const float4*>(x + ((size_t)b * C + cg + c) * L + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                float v[4] = {xv[c].x, xv[c].y, xv[c].z, xv[c].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (INA) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[c][k] = fmaf(v[j], g[2 * j + k], acc[c][k]);      // sample 2 (q + j) + k - 1
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CG; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float r = acc[c][k];
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) r += __shfl_xor(r, o, 64);
+                if (lane == 0) wsum[wv][c * 4 + k] = r;
+            }
+        __syncthreads();
+        if (tid < CG * 4 && cg + tid / 4 < C)
+            partial[(size_t)blockIdx.x * C * 4 + (size_t)cg * 4 + tid] =
+                (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
+        __syncthreads();
+    }
+}
+
 bool convt1_geom(const ConvP& p) {
     return p.Cin == 1 && p.groups == 1 && p.stride == 2 && p.K == 4 && p.pad == 1 && p.dil == 1 &&
            p.Lin == 2 * p.Lout && p.Cout >= 1 && p.Cout <= 512 && (long long)p.B * ((p.Lout + 3) / 4) < (1ll << 31);
@@ -601,7 +670,11 @@ int mst_convt1_bwd_weight(const ConvP& p, const float* x, const float* gy, const
     if (!ws || ws_bytes < mst_convt1_wgrad_ws(p)) return MS_ERR_WORKSPACE;
     const int lpw = convt1_lines_per_wg(p), nwg = ms_ceil_div(p.B, lpw);
     float* partial = (float*)ws;
-    if (p.in_act) hipLaunchKernelGGL((k_convt1_wgrad<true>), dim3(nwg), dim3(256), 0, s, p.B, p.Cout, p.Lout, p.act, p.slope, lpw, x, gy, y_act, partial);
+    const bool v4 = p.Lout % 4 == 0 && p.Lout / 4 <= 256 &&
+                    ((((uintptr_t)x) | ((uintptr_t)gy) | ((uintptr_t)(y_act ? y_act : gy))) & 15) == 0;
+    if (v4 && p.in_act) hipLaunchKernelGGL((k_convt1_wgrad_v4<true>), dim3(nwg), dim3(256), 0, s, p.B, p.Cout, p.Lout, p.act, p.slope, lpw, x, gy, y_act, partial);
+    else if (v4) hipLaunchKernelGGL((k_convt1_wgrad_v4<false>), dim3(nwg), dim3(256), 0, s, p.B, p.Cout, p.Lout, p.act, p.slope, lpw, x, gy, y_act, partial);
+    else if (p.in_act) hipLaunchKernelGGL((k_convt1_wgrad<true>), dim3(nwg), dim3(256), 0, s, p.B, p.Cout, p.Lout, p.act, p.slope, lpw, x, gy, y_act, partial);
     else hipLaunchKernelGGL((k_convt1_wgrad<false>), dim3(nwg), dim3(256), 0, s, p.B, p.Cout, p.Lout, p.act, p.slope, lpw, x, gy, y_act, partial);
     MS_CHECK_LAUNCH();
     return msk_reduce_partials(partial, (size_t)p.Cout * 4, nwg, (size_t)p.Cout * 4, 0, gw, nullptr, beta, s);
