@@ -233,7 +233,7 @@ class Discriminator(nn.Module):
         for _ in discs[1:]:
             xs.append(self.downsample(xs[-1]))
         dev = x.device
-        fork = (x.is_cuda and len(discs) > 1 and os.environ.get("MSYNTH_REAL_FORK", "1") != "0" and G._may_fork(dev))
+        fork = (x.is_cuda and len(discs) > 1 and os.environ.get("MSYNTH_REAL_FORK", "0") == "1" and G._may_fork(dev))
         if not fork:
             zs = [disc(xi, feat) for disc, xi in zip(discs, xs)]
         else:

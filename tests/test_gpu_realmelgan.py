@@ -506,7 +506,12 @@ def test_realmelgan_forked_replay_gradients_bitwise(monkeypatch):
         return out
 
     ref = run("0", "0")
-    for graph, fork in (("0", "1"), ("1", "1")):
+    # forked + replayed is opt-in (MSYNTH_TEST_FORK_GRAPH=1): it reproduced the reference bitwise in every run of this test,
+    # and the process died ONCE in hipGraphLaunch (torch/cuda/graphs.py replay) in seven full-suite runs of r03 -- a product
+    # default must not do that, so the forked variant is off unless MSYNTH_REAL_FORK=1 and CI replays the unforked graph
+    import os
+    modes = [("0", "1"), ("1", "0")] + ([("1", "1")] if os.environ.get("MSYNTH_TEST_FORK_GRAPH") == "1" else [])
+    for graph, fork in modes:
         got = run(graph, fork)
         for i in range(6):
             assert got[i][0] == ref[i][0], (graph, fork, i, got[i][0], ref[i][0])
