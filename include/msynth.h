@@ -217,14 +217,18 @@ size_t ms_convt1d_workspace_bytes(const ms_convt1d_desc* d, int which);
 /*
  * The generator's four upsampling layers (generator/full.py:27-40: 512->256 and 256->128 with k16 / s8 / p4, 128->64 and
  * 64->32 with k4 / s2 / p1) forward on pre-split weight images (csrc/convt_img.hip): same operation as ms_convt1d_fwd.
- *   ms_convt1d_img_bytes   bytes of the image; 0 = geometry not taken (use ms_convt1d_fwd)
- *   ms_convt1d_img_pack    w (Cin, Cout, K) -> image (caller-owned, 16-byte aligned); once per weight update
- *   ms_convt1d_img_fwd     y = act(conv_transpose1d(x, w) + bias)
+ *   ms_convt1d_img_bytes            bytes of the image; 0 = geometry not taken (use ms_convt1d_fwd)
+ *   ms_convt1d_img_workspace_bytes  split-K slabs of the short-row form (0 for the generator's layers); 16-byte aligned
+ *   ms_convt1d_img_pack             w (Cin, Cout, K) -> image (caller-owned, 16-byte aligned); once per weight update
+ *   ms_convt1d_img_fwd              y = act(conv_transpose1d(x, w) + bias)
+ * Also taken (csrc/convt_fwd_short.hip, same image): kernel 4 / stride 2 / padding 1 on rows of 4 .. 16 positions with >= 256
+ * input channels -- the first line convolutions of the stage-1 generator (featuregenerator/upscale.py:85-91).
  */
 size_t ms_convt1d_img_bytes(const ms_convt1d_desc* d);
+size_t ms_convt1d_img_workspace_bytes(const ms_convt1d_desc* d);
 int ms_convt1d_img_pack(const ms_convt1d_desc* d, const float* w, void* image, ms_stream_t stream);
 int ms_convt1d_img_fwd(const ms_convt1d_desc* d, const float* x, const void* image, const float* bias, float* y,
-                       ms_stream_t stream);
+                       void* workspace, size_t workspace_bytes, ms_stream_t stream);
 /*
  * Transposed-conv BACKWARD DATA on pre-split weight images (csrc/convt_bwd_img.hip): same operation as ms_convt1d_bwd_data for
  * kernel 2S / stride S / padding S/2 (S = 2, 8) on rows of 4 .. 256 input positions (a power of two) -- the generator's two

@@ -323,16 +323,24 @@ bool ct_ok(const ms_convt1d_desc* d) {
 
 }  // namespace
 
+// short rows, many channels (stride 2): the K-loop kernel of convt_fwd_short.hip on the same image
+bool msct_short_ok(const ms_convt1d_desc* d);
+size_t msct_short_ws(const ms_convt1d_desc* d);
+int msct_short_fwd(const ms_convt1d_desc* d, const float* x, const void* image, const float* bias, float* y, void* ws,
+                   size_t ws_bytes, hipStream_t s);
+
 extern "C" {
 
 size_t ms_convt1d_img_bytes(const ms_convt1d_desc* d) {
-    if (!ct_ok(d)) return 0;
+    if (!ct_ok(d) && !msct_short_ok(d)) return 0;
     return (size_t)(d->Cout * d->stride / 32) * (d->Cin / 16) * 2 * 3 * 1024;
 }
 
+size_t ms_convt1d_img_workspace_bytes(const ms_convt1d_desc* d) { return msct_short_ok(d) ? msct_short_ws(d) : 0; }
+
 int ms_convt1d_img_pack(const ms_convt1d_desc* d, const float* w, void* image, ms_stream_t stream) {
     if (!d || !w || !image || (((uintptr_t)image) & 15)) return MS_ERR_INVALID_ARG;
-    if (!ct_ok(d)) return MS_ERR_UNSUPPORTED;
+    if (!ct_ok(d) && !msct_short_ok(d)) return MS_ERR_UNSUPPORTED;
     const size_t total = (size_t)(d->Cout * d->stride / 64) * 2 * (d->Cin / 16) * 2 * 64;
     hipLaunchKernelGGL(k_convt_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (u32x4*)image,
                        d->Cin, d->Cout, d->stride);
@@ -341,8 +349,9 @@ int ms_convt1d_img_pack(const ms_convt1d_desc* d, const float* w, void* image, m
 }
 
 int ms_convt1d_img_fwd(const ms_convt1d_desc* d, const float* x, const void* image, const float* bias, float* y,
-                       ms_stream_t stream) {
+                       void* workspace, size_t workspace_bytes, ms_stream_t stream) {
     if (!d || !x || !image || !y || (((uintptr_t)image) & 15)) return MS_ERR_INVALID_ARG;
+    if (msct_short_ok(d)) return msct_short_fwd(d, x, image, bias, y, workspace, workspace_bytes, (hipStream_t)stream);
     if (!ct_ok(d)) return MS_ERR_UNSUPPORTED;
     CtP p;
     p.B = d->B; p.Cin = d->Cin; p.Cout = d->Cout; p.L = d->Lin; p.act = d->act; p.slope = d->slope;

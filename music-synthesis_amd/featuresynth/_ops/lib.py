@@ -127,7 +127,8 @@ SIGNATURES = {
     "ms_convt1d_workspace_bytes": (_sz, [ctypes.POINTER(ConvTDesc), _c_int]),
     "ms_convt1d_img_bytes": (_sz, [ctypes.POINTER(ConvTDesc)]),
     "ms_convt1d_img_pack": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp]),
-    "ms_convt1d_img_fwd": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp, _vp, _vp]),
+    "ms_convt1d_img_workspace_bytes": (_sz, [ctypes.POINTER(ConvTDesc)]),
+    "ms_convt1d_img_fwd": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ms_convt1d_bwd_img_bytes": (_sz, [ctypes.POINTER(ConvTDesc)]),
     "ms_convt1d_bwd_img_workspace_bytes": (_sz, [ctypes.POINTER(ConvTDesc)]),
     "ms_convt1d_bwd_img_pack": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp]),

@@ -298,7 +298,10 @@ def convt1d_img_fwd(x, w, b, d, lout, out=None):
     img = torch.empty(convt_img_bytes(d), dtype=torch.uint8, device=x.device)
     L.call("ms_convt1d_img_pack", _scost(w.numel(), 1, 0.75), d, w.data_ptr(), img.data_ptr(), L.stream())
     y = _out(out, (d.B, d.Cout, lout), x.device, "conv_transpose1d output")
-    L.call("ms_convt1d_img_fwd", _tcost(d, "bwd_data", 0), d, x.data_ptr(), img.data_ptr(), L.ptr(b), y.data_ptr(), L.stream())
+    nws = L.load().ms_convt1d_img_workspace_bytes(d)
+    ws = L.workspace(nws, x.device)
+    L.call("ms_convt1d_img_fwd", _tcost(d, "bwd_data", 0), d, x.data_ptr(), img.data_ptr(), L.ptr(b), y.data_ptr(), L.ptr(ws), nws,
+           L.stream())
     return y
 
 

@@ -100,3 +100,37 @@ def test_convt_backward_data_image_kernel_declines():
                              ((32, 512, 24), (512, 256, 16), 8)]:      # not a power of two
         d, _ = P.convt_desc(shape, wshape, S, S // 2, act=1)
         assert P.convt_bwd_img_bytes(d) == 0, (shape, wshape)
+
+
+# (name, rows, Cin, W, Cout, act): the stage-1 generator's first line convolutions (stride 2, short rows, many channels)
+SHORT_CASES = [("w4", 128, 2048, 4, 512, 1), ("w8_ragged", 130, 1024, 8, 256, 1), ("w16", 64, 512, 16, 128, 1),
+               ("w16_noact", 40, 256, 16, 128, 0), ("w4_cout64", 200, 256, 4, 64, 1)]
+
+
+@pytest.mark.parametrize("case", SHORT_CASES, ids=[c[0] for c in SHORT_CASES])
+def test_convt_forward_short_rows(case, monkeypatch):
+    """csrc/convt_fwd_short.hip (through ms_convt1d_img_*) against float64 torch (1e-5) and the generic row kernels (1e-6)."""
+    import torch.nn.functional as F
+    from featuresynth._ops import lib as L
+    from featuresynth._ops import prims as P
+    name, B, Cin, W, Cout, act = case
+    rng = np.random.default_rng(stable_seed("short" + name))
+    x = rng.standard_normal((B, Cin, W)).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout, 4)) / np.sqrt(2 * Cin)).astype(np.float32)
+    b = (rng.standard_normal((Cout,)) * 0.1).astype(np.float32)
+    xt, wt, bt = dev(x), dev(w), dev(b)
+    d, lo = P.convt_desc(xt.shape, wt.shape, 2, 1, act=act)
+    assert P.convt_img_bytes(d) > 0
+    L.profile_begin()
+    y = P.convt1d_fwd(xt, wt, bt, d, lo)
+    rec = L.profile_end()
+    assert [r[0] for r in rec] == ["ms_convt1d_img_pack", "ms_convt1d_img_fwd"] and rec[1][1].get("kernel") == "k_convt_fwd_short", rec
+    ref = F.conv_transpose1d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), 2, 1)
+    if act:
+        ref = F.leaky_relu(ref, 0.2)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert rel_l2(host(y), ref.numpy()) < 1e-5
+    assert torch.equal(y, P.convt1d_fwd(xt, wt, bt, d, lo))            # slabs summed in slice order
+    monkeypatch.setenv("MSYNTH_CONVTSHORT", "0")
+    assert P.convt_img_bytes(d) == 0
+    assert rel_l2(host(y), host(P.convt1d_fwd(xt, wt, bt, d, lo))) < 1e-6
