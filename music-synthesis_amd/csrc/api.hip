@@ -89,7 +89,7 @@ const char* ms_status_string(int status) {
 // 160-170 for the same layer at L = 32.  For such layers the operands are copied into rows padded with zeros to
 // L' = 4 ceil(L / 4) (a few MB: microseconds), the conv runs on the padded problem through the aligned paired kernel,
 // and the valid columns are copied back.  Zero columns behind a row are what the conv's zero padding reads anyway, so
-// the valid outputs are unchanged; the padded outputs are discarded.  Measured (tools/microbench_pad4.py, B = 64):
+// the valid outputs are unchanged; the padded outputs are discarded.  Measured (tools/scratch/microbench_pad4.py, B = 64):
 // L = 17 forward 197 -> 150 us, backward 232 -> 164 us; L = 33: 267 -> 212 / 379 -> 241 us.  With fewer than ~1000
 // columns (B = 32 at L = 17, any batch at L = 9) the extra columns cost more than the loader saves: not padded.
 namespace {

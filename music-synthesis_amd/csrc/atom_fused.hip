@@ -131,7 +131,7 @@ struct AtomCfg {
     static_assert(MS >= 1 && TN >= 1 && TM * WGM == MS && TN * WGN * 32 == NTP, "tile shape");
 };
 
-// DBG (tools/probe_atom.py only; 0 in the product) -- timing probes, results are garbage: 1 = weight fragments loaded
+// DBG (tools/scratch/probe_atom.py only; 0 in the product) -- timing probes, results are garbage: 1 = weight fragments loaded
 // once (no streaming), 2 = B fragments read once per GEMM (no LDS traffic in the K loop), 3 = no global stores,
 // 4 = no x window loads / staging, 5 = no MFMAs.
 //

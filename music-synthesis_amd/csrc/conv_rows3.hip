@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void k_conv_rows3(Row2P p, const float* __rest
 // so a 32-row sub-tile multiplies two weight taps (A has K = 2) against the window columns offset by its half.
 // The epilogue scatters row (co, phase) / column q to y[co][q S + phase]: four consecutive samples per store.
 // INA: LeakyReLU applied to the input on its way into LDS (the activation in front of the transposed conv).
-// DBG (tools/dbg_r3p.py only; 0 in the product): 1 = staging without the operand split (raw bits stored),
+// DBG (tools/scratch/dbg_r3p.py only; 0 in the product): 1 = staging without the operand split (raw bits stored),
 // 2 = no MFMAs, 3 = no staging at all (no loads, no LDS stores), 4 = no global loads inside the K loop, 5 = loads but no
 // split / LDS stores -- timing probes, results are garbage.
 template <int WGM, int TM, int TN, int K, int AM, int HS = 0, bool INA = false, int DBG = 0>
@@ -886,7 +886,7 @@ int msr3p_launch(int bm, int K, int act_mode, const Row2P& p, const float* X, co
     const dim3 grid((ntiles + 1) / 2, (unsigned)((p.M + bm - 1) / bm), gz);
 #define MS3P(WGM_, TM_, TN_, K_, A_) return launch_pair<WGM_, TM_, TN_, K_, A_>(p, X, Xact, W, bias, res, Y, Yact, grid, s)
     if (bm == 128 && K == 3 && act_mode == 0) {
-        static const int dbg = getenv("MSYNTH_R3P_DBG") ? atoi(getenv("MSYNTH_R3P_DBG")) : 0;     // timing probes (tools/dbg_r3p.py)
+        static const int dbg = getenv("MSYNTH_R3P_DBG") ? atoi(getenv("MSYNTH_R3P_DBG")) : 0;     // timing probes (tools/scratch/dbg_r3p.py)
         if (dbg == 1) return launch_pair<2, 2, 2, 3, 0, 0, false, 1>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
         if (dbg == 2) return launch_pair<2, 2, 2, 3, 0, 0, false, 2>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
         if (dbg == 3) return launch_pair<2, 2, 2, 3, 0, 0, false, 3>(p, X, Xact, W, bias, res, Y, Yact, grid, s);

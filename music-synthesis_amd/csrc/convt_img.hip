@@ -312,7 +312,7 @@ bool ct_ok(const ms_convt1d_desc* d) {
     const bool shape = (d->Cin == 512 && d->Cout == 256 && d->stride == 8) || (d->Cin == 256 && d->Cout == 128 && d->stride == 8) ||
                        (d->Cin == 128 && d->Cout == 64 && d->stride == 2) || (d->Cin == 64 && d->Cout == 32 && d->stride == 2);
     if (!shape) return false;
-    // measured (tools/microbench_convt_img.py, B = 32): stride 8: 69 -> 37 us (512 -> 256), 77 -> 64 us (256 -> 128); the two
+    // measured (tools/scratch/microbench_convt_img.py, B = 32): stride 8: 69 -> 37 us (512 -> 256), 77 -> 64 us (256 -> 128); the two
     // stride-2 layers are HBM-bound and run 20 % FASTER on the paired row kernel (42 / 28 us), and at B = 1 the pack launch
     // costs more than the kernel saves: those stay on ms_convt1d_fwd's row-tile path
     if (d->stride != 8 || (long long)d->B * d->Lin < 1024) return false;

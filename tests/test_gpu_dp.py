@@ -139,7 +139,7 @@ def test_two_ranks_match_global_batch(tmp_path):
         # after Adam updates (DESIGN.md "Adam sensitivity"): d_loss ~ 6 stays tight, g_loss is a
         # small number near zero whose judge term moves at the +-lr scale PER UPDATE already made: the
         # single-process value itself moves by 4e-4 at call 6 between two kernel generations of identical
-        # accuracy (tools/dbg_dp.py with MSYNTH_GCONV3/CONVT3/PAD4 = 0 vs default: -0.003496 vs -0.003921), so
+        # accuracy (tools/scratch/dbg_dp.py with MSYNTH_GCONV3/CONVT3/PAD4 = 0 vs default: -0.003496 vs -0.003921), so
         # the gate widens with the number of updates behind the call: 1e-3, 2e-3, 3e-3
         tol = 1e-4 * abs(b) if i % 2 == 0 else 5e-4 * (i + 1)
         assert abs(a - b) <= tol, (i, mean_losses, losses)

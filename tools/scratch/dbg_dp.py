@@ -1,7 +1,7 @@
 """Loss trajectories: two gloo ranks on half batches vs one process on the concatenated batch (the comparison
 tests/test_gpu_dp.py::test_two_ranks_match_global_batch makes), printed for the kernel switches in the environment."""
 import os, sys, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch

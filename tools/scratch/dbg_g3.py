@@ -1,6 +1,6 @@
 """k_gconv_split_fwd on the long layers under the launch-shape knob MSYNTH_GW (target waves per launch)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 from featuresynth._ops import prims as P

@@ -2,7 +2,7 @@
 One process per setting (MSYNTH_REAL_FORK=0/1); prints per-parameter max |diff| of the D / G gradient buckets after the
 replayed calls against the eager (MSYNTH_GRAPH=0) run of the same setting."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import featuresynth as fs

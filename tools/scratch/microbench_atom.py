@@ -1,7 +1,7 @@
 """Fused ResidualAtom forward (one launch, csrc/atom_fused.hip) vs the two row-tile launches, at the generator's
 shapes (B = 32 and B = 1), inference and training (saved activations) mode."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 from featuresynth._ops import graph as G, prims as P

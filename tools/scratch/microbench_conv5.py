@@ -1,7 +1,7 @@
 """The discriminator's 1024 -> 1024 k5 conv: image kernel (csrc/conv5_img.hip) vs the generic row kernels, forward and
 backward data, at the three scales and both batch sizes of the train step."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 from featuresynth._ops import prims as P

@@ -1,6 +1,6 @@
 """ConvTranspose1d weight gradient: row-tile phase-split kernel vs the im2col kernel (MSYNTH_WROWS=0)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 from featuresynth._ops import prims as P, lib as L

@@ -1,7 +1,7 @@
 """ConvTranspose1d forward of the generator's four upsampling layers: paired split-bf16 kernel (conv_rows3.hip, two-tap
 form) vs the fp32-MFMA row kernel (MSYNTH_CONVT3=0), with and without the LeakyReLU in front, checked against float64."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 import torch.nn.functional as F

@@ -1,6 +1,6 @@
 """Transposed-conv backward data: image kernel (csrc/convt_bwd_img.hip) vs the fp32 row-tile path, per layer shape."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import numpy as np, torch
 from featuresynth._ops import prims as P

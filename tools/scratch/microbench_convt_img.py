@@ -1,7 +1,7 @@
 """ConvTranspose1d forward of the generator's four layers: image kernel (csrc/convt_img.hip) vs the row-tile kernels
 (MSYNTH_CONVTIMG=0 is read once per process: the generic path is timed through ms_convt1d_fwd's own entry)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 from featuresynth._ops import prims as P, lib as L

@@ -1,7 +1,7 @@
 """Grouped k41 / stride-4 convs of the discriminator at the BASELINE shapes (3 scales x 4 layers, B = 64 and 32):
 split-bf16 kernels (gconv_split.hip) vs the fp32-MFMA kernels (MSYNTH_GCONV3=0), each checked against float64."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 import torch.nn.functional as F

@@ -1,6 +1,6 @@
 """The discriminator's 1024->1024 k5 convolutions at L = 32 / 17 / 9: tile shape sweep (MSYNTH_ROWCFG)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 from featuresynth._ops import prims as P

@@ -1,7 +1,7 @@
 """The D 1024->1024 k5 conv at the pooled scales (rows of 17 / 9 samples): rows padded to a multiple of 4 and run on
 the aligned paired kernel (default) vs the dword loader of the four-wave kernel (MSYNTH_PAD4=0)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 from featuresynth._ops import prims as P, lib as L

@@ -1,7 +1,7 @@
 """Row-tile forward / backward-data kernels at the BASELINE shapes: pipelined kernel vs the first generation
 (MSYNTH_ROWS2=0), with the max difference between the two."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 from featuresynth._ops import prims as P, lib as L

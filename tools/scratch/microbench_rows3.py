@@ -1,7 +1,7 @@
 """Dense row-tile convs at the BASELINE shapes: split-bf16 kernel (conv_rows3.hip) vs the fp32-MFMA pipelined
 kernel (MSYNTH_ROWS3=0), with the difference between the two."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 from featuresynth._ops import prims as P, lib as L

@@ -1,7 +1,7 @@
 """Row-tile split-K: time the under-filled layers with MSYNTH_SPLIT_WGS = 0 (off) and the default,
 and report the max difference between the two results.  GPU only."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 from featuresynth._ops import prims as P, lib as L

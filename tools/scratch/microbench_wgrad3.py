@@ -1,7 +1,7 @@
 """Dense k3 weight gradients at the BASELINE shapes: split-bf16 kernel (k_wgrad_rows3) vs the fp32-MFMA row kernel
 (MSYNTH_WROWS3=0): single layers and the batched six-layer launch of a ResidualStack."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 from featuresynth._ops import prims as P, lib as L

@@ -1,7 +1,7 @@
 """Weight gradient of the many-channel k5 conv on short rows: split-bf16 kernel (wgrad_k5.hip) vs the fp32-MFMA row-tile
 kernel (MSYNTH_WGRAD5=0), both against float64."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 import torch.nn.functional as F

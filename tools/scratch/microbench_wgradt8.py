@@ -1,7 +1,7 @@
 """Weight gradient of the stride-8 transposed convs: split-bf16 kernel (wgrad_convt.hip) vs the fp32-MFMA phase-split
 row kernel (MSYNTH_WGRADT8=0), both against float64."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 import torch.nn.functional as F

@@ -2,7 +2,7 @@
 2 no B-fragment LDS reads in the K loop | 3 no global stores | 4 no x window staging | 5 no MFMAs.
   for d in 0 1 2 3 4 5; do MSYNTH_ATOM_DBG=$d python3 tools/probe_atom.py; done"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 from featuresynth._ops import graph as G, prims as P

@@ -2,7 +2,7 @@
 0 product kernel | 1 staging without the operand split | 2 no MFMAs | 3 no staging (MFMAs + fragment reads only).
 One process per variant (the switch is read once):  for d in 0 1 2 3; do MSYNTH_R3P_DBG=$d python3 tools/probe_r3p.py; done"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import torch
 from featuresynth._ops import prims as P

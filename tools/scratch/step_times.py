@@ -1,6 +1,6 @@
 """GPU time of the replayed D-step and G-step graphs (HIP events) and the CPU-side overhead per call."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis_amd"))
 import numpy as np, torch
 import featuresynth as fs
