@@ -117,6 +117,24 @@ def atom_forward(h, w0, b0, w1, b1, dil, save, image=None):
     return out, (d0, d1, h, t, u)
 
 
+def pack_convt_images(x_shape, params, backward=False):
+    """Weight images of the generator's transposed convs that an image kernel takes (forward: csrc/convt_img.hip; backward
+    data: csrc/convt_bwd_img.hip) -> {parameter index of the layer's weight: image}."""
+    B, _, Lg = x_shape
+    images = {}
+    i = 2
+    for stride, pad in G_UPSAMPLE:
+        w = params[i]
+        dt, lo = P.convt_desc((B, w.shape[0], Lg), w.shape, stride, pad, act=L.ACT_LRELU)
+        if backward and P.convt_bwd_img_bytes(dt):
+            images[i] = P.convt_bwd_img_pack(dt, w)
+        elif not backward and P.convt_img_bytes(dt):
+            images[i] = P.convt_img_pack(dt, w)
+        Lg = lo
+        i += 2 + 4 * len(DILATIONS)
+    return images
+
+
 def pack_atom_images(x_shape, params, backward=False):
     """Pre-splits the weights of every generator atom the fused kernel takes -- ONE launch per forward (backward) pass
     (the images are only valid for the weights as they are now: they are rebuilt on every pass, 9 MB).
@@ -141,14 +159,31 @@ def pack_atom_images(x_shape, params, backward=False):
 
 
 def pack_atom_images_aside(x_shape, params, device, with_backward=False):
-    """pack_atom_images on a side stream of its own, beside what the caller issues next (the first conv and the first
-    transposed conv): -> (forward images, backward images or None, event to wait for before the first atom -- None when
-    the packs ran on the caller's stream).  with_backward: the backward pass of the same step multiplies by the same
-    weights, its images are packed here too (they are off the critical path for good)."""
+    """Every weight image of a generator pass, packed on a side stream of its own beside what the caller issues next:
+    -> (forward images, backward images or None, event behind the transposed convs' forward images, event behind everything)
+    -- the events are None when the packs ran on the caller's stream.  Order on the side stream: transposed-conv forward images
+    (the first is needed right behind the first conv), atom forward images, then -- with_backward: the backward pass of the same
+    step multiplies by the same weights -- the backward images, which are thereby off the critical path for good.
+    Keys: parameter index of the layer's (first) weight."""
     # (a fork + join costs ~15 us of dependency latency inside a replayed graph: only where the pass is long enough to hide a
     #  pack launch behind -- measured at B = 1: 275 us on one stream, 311 us forked)
+    def pack_all():
+        images = pack_convt_images(x_shape, params)
+        ev_t = None
+        if side is not None:
+            ev_t = torch.cuda.Event()
+            ev_t.record(side)
+        images.update(pack_atom_images(x_shape, params))
+        images_bwd = None
+        if with_backward:
+            images_bwd = pack_atom_images(x_shape, params, True)
+            images_bwd.update(pack_convt_images(x_shape, params, True))
+        return images, images_bwd, ev_t
+
+    side = None
     if not _may_fork(device) or x_shape[0] * x_shape[2] < 256 or os.environ.get("MSYNTH_PACKASIDE", "1") == "0":
-        return pack_atom_images(x_shape, params), (pack_atom_images(x_shape, params, True) if with_backward else None), None
+        images, images_bwd, _ = pack_all()
+        return images, images_bwd, None, None
     main = torch.cuda.current_stream(device)
     key = (device.index, "pack")
     if key not in _SIDE_STREAMS:
@@ -156,14 +191,13 @@ def pack_atom_images_aside(x_shape, params, device, with_backward=False):
     side = _SIDE_STREAMS[key]
     side.wait_stream(main)
     with forked(side):
-        images = pack_atom_images(x_shape, params)
-        images_bwd = pack_atom_images(x_shape, params, True) if with_backward else None
+        images, images_bwd, ev_t = pack_all()
         ev = torch.cuda.Event()
         ev.record(side)
     for group in (images, images_bwd or {}):
         for t in group.values():
             t.record_stream(main)       # (allocated on the side stream, read on the caller's)
-    return images, images_bwd, ev
+    return images, images_bwd, ev_t, ev
 
 
 def atom_backward(rec, w0, w1, g, sink, i, need_wgrad=True, need_gx=True, fork=None, batch=None, image_bwd=None):
@@ -227,7 +261,7 @@ def gen_forward(x, params, save):
                            (params[0].shape[1], tuple(x.shape)))
     i = 0
     tape = []
-    images, images_bwd, packed = pack_atom_images_aside(x.shape, params, x.device, with_backward=save)
+    images, images_bwd, packed_t, packed = pack_atom_images_aside(x.shape, params, x.device, with_backward=save)
     w, b = params[i], params[i + 1]; i += 2
     d, lo = P.conv_desc(x.shape, w.shape, pad=3, pad_mode=L.PAD_REFLECT, act=L.ACT_LRELU)
     h, _ = P.conv1d_fwd(x, w, b, d, lo)
@@ -236,7 +270,10 @@ def gen_forward(x, params, save):
         w, b = params[i], params[i + 1]; i += 2
         dt, lo = P.convt_desc(h.shape, w.shape, stride, pad, act=L.ACT_LRELU)
         hin = h
-        h = P.convt1d_fwd(hin, w, b, dt, lo)
+        if packed_t is not None:
+            torch.cuda.current_stream(x.device).wait_event(packed_t)
+            packed_t = None
+        h = P.convt1d_fwd(hin, w, b, dt, lo, img=images.get(i - 2))
         tape.append(("convT", dt, hin, h))
         if packed is not None:
             torch.cuda.current_stream(x.device).wait_event(packed)
@@ -275,7 +312,11 @@ def gen_backward(tape, params, gy, sink=None, need_gx=False, cut=None):
     deferred = []
     conv0 = tape[0]
     stash = [rec for rec in tape if rec[0] == "images_bwd"]
-    images_bwd = stash[0][1] if stash else pack_atom_images(conv0[2].shape, params, backward=True)
+    if stash:
+        images_bwd = stash[0][1]
+    else:
+        images_bwd = pack_atom_images(conv0[2].shape, params, backward=True)
+        images_bwd.update(pack_convt_images(conv0[2].shape, params, True))
     for rec in reversed(tape):
         kind = rec[0]
         if kind == "images_bwd":
@@ -308,7 +349,7 @@ def gen_backward(tape, params, gy, sink=None, need_gx=False, cut=None):
                 deferred.append(late)
             else:
                 fork.run(lambda: sink.put(i, *P.convt1d_bwd_weight(hin, g, h, dt, params[i].shape, gw, gb, acc)), hin, g, h)
-            g = P.convt1d_bwd_data(g, h, params[i], dt)
+            g = P.convt1d_bwd_data(g, h, params[i], dt, img=images_bwd.get(i))
         else:  # conv0 (reflection-padded): the gradient reaches the mel features only on request
             _, d, x, h = rec
             i -= 2

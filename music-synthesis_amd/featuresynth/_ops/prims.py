@@ -274,10 +274,11 @@ def convt_desc(x_shape, w_shape, stride, pad, act=L.ACT_NONE, in_act=L.ACT_NONE)
     return d, lout
 
 
-def convt1d_fwd(x, w, b, d, lout, out=None):
+def convt1d_fwd(x, w, b, d, lout, out=None, img=None):
+    """img: the layer's pre-packed forward weight image (convt_img_pack), when the caller packed it ahead."""
     L.require(x, "conv_transpose1d input"); L.require(w, "conv_transpose1d weight")
     if convt_img_bytes(d):
-        return convt1d_img_fwd(x, w, b, d, lout, out=out)
+        return convt1d_img_fwd(x, w, b, d, lout, out=out, img=img)
     y = _out(out, (d.B, d.Cout, lout), x.device, "conv_transpose1d output")
     lib = L.load()
     nws = lib.ms_convt1d_workspace_bytes(d, 0)
@@ -292,11 +293,19 @@ def convt_img_bytes(d):
     return int(L.load().ms_convt1d_img_bytes(d))
 
 
-def convt1d_img_fwd(x, w, b, d, lout, out=None):
-    """ConvTranspose1d forward on a pre-split weight image (packed here: one small launch per call)."""
-    L.require(x, "conv_transpose1d input"); L.require(w, "conv_transpose1d weight")
-    img = torch.empty(convt_img_bytes(d), dtype=torch.uint8, device=x.device)
+def convt_img_pack(d, w):
+    """-> forward weight image of a transposed conv the image kernels take (csrc/convt_img.hip, convt_fwd_short.hip)."""
+    L.require(w, "conv_transpose1d weight")
+    img = torch.empty(convt_img_bytes(d), dtype=torch.uint8, device=w.device)
     L.call("ms_convt1d_img_pack", _scost(w.numel(), 1, 0.75), d, w.data_ptr(), img.data_ptr(), L.stream())
+    return img
+
+
+def convt1d_img_fwd(x, w, b, d, lout, out=None, img=None):
+    """ConvTranspose1d forward on a pre-split weight image (packed here unless the caller did: one small launch)."""
+    L.require(x, "conv_transpose1d input")
+    if img is None:
+        img = convt_img_pack(d, w)
     y = _out(out, (d.B, d.Cout, lout), x.device, "conv_transpose1d output")
     nws = L.load().ms_convt1d_img_workspace_bytes(d)
     ws = L.workspace(nws, x.device)
@@ -310,15 +319,23 @@ def convt_bwd_img_bytes(d):
     return int(L.load().ms_convt1d_bwd_img_bytes(d))
 
 
-def convt1d_bwd_data(gy, y_act, w, d, out=None):
+def convt_bwd_img_pack(d, w):
+    """-> backward-data weight image of a transposed conv (csrc/convt_bwd_img.hip)."""
+    L.require(w, "conv_transpose1d weight")
+    img = torch.empty(convt_bwd_img_bytes(d), dtype=torch.uint8, device=w.device)
+    L.call("ms_convt1d_bwd_img_pack", _scost(w.numel(), 1, 1.5, 0), d, w.data_ptr(), img.data_ptr(), L.stream())
+    return img
+
+
+def convt1d_bwd_data(gy, y_act, w, d, out=None, img=None):
+    """img: the layer's pre-packed backward-data image (convt_bwd_img_pack), when the caller packed it ahead."""
     L.require(gy, "conv_transpose1d grad_output")
     gx = _out(out, (d.B, d.Cin, d.Lin), gy.device, "conv_transpose1d grad_input")
     lib = L.load()
     nimg = convt_bwd_img_bytes(d)
     if nimg:
-        L.require(w, "conv_transpose1d weight")
-        img = torch.empty(nimg, dtype=torch.uint8, device=gy.device)
-        L.call("ms_convt1d_bwd_img_pack", _scost(w.numel(), 1, 1.5, 0), d, w.data_ptr(), img.data_ptr(), L.stream())
+        if img is None:
+            img = convt_bwd_img_pack(d, w)
         nws = lib.ms_convt1d_bwd_img_workspace_bytes(d)
         ws = L.workspace(nws, gy.device)
         L.call("ms_convt1d_bwd_img_data", _tcost(d, "fwd", 1, extra_reads=int(y_act is not None)),
