@@ -116,6 +116,9 @@ def main():
                          "variant of experiment/realmelgan.py (SURVEY.md 8(f) row 1, 128 mels); twostage = "
                          "BASELINE config 5: every step is one stage-1 trainer call (2-D conv mel GAN, "
                          "featureexperiment.py) plus one stage-2 trainer call (the headline vocoder, 128 mels)")
+    ap.add_argument("--prime", type=int, default=60,
+                    help="untimed calls in front of the warm-up steps, on top of the four that load code objects and capture the "
+                         "graphs (clock ramp); the profiling scripts pass 0 to keep their traces at 15 D+G pairs")
     ap.add_argument("--no-gforward", action="store_true",
                     help="skip the BASELINE config-2 leg (generator forward, B=1): keeps its B=1 dispatches out "
                          "of a rocprofv3 trace of the train step")
@@ -220,7 +223,7 @@ def main():
     # those one-off costs into the timed region
     # ... and the clocks: a 20-step timed region is 70 ms, shorter than the GPU's ramp under a fresh load (measured: 3.49 ms
     # per step over 20 steps, 3.45 over 600 on the same box) -- 60 more untimed calls (~0.2 s) before the W warm-up steps
-    for i in range(4 + 60):
+    for i in range(4 + args.prime):
         last.update(call(i))
     for i in range(args.warmup):
         last.update(call(i))

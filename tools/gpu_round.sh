@@ -17,6 +17,6 @@ tail -25 gpurun_out/bench.log; cat gpurun_out/bench.json
 [ $rc -ne 0 ] && exit $rc
 if [ -n "$PROFILE" ]; then
   echo "== rocprofv3"
-  cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 6 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log
+  cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --prime 0 --steps 10 --warmup 6 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log
   echo "rocprof rc=$?"; cd $GRAFT_REPO_ROOT; find gpurun_out/prof -name "*stats*" | head
 fi

@@ -12,7 +12,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   d=$R/gpurun_out/pmc_$c
   rm -rf $d
   MSYNTH_STREAMS=0 MSYNTH_GRAPH=0 timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- \
-      python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline > $R/gpurun_out/pmc_$c.json 2> $R/gpurun_out/pmc_$c.log
+      python3 $R/bench.py --prime 0 --steps 4 --warmup 2 --no-cpu-baseline --no-roofline > $R/gpurun_out/pmc_$c.json 2> $R/gpurun_out/pmc_$c.log
   echo "pmc $c rc=$?"
 done
 cd $R

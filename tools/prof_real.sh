@@ -3,7 +3,7 @@
 export TMPDIR=/tmp MSYNTH_STREAMS=0
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/prof_real
-cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_real -- python3 $R/bench.py --model realmelgan --steps 10 --warmup 6 > $R/gpurun_out/prof_real.json 2> $R/gpurun_out/prof_real.log
+cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_real -- python3 $R/bench.py --prime 0 --model realmelgan --steps 10 --warmup 6 > $R/gpurun_out/prof_real.json 2> $R/gpurun_out/prof_real.log
 cd $R
 python3 - <<'PY'
 import csv, glob

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp MSYNTH_STREAMS=${MSYNTH_STREAMS:-0}
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/prof_serial
-cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_serial -- python3 $R/bench.py --steps 10 --warmup 6 --no-cpu-baseline --no-roofline > $R/gpurun_out/prof_serial.json 2> $R/gpurun_out/prof_serial.log
+cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_serial -- python3 $R/bench.py --prime 0 --steps 10 --warmup 6 --no-cpu-baseline --no-roofline > $R/gpurun_out/prof_serial.json 2> $R/gpurun_out/prof_serial.log
 echo "rc=$?"; cd $R
 python3 - <<'PY'
 import csv, glob
