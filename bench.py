@@ -15,8 +15,9 @@ contract, train.py:39-42,74).  value = world * B * 8192 * K / max-over-ranks(wal
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline      dominant kernel (by device time in an instrumented eager D+G pass): algorithmic
-                FLOPs per launch / mean launch duration measured with HIP events on the launch
-                stream (raw readings: nothing subtracted), against the ceiling of the pipe the kernel
+                FLOPs per launch / mean DEVICE duration of the launch (the dispatches' own begin / end
+                timestamps through hipExtLaunchKernelGGL events: what rocprofv3 reports; the stream-event
+                reading around the call is kept beside it), against the ceiling of the pipe the kernel
                 runs on -- bf16 MFMA peak / 6 = 416.7 TFLOP/s for the split-bf16 kernels (six bf16
                 products per fp32 multiply), 157.3 for fp32-input MFMA, 8 TB/s for streams -- with the
                 fraction of the fp32 roofline (157.3) quoted beside it
@@ -272,7 +273,8 @@ def main():
     if share:
         result["rehearsal"] = "ranks share cuda:0 over gloo: control-flow check only, not a measurement"
     if rank == 0 and not args.no_roofline:
-        # instrumented eager pass: HIP events around every C-ABI launch on the launch stream
+        # instrumented eager pass: every kernel the library launches carries its dispatch's begin / end timestamps
+        # (ms_profile_kernels), plus a stream event pair around every C-ABI call for comparison
         s, f = batches[0]
         os.environ["MSYNTH_STREAMS"] = "0"      # serialise the discriminator scales: clean per-kernel times
         L.profile_begin()
@@ -282,15 +284,16 @@ def main():
         rec, ev_ms = L.profile_end(calibrate=True)
         os.environ.pop("MSYNTH_STREAMS", None)
         del out_d, out_g
-        # Raw event readings.  (r02 subtracted the reading of an EMPTY event pair, 4.6-4.9 us, from every launch;
-        # the rocprofv3 serial trace refuted that: traced durations sit 1-2 us BELOW the raw readings, not 5.  The
-        # empty-pair reading is still reported, as information about the instrument.)
-        log("[bench] empty event pair: %.2f us (reported only; launch times below are raw event readings)" % (ev_ms * 1e3))
+        # Device durations.  (r02 took stream-event readings minus the reading of an EMPTY event pair, 4.6-4.9 us, and
+        # over-corrected by 8 %; r03 first took the raw event readings, which sit 0.2-2.5 us above the traced durations
+        # depending on the box; now the durations ARE the dispatch timestamps, the event readings are only reported.)
+        log("[bench] empty event pair: %.2f us (reported only)" % (ev_ms * 1e3))
         agg = {}
         for name, cost, ms in rec:
             k = cost.get("kernel") or name
-            a = agg.setdefault(k, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0})
+            a = agg.setdefault(k, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0, "event_ms": 0.0})
             a["ms"] += ms; a["n"] += 1
+            a["event_ms"] += cost.get("event_ms", ms)
             a["flops"] += cost.get("flops", 0); a["bytes"] += cost.get("bytes", 0)
         tot_ms = sum(a["ms"] for a in agg.values())
         top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
@@ -312,8 +315,8 @@ def main():
         # only in tile shape / taps / fused epilogue; rocprofv3 lists them separately)
         fam = {}
         for k_, a_ in agg.items():
-            f_ = fam.setdefault(k_.split("<")[0], {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0, "inst": {}})
-            for key in ("ms", "n", "flops", "bytes"):
+            f_ = fam.setdefault(k_.split("<")[0], {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0, "event_ms": 0.0, "inst": {}})
+            for key in ("ms", "n", "flops", "bytes", "event_ms"):
                 f_[key] += a_[key]
             f_["inst"][k_] = {"launches": a_["n"], "avg_launch_us": 1e3 * a_["ms"] / a_["n"],
                               "tflops": a_["flops"] / a_["ms"] / 1e9 if a_["ms"] else 0.0}
@@ -362,8 +365,10 @@ def main():
                 roof["traffic_source"] = "profiles/r03_pmc_traffic.json is for code %s, benched code is %s: not quoted" % (
                     pmc.get("code_version"), ver)
         roof.update({"kernel": k, "launches_per_DG_pair": a["n"], "avg_launch_us": avg_s * 1e6,
-                     "timing": "HIP events on the launch stream around every launch of an eager, stream-serialised "
-                               "D+G pass; raw readings (they sit 1-2 us above rocprofv3's kernel durations)",
+                     "timing": "device begin / end timestamps of every kernel (hipExtLaunchKernelGGL start / stop events -- the "
+                               "durations rocprofv3 reports) in an eager, stream-serialised D+G pass; a C-ABI call that launches "
+                               "several kernels (split-K finish, pack) is charged their sum",
+                     "avg_launch_us_stream_events": 1e3 * a["event_ms"] / a["n"],
                      "event_pair_overhead_us": ev_ms * 1e3,
                      "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
                      "share_of_kernel_time": a["ms"] / tot_ms,

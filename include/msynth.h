@@ -192,6 +192,13 @@ const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which);
 const char* ms_last_kernel_name(void);
 void ms_last_kernel_clear(void);
 
+/* Profiling aid: ms_profile_kernels(1) puts the calling THREAD into profile mode -- every kernel the library launches from it is
+ * then bracketed by the dispatch's own begin / end timestamps (hipExtLaunchKernelGGL start / stop events: what rocprofv3 reports as
+ * the kernel's duration) and waited for; ms_profile_take() returns the number of kernels launched since the last take and their
+ * summed device time in microseconds.  Not capturable into a hipGraph while on; off (0) by default. */
+void ms_profile_kernels(int on);
+int ms_profile_take(double* device_us);
+
 /* nn.ConvTranspose1d geometry.  w is (Cin, Cout, K).  Lout = (Lin-1)*stride - 2*pad + K */
 typedef struct ms_convt1d_desc {
     int32_t B, Cin, Lin, Cout, K, stride, pad;

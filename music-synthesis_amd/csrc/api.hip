@@ -17,6 +17,21 @@ void ms_note_kernel(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local int g_prof_on = 0, g_prof_launches = 0;
+static thread_local double g_prof_us = 0.0;
+
+bool ms_prof_on() { return g_prof_on != 0; }
+
+void ms_prof_add(hipEvent_t e0, hipEvent_t e1) {
+    float ms = 0.f;
+    if (e0 && e1 && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+        g_prof_us += 1e3 * (double)ms;
+        ++g_prof_launches;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+}
+
 namespace {
 
 bool make_conv(const ms_conv1d_desc* d, ConvP* p) {
@@ -67,6 +82,20 @@ bool make_convt(const ms_convt1d_desc* d, ConvP* p) {
 extern "C" {
 
 int ms_version(void) { return MSYNTH_VERSION; }
+
+void ms_profile_kernels(int on) {
+    g_prof_on = on ? 1 : 0;
+    g_prof_us = 0.0;
+    g_prof_launches = 0;
+}
+
+int ms_profile_take(double* device_us) {
+    const int n = g_prof_launches;
+    if (device_us) *device_us = g_prof_us;
+    g_prof_us = 0.0;
+    g_prof_launches = 0;
+    return n;
+}
 
 const char* ms_last_kernel_name(void) { return g_last_kernel; }
 void ms_last_kernel_clear(void) { g_last_kernel[0] = 0; }

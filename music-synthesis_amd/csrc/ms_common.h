@@ -16,6 +16,27 @@
 // caller so that a profiler line can be matched to a layer without re-deriving the dispatch (thread-local).
 void ms_note_kernel(const char* fmt, ...);
 
+// Profiling aid (ms_profile_kernels / ms_profile_take, api.hip): while a thread is in profile mode every kernel launch of the
+// library carries a start / stop event pair (hipExtLaunchKernelGGL: the events take the dispatch's own begin / end timestamps,
+// the durations rocprofv3 reports), is waited for, and its device time is added to the thread's counter.  Outside profile mode
+// a launch is the plain <<< >>> it always was (capturable, no events).
+#include <hip/hip_ext.h>
+bool ms_prof_on();
+void ms_prof_add(hipEvent_t e0, hipEvent_t e1);
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                       \
+    do {                                                                                                   \
+        if (ms_prof_on()) {                                                                                \
+            hipEvent_t ms_e0_ = nullptr, ms_e1_ = nullptr;                                                 \
+            (void)hipEventCreate(&ms_e0_);                                                                 \
+            (void)hipEventCreate(&ms_e1_);                                                                 \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, ms_e0_, ms_e1_, 0, __VA_ARGS__);     \
+            ms_prof_add(ms_e0_, ms_e1_);                                                                   \
+        } else {                                                                                           \
+            (kernel)<<<(grid), (block), (shmem), (stream)>>>(__VA_ARGS__);                                 \
+        }                                                                                                  \
+    } while (0)
+
 struct ConvP {  // kernel-side copy of ms_conv1d_desc (+ derived sizes)
     int B, Cin, Lin, Cout, Lout, K, stride, pad, dil, groups, Cg, Og, pad_mode, act;
     float slope;

@@ -120,6 +120,8 @@ SIGNATURES = {
     "ms_convt1d_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvTDesc), _c_int]),
     "ms_last_kernel_name": (ctypes.c_char_p, []),
     "ms_last_kernel_clear": (None, []),
+    "ms_profile_kernels": (None, [_c_int]),
+    "ms_profile_take": (_c_int, [ctypes.POINTER(ctypes.c_double)]),
     "ms_convt1d_out_len": (_c_int, [ctypes.POINTER(ConvTDesc)]),
     "ms_convt1d_fwd": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ms_convt1d_bwd_data": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -244,18 +246,22 @@ PROFILE = None      # list of (symbol, cost dict, start event, end event) while 
 
 
 def profile_begin():
+    """Per-launch timing on: every C-ABI call is recorded with (a) the device time of the kernels it launched, taken from the
+    dispatches' own begin / end timestamps (ms_profile_kernels: what rocprofv3 reports), and (b) a stream event pair around
+    the call (reads 0.2-2.5 us more per kernel: launch latency).  The calling thread's launches are serialised while on."""
     global PROFILE
     PROFILE = []
+    load().ms_profile_kernels(1)
 
 
 def profile_end(calibrate=False):
-    """-> list of (symbol, cost, milliseconds); synchronises the device.
+    """-> list of (symbol, cost, milliseconds); synchronises the device.  The milliseconds are the device time of the
+    call's kernels (cost["event_ms"] keeps the stream-event reading, cost["kernels"] their number).
 
-    calibrate=True also returns the instrument's own reading: the median time between two event records
-    with NOTHING between them on the same stream (the records are stream commands themselves), which the
-    caller may subtract from every measurement."""
+    calibrate=True also returns the reading of an EMPTY stream event pair (the records are stream commands themselves)."""
     global PROFILE
     rec, PROFILE = PROFILE, None
+    load().ms_profile_kernels(0)
     empty = []
     if calibrate:
         for _ in range(64):
@@ -263,7 +269,11 @@ def profile_end(calibrate=False):
             e0.record(); e1.record()
             empty.append((e0, e1))
     torch.cuda.synchronize()
-    out = [(name, cost, e0.elapsed_time(e1)) for name, cost, e0, e1 in rec]
+    out = []
+    for name, cost, e0, e1, dev_us, nk in rec:
+        ev_ms = e0.elapsed_time(e1)
+        cost["event_ms"], cost["kernels"] = ev_ms, nk
+        out.append((name, cost, dev_us * 1e-3 if nk else ev_ms))
     if not calibrate:
         return out
     gaps = sorted(e0.elapsed_time(e1) for e0, e1 in empty)
@@ -287,4 +297,6 @@ def call(name, cost_fn, *args):
     noted = lib.ms_last_kernel_name().decode()
     if noted:                   # the instantiation the launcher really dispatched (split-K aware)
         cost["kernel"] = noted
-    PROFILE.append((name, cost, e0, e1))
+    dev_us = ctypes.c_double(0.0)
+    nk = lib.ms_profile_take(ctypes.byref(dev_us))
+    PROFILE.append((name, cost, e0, e1, dev_us.value, nk))
