@@ -567,3 +567,26 @@ def test_audio_frontend_vs_oracle(rates):
     if a.shape[-1] >= 1024 and target == 22050:
         mel = Audio2Mel(n_mel_channels=128).cuda()(a[:1].contiguous())
         assert mel.shape[1] == 128 and torch.isfinite(mel).all()
+
+
+def test_profile_mode_reports_device_time():
+    """ms_profile_kernels / ms_profile_take (bench.py's roofline durations): in profile mode every C-ABI call reports the
+    device time of the kernels it launched; the result of the call is unchanged and the mode switches off cleanly."""
+    from featuresynth._ops import lib as L
+    from featuresynth._ops import prims as P
+    x = dev(np.random.default_rng(0).standard_normal((8, 64, 512)))
+    w = dev(np.random.default_rng(1).standard_normal((64, 64, 3)) * 0.05)
+    d, lo = P.conv_desc(x.shape, w.shape, pad=1, act=L.ACT_LRELU)
+    ref, _ = P.conv1d_fwd(x, w, None, d, lo)
+    L.profile_begin()
+    y, _ = P.conv1d_fwd(x, w, None, d, lo)
+    rec = L.profile_end()
+    assert len(rec) == 1 and rec[0][1]["kernels"] >= 1
+    assert 0.5e-3 < rec[0][2] < 5.0 and rec[0][2] <= rec[0][1]["event_ms"] * 1.05       # milliseconds; device <= event reading
+    assert torch.equal(y, ref)
+    assert L.load().ms_profile_take(None) == 0           # off again: nothing is counted
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):                            # and launches are capturable again
+        y2, _ = P.conv1d_fwd(x, w, None, d, lo)
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(y2, ref)

@@ -84,6 +84,29 @@ def test_workload_spec_matches_survey():
     assert W.roofline_seconds(W.g_step_launches(32), 8e12, 157.3e12) > 0
 
 
+def test_stage1_workload_spec():
+    """Layer spec of the stage-1 networks (bench.py --model twostage: step_roofline) against the modules themselves: parameter
+    counts, output geometry, and the forward MACs of the transposed-conv stack counted from the layer shapes."""
+    import featuresynth as fs
+    from featuresynth import _workload as W
+    g = fs.featuregenerator.SpectrogramFeatureGenerator(out_channels=128, noise_dim=128)
+    d = fs.featurediscriminator.SpectrogramFeatureDiscriminator(feature_channels=128, channels=256)
+    assert sum(p.numel() for p in g.parameters()) == W.S1_NPARAM_G
+    assert sum(p.numel() for p in d.parameters()) == W.S1_NPARAM_D
+    H = Wd = 4
+    macs = 128 * 16384
+    for layer, (cin, cout, kh, sh) in zip(g.stack, W.S1_G):
+        assert tuple(layer.weight.shape) == (cin, cout, kh, 4) and layer.stride == (sh, 2)
+        macs += H * Wd * cin * cout * kh * 4
+        H, Wd = H * sh, 2 * Wd
+    assert (H, Wd) == (128, 512)
+    fwd = W.totals(W.stage1_generator_launches(1, "fwd"))
+    assert fwd["flops"] == 2 * macs
+    dsteps, gsteps = W.totals(W.stage1_d_step_launches(32)), W.totals(W.stage1_g_step_launches(32))
+    assert 300e9 < dsteps["flops"] < 400e9 and 350e9 < gsteps["flops"] < 450e9
+    assert [m.dilation[0] for m in d.stack.main] == list(W.S1_D_DIL)
+
+
 def test_synthetic_inputs_are_deterministic():
     from featuresynth._synthetic import synthetic_features, synthetic_samples, synthetic_state_dict
     a, b = synthetic_samples(2, 64, rank=3), synthetic_samples(2, 64, rank=3)
