@@ -39,6 +39,7 @@ for p in (ROOT, os.path.join(ROOT, "music-synthesis_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK = 8.0e12        # B/s   (MI355X_MICROARCH.md: HBM3E peak)
+PMC_FILE = "r04_pmc_traffic.json"      # profiles/: TCC traffic of every kernel (tools/pmc_traffic.sh), stamped with code_version()
 F32_PEAK = 157.3e12      # FLOP/s (fp32 vector == fp32-input MFMA peak)
 WINDOW = 8192
 
@@ -63,7 +64,23 @@ def code_version():
     return h.hexdigest()[:12]
 
 
-BF16_PEAK = 2500.0e12    # FLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
+BF16_PEAK = 2500.0e12    # FLOP/s dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)
+
+# kernel templates that run fp32 arithmetic on the 16-bit matrix pipe with split operands -> partial products per multiply
+SPLIT6 = ("k_conv_rows3", "k_wgrad_rows3", "k_gconv_split", "k_wgrad_k5_split", "k_wgrad_convt8_split", "k_conv5_img",
+          "k_convt_img", "k_convt_bwd_img", "k_convt_fwd_short", "k_wgrad_convt2_short", "k_gconv_img")
+
+
+def pipe_products(template, instantiations=()):
+    """0: not a split-operand kernel; 6 / 3: products per fp32 multiply of the scheme the template's launches used."""
+    if template.startswith("k_atom_fwd") or template.startswith("k_stack_fwd"):
+        nps = set()
+        for name in instantiations:
+            args = name[name.index("<") + 1:].rstrip(">").split(",") if "<" in name else []
+            if len(args) >= 5:
+                nps.add(int(args[4]))
+        return 6 if nps == {3} else 3
+    return 6 if template.startswith(SPLIT6) else 0
 
 
 def host_cpu_share(cap=16):
@@ -247,7 +264,7 @@ def main():
     result = {
         "metric": "GAN train-step audio samples/sec (22.05 kHz, 8192-sample window)",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "warmup": args.warmup, "prime": 4 + args.prime, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": ("stage-2 GAN train step: alternating D/G trainer calls, MelGAN "
@@ -323,12 +340,13 @@ def main():
         k, a = sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[0]
         avg_s = a["ms"] / a["n"] / 1e3
         fl, by = a["flops"] / a["n"], a["bytes"] / a["n"]
-        split_pipe = k.startswith(("k_atom_fwd", "k_conv_rows3", "k_wgrad_rows3", "k_gconv_split", "k_wgrad_k5_split",
-                                   "k_wgrad_convt8_split"))
-        # ceiling of the pipe the kernel runs on: fp32 FLOPs executed on the bf16 matrix pipe with every fp32
-        # operand split exactly into three bf16 pieces and six partial products per multiply (conv_rows3.hip) can
-        # go no faster than bf16 peak / 6; the fp32-input MFMA kernels no faster than the fp32 peak
-        pipe_peak = BF16_PEAK / 6 if split_pipe else F32_PEAK
+        # ceiling of the pipe the kernel runs on: fp32 FLOPs executed on the 16-bit matrix pipe with split operands can go no
+        # faster than its peak / (partial products per fp32 multiply): 6 for the exact three-piece bf16 split (conv_rows3.hip),
+        # 3 for the block-scaled two-piece fp16 split (atom_fused.hip, NP = 2); the fp32-input MFMA kernels no faster than
+        # the fp32 peak.  The launchers' noted names carry the scheme (k_atom_fwd's fifth template argument = pieces).
+        products = pipe_products(k, a["inst"])
+        split_pipe = products > 0
+        pipe_peak = BF16_PEAK / products if split_pipe else F32_PEAK
         compute_bound = fl / pipe_peak >= by / HBM_PEAK
         if compute_bound:
             roof = {"bound": "mfma", "achieved": fl / avg_s / 1e12, "peak": pipe_peak / 1e12,
@@ -338,8 +356,11 @@ def main():
                     "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
         if compute_bound:
-            roof["pipe"] = ("bf16 MFMA, exact 3-way operand split, 6 products per fp32 multiply, fp32 accumulate: "
-                            "peak = 2500 / 6" if split_pipe else "fp32-input MFMA")
+            roof["pipe"] = ({6: "bf16 MFMA, exact 3-way operand split, 6 products per fp32 multiply, fp32 accumulate: peak = 2500 / 6",
+                             3: "fp16 MFMA, block-scaled 2-way operand split (22 significand bits), 3 products per fp32 multiply, "
+                                "fp32 accumulate: peak = 2500 / 3"}[products] if split_pipe else "fp32-input MFMA")
+            if products == 3:                                   # continuity with the r02 / r03 lines, priced on 2500 / 6
+                roof["frac_of_six_product_pipe"] = roof["achieved"] / (BF16_PEAK / 6 / 1e12)
             roof["fp32_peak"] = F32_PEAK / 1e12                  # SURVEY 8(d)'s fp32 roofline, for continuity
             roof["frac_of_fp32_peak"] = roof["achieved"] / roof["fp32_peak"]
         roof["traffic"] = None
@@ -348,7 +369,7 @@ def main():
         # collected on THIS code (code_version stamp)
         ver = code_version()
         roof["code_version"] = ver
-        pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+        pmc_file = os.path.join(ROOT, "profiles", PMC_FILE)
         if os.path.exists(pmc_file):
             with open(pmc_file) as fh:
                 pmc = json.load(fh)
@@ -360,10 +381,10 @@ def main():
                         nd += rec_["dispatches"]
                 if nd:
                     roof["traffic"] = tb / nd
-                    roof["traffic_source"] = "profiles/r03_pmc_traffic.json (%d dispatches, code %s)" % (nd, ver)
+                    roof["traffic_source"] = "profiles/%s (%d dispatches, code %s)" % (PMC_FILE, nd, ver)
             else:
-                roof["traffic_source"] = "profiles/r03_pmc_traffic.json is for code %s, benched code is %s: not quoted" % (
-                    pmc.get("code_version"), ver)
+                roof["traffic_source"] = "profiles/%s is for code %s, benched code is %s: not quoted" % (
+                    PMC_FILE, pmc.get("code_version"), ver)
         roof.update({"kernel": k, "launches_per_DG_pair": a["n"], "avg_launch_us": avg_s * 1e6,
                      "timing": "device begin / end timestamps of every kernel (hipExtLaunchKernelGGL start / stop events -- the "
                                "durations rocprofv3 reports) in an eager, stream-serialised D+G pass; a C-ABI call that launches "
@@ -394,6 +415,14 @@ def main():
             "algorithmic_gflop_per_DG_pair": W.totals(launches)["flops"] / 1e9,
             "algorithmic_mb_per_DG_pair": W.totals(launches)["bytes"] / 1e6,
             "kernel_ms_per_DG_pair_eager": tot_ms}
+        # whole-pair HBM traffic from the TCC counters over the algorithmic bytes (same code_version rule as roofline.traffic)
+        sr = result["step_roofline"]
+        sr["traffic_ratio"] = None
+        if os.path.exists(pmc_file) and pmc.get("code_version") == ver and pmc.get("dg_pairs"):
+            tot_b = sum(r_["hbm_bytes_per_launch"] * r_["dispatches"] for r_ in pmc.get("kernels", {}).values())
+            sr["pmc_hbm_mb_per_DG_pair"] = tot_b / pmc["dg_pairs"] / 1e6
+            sr["traffic_ratio"] = sr["pmc_hbm_mb_per_DG_pair"] / sr["algorithmic_mb_per_DG_pair"]
+            sr["traffic_source"] = "profiles/%s (%d D+G pairs, eager, code %s)" % (PMC_FILE, pmc["dg_pairs"], ver)
 
     if rank == 0 and args.model == "twostage":
         # step roofline of the two-stage pair (no per-kernel leg): layer specs of both stages, _workload.py

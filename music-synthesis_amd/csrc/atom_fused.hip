@@ -1,28 +1,41 @@
 // Fused ResidualAtom forward:  out = x + lrelu(conv1_k3(lrelu(conv_d_k3_dil(x) + b0)) + b1)  in ONE launch
-// (reference util/modules.py:350-388; 24 of the generator's 30 convs are the two halves of such an atom).
+// (reference util/modules.py:350-388; 24 of the generator's 30 convs are the two halves of such an atom), and its
+// backward data (MODE 2).
 //
-// Same arithmetic as the two row-tile launches it replaces (conv_rows3.hip): fp32 operands split exactly into
-// three bf16 pieces, six partial products per multiply on v_mfma_f32_32x32x16_bf16, fp32 accumulation, chunks of
-// 16 input channels, taps inside a chunk -- so the intermediate t and the output are bitwise what the unfused
-// pair computes from the same weights.  What changes is where the data lives:
-//
-//   * a workgroup (4 waves) owns NO = NTP - 4 output columns of one batch row for ALL C channels.  It stages the
-//     input window x[:, c0-1-d .. c0+NTP+d) ONCE (all channels: the whole contraction is LDS-resident, there is
-//     no K-loop staging and no barrier inside either GEMM), computes t on the NTP columns c0-1 .. c0+NTP-2
-//     (one halo column each side for the k3 / dil 1 conv that follows), writes lrelu(t) -- split into its bf16
-//     pieces straight from the accumulators -- over the dead x window, and runs the second GEMM from there.
-//     t never travels to HBM (training additionally stores t and u = lrelu(conv1 + b1) for the backward pass);
+//   * a workgroup (4 waves; 8 at 256 channels) owns NO = NTP - 4 output columns of one batch row for ALL C channels.  It
+//     stages the input window x[:, c0-1-d .. c0+NTP+d) ONCE (all channels: the whole contraction is LDS-resident, there is
+//     no K-loop staging and no barrier inside either GEMM), computes t on the NTP columns c0-1 .. c0+NTP-2 (one halo
+//     column each side for the k3 / dil 1 conv that follows), writes lrelu(t) -- split into its 16-bit pieces straight
+//     from the accumulators -- over the dead x window, and runs the second GEMM from there.  t never travels to HBM
+//     (training additionally stores t and u = lrelu(conv1 + b1) for the backward pass);
 //   * the weights are PRE-SPLIT once per step by k_atom_pack into fragment-linear images (one 1 KiB block per
 //     (32 output rows, 16-channel chunk, tap, piece) in exactly the order the MFMA A operand wants them) and
-//     stream from L2 straight into registers, one chunk ahead: no LDS traffic, no vector work for weights at all
-//     (in the unfused kernels every workgroup re-splits every weight it stages: ~45 % of their staging work).
-//   MFMA issue is then only interleaved with the B-fragment ds_reads; the vector work left is one split per
-//   input element (prologue) and one per t element (between the GEMMs), hidden by the second workgroup on the CU.
+//     stream from L2 straight into registers through a ring of AD chunk buffers: no LDS traffic, no vector work for
+//     weights at all.
 //
-// LDS: [chunk][column][3 pieces x 16 channels bf16 | 16 pad] = 112 B per (column, chunk) as in conv_rows3.hip
-// (fragment reads and 8-byte staging stores conflict-free).  C = 64, d = 9: 4 x 150 x 112 = 67 KB -> 2 WGs / CU.
+// Two operand schemes on the 16-bit matrix pipe, fp32 in / fp32 accumulate / fp32 out either way (template NP):
+//   NP = 3  every fp32 operand split EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits), six partial products
+//           per multiply on v_mfma_f32_32x32x16_bf16 (conv_rows3.hip's arithmetic, bitwise equal to the two row-tile
+//           launches).  Ceiling 2500 / 6 TFLOP/s.
+//   NP = 2  (r04) block-scaled two-piece fp16: per tile the window (and later the t tile) is multiplied by a power of two S
+//           that puts its largest magnitude at 2^14, then x S = h + l 2^-11 with h = fp16(x S), l = fp16((x S - h) 2^11):
+//           11 + 11 significand bits, every element within 2^-22 of its fp32 value RELATIVE TO THE TILE MAXIMUM's
+//           binade (elements more than 2^14 below the tile maximum keep fewer bits; they do not matter in a dot product
+//           with it).  Products h h' -> one accumulator, h l' + l h' -> a second one (scaled 2^11), the dropped l l' is
+//           below 2^-22: THREE products on v_mfma_f32_32x32x16_f16 instead of six, 4 instead of 6 bytes per operand
+//           element in LDS and in the weight stream.  Power-of-two scalings are exact; the result differs from the fp32
+//           FMA chain by what two fp32 summation orders differ by (measured against float64: tests/test_gpu_atom.py).
+//           Weights are pre-scaled by 2^6 (|w| < 2^9 assumed: anything larger overflows fp16 loudly to inf).
+//           Ceiling 2500 / 3 TFLOP/s.
+//
+// LDS: [chunk][column][NP pieces x 16 channels x 2 B | 16 pad] = 112 / 80 B per (column, chunk): an odd multiple of 16 B, so
+// fragment reads and the 8-byte staging stores are conflict-free.
 #include "ms_common.h"
 #include <stdlib.h>
+#include <type_traits>
+#ifndef ATOM_LB3
+#define ATOM_LB3 0
+#endif
 
 namespace {
 
@@ -31,36 +44,66 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int XRS = 112;          // bytes per LDS column of one 16-channel chunk: 3 pieces x 32 + 16
+constexpr float WSCALE = 64.f;            // NP = 2: weights are packed as fp16 pieces of 64 w
+constexpr float CROSS = 1.f / 2048.f;     // NP = 2: scale of the low piece
 
-// (a, b) -> three packed bf16 pairs with a = h.lo + m.lo + l.lo exactly (conv_rows3.hip)
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+template <int NP> __host__ __device__ constexpr int xrs() { return NP * 32 + 16; }   // bytes per LDS column of one chunk
+
+// (a, b) -> NP packed 16-bit pairs.  NP = 3: a = o[0].lo + o[1].lo + o[2].lo exactly (bf16, conv_rows3.hip);
+// NP = 2: a = o[0].lo + o[1].lo / 2048 to 22 bits (fp16; the caller has scaled a into fp16's range)
+template <int NP>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&o)[NP]) {
     const f32x2 v = {a, b};
-    const bf16x2 hi = __builtin_convertvector(v, bf16x2);
-    const f32x2 r1 = v - __builtin_convertvector(hi, f32x2);
-    const bf16x2 mi = __builtin_convertvector(r1, bf16x2);
-    const f32x2 r2 = r1 - __builtin_convertvector(mi, f32x2);
-    const bf16x2 lo = __builtin_convertvector(r2, bf16x2);
-    h = __builtin_bit_cast(unsigned, hi);
-    m = __builtin_bit_cast(unsigned, mi);
-    l = __builtin_bit_cast(unsigned, lo);
+    if constexpr (NP == 3) {
+        const bf16x2 hi = __builtin_convertvector(v, bf16x2);
+        const f32x2 r1 = v - __builtin_convertvector(hi, f32x2);
+        const bf16x2 mi = __builtin_convertvector(r1, bf16x2);
+        const f32x2 r2 = r1 - __builtin_convertvector(mi, f32x2);
+        const bf16x2 lo = __builtin_convertvector(r2, bf16x2);
+        o[0] = __builtin_bit_cast(unsigned, hi);
+        o[1] = __builtin_bit_cast(unsigned, mi);
+        o[2] = __builtin_bit_cast(unsigned, lo);
+    } else {
+        const f16x2 hi = __builtin_convertvector(v, f16x2);
+        const f32x2 r = (v - __builtin_convertvector(hi, f32x2)) * 2048.f;
+        const f16x2 lo = __builtin_convertvector(r, f16x2);
+        o[0] = __builtin_bit_cast(unsigned, hi);
+        o[1] = __builtin_bit_cast(unsigned, lo);
+    }
 }
 
-__device__ __forceinline__ void split_quad(const float (&e)[4], uint2 (&o)[3]) {
-    unsigned h0, m0, l0, h1, m1, l1;
-    split_pair(e[0], e[1], h0, m0, l0);
-    split_pair(e[2], e[3], h1, m1, l1);
-    o[0] = make_uint2(h0, h1);
-    o[1] = make_uint2(m0, m1);
-    o[2] = make_uint2(l0, l1);
+template <int NP>
+__device__ __forceinline__ void split_quad(const float (&e)[4], uint2 (&o)[NP]) {
+    unsigned a[NP], b[NP];
+    split_pair<NP>(e[0], e[1], a);
+    split_pair<NP>(e[2], e[3], b);
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) o[pp] = make_uint2(a[pp], b[pp]);
+}
+
+// block scale of a tile whose largest magnitude is m: S = 2^k with m S in [2^14, 2^15), and 1 / S (both exact powers of
+// two); 1 for a zero / denormal-range / non-finite maximum
+__device__ __forceinline__ void block_scale(float m, float& S, float& invS) {
+    const unsigned eb = (__builtin_bit_cast(unsigned, m) >> 23) & 0xFFu;
+    const bool ok = eb >= 16u && eb <= 250u;
+    S = ok ? __builtin_bit_cast(float, (268u - eb) << 23) : 1.f;
+    invS = ok ? __builtin_bit_cast(float, (eb - 14u) << 23) : 1.f;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
 }
 
 // ---- weight image ------------------------------------------------------------------------------------------
-// image[conv][ms][chunk][tap][piece][lane] (16 B each): lane's A fragment of v_mfma_f32_32x32x16_bf16 for output
-// rows ms*32 + (lane & 31), contraction channels chunk*16 + 8*(lane >> 5) + 0..7, tap `tap`.
-__host__ __device__ constexpr size_t atom_conv_image_u4(int C) { return (size_t)(C / 32) * (C / 16) * 9 * 64; }
+// image[conv][ms][chunk][tap][piece][lane] (16 B each): lane's A fragment of the 32x32x16 MFMA for output rows
+// ms*32 + (lane & 31), contraction channels chunk*16 + 8*(lane >> 5) + 0..7, tap `tap`.
+__host__ __device__ constexpr size_t atom_conv_image_u4(int C, int NP) { return (size_t)(C / 32) * (C / 16) * 3 * NP * 64; }
 
 struct AtomPackJob {
     const float* w0;
@@ -69,6 +112,7 @@ struct AtomPackJob {
     int C;
     int first_block;     // prefix sum of blocks over the jobs
     int backward;        // 1: the images of the backward-data pass (rows = input channels, taps flipped, conv1 first)
+    int np;              // pieces per element (3: bf16 x 3, 2: fp16 x 2 of 64 w)
 };
 constexpr int ATOM_PACK_MAX = 16;
 struct AtomPackTable {
@@ -76,7 +120,7 @@ struct AtomPackTable {
     AtomPackJob job[ATOM_PACK_MAX];
 };
 
-// one thread = one lane's 16-byte fragment of all three pieces of one (conv, ms, chunk, tap)
+// one thread = one lane's 16-byte fragment of all pieces of one (conv, ms, chunk, tap)
 __global__ __launch_bounds__(256) void k_atom_pack(AtomPackTable t) {
     int j = 0;
 #pragma unroll 1
@@ -108,16 +152,23 @@ __global__ __launch_bounds__(256) void k_atom_pack(AtomPackTable t) {
             a = w[((size_t)(k0 + 2 * q) * C + row) * 3 + (2 - tap)];
             b = w[((size_t)(k0 + 2 * q + 1) * C + row) * 3 + (2 - tap)];
         }
-        split_pair(a, b, pc[0][q], pc[1][q], pc[2][q]);
+        if (jb.np == 3) {
+            unsigned o[3];
+            split_pair<3>(a, b, o);
+            pc[0][q] = o[0]; pc[1][q] = o[1]; pc[2][q] = o[2];
+        } else {
+            unsigned o[2];
+            split_pair<2>(a * WSCALE, b * WSCALE, o);
+            pc[0][q] = o[0]; pc[1][q] = o[1]; pc[2][q] = 0u;
+        }
     }
-    u32x4* dst = jb.image + (size_t)conv * atom_conv_image_u4(C) + ((size_t)((ms * NC + chunk) * 3 + tap) * 3) * 64 + lane;
-#pragma unroll
-    for (int pp = 0; pp < 3; ++pp) dst[pp * 64] = u32x4{pc[pp][0], pc[pp][1], pc[pp][2], pc[pp][3]};
+    u32x4* dst = jb.image + (size_t)conv * atom_conv_image_u4(C, jb.np) + ((size_t)((ms * NC + chunk) * 3 + tap) * jb.np) * 64 + lane;
+    for (int pp = 0; pp < jb.np; ++pp) dst[pp * 64] = u32x4{pc[pp][0], pc[pp][1], pc[pp][2], pc[pp][3]};
 }
 
 // ---- the fused kernel ---------------------------------------------------------------------------------------
 struct AtomP {
-    int B, C, L, dil, NO, tiles_per_row, NXA;      // NXA: allocated LDS columns per chunk (>= NTP + 2 dil + 3)
+    int B, C, L, dil, NO, tiles_per_row;           // NO: output columns per tile
     float slope;
 };
 
@@ -136,23 +187,35 @@ struct AtomCfg {
 // 4 = no x window loads / staging, 5 = no MFMAs.
 //
 // Persistent workgroups: the grid is the number of workgroups the chip holds at once; each walks the tiles
-// blockIdx.x, + gridDim.x, ...  Per tile:   [x window(t) registers -> split -> LDS] [issue the x window loads of tile
-// t + 1 into registers] [GEMM 1] [t tile -> LDS (+ stores of t)] [GEMM 2] [stores of y (and u)] -- the next tile's loads
-// and this tile's stores travel under the two GEMMs, so HBM and the matrix pipe overlap inside ONE workgroup.
+// blockIdx.x, + gridDim.x, ...  Per tile:   [x window(t) registers -> split -> LDS] [GEMM 1] [issue the x window loads of
+// tile t + 1 into registers] [t tile -> LDS (+ stores of t)] [GEMM 2] [stores of y (and u)] -- the next tile's loads and this
+// tile's stores travel under the GEMMs, so HBM and the matrix pipe overlap inside ONE workgroup.
+// (A wave's vector-memory operations complete IN ORDER: a wait for a weight fragment also waits for every older load.  NP = 2
+//  issues the next window's HBM loads BEHIND the first GEMM, so that the first wait that covers them sits a t epilogue and a
+//  chunk later; the NP = 3 form keeps r03's placement in front of the first GEMM.)
 // MODE 0: forward, inference (nothing saved);  1: forward, training (also stores t and u);
 // MODE 2: BACKWARD DATA of the atom.  With g = dL/dy:   gt = conv1^T(g * lrelu'(u)),   gx = g + conv_d^T(gt * lrelu'(t)).
 //   Same two-GEMM structure with the roles mirrored: X = g, the window is multiplied by the LeakyReLU derivative taken from
 //   u (U, read) on its way into LDS; GEMM 0 is the dilation-1 conv transposed (halo 1), its raw result gt is stored (T: the
 //   weight gradient of the dilated conv needs it) and, multiplied by the derivative from t (Tm, read), becomes the LDS operand
-//   of GEMM 1, the dilated conv transposed (halo d): a tile yields NO = NTP - 2 d output columns.
-template <int C, int NTP, int NW, int MODE, int DBG = 0>
-__global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* __restrict__ X, const u32x4* __restrict__ IMG,
+//   of GEMM 1, the dilated conv transposed (halo d): a tile yields NTP - 2 d output columns.
+// Measured and dropped in r04 (tools/scratch/probe_atom_np.py, B = 32): a ring of four fragment buffers (spills at 64 channels,
+// no gain at 128: the kernel is not bound by the weight stream's latency); the second GEMM with swapped operands so that the
+// epilogue moves 16 bytes per lane (one channel per lane: 64 scattered 16-byte pieces per instruction -- 5-15 % SLOWER than
+// dword accesses that are 128 contiguous bytes per channel row); two tile widths dealt so that the persistent workgroups get
+// equal column counts (-4 % at 128 channels, +8 % at 64 where the second GEMM body spills); a start stagger of the second
+// resident workgroup and s_setprio around the GEMMs (0 to +5 % slower).
+template <int C, int NTP, int NW, int MODE, int NP, int DBG = 0>
+__global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom_fwd(AtomP p, const float* __restrict__ X, const u32x4* __restrict__ IMG,
                                                  const float* __restrict__ b0, const float* __restrict__ b1,
                                                  float* __restrict__ Y, float* __restrict__ T, float* __restrict__ U,
                                                  const float* __restrict__ Tm) {
     constexpr bool SAVE = MODE == 1, BWD = MODE == 2;
     typedef AtomCfg<C, NTP, NW> Cfg;
     constexpr int TM = Cfg::TM, WGN = Cfg::WGN, TN = Cfg::TN, NC = Cfg::NC, ROUNDS = Cfg::ROUNDS, NT = Cfg::NT;
+    constexpr int XRS = xrs<NP>();
+    constexpr bool SC = NP == 2;                     // block-scaled fp16 pieces
+    constexpr bool XLATE = NP == 2;                  // next window's loads issued behind GEMM 1 (see above)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_atom[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: everything derived from it is scalar
@@ -212,8 +275,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
     // backward: the window of u (this tile; not prefetched: it would double the registers held across the GEMMs) gives
     // the LeakyReLU derivative the gradient window is multiplied by
     f32x4 ru[BWD ? ROUNDS : 1][4];
-    auto load_u = [&](int tile) {
-        const int bb = tile / p.tiles_per_row, cc0 = (tile - bb * p.tiles_per_row) * p.NO;
+    auto load_u = [&](int bb, int cc0) {
         const int base = 4 * bb * C * L;
 #pragma unroll
         for (int r = 0; r < (BWD ? ROUNDS : 0); ++r) {
@@ -224,7 +286,30 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                 ru[r][cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, goff, base + cc * 4 * L, 0));
         }
     };
-    auto store_x = [&]() {
+    // biases and the two block-scale exchange areas live behind the window
+    float* sbias = reinterpret_cast<float*>(smem_atom + NC * XCS);
+    float* smax1 = sbias + 2 * C;                                    // [NW]: per-wave |max| of the NEXT tile's window
+    float* smax2 = smax1 + NW;                                       // [NW]: per-wave |max| of this tile's t operand
+    // (the largest magnitude of the raw window bounds the operand: the backward pass multiplies it by 1 or the slope)
+    auto publish_window_max = [&]() {
+        if (!SC) return;
+        float m = 0.f;
+#pragma unroll
+        for (int r = 0; r < (DBG == 4 ? 0 : ROUNDS); ++r)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(rx[r][cc][e]));
+        m = wave_max(m);
+        if (lane == 0) smax1[wid] = m;
+    };
+    auto read_max = [&](const float* sm) {
+        float m = sm[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = fmaxf(m, sm[w]);
+        return m;
+    };
+    auto store_x = [&](float S) {
 #pragma unroll
         for (int r = 0; r < (DBG == 4 ? 0 : ROUNDS); ++r) {
 #pragma unroll
@@ -236,64 +321,74 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) c4[cc] = ru[r][cc][e] > 0.f ? c4[cc] : c4[cc] * p.slope;
                 }
-                uint2 o3[3];
-                split_quad(c4, o3);
+                if (SC) {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) c4[cc] *= S;
+                }
+                uint2 o3[NP];
+                split_quad<NP>(c4, o3);
                 unsigned char* dst = smem_atom + u_lbase[r] + i * XRS;
 #pragma unroll
-                for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(dst + pp * 32) = o3[pp];
+                for (int pp = 0; pp < NP; ++pp) *reinterpret_cast<uint2*>(dst + pp * 32) = o3[pp];
             }
         }
     };
 
-    // ---- A fragments: image -> registers, one chunk ahead (pinned in place: the machine scheduler would otherwise sink
-    // every load to its first use and serialise the L2 latency into the MFMA stream)
+    // ---- A fragments: image -> registers, one chunk ahead through two buffers (pinned in place: the machine scheduler would
+    // otherwise sink every load to its first use and serialise the L2 latency into the MFMA stream)
     // (buffer loads: lane part = lane * 16 + the wave's row block, everything else is a literal scalar offset -- 64-bit
     //  per-fragment pointers would be hoisted out of the tile loop and eat ~100 registers)
-    bf16x8 fa[2][TM][3][3];
+    u32x4 fa[2][TM][3][NP];
     const auto rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(IMG), 0, 0x80000000u, 0x00020000);
-    const int a_voff = lane * 16 + wm * TM * NC * 9 * 1024;
-    auto load_a = [&](int conv, int chunk, bf16x8 (&dst)[TM][3][3]) {
+    const int a_voff = lane * 16 + wm * TM * NC * 3 * NP * 1024;
+    // q: chunk counter inside a tile, 0 .. 2 NC - 1 (GEMM 0's chunks, then GEMM 1's); buffer q & 1
+    auto load_a = [&](int q) {
+        const int conv = q / NC, chunk = q % NC;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
-                for (int pp = 0; pp < 3; ++pp)
-                    dst[i][s][pp] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                        rsI, a_voff, (int)(conv * atom_conv_image_u4(C) * 16) + ((i * NC + chunk) * 9 + s * 3 + pp) * 1024, 0));
+                for (int pp = 0; pp < NP; ++pp)
+                    fa[q & 1][i][s][pp] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        rsI, a_voff, (int)(conv * atom_conv_image_u4(C, NP) * 16) + ((i * NC + chunk) * 3 * NP + s * NP + pp) * 1024, 0));
     };
 
     f32x16 acc[TM][TN];
+    f32x16 acx[SC ? TM : 1][SC ? TN : 1];            // NP = 2: the cross products h l' + l h' (scaled 2^11)
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    acc[i][j][r] = 0.f;
+                    if (SC) acx[i][j][r] = 0.f;
+                }
     };
     // one GEMM over the LDS-resident operand: B fragment of (chunk, tap s, column sub-tile j) = 16 bytes per piece at
-    // column (col0 + 32 j + l31 + s * step), channels 8h .. 8h + 7 of the chunk.  next: what the last chunk prefetches
-    // (0: conv 1's chunk 0 for the second GEMM, 1: conv 0's chunk 0 for the next tile, 2: nothing)
-    auto gemm = [&](int conv, int cs, int step, int next) {
+    // column (col0 + 32 j + l31 + s * step), channels 8h .. 8h + 7 of the chunk.  more: a next tile exists (its first chunk's
+    // fragments are requested from the tail of the second GEMM)
+    auto gemm = [&](auto gc, int step, bool more) {
+        constexpr int g = decltype(gc)::value, TNE = TN;
         const unsigned char* Bs = smem_atom + ((wn * TN) * 32 + l31) * XRS + h * 16;
-        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};      // piece pairs, smallest products first
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch) {
+            const int q = g * NC + ch, qn = q + 1;
             if (DBG == 1) {
-                if (ch == 0 && conv == 0) load_a(conv, 1, fa[1]);
-            } else if (ch + 1 < NC) load_a(conv, ch + 1, fa[(ch + 1) & 1]);
-            else if (next == 0) load_a(1, 0, fa[(ch + 1) & 1]);
-            else if (next == 1) load_a(0, 0, fa[(ch + 1) & 1]);
-            bf16x8 fb[2][TN][3];
-            auto fragb = [&](int s, bf16x8 (&dst)[TN][3]) {
+                if (q == 0) load_a(1);
+            } else if (qn < 2 * NC) load_a(qn);
+            else if (more) load_a(0);
+            u32x4 fb[2][TNE][NP];
+            auto fragb = [&](int s, u32x4 (&dst)[TNE][NP]) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TNE; ++j)
 #pragma unroll
-                    for (int pp = 0; pp < 3; ++pp)
-                        dst[j][pp] = *reinterpret_cast<const bf16x8*>(Bs + ch * cs + (j * 32 + s * step) * XRS + pp * 32);
+                    for (int pp = 0; pp < NP; ++pp)
+                        dst[j][pp] = *reinterpret_cast<const u32x4*>(Bs + ch * XCS + (j * 32 + s * step) * XRS + pp * 32);
             };
-            // (C = 32: one fragment buffer -- the twelve registers of the second one are what keeps three waves per SIMD, and
+            // (C = 32: one fragment buffer -- the registers of the second one are what keeps three waves per SIMD, and
             //  with three waves the other two cover the ds_read latency)
             constexpr bool FB2 = C != 32;
             if (FB2 && (DBG != 2 || ch == 0)) fragb(0, fb[0]);
@@ -303,18 +398,35 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                 if (!FB2 && (DBG != 2 || (ch == 0 && s == 0))) fragb(s, fb[s & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (DBG == 5) continue;
+                if constexpr (NP == 3) {
+                    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};      // piece pairs, smallest products first
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TNE; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                    __builtin_bit_cast(bf16x8, fa[q & 1][i][s][PA[t]]), __builtin_bit_cast(bf16x8, fb[s & 1][j][PB[t]]),
+                                    acc[i][j], 0, 0, 0);
+                } else {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ch & 1][i][s][PA[t]], fb[s & 1][j][PB[t]],
-                                                                                acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TNE; ++j) {
+                            const f16x8 ah = __builtin_bit_cast(f16x8, fa[q & 1][i][s][0]), al = __builtin_bit_cast(f16x8, fa[q & 1][i][s][1]);
+                            const f16x8 bh = __builtin_bit_cast(f16x8, fb[s & 1][j][0]), bl = __builtin_bit_cast(f16x8, fb[s & 1][j][1]);
+                            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acx[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
+                            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acx[i][j], 0, 0, 0);
+                        }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
 
     // per-lane parts of the result offsets (bytes): column n of sub-tile j, channel half h
     int o_lane[TN];
@@ -323,20 +435,28 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
 
     int tile = blockIdx.x;
     if (tile < ntiles) load_x(tile);
-    load_a(0, 0, fa[0]);
+    load_a(0);
     // biases: once per workgroup into LDS behind the window (an epilogue then waits ~100 cycles for a ds_read, not for L2)
-    float* sbias = reinterpret_cast<float*>(smem_atom + NC * XCS);
     if (!BWD) {
         for (int i = tid; i < 2 * C; i += NT) sbias[i] = i < C ? b0[i] : b1[i - C];
     }
+    if (SC) {
+        publish_window_max();                        // (waits for the first window)
+        __syncthreads();
+    }
     // PRE: the per-tile dependent loads of the epilogues (the residual; backward: t for the derivative) are issued a GEMM
-    // ahead of their use where the registers allow (<= 64 channels): with 2-3 workgroups per CU every memory round trip a
-    // tile waits for is throughput lost
-    constexpr bool PRE = C <= 64;
+    // ahead of their use where the registers allow: with 2-3 workgroups per CU every memory round trip a tile waits for is
+    // throughput lost
+#ifndef ATOM_PRE32
+#define ATOM_PRE32 0
+#endif
+    constexpr bool PRE = C == 64 || (C == 32 && (NP == 3 || ATOM_PRE32));
     for (; tile < ntiles; tile += gridDim.x) {
         const int b = tile / p.tiles_per_row, c0 = (tile - b * p.tiles_per_row) * p.NO;
+        const int no = p.NO;
+        const int wcol = wn * TN * 32;                               // first tile column of this wave's sub-tiles
         const int base = 4 * (b * C * L + c0);                      // byte offset of (row b, channel 0, column c0)
-        if (BWD) load_u(tile);
+        if (BWD) load_u(b, c0);
         int L4;                                                      // 4 L, opaque to the optimiser: the per-channel scalar offsets
         asm volatile("s_mov_b32 %0, %1" : "=s"(L4) : "s"(4 * L));    // are then formed where they are used (2 scalar ops), not hoisted
         constexpr bool PRE_T = BWD && C == 64;          // (C = 32: measured slower with the derivative operand hoisted)
@@ -346,7 +466,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int gc = c0 - h2 + (wn * TN + j) * 32 + l31;
+                    const int gc = c0 - h2 + wcol + j * 32 + l31;
                     const unsigned o_m = (gc >= 0 && gc < L) ? (unsigned)o_lane[j] : OOB;
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -354,31 +474,30 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                             rsM, o_m, base + ((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2)) * L4, 0));
                 }
         }
-        store_x();                                                   // (waits for this tile's window)
+        float S1 = 1.f, iS1 = 1.f;
+        if (SC) block_scale(read_max(smax1), S1, iS1);              // (published behind the previous tile / in the prologue)
+        store_x(S1);                                                 // (waits for this tile's window)
         zero_acc();
         const int nxt = tile + gridDim.x;
-        if (nxt < ntiles) load_x(nxt);                              // travels under both GEMMs
+        if (!XLATE && nxt < ntiles) load_x(nxt);                    // travels under both GEMMs
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                             // x window staged
-        gemm(0, XCS, h1, 0);                                         // t (pre-activation) on columns c0-h2 .. c0-h2+NTP-1
+        gemm(I0{}, h1, nxt < ntiles);                                // t (pre-activation) on columns c0-h2 .. c0-h2+NTP-1
+        if (XLATE && nxt < ntiles) load_x(nxt);                     // travels under the t epilogue and the second GEMM
+        __builtin_amdgcn_sched_barrier(0);
 
-        unsigned o_y[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = (wn * TN + j) * 32 + l31;
-            o_y[j] = (n < p.NO && c0 + n < L) ? (unsigned)o_lane[j] : OOB;
-        }
-
-        __syncthreads();                                             // every wave is done with the x window: t overwrites it
+        // ---- t epilogue, first half: accumulators -> the second GEMM's operand values, in place (fp32); stores of t
+        const float k1 = SC ? iS1 * (1.f / WSCALE) : 1.f;           // undoes the window's and the weights' scales
+        float tmax = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int col = (wn * TN + j) * 32 + l31;           // t tile column <-> global column c0 - h2 + col
+                const int col = wcol + j * 32 + l31;                // t tile column <-> global column c0 - h2 + col
                 const int gc = c0 - h2 + col;
                 const bool inrow = gc >= 0 && gc < L;                // outside the row t is the second conv's ZERO padding
                 // the tile's own columns of t are stored (forward training: the saved activation; backward: the raw gt)
-                const unsigned o_t = (MODE != 0 && DBG != 3 && inrow && col >= h2 && col < h2 + p.NO) ? (unsigned)o_lane[j] : OOB;
+                const unsigned o_t = (MODE != 0 && DBG != 3 && inrow && col >= h2 && col < h2 + no) ? (unsigned)o_lane[j] : OOB;
                 float tm[BWD ? 16 : 1];                              // backward: t itself, for the derivative
                 if (PRE_T) {
 #pragma unroll
@@ -398,12 +517,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                         const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + ch0);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float v = acc[i][j][4 * g + q] + bv[q];
+                            float v = acc[i][j][4 * g + q];
+                            if (SC) v = (v + acx[i][j][4 * g + q] * CROSS) * k1;
+                            v += bv[q];
                             e[q] = inrow ? (v > 0.f ? v : v * p.slope) : 0.f;
                         }
                     } else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) e[q] = acc[i][j][4 * g + q];
+                        for (int q = 0; q < 4; ++q) {
+                            float v = acc[i][j][4 * g + q];
+                            if (SC) v = (v + acx[i][j][4 * g + q] * CROSS) * k1;
+                            e[q] = v;
+                        }
                     }
                     if (MODE != 0) {
 #pragma unroll
@@ -414,13 +539,45 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
 #pragma unroll
                         for (int q = 0; q < 4; ++q) e[q] = inrow ? (tm[4 * g + q] > 0.f ? e[q] : e[q] * p.slope) : 0.f;
                     }
-                    uint2 o3[3];
-                    split_quad(e, o3);
-                    unsigned char* dst = smem_atom + (col * XRS + 8 * h) + ((chs >> 4) * TCS + (chs & 15) * 2);
 #pragma unroll
-                    for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(dst + pp * 32) = o3[pp];
+                    for (int q = 0; q < 4; ++q) {
+                        acc[i][j][4 * g + q] = e[q];
+                        if (SC) tmax = fmaxf(tmax, fabsf(e[q]));
+                    }
                 }
             }
+        if (SC) {
+            tmax = wave_max(tmax);
+            if (lane == 0) smax2[wid] = tmax;
+        }
+        __syncthreads();                                             // every wave is done with the x window: t overwrites it
+        float S2 = 1.f, iS2 = 1.f;
+        if (SC) block_scale(read_max(smax2), S2, iS2);
+        // ---- second half: split (x S2) -> LDS
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wcol + j * 32 + l31;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int chs = (wm * TM + i) * 32 + 8 * g;
+                    float e[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) e[q] = SC ? acc[i][j][4 * g + q] * S2 : acc[i][j][4 * g + q];
+                    uint2 o3[NP];
+                    split_quad<NP>(e, o3);
+                    unsigned char* dst = smem_atom + (col * XRS + 8 * h) + ((chs >> 4) * TCS + (chs & 15) * 2);
+#pragma unroll
+                    for (int pp = 0; pp < NP; ++pp) *reinterpret_cast<uint2*>(dst + pp * 32) = o3[pp];
+                }
+            }
+        unsigned o_y[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = wcol + j * 32 + l31;
+            o_y[j] = (n < no && c0 + n < L) ? (unsigned)o_lane[j] : OOB;
+        }
         float xrp[PRE ? TM : 1][PRE ? TN : 1][16];                  // the residual x values of this lane's outputs (L2-warm)
         if (PRE) {
 #pragma unroll
@@ -435,8 +592,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
         zero_acc();
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                             // t tile complete
-        gemm(1, TCS, h2, nxt < ntiles ? 1 : 2);                      // output column n reads t tile columns n, n + h2, n + 2 h2
+        gemm(I1{}, h2, nxt < ntiles);                                // output column n reads t tile columns n, n + h2, n + 2 h2
 
+        const float k2 = SC ? iS2 * (1.f / WSCALE) : 1.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -459,7 +617,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                     if (!BWD) bv = *reinterpret_cast<const f32x4*>(sbias + C + ch0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        float v = acc[i][j][4 * g + q] + bv[q];
+                        float v = acc[i][j][4 * g + q];
+                        if (SC) v = (v + acx[i][j][4 * g + q] * CROSS) * k2;
+                        v += bv[q];
                         if (!BWD) v = v > 0.f ? v : v * p.slope;
                         if (SAVE) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsU, oy, base + (chs + q) * L4, 0);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + xr[4 * g + q]), rsY, oy,
@@ -467,46 +627,64 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                     }
                 }
             }
+        if (SC && nxt < ntiles) publish_window_max();               // (waits for the next tile's window: issued a GEMM ago)
         __syncthreads();                                             // the t tile is dead: the next window may overwrite it
     }
 }
 
-template <int C, int NTP, int NW, int MODE>
-int launch_atom_mode(AtomP p, const float* x, const void* image, const float* b0, const float* b1, float* y, float* t,
-                     float* u, const float* tm, hipStream_t s) {
+// pieces per operand element: 2 (block-scaled fp16 x 2, three products) unless MSYNTH_ATOM_NP=3 (bf16 x 3, six products:
+// the r03 kernel, bitwise equal to the two row-tile launches)
+int atom_np() {
+    static const int np = (getenv("MSYNTH_ATOM_NP") && atoi(getenv("MSYNTH_ATOM_NP")) == 3) ? 3 : 2;
+    return np;
+}
+
+constexpr int MAX_DEV = 64;            // per-device launch parameters (ms_common.h: one-time launch setup)
+
+template <int C, int NTP, int NW, int MODE, int NP>
+int launch_atom_np(AtomP p, const float* x, const void* image, const float* b0, const float* b1, float* y, float* t,
+                   float* u, const float* tm, hipStream_t s) {
     p.NO = MODE == 2 ? ((NTP - 2 * p.dil) & ~3) : NTP - 4;
     if (p.NO < 4) return MS_ERR_UNSUPPORTED;
     p.tiles_per_row = (p.L + p.NO - 1) / p.NO;
-    p.NXA = NTP + 22;
-    const size_t lds = (size_t)(C / 16) * p.NXA * XRS + 2 * C * sizeof(float);       // window + both biases
+    const size_t lds = (size_t)(C / 16) * (NTP + 22) * xrs<NP>() + (2 * C + 2 * NW) * sizeof(float);       // window + biases + scale exchange
     if (lds > 158 * 1024) return MS_ERR_UNSUPPORTED;
-    const void* fn = reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, NW, MODE>);
-    static int wgs_per_cu = 0, n_cu = 0;
-    if (!wgs_per_cu) {
+    const void* fn = reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, NW, MODE, NP>);
+    static int wgs_per_cu[MAX_DEV] = {}, n_cu[MAX_DEV] = {};
+    const int dev = ms_current_device();
+    if (!__atomic_load_n(&wgs_per_cu[dev], __ATOMIC_ACQUIRE)) {      // (idempotent: racing first calls compute the same values)
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-        int nb = 0, dev = 0;
+        int nb = 0;
         hipDeviceProp_t prop;
-        (void)hipGetDevice(&dev);
         (void)hipGetDeviceProperties(&prop, dev);
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        n_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * NW, lds) != hipSuccess || nb < 1) nb = 1;
-        wgs_per_cu = nb;
+        __atomic_store_n(&wgs_per_cu[dev], nb, __ATOMIC_RELEASE);
     }
+    const long long slots = (long long)n_cu[dev] * wgs_per_cu[dev];
     const long long ntiles = (long long)p.B * p.tiles_per_row;
-    const long long slots = (long long)n_cu * wgs_per_cu;
     const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
     static const int dbg = getenv("MSYNTH_ATOM_DBG") ? atoi(getenv("MSYNTH_ATOM_DBG")) : 0;       // timing probes
-    if (dbg && MODE == 1 && NW == 4 && (C == 64 || C == 32)) {
+    if constexpr (MODE == 1 && NW == 4 && NTP * C == 128 * 64 && NP == 2) {
+        if (dbg) {
 #define MS_ATOM_DBG(D_) if (dbg == D_) { \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, NW, 1, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); \
-            hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, 1, D_>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u, tm); MS_CHECK_LAUNCH(); return MS_OK; }
-        MS_ATOM_DBG(1) MS_ATOM_DBG(2) MS_ATOM_DBG(3) MS_ATOM_DBG(4) MS_ATOM_DBG(5)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, NW, 1, NP, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); \
+            hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, 1, NP, D_>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u, tm); MS_CHECK_LAUNCH(); return MS_OK; }
+            MS_ATOM_DBG(1) MS_ATOM_DBG(2) MS_ATOM_DBG(3) MS_ATOM_DBG(4) MS_ATOM_DBG(5)
 #undef MS_ATOM_DBG
+        }
     }
-    ms_note_kernel("k_atom_fwd<%d, %d, %d, %d>", C, NTP, NW, MODE);
-    hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, MODE>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u, tm);
+    ms_note_kernel("k_atom_fwd<%d, %d, %d, %d, %d>", C, NTP, NW, MODE, NP);
+    hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, MODE, NP>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u, tm);
     MS_CHECK_LAUNCH();
     return MS_OK;
+}
+
+template <int C, int NTP, int NW, int MODE>
+int launch_atom_mode(const AtomP& p, const float* x, const void* image, const float* b0, const float* b1, float* y, float* t,
+                     float* u, const float* tm, hipStream_t s) {
+    if (atom_np() == 3) return launch_atom_np<C, NTP, NW, MODE, 3>(p, x, image, b0, b1, y, t, u, tm, s);
+    return launch_atom_np<C, NTP, NW, MODE, 2>(p, x, image, b0, b1, y, t, u, tm, s);
 }
 
 // mode 0 / 1: forward (t, u: the saved activations, both or neither);  mode 2: backward data (x = g, u and tm read, t = gt out)
@@ -520,13 +698,14 @@ int launch_atom(int mode, const AtomP& p, const float* x, const void* image, con
 
 int dispatch_atom(int mode, const ms_atom_desc* d, const float* x, const void* image, const float* b0, const float* b1,
                   float* y, float* t, float* u, const float* tm, hipStream_t s) {
-    AtomP p;
+    AtomP p = {};
     p.B = d->B; p.C = d->C; p.L = d->L; p.dil = d->dil; p.slope = d->slope;
     // tile width: the widest tile whose grid still spreads over the chip; narrow tiles when the whole problem is a few
     // dozen tiles (B = 1 inference: latency, not throughput)
     const long long cols = (long long)d->B * d->L;
     switch (d->C) {
         case 32: return launch_atom<32, 128, 4>(mode, p, x, image, b0, b1, y, t, u, tm, s);
+#ifndef ATOM_ONLY32
         case 64:
             if (cols < 124 * 128) return launch_atom<64, 64, 4>(mode, p, x, image, b0, b1, y, t, u, tm, s);
             return launch_atom<64, 128, 4>(mode, p, x, image, b0, b1, y, t, u, tm, s);
@@ -536,6 +715,7 @@ int dispatch_atom(int mode, const ms_atom_desc* d, const float* x, const void* i
         case 256:
             if (cols < 60 * 64 && mode != 2) return launch_atom<256, 32, 8>(mode, p, x, image, b0, b1, y, t, u, tm, s);
             return launch_atom<256, 64, 8>(mode, p, x, image, b0, b1, y, t, u, tm, s);
+#endif
         default: return MS_ERR_UNSUPPORTED;
     }
 }
@@ -554,7 +734,7 @@ extern "C" {
 
 size_t ms_residual_atom_image_bytes(int32_t C) {
     if (C <= 0 || C % 32) return 0;
-    return 2 * atom_conv_image_u4(C) * 16;
+    return 2 * atom_conv_image_u4(C, 3) * 16;                    // (the larger of the two piece schemes)
 }
 
 int ms_residual_atom_supported(const ms_atom_desc* d) {
@@ -578,6 +758,7 @@ int ms_residual_atom_pack_multi(const ms_atom_pack_desc* d, ms_stream_t stream) 
         t.job[i].C = C;
         t.job[i].first_block = blocks;
         t.job[i].backward = d->backward[i] ? 1 : 0;
+        t.job[i].np = atom_np();
         const int total = 2 * (C / 32) * (C / 16) * 3 * 64;
         blocks += (total + 255) / 256;
     }

@@ -15,8 +15,15 @@
 //     LDS, so rows of any length need no padding pass (api.hip pad4) and no dword loader;
 //   * split-K over channel slices fills the chip (tiles x slices ~ 512 workgroups); slices write raw slabs, a small finish
 //     kernel sums them in slice order (deterministic) and applies bias + LeakyReLU / the gradient add.
-// Arithmetic: the same exact 3-piece split and six products per multiply as conv_rows3.hip, fp32 accumulation; the
-// accumulation order differs from the row kernels' (other chunk / slice grouping): results agree to ~1e-7, not bitwise.
+// Arithmetic (template NP, as in atom_fused.hip):
+//   NP = 3  the exact 3-piece bf16 split and six products per multiply of conv_rows3.hip, fp32 accumulation;
+//   NP = 2  (r04, default) block-scaled two-piece fp16 operands, THREE products per multiply on v_mfma_f32_32x32x16_f16.  The
+//           block here is (batch row, 16-channel chunk): all five taps of an output column read that row's LDS segment, so
+//           one power-of-two scale per segment factors out of the chunk's partial sum.  The staging lanes of a row (16-64
+//           consecutive lanes of one wave) find the row's largest magnitude by lane shuffles -- no barrier --, scale, split,
+//           and leave 1 / scale in LDS; the MFMA waves start every chunk from zero accumulators and fold
+//           (acc + 2^-11 cross) / scale into the running fp32 sums (64 vector FMAs per 30 MFMAs, in the MFMAs' issue shadow).
+// The accumulation order differs from the row kernels' (other chunk / slice grouping): results agree to ~1e-7, not bitwise.
 #include "ms_common.h"
 #include <stdlib.h>
 
@@ -27,39 +34,64 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int XRS = 112;                 // bytes per LDS column of a 16-channel chunk: 3 pieces x 32 + 16
+template <int NP> __host__ __device__ constexpr int xrs() { return NP * 32 + 16; }   // bytes per LDS column of a 16-channel chunk
 constexpr int K5 = 5;
-constexpr int PX_MAX = 350;              // LDS columns per buffer (39.2 KB; two buffers, two workgroups per CU)
+constexpr int PX_MAX = 350;              // LDS columns per buffer (39.2 / 28 KB; two buffers)
+constexpr int R_MAX = 64;                // batch rows per tile (scale slots)
 constexpr unsigned OOB = 0xF0000000u;
+constexpr float WSCALE = 64.f;           // NP = 2: weights are packed as fp16 pieces of 64 w (|w| < 2^9)
+constexpr float CROSS = 1.f / 2048.f;    // NP = 2: weight of the low piece
 
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+// (a, b) -> NP packed 16-bit pairs: NP = 3 exact bf16 pieces; NP = 2 fp16 pieces a = o[0] + o[1] / 2048 (22 bits; the caller
+// has scaled a into fp16's range)
+template <int NP>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&o)[NP]) {
     const f32x2 v = {a, b};
-    const bf16x2 hi = __builtin_convertvector(v, bf16x2);
-    const f32x2 r1 = v - __builtin_convertvector(hi, f32x2);
-    const bf16x2 mi = __builtin_convertvector(r1, bf16x2);
-    const f32x2 r2 = r1 - __builtin_convertvector(mi, f32x2);
-    const bf16x2 lo = __builtin_convertvector(r2, bf16x2);
-    h = __builtin_bit_cast(unsigned, hi);
-    m = __builtin_bit_cast(unsigned, mi);
-    l = __builtin_bit_cast(unsigned, lo);
+    if constexpr (NP == 3) {
+        const bf16x2 hi = __builtin_convertvector(v, bf16x2);
+        const f32x2 r1 = v - __builtin_convertvector(hi, f32x2);
+        const bf16x2 mi = __builtin_convertvector(r1, bf16x2);
+        const f32x2 r2 = r1 - __builtin_convertvector(mi, f32x2);
+        const bf16x2 lo = __builtin_convertvector(r2, bf16x2);
+        o[0] = __builtin_bit_cast(unsigned, hi);
+        o[1] = __builtin_bit_cast(unsigned, mi);
+        o[2] = __builtin_bit_cast(unsigned, lo);
+    } else {
+        const f16x2 hi = __builtin_convertvector(v, f16x2);
+        const f32x2 r = (v - __builtin_convertvector(hi, f32x2)) * 2048.f;
+        const f16x2 lo = __builtin_convertvector(r, f16x2);
+        o[0] = __builtin_bit_cast(unsigned, hi);
+        o[1] = __builtin_bit_cast(unsigned, lo);
+    }
 }
 
-__device__ __forceinline__ void split_quad(const float (&e)[4], uint2 (&o)[3]) {
-    unsigned h0, m0, l0, h1, m1, l1;
-    split_pair(e[0], e[1], h0, m0, l0);
-    split_pair(e[2], e[3], h1, m1, l1);
-    o[0] = make_uint2(h0, h1);
-    o[1] = make_uint2(m0, m1);
-    o[2] = make_uint2(l0, l1);
+template <int NP>
+__device__ __forceinline__ void split_quad(const float (&e)[4], uint2 (&o)[NP]) {
+    unsigned a[NP], b[NP];
+    split_pair<NP>(e[0], e[1], a);
+    split_pair<NP>(e[2], e[3], b);
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) o[pp] = make_uint2(a[pp], b[pp]);
+}
+
+// block scale of values whose largest magnitude is m: S = 2^k with m S in [2^14, 2^15), and 1 / S; 1 for a zero /
+// denormal-range / non-finite maximum (atom_fused.hip)
+__device__ __forceinline__ void block_scale(float m, float& S, float& invS) {
+    const unsigned eb = (__builtin_bit_cast(unsigned, m) >> 23) & 0xFFu;
+    const bool ok = eb >= 16u && eb <= 250u;
+    S = ok ? __builtin_bit_cast(float, (268u - eb) << 23) : 1.f;
+    invS = ok ? __builtin_bit_cast(float, (eb - 14u) << 23) : 1.f;
 }
 
 // image[ms][chunk][tap][piece][lane] (16 B): rows ms*32 + (lane & 31), contraction channels chunk*16 + 8*(lane >> 5) + 0..7
 //   forward:        A[row = co][k = ci][tap] = W[co][ci][tap]
 //   backward data:  A[row = ci][k = co][tap] = W[co][ci][4 - tap]
 __global__ __launch_bounds__(256) void k_conv5_pack(const float* __restrict__ W, u32x4* __restrict__ img, int M, int CK,
-                                                   int backward) {
+                                                   int backward, int np) {
     const int NC = CK / 16;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over ms x chunk x tap x lane
     const size_t total = (size_t)(M / 32) * NC * K5 * 64;
@@ -81,11 +113,18 @@ __global__ __launch_bounds__(256) void k_conv5_pack(const float* __restrict__ W,
             a = W[((size_t)(k0 + 2 * q) * M + row) * K5 + (K5 - 1 - tap)];
             b = W[((size_t)(k0 + 2 * q + 1) * M + row) * K5 + (K5 - 1 - tap)];
         }
-        split_pair(a, b, pc[0][q], pc[1][q], pc[2][q]);
+        if (np == 3) {
+            unsigned o[3];
+            split_pair<3>(a, b, o);
+            pc[0][q] = o[0]; pc[1][q] = o[1]; pc[2][q] = o[2];
+        } else {
+            unsigned o[2];
+            split_pair<2>(a * WSCALE, b * WSCALE, o);
+            pc[0][q] = o[0]; pc[1][q] = o[1]; pc[2][q] = 0u;
+        }
     }
-    u32x4* dst = img + ((size_t)((ms * NC + chunk) * K5 + tap) * 3) * 64 + lane;
-#pragma unroll
-    for (int pp = 0; pp < 3; ++pp) dst[pp * 64] = u32x4{pc[pp][0], pc[pp][1], pc[pp][2], pc[pp][3]};
+    u32x4* dst = img + ((size_t)((ms * NC + chunk) * K5 + tap) * np) * 64 + lane;
+    for (int pp = 0; pp < np; ++pp) dst[pp * 64] = u32x4{pc[pp][0], pc[pp][1], pc[pp][2], pc[pp][3]};
 }
 
 struct C5P {
@@ -99,11 +138,13 @@ struct C5P {
 };
 
 // MODE 0: forward (X = x); MODE 1: backward data (X = gy, multiplied on load by act'(Xact) when Xact != nullptr)
-template <int MODE>
+template <int MODE, int NP>
 __global__ __launch_bounds__(512, 2) void k_conv5_img(C5P p, const float* __restrict__ X, const float* __restrict__ Xact,
                                                      const u32x4* __restrict__ IMG, const float* __restrict__ bias,
                                                      const float* __restrict__ add, float* __restrict__ Y,
                                                      float* __restrict__ slabs) {
+    constexpr int XRS = xrs<NP>();
+    constexpr bool SC = NP == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem5[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,6 +155,7 @@ __global__ __launch_bounds__(512, 2) void k_conv5_img(C5P p, const float* __rest
     const int nchunks = (cend - cbeg) / 16;
     const int buf_bytes = p.PX * XRS;
     const bool masked = MODE == 1 && Xact != nullptr;
+    float* sinv = reinterpret_cast<float*>(smem5 + 2 * buf_bytes);       // NP = 2: [2 buffers][R_MAX] 1 / scale of a row's chunk
 
     // (true sizes: a 4-sample vector that starts inside the last row may reach past the tensor -- those dwords read 0.0)
     const unsigned x_bytes = 4u * (unsigned)(p.B * p.CK * L);
@@ -122,9 +164,10 @@ __global__ __launch_bounds__(512, 2) void k_conv5_img(C5P p, const float* __rest
     const auto rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(IMG), 0, 0x80000000u, 0x00020000);
 
     // ---- staging units (two rounds of 512): unit = (batch row r, channel quad cq, 4-sample vector v); 16 consecutive
-    // lanes = 4 quads x 4 consecutive vectors.  Rows are contiguous runs of L floats, 4-byte aligned (any L).
+    // lanes = 4 quads x 4 consecutive vectors; a row = NVG (a power of two for NP = 2) consecutive 16-lane groups of ONE
+    // wave.  Rows are contiguous runs of L floats, 4-byte aligned (any L).
     unsigned u_goff[2];
-    int u_l[2], u_lbase[2];
+    int u_l[2], u_lbase[2], u_r[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int u = tid + 512 * k;
@@ -134,6 +177,7 @@ __global__ __launch_bounds__(512, 2) void k_conv5_img(C5P p, const float* __rest
         u_goff[k] = ok ? 4u * (unsigned)((((b0 + r) * p.CK) + 4 * cq) * L + 4 * v) : OOB;       // + (c0 + cc) * L * 4 (scalar)
         u_l[k] = ok ? 4 * v : (1 << 20);
         u_lbase[k] = (r * p.SS + 2 + 4 * v) * XRS + cq * 8;
+        u_r[k] = (r < p.R && (u & (16 * p.NVG - 1)) == 0) ? r : -1;           // the lane that publishes the row's 1 / scale
     }
     f32x4 rx[2][4], rxa[MODE == 1 ? 2 : 1][4];
     auto load_x = [&](int c0, bool live) {
@@ -147,9 +191,36 @@ __global__ __launch_bounds__(512, 2) void k_conv5_img(C5P p, const float* __rest
                     rxa[k][cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, u_goff[k], so + cc * 4 * L, 0));
             }
     };
-    auto store_x = [&](unsigned char* buf) {
+    // NP = 2: the scale of a row is STICKY across the chunks of the K loop: it moves only when the row's largest magnitude
+    // in a chunk, times the current scale, leaves [2^8, 2^15) (no overflow; fp16's normal range still holds every element
+    // down to 2^-22 of that maximum with 11 + 11 bits).  The MFMA waves can then keep accumulating across chunks and fold
+    // their partial sums into the running sums only where a scale has moved.
+    float Scur[2] = {0.f, 0.f};
+    auto store_x = [&](unsigned char* buf, float* inv_out) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 2; ++k) {
+            if (SC) {
+                // the row's largest magnitude in this chunk (the raw gradient bounds the masked one).  The row's lanes are
+                // 16 NVG consecutive lanes of this wave; lanes without a unit hold zeros (out-of-range loads)
+                float m = 0.f;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(rx[k][cc][e]));
+                // 16 lanes by DPP (quad swaps, half-row mirror, row mirror), wider spans by lane shuffles
+                m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, true)));
+                m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, true)));
+                m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x141, 0xF, 0xF, true)));
+                m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x140, 0xF, 0xF, true)));
+                for (int o = 16; o < 16 * p.NVG; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                const float ms = m * Scur[k];
+                if (!(ms >= 256.f && ms < 32768.f) && m > 0.f) {         // (also the first chunk: Scur = 0)
+                    float inv;
+                    block_scale(m * 4.f, Scur[k], inv);                  // largest magnitude at 2^12: room to grow and to shrink
+                }
+                if (Scur[k] == 0.f) Scur[k] = 1.f;                       // an all-zero row so far
+                if (u_r[k] >= 0) inv_out[u_r[k]] = 1.f / Scur[k];        // (a power of two: exact)
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (u_l[k] + e >= L) continue;                        // behind the row: the halo stays zero
@@ -158,29 +229,31 @@ __global__ __launch_bounds__(512, 2) void k_conv5_img(C5P p, const float* __rest
                 for (int cc = 0; cc < 4; ++cc) {
                     c4[cc] = rx[k][cc][e];
                     if (masked) c4[cc] = rxa[k][cc][e] > 0.f ? c4[cc] : c4[cc] * p.slope;
+                    if (SC) c4[cc] *= Scur[k];
                 }
-                uint2 o3[3];
-                split_quad(c4, o3);
+                uint2 o3[NP];
+                split_quad<NP>(c4, o3);
                 unsigned char* dst = buf + u_lbase[k] + e * XRS;
 #pragma unroll
-                for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(dst + pp * 32) = o3[pp];
+                for (int pp = 0; pp < NP; ++pp) *reinterpret_cast<uint2*>(dst + pp * 32) = o3[pp];
             }
+        }
     };
 
-    // ---- A fragments: one chunk (5 taps x 3 pieces) in registers, refilled tap by tap for the next chunk
-    bf16x8 fa[K5][3];
+    // ---- A fragments: one chunk (5 taps x NP pieces) in registers, refilled tap by tap for the next chunk
+    u32x4 fa[K5][NP];
     const int NC = p.CK / 16;
     const int a_voff = lane * 16;
-    const int a_row = ((blockIdx.y * 2 + wm) * NC) * (K5 * 3 * 1024);          // byte offset of (ms, chunk 0)
+    const int a_row = ((blockIdx.y * 2 + wm) * NC) * (K5 * NP * 1024);          // byte offset of (ms, chunk 0)
     auto load_a_tap = [&](int chunk_abs, int t) {
-        const int so = a_row + chunk_abs * (K5 * 3 * 1024) + t * 3 * 1024;
+        const int so = a_row + chunk_abs * (K5 * NP * 1024) + t * NP * 1024;
 #pragma unroll
-        for (int pp = 0; pp < 3; ++pp)
-            fa[t][pp] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsI, a_voff, so + pp * 1024, 0));
+        for (int pp = 0; pp < NP; ++pp)
+            fa[t][pp] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsI, a_voff, so + pp * 1024, 0));
     };
 
     // ---- B fragment bases: MFMA column n = wn*64 + j*32 + l31 -> (row r, sample l)
-    int bbase[2];
+    int bbase[2], brow[2];
     unsigned o_lane[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -188,6 +261,7 @@ __global__ __launch_bounds__(512, 2) void k_conv5_img(C5P p, const float* __rest
         const int r = n / L, l = n - r * L;
         const bool ok = r < p.R && b0 + r < p.B;
         bbase[j] = ok ? (r * p.SS + l) * XRS + h * 16 : h * 16;
+        brow[j] = r < p.R ? r : 0;
         o_lane[j] = ok ? 4u * (unsigned)((r * p.M + 4 * h) * L + l) : OOB;        // + ((b0*M + m) * L) * 4 (scalar)
     }
 
@@ -195,54 +269,90 @@ __global__ __launch_bounds__(512, 2) void k_conv5_img(C5P p, const float* __rest
     {
         const u32x4 z = {0u, 0u, 0u, 0u};
         for (int i = tid * 16; i < 2 * buf_bytes; i += 512 * 16) *reinterpret_cast<u32x4*>(smem5 + i) = z;
+        if (SC && tid < 2 * R_MAX) sinv[tid] = 1.f;
     }
     load_x(cbeg, true);
 #pragma unroll
     for (int t = 0; t < K5; ++t) load_a_tap(cbeg / 16, t);
     __syncthreads();
-    store_x(smem5);
+    store_x(smem5, sinv);
     load_x(cbeg + 16, nchunks > 1);
     __syncthreads();
 
-    f32x16 acc[2];
+    f32x16 acc[2];                                   // the running sums (NP = 2: fp32, unscaled except for WSCALE)
+    f32x16 cm[SC ? 2 : 1], cx[SC ? 2 : 1];          // NP = 2: main / cross partial sums under the rows' current scales
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            acc[j][r] = 0.f;
+            if (SC) cm[j][r] = cx[j][r] = 0.f;
+        }
+    float inv_cur[2] = {1.f, 1.f};
+    auto fold = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[j][r] = fmaf(fmaf(cx[j][r], CROSS, cm[j][r]), inv_cur[j], acc[j][r]);
+                cm[j][r] = cx[j][r] = 0.f;
+            }
+    };
 
-    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll 1
     for (int ch = 0; ch < nchunks; ++ch) {
         const unsigned char* Xs = smem5 + (ch & 1) * buf_bytes;
         unsigned char* Xn = smem5 + ((ch & 1) ^ 1) * buf_bytes;
         const bool more = ch + 1 < nchunks;
         const int a_next = (cbeg / 16) + (more ? ch + 1 : ch);
-        bf16x8 fb[2][2][3];
-        auto fragb = [&](int t, bf16x8 (&dst)[2][3]) {
+        u32x4 fb[2][2][NP];
+        auto fragb = [&](int t, u32x4 (&dst)[2][NP]) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int pp = 0; pp < 3; ++pp)
-                    dst[j][pp] = *reinterpret_cast<const bf16x8*>(Xs + bbase[j] + t * XRS + pp * 32);
+                for (int pp = 0; pp < NP; ++pp)
+                    dst[j][pp] = *reinterpret_cast<const u32x4*>(Xs + bbase[j] + t * XRS + pp * 32);
         };
+        if (SC) {
+            // a row's scale moved: what was accumulated under the old scale goes to the running sums first (rare)
+            const float i0 = sinv[(ch & 1) * R_MAX + brow[0]], i1 = sinv[(ch & 1) * R_MAX + brow[1]];
+            if (__any(i0 != inv_cur[0] || i1 != inv_cur[1])) {
+                if (ch > 0) fold();
+                inv_cur[0] = i0; inv_cur[1] = i1;
+            }
+        }
         fragb(0, fb[0]);
 #pragma unroll
         for (int t = 0; t < K5; ++t) {
             if (t + 1 < K5) fragb(t + 1, fb[(t + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NP == 3) {
+                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-            for (int s = 0; s < 6; ++s)
+                for (int s = 0; s < 6; ++s)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][PA[s]], fb[t & 1][j][PB[s]], acc[j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[t][PA[s]]),
+                                                                         __builtin_bit_cast(bf16x8, fb[t & 1][j][PB[s]]), acc[j], 0, 0, 0);
+            } else {
+                const f16x8 ah = __builtin_bit_cast(f16x8, fa[t][0]), al = __builtin_bit_cast(f16x8, fa[t][1]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f16x8 bh = __builtin_bit_cast(f16x8, fb[t & 1][j][0]), bl = __builtin_bit_cast(f16x8, fb[t & 1][j][1]);
+                    cx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, cx[j], 0, 0, 0);
+                    cm[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, cm[j], 0, 0, 0);
+                    cx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, cx[j], 0, 0, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             load_a_tap(a_next, t);                                     // this tap's registers are free: the next chunk's tap
-            if (t == 1 && more) store_x(Xn);                           // chunk ch+1: registers -> the other buffer
+            if (t == 1 && more) store_x(Xn, sinv + ((ch & 1) ^ 1) * R_MAX);   // chunk ch+1: registers -> the other buffer
             if (t == 2) load_x(cbeg + (ch + 2) * 16, ch + 2 < nchunks);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
+    if (SC) fold();
 
     // ---- epilogue: dword stores straight from the accumulators (32 lanes = 32 consecutive samples of one or two rows)
     int L4;
@@ -262,6 +372,7 @@ __global__ __launch_bounds__(512, 2) void k_conv5_img(C5P p, const float* __rest
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v = acc[j][4 * g + q];
+                if (SC) v *= 1.f / WSCALE;
                 if (fused) {
                     if (MODE == 0) {
                         v += bv[q];
@@ -289,6 +400,12 @@ __global__ __launch_bounds__(256) void k_conv5_finish(const float* __restrict__ 
     }
 }
 
+// pieces per operand element: 2 (block-scaled fp16 x 2, three products) unless MSYNTH_C5_NP=3 (bf16 x 3, six products)
+int c5_np() {
+    static const int np = (getenv("MSYNTH_C5_NP") && atoi(getenv("MSYNTH_C5_NP")) == 3) ? 3 : 2;
+    return np;
+}
+
 bool c5_geometry(const ConvP& c, bool backward, C5P* p) {
     if (c.K != 5 || c.stride != 1 || c.dil != 1 || c.pad != 2 || c.groups != 1 || c.pad_mode != MS_PAD_ZERO || c.in_act) return false;
     if (c.Lout != c.Lin || c.Lin < 1 || c.Lin > 64) return false;
@@ -306,7 +423,14 @@ bool c5_geometry(const ConvP& c, bool backward, C5P* p) {
     p->PX = R * p->SS;
     p->NV = (c.Lin + 3) / 4;
     p->NVG = (p->NV + 3) / 4;
-    if (R * p->NVG * 16 > 1024) return false;              // two staging rounds of 512 units
+    if (c5_np() == 2) {                                      // a row's staging lanes = a power-of-two span inside one wave
+        while (p->NVG & (p->NVG - 1)) ++p->NVG;
+        if (p->NVG > 4 || R > R_MAX) return false;
+    }
+    while (R > 1 && R * p->NVG * 16 > 1024) --R;            // two staging rounds of 512 units
+    if (R * p->NVG * 16 > 1024) return false;
+    p->R = R;
+    p->PX = R * p->SS;
     p->act = c.act; p->slope = c.slope;
     // split-K: tiles x slices ~ the 512 resident workgroups, at least 8 chunks per slice, at most 8 slices / 64 MiB of slabs
     const int tiles = (M / 64) * ((c.B + R - 1) / R);
@@ -328,8 +452,8 @@ bool c5_enabled() {
     return !(sw && atoi(sw) == 0);
 }
 
-template <int MODE>
-int c5_launch(const C5P& p, const float* X, const float* Xact, const void* image, const float* bias, const float* add, float* Y,
+template <int MODE, int NP>
+int c5_launch_np(const C5P& p, const float* X, const float* Xact, const void* image, const float* bias, const float* add, float* Y,
               void* ws, size_t ws_bytes, hipStream_t s) {
     float* slabs = nullptr;
     if (p.nsplit > 1) {
@@ -337,16 +461,16 @@ int c5_launch(const C5P& p, const float* X, const float* Xact, const void* image
         if (!ws || ws_bytes < need || (((uintptr_t)ws) & 15)) return MS_ERR_WORKSPACE;
         slabs = (float*)ws;
     }
-    const size_t lds = (size_t)2 * p.PX * XRS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_img<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * PX_MAX * XRS);
-        attr_set = true;
+    const size_t lds = (size_t)2 * p.PX * xrs<NP>() + 2 * R_MAX * sizeof(float);
+    static unsigned long long attr_set = 0;
+    if (ms_first_on_device(attr_set)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_img<MODE, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * PX_MAX * xrs<NP>() + 2 * R_MAX * sizeof(float));
+        ms_done_on_device(attr_set);
     }
     const dim3 grid((unsigned)((p.B + p.R - 1) / p.R), (unsigned)(p.M / 64), (unsigned)p.nsplit);
-    ms_note_kernel("k_conv5_img<%d>", MODE);
-    hipLaunchKernelGGL((k_conv5_img<MODE>), grid, dim3(512), lds, s, p, X, Xact, (const u32x4*)image, bias, add, Y, slabs);
+    ms_note_kernel("k_conv5_img<%d, %d>", MODE, NP);
+    hipLaunchKernelGGL((k_conv5_img<MODE, NP>), grid, dim3(512), lds, s, p, X, Xact, (const u32x4*)image, bias, add, Y, slabs);
     MS_CHECK_LAUNCH();
     if (p.nsplit > 1) {
         const long long total = p.zstride;
@@ -357,6 +481,13 @@ int c5_launch(const C5P& p, const float* X, const float* Xact, const void* image
         MS_CHECK_LAUNCH();
     }
     return MS_OK;
+}
+
+template <int MODE>
+int c5_launch(const C5P& p, const float* X, const float* Xact, const void* image, const float* bias, const float* add, float* Y,
+              void* ws, size_t ws_bytes, hipStream_t s) {
+    if (c5_np() == 3) return c5_launch_np<MODE, 3>(p, X, Xact, image, bias, add, Y, ws, ws_bytes, s);
+    return c5_launch_np<MODE, 2>(p, X, Xact, image, bias, add, Y, ws, ws_bytes, s);
 }
 
 bool to_convp(const ms_conv1d_desc* d, ConvP* p) {
@@ -395,7 +526,7 @@ int ms_conv1d_img_pack(const ms_conv1d_desc* d, const float* w, int backward, vo
     if (!c5_geometry(c, backward != 0, &p)) return MS_ERR_UNSUPPORTED;
     const size_t total = (size_t)(p.M / 32) * (p.CK / 16) * K5 * 64;
     hipLaunchKernelGGL(k_conv5_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (u32x4*)image, p.M,
-                       p.CK, backward ? 1 : 0);
+                       p.CK, backward ? 1 : 0, c5_np());
     MS_CHECK_LAUNCH();
     return MS_OK;
 }

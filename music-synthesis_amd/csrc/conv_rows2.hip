@@ -461,11 +461,11 @@ int launch_inst(const Row2P& p, const float* X, const float* Xact, const float* 
     if (EPI_S == 0 && fl < (size_t)BM * (BN + 4)) fl = (size_t)BM * (BN + 4);   // output transpose tile
     const size_t lds = (fl + 256) * sizeof(float);
     if (lds > 150 * 1024) return MS_ERR_UNSUPPORTED;
-    static bool attr_set = false;                    // > 64 KiB of dynamic LDS needs the opt-in once
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;                    // > 64 KiB of dynamic LDS needs the opt-in once
+    if (ms_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rows2<WGM, WGN, TM, TN, K, CC, AM, EPI_S, IN_S>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
+        ms_done_on_device(attr_set);
     }
     Row2P pp = p;
     pp.scratch_off = (int)fl;

@@ -767,11 +767,11 @@ int launch_pair(const Row2P& p, const float* X, const float* Xact, const float* 
     const size_t by = ldsp_bytes<WGM * TM * 32, HS ? 2 : K>(p);
     const size_t lds = by + 512 * 8;
     if (lds > 158 * 1024) return MS_ERR_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (ms_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rows3p<WGM, TM, TN, K, AM, HS, INA, DBG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-        attr_set = true;
+        ms_done_on_device(attr_set);
     }
     Row2P pp = p;
     pp.scratch_off = (int)by;
@@ -797,11 +797,11 @@ int launch_inst(const Row2P& p, const float* X, const float* Xact, const float* 
     const size_t by = lds_bytes<WGM, WGN, TM, TN, K, AM>(p);
     const size_t lds = by + 256 * 8;
     if (lds > 156 * 1024) return MS_ERR_UNSUPPORTED;
-    static bool attr_set = false;                    // > 64 KiB of dynamic LDS needs the opt-in once
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;                    // > 64 KiB of dynamic LDS needs the opt-in once
+    if (ms_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_rows3<WGM, WGN, TM, TN, K, AM, VEC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-        attr_set = true;
+        ms_done_on_device(attr_set);
     }
     Row2P pp = p;
     pp.scratch_off = (int)by;

@@ -347,11 +347,11 @@ int cb_launch(const CbP& p, const float* gy, const float* ya, const void* image,
         slabs = (float*)ws;
     }
     const size_t lds = (size_t)2 * p.PX * XRS;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (ms_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convt_bwd_img<S, TM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   2 * PX_MAX * XRS);
-        attr_set = true;
+        ms_done_on_device(attr_set);
     }
     const dim3 grid((unsigned)((p.B + p.R - 1) / p.R), (unsigned)(p.M / (64 * TM)), (unsigned)p.nsplit);
     ms_note_kernel("k_convt_bwd_img<%d, %d>", S, TM);

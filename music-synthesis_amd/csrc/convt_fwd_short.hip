@@ -290,11 +290,11 @@ int msct_short_fwd(const ms_convt1d_desc* d, const float* x, const void* image, 
         slabs = (float*)ws;
     }
     const size_t lds = (size_t)2 * p.PX * XRS;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (ms_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convt_fwd_short), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   2 * PX_MAX * XRS);
-        attr_set = true;
+        ms_done_on_device(attr_set);
     }
     const dim3 grid((unsigned)((p.B + p.R - 1) / p.R), (unsigned)(p.Cout / 64), (unsigned)p.nsplit);
     ms_note_kernel("k_convt_fwd_short");

@@ -284,19 +284,19 @@ int launch_ct(CtP p, const float* x, const void* image, const float* bias, float
     if (ncg % WGM) return MS_ERR_UNSUPPORTED;
     p.mtiles = ncg / WGM;
     const void* fn = reinterpret_cast<const void*>(&k_convt_img<CIN, S, NTP, WGM>);
-    static int wgs_per_cu = 0, n_cu = 0;
-    if (!wgs_per_cu) {
+    static int wgs_per_cu[64] = {}, n_cu[64] = {};                   // per device (ms_common.h: one-time launch setup)
+    const int dev = ms_current_device();
+    if (!__atomic_load_n(&wgs_per_cu[dev], __ATOMIC_ACQUIRE)) {
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-        int nb = 0, dev = 0;
+        int nb = 0;
         hipDeviceProp_t prop;
-        (void)hipGetDevice(&dev);
         (void)hipGetDeviceProperties(&prop, dev);
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        n_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, lds) != hipSuccess || nb < 1) nb = 1;
-        wgs_per_cu = nb;
+        __atomic_store_n(&wgs_per_cu[dev], nb, __ATOMIC_RELEASE);
     }
     const long long ntiles = (long long)p.B * p.tiles_per_row * p.mtiles;
-    const long long slots = (long long)n_cu * wgs_per_cu;
+    const long long slots = (long long)n_cu[dev] * wgs_per_cu[dev];
     const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
     ms_note_kernel("k_convt_img<%d, %d, %d, %d>", CIN, S, NTP, WGM);
     hipLaunchKernelGGL((k_convt_img<CIN, S, NTP, WGM>), grid, dim3(256), lds, s, p, x, (const u32x4*)image, bias, y);

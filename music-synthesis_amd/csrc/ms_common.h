@@ -37,6 +37,23 @@ void ms_prof_add(hipEvent_t e0, hipEvent_t e1);
         }                                                                                                  \
     } while (0)
 
+
+// Launch parameters that are set / queried once are cached PER DEVICE (a process may drive several GPUs: the > 64 KiB
+// dynamic-LDS opt-in is a per-device function attribute, CU counts differ) and without locks: the first callers on a device
+// may race, they all compute and store the same values.  ms_first_on_device(mask): true until the calling site has
+// finished its one-time work on the current device (call ms_done_on_device(mask) then).
+static inline int ms_current_device() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev & 63;
+}
+static inline bool ms_first_on_device(const unsigned long long& mask) {
+    return !((__atomic_load_n(&mask, __ATOMIC_ACQUIRE) >> ms_current_device()) & 1ull);
+}
+static inline void ms_done_on_device(unsigned long long& mask) {
+    __atomic_fetch_or(&mask, 1ull << ms_current_device(), __ATOMIC_RELEASE);
+}
+
 struct ConvP {  // kernel-side copy of ms_conv1d_desc (+ derived sizes)
     int B, Cin, Lin, Cout, Lout, K, stride, pad, dil, groups, Cg, Og, pad_mode, act;
     float slope;

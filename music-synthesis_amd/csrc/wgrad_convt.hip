@@ -237,11 +237,11 @@ int mswt8_bwd_weight(const ConvP& p, const float* x, const float* gy, const floa
     q.act = p.act; q.in_act = p.in_act ? 1 : 0; q.slope = p.slope;
     q.stride = (size_t)p.Cout * p.Cin * TK;
     const int nz = (q.nsteps + q.sps - 1) / q.sps;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (ms_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_convt8_split),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG);
-        attr_set = true;
+        ms_done_on_device(attr_set);
     }
     float* partial = (float*)ws;
     hipLaunchKernelGGL(k_wgrad_convt8_split, dim3(p.Cout / TCI, p.Cin / TCO, nz), dim3(NT), 2 * IMG, s, q, x, gy,

@@ -278,13 +278,13 @@ int msw5_bwd_weight(const ConvP& p, const float* x, const float* gy, const float
     const dim3 grid(p.Cout / TCO, p.Cin / TCI, nz);
     const bool vec = p.Lin % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)gy) & 15) == 0 &&
                      (!y_act || (((uintptr_t)y_act) & 15) == 0);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (ms_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_k5_split<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_k5_split<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG);
-        attr_set = true;
+        ms_done_on_device(attr_set);
     }
     float* partial = (float*)ws;
     if (vec) hipLaunchKernelGGL((k_wgrad_k5_split<true>), grid, dim3(256), 2 * IMG, s, q, x, gy, y_act, partial);

@@ -784,11 +784,11 @@ WrPlan plan_wrows(const ConvP& c) {
 template <int K, int TM, bool VEC, int KPI, int AK>
 void launch_wrows_ak(const WrPlan& q, const float* x, const float* gy, const float* y_act,
                      float* partial, hipStream_t s) {
-    static bool attr_set = false;                    // > 64 KiB of dynamic LDS needs the opt-in once
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;                    // > 64 KiB of dynamic LDS needs the opt-in once
+    if (ms_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_rows<K, TM, VEC, KPI, AK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
+        ms_done_on_device(attr_set);
     }
     hipLaunchKernelGGL((k_wgrad_rows<K, TM, VEC, KPI, AK>), q.grid, dim3(256), q.lds, s, q.p, x,
                        (const float*)nullptr, gy, y_act, partial, q.stride_floats, q.mp);
@@ -815,11 +815,11 @@ bool wrows3_ok(const WrPlan& q, int K, int TM, bool vec, bool has_yact) {
 // plan's grid / batching descriptor are re-derived for 64-row tiles; the slab layout does not depend on it.
 void launch_wrows3(const WrPlan& q, const float* x, const float* gy, const float* y_act, float* partial, hipStream_t s) {
     const size_t lds = w3_lds_bytes(64);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (ms_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_rows3<1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
+        ms_done_on_device(attr_set);
     }
     WrMulti mp = q.mp;
     const int tiles_m = q.p.M / 64;
@@ -936,11 +936,11 @@ WrPlan plan_wrows_t(const ConvP& c) {
 template <int TM, int KPI, int AK, int XS>
 void launch_wrows_t(const WrPlan& q, const float* gy, const float* y_act, const float* x, float* partial,
                     hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (ms_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_rows<3, TM, true, KPI, AK, XS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
+        ms_done_on_device(attr_set);
     }
     hipLaunchKernelGGL((k_wgrad_rows<3, TM, true, KPI, AK, XS>), q.grid, dim3(256), q.lds, s, q.p, gy, y_act, x,
                        (const float*)nullptr, partial, q.stride_floats, q.mp);
@@ -1332,11 +1332,11 @@ int msw32_bwd_weight(const ConvP& c, const float* x, const float* gy, const floa
     const size_t stride = 32 * 32 * 3 + 32;
     float* partial = (float*)ws;
     const size_t lds = (size_t)4 * W32_WF * sizeof(float);
-    static bool attr_set = false;                    // > 64 KiB of dynamic LDS needs the opt-in once
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;                    // > 64 KiB of dynamic LDS needs the opt-in once
+    if (ms_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad32<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-        attr_set = true;
+        ms_done_on_device(attr_set);
     }
     if (y_act && c.act == MS_ACT_LRELU)
         hipLaunchKernelGGL(k_wgrad32<1>, dim3(g), dim3(256), lds, s, p, x, gy, y_act, partial, stride, W32Multi{});
@@ -1393,10 +1393,10 @@ int msw32_bwd_weight_multi(const ConvP* cs, int n, const float* const* x, const 
     const size_t stride = 32 * 32 * 3 + 32;
     float* partial = (float*)ws;
     const size_t lds = (size_t)4 * W32_WF * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (ms_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-        attr_set = true;
+        ms_done_on_device(attr_set);
     }
     hipLaunchKernelGGL(k_wgrad32<1>, dim3(n * g_per), dim3(256), lds, s, p, x[0], gy[0], y_act[0], partial, stride, mp);
     MS_CHECK_LAUNCH();

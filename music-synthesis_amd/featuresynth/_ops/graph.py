@@ -288,8 +288,16 @@ def gen_forward(x, params, save):
     y, _ = P.conv1d_fwd(h, w, b, d, lo)
     tape.append(("last", d, h, y))
     if images_bwd is not None:
-        tape.append(("images_bwd", images_bwd))      # (gen_backward: no pack launch in front of the backward chain)
+        # (gen_backward: no pack launch in front of the backward chain.)  The images hold the weights as they were at THIS
+        # moment and bypass save_for_backward: the parameters' version counters travel with them
+        tape.append(("images_bwd", images_bwd, _param_versions(params)))
     return y, (tape if save else None)
+
+
+def _param_versions(params):
+    """In-place modification counters of the tensors a weight image was packed from (what autograd's saved-tensor check
+    looks at): an image is only used by a backward pass that sees the same versions."""
+    return tuple(int(getattr(p, "_version", 0)) for p in params)
 
 
 G_TAIL_PARAM = 4        # first parameter behind the generator's "tail" (conv0 + the first transposed conv)
@@ -312,9 +320,9 @@ def gen_backward(tape, params, gy, sink=None, need_gx=False, cut=None):
     deferred = []
     conv0 = tape[0]
     stash = [rec for rec in tape if rec[0] == "images_bwd"]
-    if stash:
+    if stash and stash[0][2] == _param_versions(params):
         images_bwd = stash[0][1]
-    else:
+    else:           # no stash, or a parameter was modified in place between forward and backward: pack from the weights as they are
         images_bwd = pack_atom_images(conv0[2].shape, params, backward=True)
         images_bwd.update(pack_convt_images(conv0[2].shape, params, True))
     for rec in reversed(tape):
@@ -494,16 +502,32 @@ def _side_streams(device, n):
     return _SIDE_STREAMS[key]
 
 
+def begin_step():
+    """Forks are tracked per trainer step: whatever earlier steps (the hand-scheduled path forks too and never calls
+    join_side_streams) left in the set is not this step's business."""
+    _FORKED_SINCE_JOIN.clear()
+
+
 def join_side_streams(device):
-    """The caller's stream waits for every side stream of this device.  The autograd engine runs a node's backward on the
-    stream its forward ran on and syncs only what it accumulates itself: a Function that wrote parameter gradients straight
-    into FlatAdam slots from a forked stream (bias gradients of convs issued under `forked`) is invisible to it, so the
-    trainers join explicitly between loss.backward() and optimizer.step()."""
+    """The caller's stream waits for every side stream of this device that work was issued on since begin_step().  The
+    autograd engine runs a node's backward on the stream its forward ran on and syncs only what it accumulates itself: a
+    Function that wrote parameter gradients straight into FlatAdam slots from a forked stream (bias gradients of convs
+    issued under `forked`) is invisible to it, so the trainers join explicitly between loss.backward() and
+    optimizer.step().  Under hipGraph capture only streams that are part of THIS capture are joined: recording an event
+    on a stream outside the capture and waiting for it from the capturing stream is not a captured dependency at all."""
     main = torch.cuda.current_stream(device)
-    for st in list(_FORKED_SINCE_JOIN):         # (only streams forked since the last join: under capture, streams of this capture)
-        if st.device == device and st != main:
-            main.wait_stream(st)
+    capturing = torch.cuda.is_current_stream_capturing()
+    for st in list(_FORKED_SINCE_JOIN):
+        if st.device != device:
+            continue
         _FORKED_SINCE_JOIN.discard(st)
+        if st == main:
+            continue
+        if capturing:
+            with torch.cuda.stream(st):
+                if not torch.cuda.is_current_stream_capturing():
+                    continue
+        main.wait_stream(st)
 
 
 def _on_aux(device):

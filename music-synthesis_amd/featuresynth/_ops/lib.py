@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "_lib", "libmsynth_hip.so")
+# (MSYNTH_LIB: another build of the same library -- kernel A/B experiments, tools/scratch; never set in normal operation)
+LIB_PATH = os.environ.get("MSYNTH_LIB") or os.path.join(os.path.dirname(_HERE), "_lib", "libmsynth_hip.so")
 
 ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
 PAD_ZERO, PAD_REFLECT = 0, 1

@@ -14,9 +14,11 @@ Two execution paths, same numbers:
     all-reduced (RCCL) in two slices: the slice that is final early in the backward travels while
     the rest of the backward runs, the other one just before the Adam graph.
 """
+import gc
 import os
 import sys
 import warnings
+import weakref
 from datetime import datetime
 
 import numpy as np
@@ -79,11 +81,36 @@ class _GraphedStep:
         assert k[0] == len(self.between), "train step: body made %d cuts, %d expected" % (k[0], len(self.between))
         return out
 
+    @staticmethod
+    def _new_graph():
+        g = torch.cuda.CUDAGraph()
+        if os.environ.get("MSYNTH_GRAPH_DOT_DIR"):      # debugging aid: keep the captured hipGraph for a DOT dump
+            g.enable_debug_mode()
+        return g
+
+    _dumped = [0]
+
+    @classmethod
+    def _dump(cls, graphs):
+        """MSYNTH_GRAPH_DOT_DIR=<dir>: every captured segment is written as <dir>/step<N>_seg<k>.dot
+        (hipGraphDebugDotPrint) -- the topology the runtime replays: branches, cross-stream edges, node kinds."""
+        d = os.environ.get("MSYNTH_GRAPH_DOT_DIR")
+        if not d:
+            return
+        os.makedirs(d, exist_ok=True)
+        for k, g in enumerate(graphs):
+            g.debug_dump(os.path.join(d, "step%d_seg%d.dot" % (cls._dumped[0], k)))
+        cls._dumped[0] += 1
+
     def _capture(self, s_in, f_in):
+        # Dead reference cycles may hold hipGraph / tensor objects of earlier trainers: collect them NOW, not at whatever
+        # allocation inside the capture trips the collector (torch >= 2.9 no longer does this in torch.cuda.graph.__enter__;
+        # destroying graph execs and returning their pools belongs in front of a capture, not inside one)
+        gc.collect()
         torch.cuda.synchronize()
         graphs = []
         if not self.between:
-            g = torch.cuda.CUDAGraph()
+            g = self._new_graph()
             # (thread-local error mode: other threads -- the RCCL watchdog polling its events -- stay legal)
             self.segment = 0
             try:
@@ -91,6 +118,7 @@ class _GraphedStep:
                     out = self.body(s_in, f_in, None)
             finally:
                 self.segment = None
+            self._dump([g])
             return [g], out
         pool = torch.cuda.graph_pool_handle()
         stream = torch.cuda.Stream()
@@ -98,7 +126,7 @@ class _GraphedStep:
         cur = [None]
 
         def begin():
-            cur[0] = torch.cuda.CUDAGraph()
+            cur[0] = self._new_graph()
             cur[0].capture_begin(pool=pool, capture_error_mode="thread_local")
 
         def end():
@@ -123,6 +151,7 @@ class _GraphedStep:
         if len(graphs) != len(self.between) + 1:
             raise RuntimeError("train step: %d graph segments captured, %d expected"
                                % (len(graphs), len(self.between) + 1))
+        self._dump(graphs)
         return graphs, out
 
     def __call__(self, samples, features):
@@ -290,11 +319,15 @@ class _TrainerBase(object):
             self._runner = None                   # the process group appeared / went away, or a bucket moved: re-plan
         if self._runner is None:
             self._runner_world = plan
+            # the runner's bodies reach the trainer through a weak reference: trainer -> runner -> closure -> trainer would be
+            # a reference cycle, and a dropped trainer's hipGraphs would then be destroyed whenever the cycle collector
+            # happens to run (possibly inside another trainer's capture) instead of when the trainer goes
+            me = weakref.ref(self)
             if world == 1 and not force_dp:
                 def body(s, f, cut):
-                    out = self._fwd_bwd(s, f)
+                    out = me()._fwd_bwd(s, f)
                     opt.step()
-                    return self._to_host(out)
+                    return me()._to_host(out)
                 self._runner = _GraphedStep(body)
             else:
                 direct = self._direct_ok()
@@ -316,19 +349,19 @@ class _TrainerBase(object):
                 def publish(out):
                     out = dict(out)
                     out["loss"] = opt.loss_slot       # summed over ranks by now; _result divides by world
-                    return self._to_host(out)
+                    return me()._to_host(out)
 
                 if off:
                     def body(s, f, cut):
                         # _fwd_bwd writes the loss into the slot and calls cut() once, where the early slice is final
-                        out = self._fwd_bwd(s, f, cut, loss_slot=opt.loss_slot)
+                        out = me()._fwd_bwd(s, f, cut, loss_slot=opt.loss_slot)
                         cut()
                         opt.step()
                         return publish(out)
                     self._runner = _GraphedStep(body, [start_early, finish])
                 else:
                     def body(s, f, cut):
-                        out = self._fwd_bwd(s, f, loss_slot=opt.loss_slot)
+                        out = me()._fwd_bwd(s, f, loss_slot=opt.loss_slot)
                         cut()
                         opt.step()
                         return publish(out)
@@ -359,6 +392,7 @@ class GeneratorTrainer(_TrainerBase):
                                       samples, features, self.discriminator.scales, cut=cut, debug=self.debug,
                                       loss_slot=loss_slot)
             return {"loss": loss, "fake": fake}
+        _graph.begin_step()
         d_params = [p for p in self.discriminator.parameters() if p.requires_grad]
         for p in d_params:          # discriminator weight grads are never used by a G-step
             p.requires_grad_(False)
@@ -425,6 +459,7 @@ class DiscriminatorTrainer(_TrainerBase):
                                 samples, features, self.discriminator.scales, cut=cut, debug=self.debug,
                                 loss_slot=loss_slot)
             return {"loss": loss}
+        _graph.begin_step()
         with torch.no_grad():       # generator grads of a D-step are discarded by the reference
             fake = self.generator(features)
         # one discriminator pass over [fake; real]: samples are independent (no batch coupling),

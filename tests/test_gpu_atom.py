@@ -1,7 +1,13 @@
 """Fused ResidualAtom forward (csrc/atom_fused.hip, one launch per atom) -- reference util/modules.py:350-388,384-388:
 x + lrelu(conv_k3_d1(lrelu(conv_k3_dil(x)))) -- against the CPU oracle and against the two row-tile launches it
-replaces (same arithmetic: bitwise), at the generator's channel counts, dilations 1 / 3 / 9, aligned and ragged tile
-counts, single and multiple batch rows, inference (no saved activations) and training mode."""
+replaces, at the generator's channel counts, dilations 1 / 3 / 9, aligned and ragged tile counts, single and multiple
+batch rows, inference (no saved activations) and training mode.
+
+r04: the fused kernel multiplies block-scaled two-piece fp16 operands (22 significand bits, three products per multiply,
+fp32 accumulation) where the row-tile launches multiply exact three-piece bf16 operands (six products): the two paths no
+longer agree bitwise but to what two fp32 summation orders differ by (gate 2e-6; measured 1-7e-7).  What stays bitwise:
+inference == training output, launch-to-launch determinism.  New gates: float64 accuracy at the bench shapes and
+invariance of the relative error under input scales from 1e-12 to 1e+6 (the block scaling)."""
 import numpy as np
 import pytest
 
@@ -59,12 +65,12 @@ def test_fused_atom_vs_oracle_and_unfused(case, save, monkeypatch):
     t_ref = O.conv1d_fwd(x, w0, b0, 1, dil, dil, 1, O.PAD_ZERO, 1)
     u_ref = O.conv1d_fwd(t_ref, w1, b1, 1, 1, 1, 1, O.PAD_ZERO, 1)
     assert rel_l2(host(y), x + u_ref) < 1e-5
-    # the two launches it replaces: small grids send them to split-K slices or to the fp32-MFMA kernels (another
-    # summation order / rounding sequence of the same accuracy): 1e-6 here, bitwise at the bench's shapes below
+    # the two launches it replaces (exact bf16 x 3 products, or split-K slices / fp32-MFMA kernels on small grids: other
+    # rounding sequences of the same accuracy)
     y2, rec2 = G.atom_forward(xt, w0t, b0t, w1t, b1t, dil, save, image=None)
 
     def agree(a, b_, what):
-        assert rel_l2(host(a), host(b_)) < 1e-6, what
+        assert rel_l2(host(a), host(b_)) < 2e-6, what
     agree(y, y2, "y")
     if save:
         assert rec[3] is not None and rec[4] is not None
@@ -77,11 +83,25 @@ def test_fused_atom_vs_oracle_and_unfused(case, save, monkeypatch):
     assert not G.atom_fused_ok(xt.shape, w0t, b0t, b1t, dil)
 
 
+def _f64_atom(x, w0, b0, w1, b1, dil):
+    """The atom in float64 on the device (stock torch ops): the yardstick both kernel paths are measured against."""
+    import torch.nn.functional as F
+    xd = x.double()
+    t = F.leaky_relu(F.conv1d(xd, w0.double(), b0.double(), padding=dil, dilation=dil), 0.2)
+    u = F.leaky_relu(F.conv1d(t, w1.double(), b1.double(), padding=1), 0.2)
+    return xd + u, t, u
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm())
+
+
 @pytest.mark.parametrize("C,Lg,dil", [(32, 8192, 9), (64, 4096, 3), (128, 2048, 1), (256, 256, 9)])
-def test_fused_atom_bitwise_at_bench_shapes(C, Lg, dil):
-    """BASELINE config 3's shapes (B = 32): the two-launch path runs the paired split-bf16 kernel without split-K --
-    the same products accumulated in the same order -- so the fused kernel must reproduce it BITWISE: output and both
-    saved activations."""
+def test_fused_atom_at_bench_shapes(C, Lg, dil):
+    """BASELINE config 3's shapes (B = 32).  Against float64 the fused kernel (fp16 x 2, three products) is as close as
+    the two row-tile launches (bf16 x 3, six exact products) -- both are bounded by fp32 accumulation, ~2-5e-7 -- and the
+    two agree to 2e-6; inference and training mode give the same output bitwise, and so do two launches."""
     from featuresynth._ops import graph as G
     from featuresynth._ops import lib as L
     from featuresynth._ops import prims as P
@@ -93,10 +113,49 @@ def test_fused_atom_bitwise_at_bench_shapes(C, Lg, dil):
     y2, rec2 = G.atom_forward(xt, w0t, b0t, w1t, b1t, dil, True, image=None)
     names = [L.load().ms_conv1d_kernel_name(rec2[k], 0).decode() for k in (0, 1)]
     assert all(n.startswith("k_conv_rows3") for n in names), names
-    assert torch.equal(rec[3], rec2[3]), "t: rel %.3e" % rel_l2(host(rec[3]), host(rec2[3]))
-    assert torch.equal(rec[4], rec2[4]) and torch.equal(y, y2)
+    yr, tr, ur = _f64_atom(xt, w0t, b0t, w1t, b1t, dil)
+    e_f = (_rel(rec[3], tr), _rel(rec[4], ur), _rel(y, yr))
+    e_u = (_rel(rec2[3], tr), _rel(rec2[4], ur), _rel(y2, yr))
+    print("C=%d vs float64: fused t %.2e u %.2e y %.2e | two launches t %.2e u %.2e y %.2e" % ((C,) + e_f + e_u))
+    assert max(e_f) < 1e-6 and max(e_u) < 1e-6
+    assert max(e_f) < 3 * max(e_u) + 1e-7, "the fused kernel must be as accurate as the exact-product path"
+    assert _rel(rec[3], rec2[3]) < 2e-6 and _rel(rec[4], rec2[4]) < 2e-6 and _rel(y, y2) < 2e-6
     y3, _ = G.atom_forward(xt, w0t, b0t, w1t, b1t, dil, False, image=img)
-    assert torch.equal(y3, y)
+    assert torch.equal(y3, y), "inference and training mode compute the same output"
+    y4, rec4 = G.atom_forward(xt, w0t, b0t, w1t, b1t, dil, True, image=img)
+    assert torch.equal(y4, y) and torch.equal(rec4[3], rec[3]) and torch.equal(rec4[4], rec[4]), "launch-to-launch determinism"
+
+
+@pytest.mark.parametrize("C,Lg", [(32, 1032), (128, 300)])
+@pytest.mark.parametrize("scale", [1e-12, 1e-6, 1.0, 1e6])
+def test_fused_atom_block_scaling(C, Lg, scale):
+    """The fp16 pieces are taken from a tile scaled by a power of two so that its largest magnitude sits at 2^14: the
+    relative error against float64 must not depend on the magnitude of the data (fp16 alone spans 2^-24 .. 2^16).
+    Biases scale with the input so that the outputs stay a homogeneous function of it; one input element per row is
+    made 2^10 times larger than the rest (a tile whose maximum is an outlier)."""
+    from featuresynth._ops import graph as G
+    from featuresynth._ops import prims as P
+    x, w0, b0, w1, b1 = _inputs("scale_%d" % C, 2, C, Lg)
+    x[:, 0, 5] *= 1024.0
+    xt, w0t, w1t = dev(x * scale), dev(w0), dev(w1)
+    b0t, b1t = dev(b0 * scale), dev(b1 * scale)
+    img = P.atom_image(C, xt.device)
+    P.atom_pack([(w0t, w1t, img)])
+    y, rec = G.atom_forward(xt, w0t, b0t, w1t, b1t, 3, True, image=img)
+    yr, tr, ur = _f64_atom(xt, w0t, b0t, w1t, b1t, 3)
+    e = (_rel(rec[3], tr), _rel(rec[4], ur), _rel(y, yr))
+    print("C=%d scale %g: t %.2e u %.2e y %.2e" % ((C, scale) + e))
+    assert max(e) < 2e-6, e
+    # backward data with gradient-sized magnitudes
+    g = dev(np.random.default_rng(7).standard_normal(x.shape).astype(np.float32) * scale * 1e-3)
+    imgb = P.atom_image(C, xt.device)
+    P.atom_pack([(w0t, w1t, imgb)], backward=True)
+    gt, gx = P.atom_bwd_data(g, rec[4], rec[3], imgb, 3)
+    import torch.nn.functional as F
+    gd = g.double() * torch.where(rec[4] > 0, 1.0, 0.2).double()
+    gt_r = F.conv_transpose1d(gd, w1t.double(), padding=1)
+    gx_r = F.conv_transpose1d(gt_r * torch.where(rec[3] > 0, 1.0, 0.2).double(), w0t.double(), padding=3, dilation=3)
+    assert _rel(gt, gt_r) < 2e-6 and _rel(gx - g, gx_r) < 2e-6, (_rel(gt, gt_r), _rel(gx - g, gx_r))
 
 
 def test_fused_atom_pack_is_per_call_and_multi():
@@ -163,11 +222,14 @@ def test_fused_atom_backward_vs_oracle_and_unfused(case):
     # the two launches
     gt2 = P.conv1d_bwd_data(gt_d, u, w1t, d1)
     gx2 = P.conv1d_bwd_data(gt2, t, w0t, d0, gx_add=gt_d)
-    assert rel_l2(host(gt), host(gt2)) < 1e-6 and rel_l2(host(gx), host(gx2)) < 1e-6
+    assert rel_l2(host(gt), host(gt2)) < 2e-6 and rel_l2(host(gx), host(gx2)) < 2e-6
 
 
 @pytest.mark.parametrize("C,Lg,dil", [(32, 8192, 9), (64, 4096, 3), (128, 2048, 1), (256, 256, 3)])
-def test_fused_atom_backward_bitwise_at_bench_shapes(C, Lg, dil):
+def test_fused_atom_backward_at_bench_shapes(C, Lg, dil):
+    """Backward data at BASELINE config 3's shapes with gradient-sized inputs (1e-6): against float64 torch both paths sit at
+    fp32 accumulation level, they agree to 2e-6, and the fused launch is deterministic."""
+    import torch.nn.functional as F
     from featuresynth._ops import graph as G
     from featuresynth._ops import lib as L
     from featuresynth._ops import prims as P
@@ -175,7 +237,7 @@ def test_fused_atom_backward_bitwise_at_bench_shapes(C, Lg, dil):
     xt, w0t, b0t, w1t, b1t = (dev(a) for a in (x, w0, b0, w1, b1))
     y, rec = G.atom_forward(xt, w0t, b0t, w1t, b1t, dil, True, image=None)
     d0, d1, _, t, u = rec
-    g = dev(np.random.default_rng(5).standard_normal((32, C, Lg)).astype(np.float32))
+    g = dev(np.random.default_rng(5).standard_normal((32, C, Lg)).astype(np.float32) * 1e-6)
     img = P.atom_image(C, xt.device)
     P.atom_pack([(w0t, w1t, img)], backward=True)
     gt, gx = P.atom_bwd_data(g, u, t, img, dil)
@@ -183,5 +245,13 @@ def test_fused_atom_backward_bitwise_at_bench_shapes(C, Lg, dil):
     gx2 = P.conv1d_bwd_data(gt2, t, w0t, d0, gx_add=g)
     names = [L.load().ms_conv1d_kernel_name(dd, 1).decode() for dd in (d0, d1)]
     assert all(n.startswith("k_conv_rows3") for n in names), names
-    assert torch.equal(gt, gt2), "gt: rel %.3e (%s)" % (rel_l2(host(gt), host(gt2)), names)
-    assert torch.equal(gx, gx2), "gx: rel %.3e (%s)" % (rel_l2(host(gx), host(gx2)), names)
+    gd = g.double() * torch.where(u > 0, 1.0, 0.2).double()
+    gt_r = F.conv_transpose1d(gd, w1t.double(), padding=1)
+    gx_r = F.conv_transpose1d(gt_r * torch.where(t > 0, 1.0, 0.2).double(), w0t.double(), padding=dil, dilation=dil)
+    e_f = (_rel(gt, gt_r), _rel(gx - g, gx_r))
+    e_u = (_rel(gt2, gt_r), _rel(gx2 - g, gx_r))
+    print("C=%d backward vs float64: fused gt %.2e gx-g %.2e | two launches gt %.2e gx-g %.2e" % ((C,) + e_f + e_u))
+    assert max(e_f) < 1e-6 and max(e_u) < 1e-6
+    assert _rel(gt, gt2) < 2e-6 and _rel(gx - g, gx2 - g) < 2e-6
+    gt3, gx3 = P.atom_bwd_data(g, u, t, img, dil)
+    assert torch.equal(gt3, gt) and torch.equal(gx3, gx), "launch-to-launch determinism"

@@ -44,7 +44,7 @@ def test_conv5_image_kernel_vs_oracle_and_generic(case):
     y_ref = O.conv1d_fwd(x, w, b, 1, 2, 1, 1, O.PAD_ZERO, act)
     assert rel_l2(host(y), y_ref) < 1e-5
     y2, _ = P.conv1d_fwd(xt, wt, bt, d, lo)
-    assert rel_l2(host(y), host(y2)) < 1e-6
+    assert rel_l2(host(y), host(y2)) < 2e-6        # (fp16 x 2 / three products here, bf16 x 3 / six exact products there)
     # backward data, LeakyReLU derivative from the device's own activations, with and without the gradient add
     gy = rng.standard_normal(y_ref.shape).astype(np.float32)
     add = rng.standard_normal(x.shape).astype(np.float32)
@@ -57,9 +57,20 @@ def test_conv5_image_kernel_vs_oracle_and_generic(case):
     gx_a = P.conv1d_img_bwd_data(gyt, ya, img_b, d, gx_add=addt)
     assert rel_l2(host(gx_a), gx_ref + add) < 1e-5
     gx2 = P.conv1d_bwd_data(gyt, ya, wt, d, gx_add=addt)
-    assert rel_l2(host(gx_a), host(gx2)) < 1e-6
+    assert rel_l2(host(gx_a), host(gx2)) < 2e-6
     # deterministic (split-K slabs summed in slice order)
     assert torch.equal(P.conv1d_img_fwd(xt, img_f, bt, d, lo), y)
+    # block scaling (r04): the relative error does not depend on the magnitude of the data, nor on one channel range being
+    # 2^12 louder than the rest (the scale of a row moves between chunks: partial sums are folded under the old scale)
+    for scale in (1e-9, 1e4):
+        xs = x * scale
+        xs[:, Cin // 2:Cin // 2 + 16] *= 4096.0
+        ys = P.conv1d_img_fwd(dev(xs), img_f, dev(b * scale), d, lo)
+        ys_ref = torch.nn.functional.conv1d(dev(xs).double(), wt.double(), dev(b * scale).double(), padding=2)
+        if act:
+            ys_ref = torch.nn.functional.leaky_relu(ys_ref, 0.2)
+        e = float((ys.double() - ys_ref).norm() / ys_ref.norm())
+        assert e < 2e-6, (scale, e)
 
 
 def test_conv5_image_used_by_the_discriminator_and_switchable(monkeypatch):
