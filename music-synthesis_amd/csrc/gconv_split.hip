@@ -31,8 +31,43 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int GK = 41, GS = 4, GCG = 4;
+constexpr float WSCALE = 64.f;            // fp16 pieces of the weights are taken from 64 w (|w| < 2^9)
+constexpr float CROSS = 1.f / 2048.f;     // weight of the low fp16 piece
+
+// Block-scaled two-piece fp16 split (r04, atom_fused.hip): (a, b) scaled into fp16's range by the caller ->
+// a = h.lo + l.lo / 2048 to 22 significand bits; products h h' + (h l' + l h') / 2048: three MFMAs instead of six.
+__device__ __forceinline__ void split_pair2(float a, float b, unsigned& h, unsigned& l) {
+    const f32x2 v = {a, b};
+    const f16x2 hi = __builtin_convertvector(v, f16x2);
+    const f32x2 r = (v - __builtin_convertvector(hi, f32x2)) * 2048.f;
+    const f16x2 lo = __builtin_convertvector(r, f16x2);
+    h = __builtin_bit_cast(unsigned, hi);
+    l = __builtin_bit_cast(unsigned, lo);
+}
+
+// S = 2^k with m S in [2^14, 2^15), and 1 / S (exact powers of two); 1 for a zero / denormal-range / non-finite maximum
+__device__ __forceinline__ void block_scale(float m, float& S, float& invS) {
+    const unsigned eb = (__builtin_bit_cast(unsigned, m) >> 23) & 0xFFu;
+    const bool ok = eb >= 16u && eb <= 250u;
+    S = ok ? __builtin_bit_cast(float, (268u - eb) << 23) : 1.f;
+    invS = ok ? __builtin_bit_cast(float, (eb - 14u) << 23) : 1.f;
+}
+
+// largest value over the wave, wave-uniform: 16 lanes by DPP (quad swaps, half-row mirror, row mirror), the four rows by readlane
+__device__ __forceinline__ float wave_max_dpp(float m) {
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, true)));
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, true)));
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x141, 0xF, 0xF, true)));
+    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x140, 0xF, 0xF, true)));
+    const int b = __builtin_bit_cast(int, m);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
 constexpr int NG = 6;                         // tap groups of 8
 
 // (a, b) -> three packed bf16 pairs with a = h.lo + m.lo + l.lo exactly (same for b in the high halves)
@@ -57,7 +92,7 @@ struct GF {
     static constexpr int RP = RB == 1 ? 80 : (RB == 2 ? 56 : 28);   // row pitch in quads (see header)
     static constexpr int ROWS = 4 * RB;
     static constexpr int PIECE_BYTES = ROWS * RP * 8;
-    static constexpr int WAVE_BYTES = 3 * PIECE_BYTES;
+    static constexpr int WAVE_BYTES = 2 * PIECE_BYTES;               // forward: two fp16 pieces
     static constexpr int NIT = (ROWS * NQR + 63) / 64;              // staged quads per lane
     static_assert(NQR <= RP, "row pitch");
     static_assert(NQR < RP || (ROWS * NQR) % 64 == 0, "a spare quad for the lanes without an item");
@@ -151,15 +186,14 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, in
             }
         }
     };
-    // registers -> LDS: split into pieces, one 8-byte quad per piece
-    auto stage_item = [&](const f32x4& v, int lds_off) {
-        unsigned h0, m0, l0, h1, m1, l1;
-        split_pair(v[0], v[1], h0, m0, l0);
-        split_pair(v[2], v[3], h1, m1, l1);
+    // registers -> LDS: scaled by the unit's power-of-two block scale, split into two fp16 pieces, one 8-byte quad per piece
+    auto stage_item = [&](const f32x4& v, int lds_off, float S) {
+        unsigned h0, l0, h1, l1;
+        split_pair2(v[0] * S, v[1] * S, h0, l0);
+        split_pair2(v[2] * S, v[3] * S, h1, l1);
         unsigned char* d = lds + wv_off + lds_off;
         *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(d + C::PIECE_BYTES) = make_uint2(m0, m1);
-        *reinterpret_cast<uint2*>(d + 2 * C::PIECE_BYTES) = make_uint2(l0, l1);
+        *reinterpret_cast<uint2*>(d + C::PIECE_BYTES) = make_uint2(l0, l1);
     };
 
     int unit = blockIdx.x * 4 + wid;
@@ -169,8 +203,8 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, in
     f32x4 xp[C::NIT];
     gload(xp, ld); advance(ld);
 
-    // ---- weight fragments: lane (co = n, ci = kg) holds w[g*Og + co][ci][8G .. 8G+7] in three pieces
-    bf16x8 A[NG][3];
+    // ---- weight fragments: lane (co = n, ci = kg) holds 64 w[g*Og + co][ci][8G .. 8G+7] in two fp16 pieces
+    f16x8 A[NG][2];
     {
         const bool ok = n < p.Og;
         const float* wr = w + ((size_t)(g * p.Og + (ok ? n : 0)) * GCG + kg) * GK;
@@ -179,16 +213,15 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, in
         for (int j = 0; j < NG * 8; ++j) wv[j] = j < GK ? wr[j] : 0.f;
 #pragma unroll
         for (int G = 0; G < NG; ++G) {
-            u32x4 h, m, l;
+            u32x4 h, l;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                unsigned hh, mm, ll;
-                split_pair(ok ? wv[8 * G + 2 * q] : 0.f, ok ? wv[8 * G + 2 * q + 1] : 0.f, hh, mm, ll);
-                h[q] = hh; m[q] = mm; l[q] = ll;
+                unsigned hh, ll;
+                split_pair2(ok ? wv[8 * G + 2 * q] * WSCALE : 0.f, ok ? wv[8 * G + 2 * q + 1] * WSCALE : 0.f, hh, ll);
+                h[q] = hh; l[q] = ll;
             }
-            A[G][0] = __builtin_bit_cast(bf16x8, h);
-            A[G][1] = __builtin_bit_cast(bf16x8, m);
-            A[G][2] = __builtin_bit_cast(bf16x8, l);
+            A[G][0] = __builtin_bit_cast(f16x8, h);
+            A[G][1] = __builtin_bit_cast(f16x8, l);
         }
     }
     const float eslope = p.act == MS_ACT_LRELU ? p.slope : 1.f;      // in [0, 1] (msg3_fwd_applicable)
@@ -200,21 +233,21 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, in
         bq[r] = (bias && rok[r]) ? bias[g * p.Og + kg * 4 + r] : 0.f;
     }
 
-    auto unit_mfma_store = [&]() {
-        unsigned rbo[3];
+    auto unit_mfma_store = [&](float kscale) {
+        unsigned rbo[2];
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) rbo[pc] = rb0 + pc * C::PIECE_BYTES;
-        f32x4 acc[4];
+        for (int pc = 0; pc < 2; ++pc) rbo[pc] = rb0 + pc * C::PIECE_BYTES;
+        f32x4 acc[4], acx[4];                        // main (h h') / cross (h l' + l h', scaled 2^11) sums of the four tiles
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < 4; ++s) acc[s] = acx[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // Fragment reads are hand-issued ds_read2_b64 (two quads -> one 4-register operand; the compiler's own
         // pairing of the 8-byte reads put the halves in unrelated registers and paid ~140 v_mov per unit).  The
-        // reads of step H+1 are in flight during the MFMAs of step H: counted wait on the older six.
-        u32x4 f[2][2][3];
+        // reads of step H+1 are in flight during the MFMAs of step H: counted wait on the older four.
+        u32x4 f[2][2][2];
 #define MS_G3_READ(H_, buf)                                                                                     \
     _Pragma("unroll") for (int par = 0; par < 2; ++par) {                                                       \
         const int c0 = 2 * (H_) + par, c1 = c0 + 1;                                                             \
-        _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                                        \
+        _Pragma("unroll") for (int pc = 0; pc < 2; ++pc)                                                        \
             asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3"                                            \
                          : "=v"(f[buf][par][pc])                                                                \
                          : "v"(rbo[pc]), "n"((c0 & 3) * C::SUBP + (c0 >> 2)), "n"((c1 & 3) * C::SUBP + (c1 >> 2))); \
@@ -225,29 +258,39 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, in
             const int cur = H & 1;
             if (H < NG) {
                 MS_G3_READ(H + 1, cur ^ 1);
-                asm volatile("s_waitcnt lgkmcnt(6)"
-                             : "+v"(f[cur][0][0]), "+v"(f[cur][0][1]), "+v"(f[cur][0][2]), "+v"(f[cur][1][0]),
-                               "+v"(f[cur][1][1]), "+v"(f[cur][1][2]));
+                asm volatile("s_waitcnt lgkmcnt(4)"
+                             : "+v"(f[cur][0][0]), "+v"(f[cur][0][1]), "+v"(f[cur][1][0]), "+v"(f[cur][1][1]));
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(f[cur][0][0]), "+v"(f[cur][0][1]), "+v"(f[cur][0][2]), "+v"(f[cur][1][0]),
-                               "+v"(f[cur][1][1]), "+v"(f[cur][1][2]));
+                             : "+v"(f[cur][0][0]), "+v"(f[cur][0][1]), "+v"(f[cur][1][0]), "+v"(f[cur][1][1]));
             }
-            // six partial products, smallest first: (a1 b3) (a3 b1) (a2 b2) (a1 b2) (a2 b1) (a1 b1); the four
+            // three partial products per tile: (a_h b_l) (a_l b_h) into the cross sum, (a_h b_h) into the main sum; the
             // tiles' accumulator chains are interleaved so that dependent MFMAs sit 2-4 issues apart
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
-                const bf16x8 f0 = __builtin_bit_cast(bf16x8, f[cur][0][PB[i]]);
-                const bf16x8 f1 = __builtin_bit_cast(bf16x8, f[cur][1][PB[i]]);
-                if (H < NG) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[H][PA[i]], f0, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[H][PA[i]], f1, acc[1], 0, 0, 0);
-                }
-                if (H >= 1) {
-                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[H - 1][PA[i]], f0, acc[2], 0, 0, 0);
-                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[H - 1][PA[i]], f1, acc[3], 0, 0, 0);
-                }
+            const f16x8 f0h = __builtin_bit_cast(f16x8, f[cur][0][0]), f0l = __builtin_bit_cast(f16x8, f[cur][0][1]);
+            const f16x8 f1h = __builtin_bit_cast(f16x8, f[cur][1][0]), f1l = __builtin_bit_cast(f16x8, f[cur][1][1]);
+            if (H < NG) {
+                acx[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H][0], f0l, acx[0], 0, 0, 0);
+                acx[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H][0], f1l, acx[1], 0, 0, 0);
+            }
+            if (H >= 1) {
+                acx[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H - 1][0], f0l, acx[2], 0, 0, 0);
+                acx[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H - 1][0], f1l, acx[3], 0, 0, 0);
+            }
+            if (H < NG) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H][0], f0h, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H][0], f1h, acc[1], 0, 0, 0);
+            }
+            if (H >= 1) {
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H - 1][0], f0h, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H - 1][0], f1h, acc[3], 0, 0, 0);
+            }
+            if (H < NG) {
+                acx[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H][1], f0h, acx[0], 0, 0, 0);
+                acx[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H][1], f1h, acx[1], 0, 0, 0);
+            }
+            if (H >= 1) {
+                acx[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H - 1][1], f0h, acx[2], 0, 0, 0);
+                acx[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H - 1][1], f1h, acx[3], 0, 0, 0);
             }
         }
 #undef MS_G3_READ
@@ -266,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, in
                 float v[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const float pre = acc[s][r] + bq[r];
+                    const float pre = fmaf(fmaf(acx[s][r], CROSS, acc[s][r]), kscale, bq[r]);     // undo the block and weight scales
                     v[s] = fmaxf(pre, pre * eslope);                // LeakyReLU (slope in [0, 1]) / identity
                 }
                 if (VOUT) {
@@ -282,13 +325,21 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, in
     };
 
     for (; unit < nunits; unit += wstride) {
+        // the unit's block scale: its largest input magnitude goes to 2^14 (a wave owns the whole unit: no barrier)
+        float um = 0.f;
 #pragma unroll
-        for (int i = 0; i < C::NIT; ++i) stage_item(xp[i], it_lds[i]);
+        for (int i = 0; i < C::NIT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) um = fmaxf(um, fabsf(xp[i][e]));
+        float S, invS;
+        block_scale(wave_max_dpp(um), S, invS);
+#pragma unroll
+        for (int i = 0; i < C::NIT; ++i) stage_item(xp[i], it_lds[i], S);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (unit + wstride < nunits) gload(xp, ld);     // next unit's inputs: in flight across the MFMA loop
         advance(ld);
-        unit_mfma_store();
+        unit_mfma_store(invS * (1.f / WSCALE));
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -311,8 +362,9 @@ constexpr int WU = 64;                        // outputs per unit
 constexpr int WXQ = 75;                       // input quads per (unit, channel): 4 * 63 + 48 = 300 samples
 constexpr int WXROW = 608;                    // bytes per LDS input row (300 bf16 + pad, multiple of 8)
 constexpr int WX_PIECE = GCG * WXROW;
-constexpr int WG_PIECE = 8 * 16 * 16;         // gradient image of a piece: [t / 8][co][8 t] bf16
-constexpr int W_WAVE = 3 * (WG_PIECE + WX_PIECE);
+constexpr int WG_PIECE = 8 * 16 * 16;         // gradient image of a piece: [t / 8][co][8 t] (16-bit elements)
+constexpr int W_WAVE = 3 * (WG_PIECE + WX_PIECE);     // (sized for three pieces: the end-of-kernel reduction scratch needs it)
+constexpr int WNP = 2;                        // pieces per operand element: block-scaled fp16 x 2 (r04)
 constexpr int NKT = 3;                        // 16-tap column tiles
 
 template <bool VEC>
@@ -325,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const flo
     const int g = blockIdx.y;
     const int kind = y_act ? p.act : MS_ACT_NONE;
     unsigned char* gimg = lds + wid * W_WAVE;          // gradient pieces, then input pieces
-    unsigned char* ximg = gimg + 3 * WG_PIECE;
+    unsigned char* ximg = gimg + WNP * WG_PIECE;
 
     // ---- staging items
     // gradient: 16 co x 16 quads of 4 outputs; item i of a lane: co = (lane >> 4) + 4 i, quad tq = lane & 15
@@ -416,11 +468,16 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const flo
         }
     };
 
-    f32x4 acc[GCG][NKT];
+    // Accumulators live across all units of a wave.  Both operands are data here (no weights): the gradient tile and the input
+    // tile each carry a wave-local power-of-two scale that is STICKY from unit to unit -- it moves only when the unit's largest
+    // magnitude times the current scale leaves [2^8, 2^15) -- and when one moves, the accumulators are multiplied by the
+    // ratio of the new to the old product scale (a power of two: exact), so they always hold sums under the CURRENT scales.
+    f32x4 acc[GCG][NKT], acx[GCG][NKT];               // main (h h') / cross (h l' + l h', scaled 2^11) sums
 #pragma unroll
     for (int c = 0; c < GCG; ++c)
 #pragma unroll
-        for (int j = 0; j < NKT; ++j) acc[c][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NKT; ++j) acc[c][j] = acx[c][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float Sg = 0.f, Sx = 0.f;                          // current scales (0: none yet)
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
     // fragment addresses of this lane
@@ -435,30 +492,54 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const flo
     int b = unit / tiles, ti = unit - b * tiles;
     if (unit < nunits) gload(b, ti);
     for (; unit < nunits; unit += ustride) {
-        // ---- registers -> LDS: activation derivative, split, 8-byte quads
+        // ---- the unit's largest magnitudes -> sticky scales (the raw gradient bounds the masked one)
+        {
+            float mg = 0.f, mx = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mg = fmaxf(mg, fabsf(gv[i][k]));
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mx = fmaxf(mx, fabsf(xv[i][k]));
+            mg = wave_max_dpp(mg); mx = wave_max_dpp(mx);
+            float nSg = Sg, nSx = Sx, inv;
+            if (mg > 0.f && !(mg * Sg >= 256.f && mg * Sg < 32768.f)) block_scale(mg * 4.f, nSg, inv);   // largest magnitude at 2^12
+            if (mx > 0.f && !(mx * Sx >= 256.f && mx * Sx < 32768.f)) block_scale(mx * 4.f, nSx, inv);
+            if (nSg == 0.f) nSg = 1.f;
+            if (nSx == 0.f) nSx = 1.f;
+            if ((nSg != Sg || nSx != Sx) && Sg != 0.f) {               // (wave-uniform) a scale moved: re-express the sums
+                const float ratio = (nSg / Sg) * (nSx / Sx);
+#pragma unroll
+                for (int c = 0; c < GCG; ++c)
+#pragma unroll
+                    for (int j = 0; j < NKT; ++j) { acc[c][j] *= ratio; acx[c][j] *= ratio; }
+            }
+            Sg = nSg; Sx = nSx;
+        }
+        // ---- registers -> LDS: activation derivative, scale, split, 8-byte quads
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float e[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) e[k] = ms_act_grad(gv[i][k], ga[i][k], kind, p.slope);
             bsum[i] += (e[0] + e[1]) + (e[2] + e[3]);
-            unsigned h0, m0, l0, h1, m1, l1;
-            split_pair(e[0], e[1], h0, m0, l0);
-            split_pair(e[2], e[3], h1, m1, l1);
+            unsigned h0, l0, h1, l1;
+            split_pair2(e[0] * Sg, e[1] * Sg, h0, l0);
+            split_pair2(e[2] * Sg, e[3] * Sg, h1, l1);
             unsigned char* d = gimg + (g_tb * 16 + ((co0 + 4 * i) ^ g_tb)) * 16 + (tq & 1) * 8;
             *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(d + WG_PIECE) = make_uint2(m0, m1);
-            *reinterpret_cast<uint2*>(d + 2 * WG_PIECE) = make_uint2(l0, l1);
+            *reinterpret_cast<uint2*>(d + WG_PIECE) = make_uint2(l0, l1);
         }
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            unsigned h0, m0, l0, h1, m1, l1;
-            split_pair(xv[i][0], xv[i][1], h0, m0, l0);
-            split_pair(xv[i][2], xv[i][3], h1, m1, l1);
+            unsigned h0, l0, h1, l1;
+            split_pair2(xv[i][0] * Sx, xv[i][1] * Sx, h0, l0);
+            split_pair2(xv[i][2] * Sx, xv[i][3] * Sx, h1, l1);
             unsigned char* d = ximg + x_lds[i];
             *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(d + WX_PIECE) = make_uint2(m0, m1);
-            *reinterpret_cast<uint2*>(d + 2 * WX_PIECE) = make_uint2(l0, l1);
+            *reinterpret_cast<uint2*>(d + WX_PIECE) = make_uint2(l0, l1);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -474,13 +555,13 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const flo
         // tile j = rows t.. of tile j+1) at the price of ~70 v_mov per unit, and every MFMA group waited for its
         // own reads.
         const int niter = tvalid > 32 ? 2 * GCG : GCG;              // wave-uniform: outputs 32.. are all zero
-        bf16x8 A[2][3];
+        f16x8 A[2][WNP];
 #pragma unroll
         for (int step = 0; step < 2; ++step)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc)
-                A[step][pc] = *reinterpret_cast<const bf16x8*>((step ? a_rd1 : a_rd0) + pc * WG_PIECE);
-        u32x2 Bl[2][3][NKT], Bh[2][3][NKT];              // [iteration parity][piece][tile]
+            for (int pc = 0; pc < WNP; ++pc)
+                A[step][pc] = *reinterpret_cast<const f16x8*>((step ? a_rd1 : a_rd0) + pc * WG_PIECE);
+        u32x2 Bl[2][WNP][NKT], Bh[2][WNP][NKT];          // [iteration parity][piece][tile]
 #define MS_W3_READ(it_, pc)                                                                                   \
     _Pragma("unroll") for (int j = 0; j < NKT; ++j) {                                                         \
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                                    \
@@ -494,38 +575,31 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const flo
     asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                \
                  : "+v"(Bl[(it_) & 1][pc][0]), "+v"(Bl[(it_) & 1][pc][1]), "+v"(Bl[(it_) & 1][pc][2]),        \
                    "+v"(Bh[(it_) & 1][pc][0]), "+v"(Bh[(it_) & 1][pc][1]), "+v"(Bh[(it_) & 1][pc][2]))
-#define MS_W3_MMA(it_, pa, pb)                                                                                \
+#define MS_W3_MMA(dst, it_, pa, pb)                                                                           \
     _Pragma("unroll") for (int j = 0; j < NKT; ++j) {                                                         \
         const u32x4 bv = {Bl[(it_) & 1][pb][j][0], Bl[(it_) & 1][pb][j][1], Bh[(it_) & 1][pb][j][0],          \
                           Bh[(it_) & 1][pb][j][1]};                                                           \
-        acc[(it_) & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                          \
-            A[(it_) >> 2][pa], __builtin_bit_cast(bf16x8, bv), acc[(it_) & 3][j], 0, 0, 0);                   \
+        dst[(it_) & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                           \
+            A[(it_) >> 2][pa], __builtin_bit_cast(f16x8, bv), dst[(it_) & 3][j], 0, 0, 0);                    \
     }
-        // partial products, smallest first: (a1 b3) | (a3 b1) | (a2 b2) (a1 b2) (a2 b1) (a1 b1)
+        // per (step, channel) iteration: (a_h b_l) and (a_l b_h) into the cross sums, (a_h b_h) into the main sums; the
+        // transposing reads of a piece (lo / hi of the three column tiles: six reads) are hand-issued one group ahead of
+        // the MFMAs they feed, with counted waits
 #define MS_W3_ITER(it_)                                                                                       \
     if ((it_) < niter) {                                                                                      \
-        MS_W3_READ(it_, 1);                                                                                   \
-        MS_W3_WAIT(12, it_, 2);                                                                               \
-        MS_W3_MMA(it_, 0, 2);                                                                                 \
+        MS_W3_WAIT(6, it_, 1);                                                                                \
+        MS_W3_MMA(acx, it_, 0, 1);                                                                            \
         if ((it_) + 1 < niter) {                                                                              \
-            MS_W3_READ((it_) + 1, 2);                                                                         \
-            MS_W3_WAIT(12, it_, 0);                                                                           \
-        } else {                                                                                              \
+            MS_W3_READ((it_) + 1, 1);                                                                         \
             MS_W3_WAIT(6, it_, 0);                                                                            \
-        }                                                                                                     \
-        MS_W3_MMA(it_, 2, 0);                                                                                 \
-        if ((it_) + 1 < niter) {                                                                              \
-            MS_W3_READ((it_) + 1, 0);                                                                         \
-            MS_W3_WAIT(12, it_, 1);                                                                           \
         } else {                                                                                              \
-            MS_W3_WAIT(0, it_, 1);                                                                            \
+            MS_W3_WAIT(0, it_, 0);                                                                            \
         }                                                                                                     \
-        MS_W3_MMA(it_, 1, 1);                                                                                 \
-        MS_W3_MMA(it_, 0, 1);                                                                                 \
-        MS_W3_MMA(it_, 1, 0);                                                                                 \
-        MS_W3_MMA(it_, 0, 0);                                                                                 \
+        MS_W3_MMA(acx, it_, 1, 0);                                                                            \
+        MS_W3_MMA(acc, it_, 0, 0);                                                                            \
+        if ((it_) + 1 < niter) { MS_W3_READ((it_) + 1, 0); }                                                  \
     }
-        MS_W3_READ(0, 2);
+        MS_W3_READ(0, 1);
         MS_W3_READ(0, 0);
         MS_W3_ITER(0) MS_W3_ITER(1) MS_W3_ITER(2) MS_W3_ITER(3)
         MS_W3_ITER(4) MS_W3_ITER(5) MS_W3_ITER(6) MS_W3_ITER(7)
@@ -540,6 +614,15 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const flo
 
     // ---- one slab per WORKGROUP: the four waves' accumulators are summed through LDS (the staging images are
     // free now), wave c writes input channel c.  D[co][k]: lane (k = lane & 15, co quad = lane >> 4), rows r.
+    {
+        const float kfin = (Sg != 0.f) ? 1.f / (Sg * Sx) : 0.f;       // (powers of two: exact) undo the current scales
+#pragma unroll
+        for (int c = 0; c < GCG; ++c)
+#pragma unroll
+            for (int j = 0; j < NKT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[c][j][r] = fmaf(acx[c][j][r], CROSS, acc[c][j][r]) * kfin;
+    }
     __syncthreads();
     static_assert((4 * GCG * NKT * 4 * 64 + 64) * 4 <= 4 * W_WAVE, "reduction scratch fits the staging images");
     float* red = reinterpret_cast<float*>(lds);                   // [wave][c][tile][r][lane]
@@ -597,7 +680,7 @@ constexpr int BQ = 48;                        // q's per unit (3 MFMA column til
 constexpr int BNP = 64;                       // gradient positions staged per unit: q0 - 8 .. q0 + 55
 constexpr int BOCT = BNP * 16 + 32;           // bytes per octet image (== 32 mod 128)
 constexpr int B_PIECE = 2 * BOCT;
-constexpr int B_WAVE = 3 * B_PIECE;
+constexpr int B_WAVE = 2 * B_PIECE;         // two fp16 pieces (r04)
 constexpr int BJ = 6;                         // MFMA steps: taps 2J, 2J+1
 
 template <bool VEC, bool VOUT>
@@ -661,8 +744,9 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_bwd_data(ConvP p, int ti
     int b = unit / tiles, ti = unit - b * tiles;
     if (unit < nunits) gload(b, ti);
 
-    // ---- weight fragments: lane (m = (ci, r), kg = (octet, tap parity)) holds w[g*16 + 8 oct + e][ci][r + 4 (2J + tp)]
-    bf16x8 A[BJ][3];
+    // ---- weight fragments: lane (m = (ci, r), kg = (octet, tap parity)) holds 64 w[g*16 + 8 oct + e][ci][r + 4 (2J + tp)]
+    // in two fp16 pieces
+    f16x8 A[BJ][2];
     {
         const int ci = n >> 2, r = n & 3;
 #pragma unroll
@@ -673,18 +757,17 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_bwd_data(ConvP p, int ti
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float v = w[((size_t)(g * 16 + 8 * oct + e) * GCG + ci) * GK + (ok ? tap : 0)];
-                wv[e] = ok ? v : 0.f;
+                wv[e] = ok ? v * WSCALE : 0.f;
             }
-            u32x4 h, m, l;
+            u32x4 h, l;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                unsigned hh, mm, ll;
-                split_pair(wv[2 * q], wv[2 * q + 1], hh, mm, ll);
-                h[q] = hh; m[q] = mm; l[q] = ll;
+                unsigned hh, ll;
+                split_pair2(wv[2 * q], wv[2 * q + 1], hh, ll);
+                h[q] = hh; l[q] = ll;
             }
-            A[J][0] = __builtin_bit_cast(bf16x8, h);
-            A[J][1] = __builtin_bit_cast(bf16x8, m);
-            A[J][2] = __builtin_bit_cast(bf16x8, l);
+            A[J][0] = __builtin_bit_cast(f16x8, h);
+            A[J][1] = __builtin_bit_cast(f16x8, l);
         }
     }
     // B fragment of (tile tq, step J): position (q0 + 16 tq + n) + 5 - 2J - tp, window index = that - (q0 - 8)
@@ -692,18 +775,25 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_bwd_data(ConvP p, int ti
     const int Lq = (p.Lin + GS - 1) / GS;
 
     for (; unit < nunits; unit += wstride) {
-        // ---- registers -> LDS: activation derivative, 4 x 4 transpose, split, one 8-byte co quad per position
+        // ---- the unit's block scale (the raw gradient bounds the masked one; a wave owns the whole unit: no barrier)
+        float um = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) um = fmaxf(um, fabsf(gv[k][j]));
+        float S, invS;
+        block_scale(wave_max_dpp(um), S, invS);
+        // ---- registers -> LDS: activation derivative, 4 x 4 transpose, scale, split, one 8-byte co quad per position
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float e[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) e[k] = ms_act_grad(gv[k][j], ga[k][j], kind, p.slope);
-            unsigned h0, m0, l0, h1, m1, l1;
-            split_pair(e[0], e[1], h0, m0, l0);
-            split_pair(e[2], e[3], h1, m1, l1);
+            for (int k = 0; k < 4; ++k) e[k] = ms_act_grad(gv[k][j], ga[k][j], kind, p.slope) * S;
+            unsigned h0, l0, h1, l1;
+            split_pair2(e[0], e[1], h0, l0);
+            split_pair2(e[2], e[3], h1, l1);
             *reinterpret_cast<uint2*>(wr + j * 16) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(wr + j * 16 + B_PIECE) = make_uint2(m0, m1);
-            *reinterpret_cast<uint2*>(wr + j * 16 + 2 * B_PIECE) = make_uint2(l0, l1);
+            *reinterpret_cast<uint2*>(wr + j * 16 + B_PIECE) = make_uint2(l0, l1);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -721,12 +811,12 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_bwd_data(ConvP p, int ti
         if (nti >= tiles) { nti -= tiles; ++nb; }
         if (unit + wstride < nunits) gload(nb, nti);
 
-        f32x4 acc[3];
+        f32x4 acc[3], acx[3];                         // main (h h') / cross (h l' + l h', scaled 2^11) sums
 #pragma unroll
-        for (int tq = 0; tq < 3; ++tq) acc[tq] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // read groups (one piece, three tiles) two groups ahead of the MFMAs they feed; partial products smallest
-        // first: (a1 b3) | (a3 b1) | (a2 b2) (a1 b2) (a2 b1) (a1 b1)
-        u32x4 Bf[2][3][3];                            // [step parity][piece][tile]
+        for (int tq = 0; tq < 3; ++tq) acc[tq] = acx[tq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // read groups (one piece, three tiles) one group ahead of the MFMAs they feed, counted waits; per step the low
+        // gradient piece first (a_h b_l), then the high one (a_l b_h, a_h b_h)
+        u32x4 Bf[2][2][3];                            // [step parity][piece][tile]
 #define MS_B3_READ(J_, pc)                                                                                    \
     _Pragma("unroll") for (int tq = 0; tq < 3; ++tq)                                                          \
         asm volatile("ds_read_b128 %0, %1 offset:%2"                                                          \
@@ -735,22 +825,18 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_bwd_data(ConvP p, int ti
 #define MS_B3_WAIT(cnt, J_, pc)                                                                               \
     asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                \
                  : "+v"(Bf[(J_) & 1][pc][0]), "+v"(Bf[(J_) & 1][pc][1]), "+v"(Bf[(J_) & 1][pc][2]))
-#define MS_B3_MMA(J_, pa, pb)                                                                                 \
+#define MS_B3_MMA(dst, J_, pa, pb)                                                                            \
     _Pragma("unroll") for (int tq = 0; tq < 3; ++tq)                                                          \
-        acc[tq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                                    \
-            A[J_][pa], __builtin_bit_cast(bf16x8, Bf[(J_) & 1][pb][tq]), acc[tq], 0, 0, 0);
+        dst[tq] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                                     \
+            A[J_][pa], __builtin_bit_cast(f16x8, Bf[(J_) & 1][pb][tq]), dst[tq], 0, 0, 0);
 #define MS_B3_STEP(J_, last)                                                                                  \
-    MS_B3_READ(J_, 1);                                                                                        \
-    MS_B3_WAIT(6, J_, 2);                                                                                     \
-    MS_B3_MMA(J_, 0, 2);                                                                                      \
-    if (!(last)) { MS_B3_READ((J_) + 1, 2); MS_B3_WAIT(6, J_, 0); } else { MS_B3_WAIT(3, J_, 0); }            \
-    MS_B3_MMA(J_, 2, 0);                                                                                      \
-    if (!(last)) { MS_B3_READ((J_) + 1, 0); MS_B3_WAIT(6, J_, 1); } else { MS_B3_WAIT(0, J_, 1); }            \
-    MS_B3_MMA(J_, 1, 1);                                                                                      \
-    MS_B3_MMA(J_, 0, 1);                                                                                      \
-    MS_B3_MMA(J_, 1, 0);                                                                                      \
-    MS_B3_MMA(J_, 0, 0);
-        MS_B3_READ(0, 2);
+    MS_B3_WAIT(3, J_, 1);                                                                                     \
+    MS_B3_MMA(acx, J_, 0, 1);                                                                                 \
+    if (!(last)) { MS_B3_READ((J_) + 1, 1); MS_B3_WAIT(3, J_, 0); } else { MS_B3_WAIT(0, J_, 0); }            \
+    MS_B3_MMA(acx, J_, 1, 0);                                                                                 \
+    MS_B3_MMA(acc, J_, 0, 0);                                                                                 \
+    if (!(last)) { MS_B3_READ((J_) + 1, 0); }
+        MS_B3_READ(0, 1);
         MS_B3_READ(0, 0);
         MS_B3_STEP(0, false) MS_B3_STEP(1, false) MS_B3_STEP(2, false)
         MS_B3_STEP(3, false) MS_B3_STEP(4, false) MS_B3_STEP(5, true)
@@ -758,6 +844,11 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_bwd_data(ConvP p, int ti
 #undef MS_B3_MMA
 #undef MS_B3_WAIT
 #undef MS_B3_READ
+        const float kscale = invS * (1.f / WSCALE);
+#pragma unroll
+        for (int tq = 0; tq < 3; ++tq)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) acc[tq][rr] = fmaf(acx[tq][rr], CROSS, acc[tq][rr]) * kscale;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll

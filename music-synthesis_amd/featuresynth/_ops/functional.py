@@ -601,23 +601,6 @@ class ConvTranspose1dExFn(Function):
         return gx, gw, (gb if ctx.has_bias else None), None, None, None, None
 
 
-class HandoffFn(Function):
-    """Identity whose backward runs on the stream its forward ran on.  A feature map computed on a forked stream has two
-    gradient producers -- the next layer's backward (forked stream) and the feature-matching loss (caller's stream) -- and
-    the engine's cross-stream accumulation of the two diverged under hipGraph replay (tools/dbg_realfork.py: generator
-    gradients of the G-step only; the D-step, whose cross-stream hand-offs all have ONE producer, was exact).  With the
-    map handed to the loss through this node, the loss gradient reaches the forked stream by a single-producer hand-off
-    and the accumulation happens between two gradients of the SAME stream."""
-
-    @staticmethod
-    def forward(ctx, x):
-        return x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, gy):
-        return gy
-
-
 class AvgPoolKFn(Function):
     """F.avg_pool1d(x, k)."""
 

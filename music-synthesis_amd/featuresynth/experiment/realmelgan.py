@@ -201,8 +201,7 @@ class NLayerDiscriminator(nn.Module):
                 feat = F_.AvgPoolKFn.apply(feat.contiguous(), feat.shape[-1] // x.shape[-1])
                 x = torch.cat([feat, x], dim=1)
             x = layer(x)
-            # (on a forked stream the map goes to the loss through a hand-off node: see functional.HandoffFn)
-            results.append(F_.HandoffFn.apply(x) if (_G._FORK_DEPTH > 0 and x.requires_grad) else x)
+            results.append(x)
         return results
 
 
@@ -221,48 +220,17 @@ class Discriminator(nn.Module):
         return F_.AvgPool421Fn.apply(x)
 
     def forward(self, x, feat=None):
-        """The three discriminators are independent (realmelgan.py:163-181): the pooled ones run on forked HIP streams
-        (parallel hipGraph branches), as the headline model's three scales do.  Every tensor that is allocated on one
-        stream and consumed on another is registered with the consumer stream (`record_stream`): the caching allocator --
-        and the private pool of a captured graph in particular -- otherwise recycles its block as soon as the Python
-        reference goes, while the other stream's kernels may not have run yet (r01/r02: replay diverged)."""
-        from .._ops import graph as G
+        """realmelgan.py:163-181: three independent discriminators on x, pool(x), pool(pool(x)), issued back to back on the
+        caller's stream.  (r01-r03 carried an opt-in variant with the pooled discriminators on forked streams, +3 % under
+        hipGraph replay; its replay died once inside hipGraphLaunch and no cause could be proven from that one stack --
+        DESIGN.md section 4, "Streams inside the graph" lists what was audited and fixed -- so r04 removed it: a switch that
+        can take the process down is not shipped.)"""
         _derive_weights(self)
         discs = list(self.model.values())
         xs = [x]
         for _ in discs[1:]:
             xs.append(self.downsample(xs[-1]))
-        dev = x.device
-        fork = (x.is_cuda and len(discs) > 1 and os.environ.get("MSYNTH_REAL_FORK", "0") == "1" and G._may_fork(dev))
-        if not fork:
-            zs = [disc(xi, feat) for disc, xi in zip(discs, xs)]
-        else:
-            main = torch.cuda.current_stream(dev)
-            side = G._side_streams(dev, len(discs) - 1)
-            ev = torch.cuda.Event()
-            ev.record(main)
-            zs = [None] * len(discs)
-            zs[0] = discs[0](xs[0], feat)                      # longest job first, on the caller's stream
-            for i in range(1, len(discs)):
-                st = side[i - 1]
-                st.wait_event(ev)
-                # (the input's gradient has two producers as well -- this discriminator's first layer, on the forked
-                #  stream, and the pooling chain, on the caller's: a hand-off node on the caller's side makes it one stream)
-                xin = F_.HandoffFn.apply(xs[i]) if xs[i].requires_grad else xs[i]
-                xin.record_stream(st)
-                xs[i].record_stream(st)
-                if feat is not None:
-                    feat.record_stream(st)
-                for m in discs[i].modules():                    # this pass's derived weights were made on the main stream
-                    w = getattr(m, "_w", None)
-                    if w is not None:
-                        w.record_stream(st)
-                with G.forked(st):
-                    zs[i] = discs[i](xin, feat)
-                for t in zs[i]:
-                    t.record_stream(main)
-            for st in side:
-                main.wait_stream(st)
+        zs = [disc(xi, feat) for disc, xi in zip(discs, xs)]
         features = [z[:-1] for z in zs]
         judgements = [z[-1] for z in zs]
         return features, judgements

@@ -479,7 +479,7 @@ def test_grouped_kernel_generations_agree(shape, monkeypatch):
         gw, gb = P.conv1d_bwd_weight(x, gy, ya, d, w.shape, gw=gw0.clone(), gb=gb0.clone(), accumulate=True)
         out[gen] = (y, gx, gw, gb)
     for a, c in zip(out["1"], out["0"]):
-        assert rel_l2(host(a), host(c)) < 1e-6
+        assert rel_l2(host(a), host(c)) < 2e-6     # (r04: block-scaled fp16 x 2 / three products against fp32 MFMA: fp32 summation-order level)
 
 
 @pytest.mark.parametrize("case", [

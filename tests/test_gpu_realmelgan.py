@@ -473,23 +473,24 @@ def test_conditioned_discriminator_through_trainers():
         print("conditioned discriminator, %s-step: worst grad rel-L2 vs reference order %.2e" % (kind, worst))
 
 
-def test_realmelgan_forked_replay_gradients_bitwise(monkeypatch):
-    """the three discriminators on forked HIP streams under hipGraph replay.  The divergence of
-    r01 / r02 was the autograd engine accumulating a gradient with TWO producers on different streams (a feature map:
-    next layer's backward on the forked stream + the feature-matching loss on the caller's; a pooled input: first layer +
-    pooling chain) -- only G-steps were affected, D-steps (single-producer hand-offs only) were exact.  With the hand-off
-    nodes (functional.HandoffFn) every accumulation is between gradients of one stream: with lr = 0 (parameters fixed)
-    the gradients of every call -- eager, capture, replay -- must equal the unforked eager run's bitwise."""
+def test_realmelgan_replay_gradients_bitwise(monkeypatch):
+    """hipGraph capture and replay of the weight-normed variant's train steps reproduce the eager execution bitwise: with
+    lr = 0 (parameters fixed) every one of D,G,D,G,D,G -- call 1 eager, call 2 captured, later calls replayed -- yields the
+    same loss and the same flat gradient bucket as the eager run.  (r03 also ran the three discriminators on forked streams
+    here; that variant was removed in r04)  Trainers are dropped between the runs: their graphs must
+    go when they go (no reference cycle through the graphed step), not whenever the cycle collector fires."""
+    import gc
+    import weakref
     import featuresynth as fs
     from featuresynth import loss as LS
     from featuresynth._synthetic import synthetic_features, synthetic_samples
     from featuresynth.experiment import realmelgan as R
     from featuresynth.train import DiscriminatorTrainer, GeneratorTrainer
     s, f = dev(synthetic_samples(2, 1024, rank=1)), dev(synthetic_features(2, 128, 4, rank=1))
+    dead = []
 
-    def run(graph, fork):
+    def run(graph):
         monkeypatch.setenv("MSYNTH_GRAPH", graph)
-        monkeypatch.setenv("MSYNTH_REAL_FORK", fork)
         g, d, _, _ = _nets()
         go = fs.FlatAdam(g.parameters(), lr=0.0, betas=(0.5, 0.9))
         do = fs.FlatAdam(d.parameters(), lr=0.0, betas=(0.5, 0.9))
@@ -503,16 +504,16 @@ def test_realmelgan_forked_replay_gradients_bitwise(monkeypatch):
             out.append((r.get("d_loss", r.get("g_loss")), host(opt.flat_grads).copy()))
         if graph == "1":
             assert dt._runner.graphs and gt._runner.graphs and not gt._runner.disabled
+        dead.append(weakref.ref(dt._runner))
         return out
 
-    ref = run("0", "0")
-    # forked + replayed is opt-in (MSYNTH_TEST_FORK_GRAPH=1): it reproduced the reference bitwise in every run of this test,
-    # and the process died ONCE in hipGraphLaunch (torch/cuda/graphs.py replay) in seven full-suite runs of r03 -- a product
-    # default must not do that, so the forked variant is off unless MSYNTH_REAL_FORK=1 and CI replays the unforked graph
-    import os
-    modes = [("0", "1"), ("1", "0")] + ([("1", "1")] if os.environ.get("MSYNTH_TEST_FORK_GRAPH") == "1" else [])
-    for graph, fork in modes:
-        got = run(graph, fork)
-        for i in range(6):
-            assert got[i][0] == ref[i][0], (graph, fork, i, got[i][0], ref[i][0])
-            assert np.array_equal(got[i][1], ref[i][1]), (graph, fork, i, float(np.abs(got[i][1] - ref[i][1]).max()))
+    gc.disable()
+    try:
+        ref = run("0")
+        got = run("1")
+        assert all(r() is None for r in dead), "a dropped trainer's graphed step must be freed by reference counting alone"
+    finally:
+        gc.enable()
+    for i in range(6):
+        assert got[i][0] == ref[i][0], (i, got[i][0], ref[i][0])
+        assert np.array_equal(got[i][1], ref[i][1]), (i, float(np.abs(got[i][1] - ref[i][1]).max()))
