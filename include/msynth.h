@@ -390,6 +390,16 @@ int ms_l1_mean_multi_fwd(const ms_l1_multi_desc* d, float* out, void* workspace,
 int ms_l1_mean_multi_bwd(const ms_l1_multi_desc* d, const float* gout, float scale,
                          ms_stream_t stream);
 /*
+ * The same sum AND its gradients in one pass over the maps, for a caller that knows the upstream gradient as a host
+ * constant (the loss is the root of a train step's backward pass: train/train.py:36, loss.backward()):
+ *     out[0] = sum_i w[i] * mean(|f_i - r_i|),     gf[i] = gconst * w[i] / n[i] * sign(f_i - r_i)   (gf[i] may be NULL)
+ * Every map must hold a multiple of 4 elements and be 16-byte aligned (workspace query returns 0 otherwise, the call
+ * MS_ERR_UNSUPPORTED: use the two calls above).
+ */
+size_t ms_l1_mean_multi_fwd_bwd_workspace_bytes(const ms_l1_multi_desc* d);
+int ms_l1_mean_multi_fwd_bwd(const ms_l1_multi_desc* d, float* out, float gconst, void* workspace,
+                             size_t workspace_bytes, ms_stream_t stream);
+/*
  * The GAN terms over the (small) judgement tensors of all discriminator scales in ONE launch each way:
  *   kind MS_JUDGE_HINGE_D:  out[0] = sum_i mean(relu(1 - r_i) + relu(1 + f_i))      (loss/loss.py:17-25)
  *   kind MS_JUDGE_NEG_MEAN: out[0] = sum_i mean(-f_i)                                (loss/loss.py:9, 68-78)

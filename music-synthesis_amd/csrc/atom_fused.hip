@@ -204,7 +204,8 @@ struct AtomCfg {
 // epilogue moves 16 bytes per lane (one channel per lane: 64 scattered 16-byte pieces per instruction -- 5-15 % SLOWER than
 // dword accesses that are 128 contiguous bytes per channel row); two tile widths dealt so that the persistent workgroups get
 // equal column counts (-4 % at 128 channels, +8 % at 64 where the second GEMM body spills); a start stagger of the second
-// resident workgroup and s_setprio around the GEMMs (0 to +5 % slower).
+// resident workgroup and s_setprio around the GEMMs (0 to +5 % slower); y / u / residual as 16-byte row-major vectors through a
+// per-wave LDS transpose (a quarter of the epilogue's vector-memory instructions: no change of the train step, +-1 %).
 template <int C, int NTP, int NW, int MODE, int NP, int DBG = 0>
 __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom_fwd(AtomP p, const float* __restrict__ X, const u32x4* __restrict__ IMG,
                                                  const float* __restrict__ b0, const float* __restrict__ b1,

@@ -540,6 +540,42 @@ __global__ __launch_bounds__(256) void k_l1_multi_bwd(L1MultiK k, const float* _
     }
 }
 
+// Forward and backward in ONE pass over the maps (r04): a train step's loss is the root of the backward pass, so the upstream
+// gradient of every L1 term is a constant the host knows (gconst) and sign(f - r) can be written while |f - r| is summed:
+// r and f are read once instead of twice (266 MB less per generator step at B = 32).  16-byte accesses (every map is a
+// multiple of 4 elements and 16-byte aligned: checked by the caller), 8192 elements per block.
+constexpr int L1M_FB_EPB = 8192;
+__global__ __launch_bounds__(256) void k_l1_multi_fwd_bwd(L1MultiK k, float* __restrict__ partials, float gconst) {
+    __shared__ float red[4];
+    const int m = l1m_map(k, blockIdx.x);
+    const float4* r = reinterpret_cast<const float4*>(k.d.r[m]);
+    const float4* f = reinterpret_cast<const float4*>(k.d.f[m]);
+    float4* gf = reinterpret_cast<float4*>(k.d.gf[m]);
+    const int64_t n4 = k.d.n[m] / 4;
+    const float g = gconst * k.d.w[m] / (float)k.d.n[m];
+    const int64_t base = (int64_t)(blockIdx.x - k.blk0[m]) * (L1M_FB_EPB / 4);
+    float4 rv[8], fv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t e = base + threadIdx.x + 256 * i;
+        const int64_t ec = e < n4 ? e : 0;
+        rv[i] = r[ec]; fv[i] = f[ec];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t e = base + threadIdx.x + 256 * i;
+        const float d0 = fv[i].x - rv[i].x, d1 = fv[i].y - rv[i].y, d2 = fv[i].z - rv[i].z, d3 = fv[i].w - rv[i].w;
+        if (e < n4) {
+            s += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+            if (gf) gf[e] = make_float4(d0 > 0.f ? g : (d0 < 0.f ? -g : 0.f), d1 > 0.f ? g : (d1 < 0.f ? -g : 0.f),
+                                        d2 > 0.f ? g : (d2 < 0.f ? -g : 0.f), d3 > 0.f ? g : (d3 < 0.f ? -g : 0.f));
+        }
+    }
+    const float tot = ms_block_sum(s, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
 bool l1m_plan(const ms_l1_multi_desc* d, L1MultiK* k, int epb = 2048) {
     if (!d || d->count <= 0 || d->count > MS_L1_MULTI_MAX) return false;
     k->d = *d;
@@ -773,6 +809,31 @@ int ms_l1_mean_multi_fwd(const ms_l1_multi_desc* d, float* out, void* ws, size_t
     const int nblk = k.blk0[MS_L1_MULTI_MAX];
     if (!ws || wsb < (size_t)nblk * sizeof(float)) return MS_ERR_WORKSPACE;
     hipLaunchKernelGGL(k_l1_multi_fwd, dim3(nblk), dim3(256), 0, (hipStream_t)stream, k, (float*)ws);
+    MS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_l1_multi_final, dim3(1), dim3(256), 0, (hipStream_t)stream, k, (const float*)ws, out);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+static bool l1m_vec_ok(const ms_l1_multi_desc* d) {
+    for (int i = 0; i < d->count; ++i)
+        if ((d->n[i] & 3) || (((uintptr_t)d->r[i] | (uintptr_t)d->f[i] | (uintptr_t)d->gf[i]) & 15)) return false;
+    return true;
+}
+
+size_t ms_l1_mean_multi_fwd_bwd_workspace_bytes(const ms_l1_multi_desc* d) {
+    L1MultiK k;
+    if (!l1m_plan(d, &k, L1M_FB_EPB) || !l1m_vec_ok(d)) return 0;
+    return (size_t)k.blk0[MS_L1_MULTI_MAX] * sizeof(float);
+}
+
+int ms_l1_mean_multi_fwd_bwd(const ms_l1_multi_desc* d, float* out, float gconst, void* ws, size_t wsb, ms_stream_t stream) {
+    L1MultiK k;
+    if (!out || !l1m_plan(d, &k, L1M_FB_EPB)) return MS_ERR_INVALID_ARG;
+    if (!l1m_vec_ok(d)) return MS_ERR_UNSUPPORTED;
+    const int nblk = k.blk0[MS_L1_MULTI_MAX];
+    if (!ws || wsb < (size_t)nblk * sizeof(float)) return MS_ERR_WORKSPACE;
+    hipLaunchKernelGGL(k_l1_multi_fwd_bwd, dim3(nblk), dim3(256), 0, (hipStream_t)stream, k, (float*)ws, gconst);
     MS_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_l1_multi_final, dim3(1), dim3(256), 0, (hipStream_t)stream, k, (const float*)ws, out);
     MS_CHECK_LAUNCH();

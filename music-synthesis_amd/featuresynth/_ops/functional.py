@@ -423,8 +423,12 @@ class MelGanDiscLossCatFn(Function):
         return (None, None) + tuple(disc_loss_cat_bwd(ctx.js, B, _c(g), need))
 
 
-def gen_loss_fwd(S, Lyr, weight, rf, ff, fj):
-    """sum_s mean(-fj_s) + weight * sum_{s,l} (1/S)(1/Lyr) l1(rf, ff) -> (0-d device tensor, fscale)."""
+def gen_loss_fwd(S, Lyr, weight, rf, ff, fj, root_grads=None):
+    """sum_s mean(-fj_s) + weight * sum_{s,l} (1/S)(1/Lyr) l1(rf, ff) -> (0-d device tensor, fscale).
+
+    root_grads: a list; when given and the loss is the ROOT of the backward pass (upstream gradient 1, the hand-scheduled
+    step), the feature-matching gradients w.r.t. ff are produced in the same pass over the maps and appended to it
+    (gen_loss_bwd is then called with need_f all False)."""
     nf = S * Lyr
     dev = fj[0].device
     fscale = float(weight) * (1.0 / S) * (1.0 / Lyr)
@@ -432,7 +436,11 @@ def gen_loss_fwd(S, Lyr, weight, rf, ff, fj):
         if P.judge_multi_ok(fj):  # ... and the S adversarial terms in one launch
             terms = torch.empty((2,), dtype=torch.float32, device=dev)
             P.judge_loss_multi_fwd(L.JUDGE_NEG_MEAN, None, list(fj), terms[0:])
-            P.l1_mean_multi_fwd(rf, ff, [1.0] * nf, terms[1:])
+            g_ff = P.l1_mean_multi_fwd_bwd(rf, ff, [1.0] * nf, terms[1:], fscale) if root_grads is not None else None
+            if g_ff is not None:
+                root_grads.extend(g_ff)
+            else:
+                P.l1_mean_multi_fwd(rf, ff, [1.0] * nf, terms[1:])
             return P.weighted_sum(terms, _coef([1.0, fscale], dev)), fscale
         terms = torch.empty((S + 1,), dtype=torch.float32, device=dev)
         for s in range(S):

@@ -164,6 +164,8 @@ SIGNATURES = {
     "ms_l1_mean_multi_workspace_bytes": (_sz, [ctypes.POINTER(L1MultiDesc)]),
     "ms_l1_mean_multi_fwd": (_c_int, [ctypes.POINTER(L1MultiDesc), _vp, _vp, _sz, _vp]),
     "ms_l1_mean_multi_bwd": (_c_int, [ctypes.POINTER(L1MultiDesc), _vp, _c_f, _vp]),
+    "ms_l1_mean_multi_fwd_bwd_workspace_bytes": (_sz, [ctypes.POINTER(L1MultiDesc)]),
+    "ms_l1_mean_multi_fwd_bwd": (_c_int, [ctypes.POINTER(L1MultiDesc), _vp, _c_f, _vp, _sz, _vp]),
     "ms_ls_g_fwd": (_c_int, [_vp, _c_i64, _vp, _vp, _sz, _vp]),
     "ms_ls_g_bwd": (_c_int, [_vp, _c_i64, _vp, _c_f, _vp, _vp]),
     "ms_ls_d_fwd": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _sz, _vp]),

@@ -670,6 +670,22 @@ def l1_mean_multi_bwd(rs, fs, ws, gout, scale, need):
     return gfs
 
 
+def l1_mean_multi_fwd_bwd(rs, fs, ws, out, gconst):
+    """out[0] = sum_i ws[i] * mean(|fs[i] - rs[i]|) AND the gradients w.r.t. every fs[i] for an upstream gradient known on
+    the host (gconst), in one pass over the maps; -> list of gradients, or None when a map is not 16-byte shaped (the
+    caller then uses the two separate calls)."""
+    gfs = [torch.empty_like(f) for f in fs]
+    d = _l1_multi_desc(rs, fs, ws, gfs)
+    lib = L.load()
+    nws = lib.ms_l1_mean_multi_fwd_bwd_workspace_bytes(d)
+    if nws == 0:
+        return None
+    wsb = L.workspace(nws, out.device)
+    n = sum(int(r.numel()) for r in rs)
+    L.call("ms_l1_mean_multi_fwd_bwd", _scost(n, 2, 1, 2), d, out.data_ptr(), float(gconst), L.ptr(wsb), nws, L.stream())
+    return gfs
+
+
 def ls_g_bwd(j, gout, scale=1.0):
     gj = torch.empty_like(j)
     L.call("ms_ls_g_bwd", _scost(j.numel(), 1, 1), j.data_ptr(), j.numel(), gout.data_ptr(), scale,

@@ -92,11 +92,17 @@ def g_step(gen_params, disc_params, samples, features, scales=2, weight=10.0, cu
     S, Lyr = len(f_feats), len(f_feats[0])
     rf = [t for grp in r_feats for t in grp]
     ff = [t for grp in f_feats for t in grp]
-    loss, fscale = F_.gen_loss_fwd(S, Lyr, weight, rf, ff, f_judges)
+    # the loss is the root of this step's backward pass (upstream gradient 1): the feature-matching gradients come out of
+    # the same pass over the 18 map pairs that sums the loss
+    root = []
+    loss, fscale = F_.gen_loss_fwd(S, Lyr, weight, rf, ff, f_judges, root_grads=root)
     if loss_slot is not None:
         loss_slot.copy_(loss)
+    fused = len(root) == len(ff)
     _, g_ff, g_fj = F_.gen_loss_bwd(S, fscale, rf, ff, f_judges, _one(dev), [False] * len(rf),
-                                    [True] * len(ff), [True] * S)
+                                    [not fused] * len(ff), [True] * S)
+    if fused:
+        g_ff = root
     g_feats = [g_ff[Lyr * s:Lyr * s + Lyr] for s in range(S)]
     gx, _ = G.melgan_backward(ctx, disc_params, g_feats, g_fj, None, need_gx=True, need_wgrad=False, k5_image_bwd=k5b)
     if debug is not None:
