@@ -18,11 +18,11 @@
 //           per multiply on v_mfma_f32_32x32x16_bf16 (conv_rows3.hip's arithmetic, bitwise equal to the two row-tile
 //           launches).  Ceiling 2500 / 6 TFLOP/s.
 //   NP = 2  (r04) block-scaled two-piece fp16: per tile the window (and later the t tile) is multiplied by a power of two S
-//           that puts its largest magnitude at 2^14, then x S = h + l 2^-11 with h = fp16(x S), l = fp16((x S - h) 2^11):
-//           11 + 11 significand bits, every element within 2^-22 of its fp32 value RELATIVE TO THE TILE MAXIMUM's
-//           binade (elements more than 2^14 below the tile maximum keep fewer bits; they do not matter in a dot product
-//           with it).  Products h h' -> one accumulator, h l' + l h' -> a second one (scaled 2^11), the dropped l l' is
-//           below 2^-22: THREE products on v_mfma_f32_32x32x16_f16 instead of six, 4 instead of 6 bytes per operand
+//           that puts its largest magnitude at 2^14, then x S = h + l with h = fp16(x S), l = fp16(x S - h): 11 + 11
+//           significand bits for every element within 2^16 of the tile maximum, an absolute error below 2^-39 of that
+//           maximum for the smaller ones (which cannot matter in a dot product with it).  Products h h' + h l' + l h' into
+//           ONE fp32 accumulator (every product of two 11-bit numbers is exact in fp32), the dropped l l' is below 2^-22:
+//           THREE products on v_mfma_f32_32x32x16_f16 instead of six, 4 instead of 6 bytes per operand
 //           element in LDS and in the weight stream.  Power-of-two scalings are exact; the result differs from the fp32
 //           FMA chain by what two fp32 summation orders differ by (measured against float64: tests/test_gpu_atom.py).
 //           Weights are pre-scaled by 2^6 (|w| < 2^9 assumed: anything larger overflows fp16 loudly to inf).
@@ -49,12 +49,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float WSCALE = 64.f;            // NP = 2: weights are packed as fp16 pieces of 64 w
-constexpr float CROSS = 1.f / 2048.f;     // NP = 2: scale of the low piece
 
 template <int NP> __host__ __device__ constexpr int xrs() { return NP * 32 + 16; }   // bytes per LDS column of one chunk
 
 // (a, b) -> NP packed 16-bit pairs.  NP = 3: a = o[0].lo + o[1].lo + o[2].lo exactly (bf16, conv_rows3.hip);
-// NP = 2: a = o[0].lo + o[1].lo / 2048 to 22 bits (fp16; the caller has scaled a into fp16's range)
+// NP = 2: a = o[0].lo + o[1].lo to 22 bits (fp16; the caller has scaled a so that its block's largest magnitude sits near 2^14:
+// the low piece of any element within 2^16 of that maximum is a normal or fully represented fp16 number, smaller elements
+// keep an absolute error below 2^-25 -- 2^-39 of the maximum)
 template <int NP>
 __device__ __forceinline__ void split_pair(float a, float b, unsigned (&o)[NP]) {
     const f32x2 v = {a, b};
@@ -69,8 +70,7 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned (&o)[NP]) 
         o[2] = __builtin_bit_cast(unsigned, lo);
     } else {
         const f16x2 hi = __builtin_convertvector(v, f16x2);
-        const f32x2 r = (v - __builtin_convertvector(hi, f32x2)) * 2048.f;
-        const f16x2 lo = __builtin_convertvector(r, f16x2);
+        const f16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);
         o[0] = __builtin_bit_cast(unsigned, hi);
         o[1] = __builtin_bit_cast(unsigned, lo);
     }
@@ -356,17 +356,13 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
     };
 
     f32x16 acc[TM][TN];
-    f32x16 acx[SC ? TM : 1][SC ? TN : 1];            // NP = 2: the cross products h l' + l h' (scaled 2^11)
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc[i][j][r] = 0.f;
-                    if (SC) acx[i][j][r] = 0.f;
-                }
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     };
     // one GEMM over the LDS-resident operand: B fragment of (chunk, tap s, column sub-tile j) = 16 bytes per piece at
     // column (col0 + 32 j + l31 + s * step), channels 8h .. 8h + 7 of the chunk.  more: a next tile exists (its first chunk's
@@ -417,9 +413,9 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
                         for (int j = 0; j < TNE; ++j) {
                             const f16x8 ah = __builtin_bit_cast(f16x8, fa[q & 1][i][s][0]), al = __builtin_bit_cast(f16x8, fa[q & 1][i][s][1]);
                             const f16x8 bh = __builtin_bit_cast(f16x8, fb[s & 1][j][0]), bl = __builtin_bit_cast(f16x8, fb[s & 1][j][1]);
-                            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acx[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i][j], 0, 0, 0);     // smallest products first
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i][j], 0, 0, 0);
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
-                            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acx[i][j], 0, 0, 0);
                         }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -451,6 +447,7 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
 #ifndef ATOM_PRE32
 #define ATOM_PRE32 0
 #endif
+    // (128 channels with the registers the single accumulator freed: measured 3 % SLOWER on the train step)
     constexpr bool PRE = C == 64 || (C == 32 && (NP == 3 || ATOM_PRE32));
     for (; tile < ntiles; tile += gridDim.x) {
         const int b = tile / p.tiles_per_row, c0 = (tile - b * p.tiles_per_row) * p.NO;
@@ -519,7 +516,7 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             float v = acc[i][j][4 * g + q];
-                            if (SC) v = (v + acx[i][j][4 * g + q] * CROSS) * k1;
+                            if (SC) v *= k1;
                             v += bv[q];
                             e[q] = inrow ? (v > 0.f ? v : v * p.slope) : 0.f;
                         }
@@ -527,7 +524,7 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             float v = acc[i][j][4 * g + q];
-                            if (SC) v = (v + acx[i][j][4 * g + q] * CROSS) * k1;
+                            if (SC) v *= k1;
                             e[q] = v;
                         }
                     }
@@ -619,7 +616,7 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float v = acc[i][j][4 * g + q];
-                        if (SC) v = (v + acx[i][j][4 * g + q] * CROSS) * k2;
+                        if (SC) v *= k2;
                         v += bv[q];
                         if (!BWD) v = v > 0.f ? v : v * p.slope;
                         if (SAVE) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsU, oy, base + (chs + q) * L4, 0);
@@ -780,9 +777,9 @@ int ms_residual_atom_bwd_supported(const ms_atom_desc* d) {
     if (!ms_residual_atom_supported(d)) return 0;
     const char* sw = getenv("MSYNTH_ATOM_BWD");                  // tuning / test switch (0: the two backward-data launches)
     if (sw && atoi(sw) == 0) return 0;
-    // a tile yields NTP - 2 dil output columns: with 64-column tiles (128 / 256 channels) dilation 9 would spend a third
-    // of the first GEMM on halo -- those atoms keep the two launches
-    if (d->C >= 128 && d->dil > 3) return 0;
+    // (a tile yields NTP - 2 dil output columns: with 64-column tiles (128 / 256 channels) dilation 9 spends 28 % of both
+    //  GEMMs on halo.  With six products per multiply that lost against the two row-tile launches; with three it wins:
+    //  B = 32: 89 vs 114 us at 128 channels, 41 vs 69 us at 256 -- r04 takes every atom of the generator.)
     return 1;
 }
 

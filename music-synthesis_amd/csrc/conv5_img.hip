@@ -21,8 +21,9 @@
 //           block here is (batch row, 16-channel chunk): all five taps of an output column read that row's LDS segment, so
 //           one power-of-two scale per segment factors out of the chunk's partial sum.  The staging lanes of a row (16-64
 //           consecutive lanes of one wave) find the row's largest magnitude by lane shuffles -- no barrier --, scale, split,
-//           and leave 1 / scale in LDS; the MFMA waves start every chunk from zero accumulators and fold
-//           (acc + 2^-11 cross) / scale into the running fp32 sums (64 vector FMAs per 30 MFMAs, in the MFMAs' issue shadow).
+//           and leave 1 / scale in LDS.  A row's scale is sticky across the chunks (it moves only when the row's chunk maximum
+//           times the scale leaves [2^8, 2^15)), so the MFMA waves keep accumulating under it and fold their partial sums
+//           into the running fp32 sums only when a scale has moved (rare).
 // The accumulation order differs from the row kernels' (other chunk / slice grouping): results agree to ~1e-7, not bitwise.
 #include "ms_common.h"
 #include <stdlib.h>
@@ -44,10 +45,9 @@ constexpr int PX_MAX = 350;              // LDS columns per buffer (39.2 / 28 KB
 constexpr int R_MAX = 64;                // batch rows per tile (scale slots)
 constexpr unsigned OOB = 0xF0000000u;
 constexpr float WSCALE = 64.f;           // NP = 2: weights are packed as fp16 pieces of 64 w (|w| < 2^9)
-constexpr float CROSS = 1.f / 2048.f;    // NP = 2: weight of the low piece
 
-// (a, b) -> NP packed 16-bit pairs: NP = 3 exact bf16 pieces; NP = 2 fp16 pieces a = o[0] + o[1] / 2048 (22 bits; the caller
-// has scaled a into fp16's range)
+// (a, b) -> NP packed 16-bit pairs: NP = 3 exact bf16 pieces; NP = 2 fp16 pieces a = o[0] + o[1] (22 bits; the caller has
+// scaled a so that its block's largest magnitude sits in [2^8, 2^15): atom_fused.hip)
 template <int NP>
 __device__ __forceinline__ void split_pair(float a, float b, unsigned (&o)[NP]) {
     const f32x2 v = {a, b};
@@ -62,8 +62,7 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned (&o)[NP]) 
         o[2] = __builtin_bit_cast(unsigned, lo);
     } else {
         const f16x2 hi = __builtin_convertvector(v, f16x2);
-        const f32x2 r = (v - __builtin_convertvector(hi, f32x2)) * 2048.f;
-        const f16x2 lo = __builtin_convertvector(r, f16x2);
+        const f16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);
         o[0] = __builtin_bit_cast(unsigned, hi);
         o[1] = __builtin_bit_cast(unsigned, lo);
     }
@@ -280,13 +279,13 @@ __global__ __launch_bounds__(512, 2) void k_conv5_img(C5P p, const float* __rest
     __syncthreads();
 
     f32x16 acc[2];                                   // the running sums (NP = 2: fp32, unscaled except for WSCALE)
-    f32x16 cm[SC ? 2 : 1], cx[SC ? 2 : 1];          // NP = 2: main / cross partial sums under the rows' current scales
+    f32x16 cm[SC ? 2 : 1];                           // NP = 2: partial sums under the rows' current scales
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             acc[j][r] = 0.f;
-            if (SC) cm[j][r] = cx[j][r] = 0.f;
+            if (SC) cm[j][r] = 0.f;
         }
     float inv_cur[2] = {1.f, 1.f};
     auto fold = [&]() {
@@ -294,8 +293,8 @@ __global__ __launch_bounds__(512, 2) void k_conv5_img(C5P p, const float* __rest
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                acc[j][r] = fmaf(fmaf(cx[j][r], CROSS, cm[j][r]), inv_cur[j], acc[j][r]);
-                cm[j][r] = cx[j][r] = 0.f;
+                acc[j][r] = fmaf(cm[j][r], inv_cur[j], acc[j][r]);
+                cm[j][r] = 0.f;
             }
     };
 
@@ -339,9 +338,9 @@ __global__ __launch_bounds__(512, 2) void k_conv5_img(C5P p, const float* __rest
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const f16x8 bh = __builtin_bit_cast(f16x8, fb[t & 1][j][0]), bl = __builtin_bit_cast(f16x8, fb[t & 1][j][1]);
-                    cx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, cx[j], 0, 0, 0);
+                    cm[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, cm[j], 0, 0, 0);
+                    cm[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, cm[j], 0, 0, 0);
                     cm[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, cm[j], 0, 0, 0);
-                    cx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, cx[j], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

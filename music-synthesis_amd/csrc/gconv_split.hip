@@ -36,15 +36,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int GK = 41, GS = 4, GCG = 4;
 constexpr float WSCALE = 64.f;            // fp16 pieces of the weights are taken from 64 w (|w| < 2^9)
-constexpr float CROSS = 1.f / 2048.f;     // weight of the low fp16 piece
 
 // Block-scaled two-piece fp16 split (r04, atom_fused.hip): (a, b) scaled into fp16's range by the caller ->
-// a = h.lo + l.lo / 2048 to 22 significand bits; products h h' + (h l' + l h') / 2048: three MFMAs instead of six.
+// a = h.lo + l.lo to 22 significand bits (block maximum in [2^8, 2^15)); products h h' + h l' + l h' into one fp32
+// accumulator: three MFMAs instead of six.
 __device__ __forceinline__ void split_pair2(float a, float b, unsigned& h, unsigned& l) {
     const f32x2 v = {a, b};
     const f16x2 hi = __builtin_convertvector(v, f16x2);
-    const f32x2 r = (v - __builtin_convertvector(hi, f32x2)) * 2048.f;
-    const f16x2 lo = __builtin_convertvector(r, f16x2);
+    const f16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);
     h = __builtin_bit_cast(unsigned, hi);
     l = __builtin_bit_cast(unsigned, lo);
 }
@@ -237,9 +236,9 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, in
         unsigned rbo[2];
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) rbo[pc] = rb0 + pc * C::PIECE_BYTES;
-        f32x4 acc[4], acx[4];                        // main (h h') / cross (h l' + l h', scaled 2^11) sums of the four tiles
+        f32x4 acc[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc[s] = acx[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < 4; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // Fragment reads are hand-issued ds_read2_b64 (two quads -> one 4-register operand; the compiler's own
         // pairing of the 8-byte reads put the halves in unrelated registers and paid ~140 v_mov per unit).  The
         // reads of step H+1 are in flight during the MFMAs of step H: counted wait on the older four.
@@ -264,17 +263,17 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, in
                 asm volatile("s_waitcnt lgkmcnt(0)"
                              : "+v"(f[cur][0][0]), "+v"(f[cur][0][1]), "+v"(f[cur][1][0]), "+v"(f[cur][1][1]));
             }
-            // three partial products per tile: (a_h b_l) (a_l b_h) into the cross sum, (a_h b_h) into the main sum; the
-            // tiles' accumulator chains are interleaved so that dependent MFMAs sit 2-4 issues apart
+            // three partial products per tile, smallest first: (a_h b_l), (a_h b_h) ... (a_l b_h); the tiles' accumulator chains
+            // are interleaved so that dependent MFMAs sit 2-4 issues apart
             const f16x8 f0h = __builtin_bit_cast(f16x8, f[cur][0][0]), f0l = __builtin_bit_cast(f16x8, f[cur][0][1]);
             const f16x8 f1h = __builtin_bit_cast(f16x8, f[cur][1][0]), f1l = __builtin_bit_cast(f16x8, f[cur][1][1]);
             if (H < NG) {
-                acx[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H][0], f0l, acx[0], 0, 0, 0);
-                acx[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H][0], f1l, acx[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H][0], f0l, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H][0], f1l, acc[1], 0, 0, 0);
             }
             if (H >= 1) {
-                acx[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H - 1][0], f0l, acx[2], 0, 0, 0);
-                acx[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H - 1][0], f1l, acx[3], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H - 1][0], f0l, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H - 1][0], f1l, acc[3], 0, 0, 0);
             }
             if (H < NG) {
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H][0], f0h, acc[0], 0, 0, 0);
@@ -285,12 +284,12 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, in
                 acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H - 1][0], f1h, acc[3], 0, 0, 0);
             }
             if (H < NG) {
-                acx[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H][1], f0h, acx[0], 0, 0, 0);
-                acx[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H][1], f1h, acx[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H][1], f0h, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H][1], f1h, acc[1], 0, 0, 0);
             }
             if (H >= 1) {
-                acx[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H - 1][1], f0h, acx[2], 0, 0, 0);
-                acx[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H - 1][1], f1h, acx[3], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H - 1][1], f0h, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[H - 1][1], f1h, acc[3], 0, 0, 0);
             }
         }
 #undef MS_G3_READ
@@ -309,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, in
                 float v[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const float pre = fmaf(fmaf(acx[s][r], CROSS, acc[s][r]), kscale, bq[r]);     // undo the block and weight scales
+                    const float pre = fmaf(acc[s][r], kscale, bq[r]);     // undo the block and weight scales
                     v[s] = fmaxf(pre, pre * eslope);                // LeakyReLU (slope in [0, 1]) / identity
                 }
                 if (VOUT) {
@@ -472,11 +471,11 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const flo
     // tile each carry a wave-local power-of-two scale that is STICKY from unit to unit -- it moves only when the unit's largest
     // magnitude times the current scale leaves [2^8, 2^15) -- and when one moves, the accumulators are multiplied by the
     // ratio of the new to the old product scale (a power of two: exact), so they always hold sums under the CURRENT scales.
-    f32x4 acc[GCG][NKT], acx[GCG][NKT];               // main (h h') / cross (h l' + l h', scaled 2^11) sums
+    f32x4 acc[GCG][NKT];
 #pragma unroll
     for (int c = 0; c < GCG; ++c)
 #pragma unroll
-        for (int j = 0; j < NKT; ++j) acc[c][j] = acx[c][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NKT; ++j) acc[c][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float Sg = 0.f, Sx = 0.f;                          // current scales (0: none yet)
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -514,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const flo
 #pragma unroll
                 for (int c = 0; c < GCG; ++c)
 #pragma unroll
-                    for (int j = 0; j < NKT; ++j) { acc[c][j] *= ratio; acx[c][j] *= ratio; }
+                    for (int j = 0; j < NKT; ++j) acc[c][j] *= ratio;
             }
             Sg = nSg; Sx = nSx;
         }
@@ -588,14 +587,14 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const flo
 #define MS_W3_ITER(it_)                                                                                       \
     if ((it_) < niter) {                                                                                      \
         MS_W3_WAIT(6, it_, 1);                                                                                \
-        MS_W3_MMA(acx, it_, 0, 1);                                                                            \
+        MS_W3_MMA(acc, it_, 0, 1);                                                                            \
         if ((it_) + 1 < niter) {                                                                              \
             MS_W3_READ((it_) + 1, 1);                                                                         \
             MS_W3_WAIT(6, it_, 0);                                                                            \
         } else {                                                                                              \
             MS_W3_WAIT(0, it_, 0);                                                                            \
         }                                                                                                     \
-        MS_W3_MMA(acx, it_, 1, 0);                                                                            \
+        MS_W3_MMA(acc, it_, 1, 0);                                                                            \
         MS_W3_MMA(acc, it_, 0, 0);                                                                            \
         if ((it_) + 1 < niter) { MS_W3_READ((it_) + 1, 0); }                                                  \
     }
@@ -621,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const flo
 #pragma unroll
             for (int j = 0; j < NKT; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[c][j][r] = fmaf(acx[c][j][r], CROSS, acc[c][j][r]) * kfin;
+                for (int r = 0; r < 4; ++r) acc[c][j][r] *= kfin;
     }
     __syncthreads();
     static_assert((4 * GCG * NKT * 4 * 64 + 64) * 4 <= 4 * W_WAVE, "reduction scratch fits the staging images");
@@ -811,9 +810,9 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_bwd_data(ConvP p, int ti
         if (nti >= tiles) { nti -= tiles; ++nb; }
         if (unit + wstride < nunits) gload(nb, nti);
 
-        f32x4 acc[3], acx[3];                         // main (h h') / cross (h l' + l h', scaled 2^11) sums
+        f32x4 acc[3];
 #pragma unroll
-        for (int tq = 0; tq < 3; ++tq) acc[tq] = acx[tq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int tq = 0; tq < 3; ++tq) acc[tq] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // read groups (one piece, three tiles) one group ahead of the MFMAs they feed, counted waits; per step the low
         // gradient piece first (a_h b_l), then the high one (a_l b_h, a_h b_h)
         u32x4 Bf[2][2][3];                            // [step parity][piece][tile]
@@ -831,9 +830,9 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_bwd_data(ConvP p, int ti
             A[J_][pa], __builtin_bit_cast(f16x8, Bf[(J_) & 1][pb][tq]), dst[tq], 0, 0, 0);
 #define MS_B3_STEP(J_, last)                                                                                  \
     MS_B3_WAIT(3, J_, 1);                                                                                     \
-    MS_B3_MMA(acx, J_, 0, 1);                                                                                 \
+    MS_B3_MMA(acc, J_, 0, 1);                                                                                 \
     if (!(last)) { MS_B3_READ((J_) + 1, 1); MS_B3_WAIT(3, J_, 0); } else { MS_B3_WAIT(0, J_, 0); }            \
-    MS_B3_MMA(acx, J_, 1, 0);                                                                                 \
+    MS_B3_MMA(acc, J_, 1, 0);                                                                                 \
     MS_B3_MMA(acc, J_, 0, 0);                                                                                 \
     if (!(last)) { MS_B3_READ((J_) + 1, 0); }
         MS_B3_READ(0, 1);
@@ -848,7 +847,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_bwd_data(ConvP p, int ti
 #pragma unroll
         for (int tq = 0; tq < 3; ++tq)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) acc[tq][rr] = fmaf(acx[tq][rr], CROSS, acc[tq][rr]) * kscale;
+            for (int rr = 0; rr < 4; ++rr) acc[tq][rr] *= kscale;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll

@@ -152,3 +152,95 @@ def test_stage1_experiment_loop_and_vocoder(tmp_path, monkeypatch):
         spec = exp.feature_generator(dev(noise))
     audio = exp.features_to_audio(host(spec)[:, :, :8])
     assert audio.shape == (1, 1, 8 * 256) and np.isfinite(audio).all()
+
+
+def test_two_stage_pair_full_size(monkeypatch):
+    """BASELINE configs[4] at its per-GPU size (B = 32): the two-stage D,G pair of bench.py --model twostage -- per step one
+    stage-1 trainer call (128 x 512 spectrograms, least-squares losses) plus one stage-2 trainer call (the headline vocoder at
+    128 mels).  (a) hipGraph replay (calls 3+) against eager execution of the same schedule: every loss and both stages'
+    flat gradient buckets agree BITWISE with lr = 0; (b) the stage-1 D-step and G-step gradients against the float64
+    torch-functional oracle (oracle/torch_graph_stage1.py on the device, LeakyReLU branches as they fall in float64) at the
+    SURVEY 8(d) gates: losses 1e-4, every parameter gradient <= 1e-3 rel-L2."""
+    import featuresynth as fs
+    import featuresynth.experiment as E
+    from featuresynth import loss as LS
+    from featuresynth._synthetic import (module_param_shapes, synthetic_features, synthetic_samples,
+                                         synthetic_state_dict)
+    from featuresynth.train import DiscriminatorTrainer, GeneratorTrainer
+    from oracle import torch_graph_stage1 as S1
+    B, T = 32, 32
+    device = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    spec = dev((rng.standard_normal((B, 128, 512)) * 0.5).astype(np.float32))
+    noise = dev(rng.standard_normal((B, 128, 1)).astype(np.float32))
+    samples, feats = dev(synthetic_samples(B, 8192, rank=3)), dev(synthetic_features(B, 128, T, rank=3))
+
+    def build():
+        torch.manual_seed(5)
+        g = fs.MelGanGenerator(T, 128)
+        d = fs.MelGanDiscriminator()
+        g.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(module_param_shapes(g), seed=7).items()})
+        d.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(module_param_shapes(d), seed=7).items()})
+        g.to(device); d.to(device)
+        s1 = E.TwoDimGeneratorFeatureExperiment(vocoder_network=g)
+        s1g = synthetic_state_dict(module_param_shapes(s1.feature_generator), seed=31, weight_scale=0.03, bias_scale=0.02)
+        s1d = synthetic_state_dict(module_param_shapes(s1.feature_disc), seed=32, weight_scale=0.03, bias_scale=0.02)
+        s1.feature_generator.load_state_dict({k: torch.from_numpy(v) for k, v in s1g.items()})
+        s1.feature_disc.load_state_dict({k: torch.from_numpy(v) for k, v in s1d.items()})
+        s1.to(device)
+        for opt in (s1.g_optim, s1.d_optim):
+            for grp in opt.param_groups:
+                grp["lr"] = 0.0
+        go = fs.FlatAdam(g.parameters(), lr=0.0, betas=(0.5, 0.9))
+        do = fs.FlatAdam(d.parameters(), lr=0.0, betas=(0.5, 0.9))
+        return (s1, DiscriminatorTrainer(g, go, d, do, LS.mel_gan_disc_loss), GeneratorTrainer(g, go, d, do, LS.mel_gan_gen_loss),
+                go, do, s1g, s1d)
+
+    def run(graph):
+        monkeypatch.setenv("MSYNTH_GRAPH", graph)
+        s1, dt, gt, go, do, s1g, s1d = build()
+        out = []
+        for i in range(6):
+            if i % 2 == 0:
+                r1 = s1.d_trainer.train(spec, noise); r2 = dt.train(samples, feats)
+                rec = (r1["d_loss"], r2["d_loss"], host(s1.d_optim.flat_grads).copy(), host(do.flat_grads).copy())
+            else:
+                r1 = s1.g_trainer.train(spec, noise); r2 = gt.train(samples, feats)
+                rec = (r1["g_loss"], r2["g_loss"], host(s1.g_optim.flat_grads).copy(), host(go.flat_grads).copy())
+            out.append(rec)
+        if graph == "1":
+            assert s1.d_trainer._runner.graphs and s1.g_trainer._runner.graphs and dt._runner.graphs and gt._runner.graphs
+        return out, s1, s1g, s1d
+
+    eager, _, _, _ = run("0")
+    replay, s1, s1g, s1d = run("1")
+    for i in range(6):
+        assert eager[i][0] == replay[i][0] and eager[i][1] == replay[i][1], (i, eager[i][:2], replay[i][:2])
+        assert np.array_equal(eager[i][2], replay[i][2]), "stage-1 bucket, call %d" % i
+        assert np.array_equal(eager[i][3], replay[i][3]), "stage-2 bucket, call %d" % i
+
+    # (b) stage-1 gradients of the last REPLAYED D / G calls against the float64 oracle (parameters never moved: lr = 0)
+    pg = {k: torch.from_numpy(v).to(device).double().requires_grad_(True) for k, v in s1g.items()}
+    pd = {k: torch.from_numpy(v).to(device).double().requires_grad_(True) for k, v in s1d.items()}
+    fake = S1.generator(pg, noise.double())
+    _, fj = S1.discriminator(pd, fake)
+    _, rj = S1.discriminator(pd, spec.double())
+    d_loss = S1.ls_disc_loss(rj, fj)
+    d_grads = torch.autograd.grad(d_loss, list(pd.values()), retain_graph=True)
+    g_loss = S1.ls_gen_loss(fj)
+    g_grads = torch.autograd.grad(g_loss, list(pg.values()))
+    assert abs(replay[4][0] - float(d_loss)) <= 1e-4 * abs(float(d_loss)), (replay[4][0], float(d_loss))
+    assert abs(replay[5][0] - float(g_loss)) <= 1e-4 * abs(float(g_loss)), (replay[5][0], float(g_loss))
+    worst = {}
+    for (net, opt, grads, call, sd) in ((s1.feature_disc, s1.d_optim, d_grads, 4, s1d), (s1.feature_generator, s1.g_optim, g_grads, 5, s1g)):
+        flat = replay[call][2]                   # the bucket as the call left it (the next call's zero_grad clears both buckets)
+        params = opt.param_groups[0]["params"]
+        names = {id(p): k for k, p in net.named_parameters()}
+        by_name = {}
+        for p, (off, n) in zip(params, opt._flat[5]):
+            by_name[names[id(p)]] = flat[off:off + n].reshape(tuple(p.shape))
+        for k, ref in zip(sd.keys(), grads):
+            worst[k] = rel_l2(by_name[k], ref.cpu().numpy())
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    print("two-stage B=32: stage-1 gradients vs float64, worst %s" % top)
+    assert top[0][1] < 1e-3, top
