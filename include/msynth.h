@@ -109,6 +109,11 @@ typedef struct ms_wgrad_multi_desc {
     float* gw[MS_WGRAD_MULTI_MAX];
     float* gb[MS_WGRAD_MULTI_MAX];              /* may be NULL per entry */
     float beta[MS_WGRAD_MULTI_MAX];             /* 0 or 1 per entry */
+    /* optional per entry (both or neither; all entries or none): MS_ATOM_AMAX_N upper bounds each whose maximum bounds
+     * |x| / |gy| over the whole tensor (ms_residual_atom_fwd / _bwd_data publish them).  With them the batched launch runs
+     * on block-scaled two-piece fp16 operands (three MFMA products per multiply), without on exact three-piece bf16 (six). */
+    const float* xmax[MS_WGRAD_MULTI_MAX];
+    const float* gmax[MS_WGRAD_MULTI_MAX];
 } ms_wgrad_multi_desc;
 size_t ms_conv1d_bwd_weight_multi_workspace_bytes(const ms_wgrad_multi_desc* d);
 int ms_conv1d_bwd_weight_multi(const ms_wgrad_multi_desc* d, void* workspace, size_t workspace_bytes,
@@ -145,8 +150,14 @@ typedef struct ms_atom_pack_desc {
 size_t ms_residual_atom_image_bytes(int32_t C);
 int ms_residual_atom_supported(const ms_atom_desc* d);
 int ms_residual_atom_pack_multi(const ms_atom_pack_desc* d, ms_stream_t stream);
+/* amax (optional, 2 * MS_ATOM_AMAX_N floats): per-workgroup largest magnitudes of the launch's two GEMM operands --
+ * forward: [0][.] of x, [1][.] of t; backward: [0][.] of gy, [1][.] of gt * lrelu'(t); entries behind the launch's grid are
+ * zero -- for a consumer that block-scales these tensors (ms_conv1d_bwd_weight_multi: xmax / gmax).  Only written when
+ * ms_residual_atom_publishes_amax() is 1. */
+#define MS_ATOM_AMAX_N 1024
+int ms_residual_atom_publishes_amax(void);
 int ms_residual_atom_fwd(const ms_atom_desc* d, const float* x, const void* image, const float* b0, const float* b1,
-                         float* y, float* t, float* y_act, ms_stream_t stream);
+                         float* y, float* t, float* y_act, float* amax, ms_stream_t stream);
 /*
  * Backward data of the atom in one launch (autograd of the op above w.r.t. x), from the two saved activations:
  *     gt = conv1d_backward_input(gy * lrelu'(y_act), w1)                     (raw: the weight gradient of the dilated conv
@@ -157,7 +168,7 @@ int ms_residual_atom_fwd(const ms_atom_desc* d, const float* x, const void* imag
  */
 int ms_residual_atom_bwd_supported(const ms_atom_desc* d);
 int ms_residual_atom_bwd_data(const ms_atom_desc* d, const float* gy, const float* y_act, const float* t,
-                              const void* image_bwd, float* gt, float* gx, ms_stream_t stream);
+                              const void* image_bwd, float* gt, float* gx, float* amax, ms_stream_t stream);
 
 /*
  * Dense k = 5 / stride 1 / padding 2 conv on short rows (L <= 64) with PRE-SPLIT weight images: the discriminator's

@@ -317,7 +317,7 @@ int ms_conv1d_bwd_weight_multi(const ms_wgrad_multi_desc* d, void* workspace, si
     if (!n) return MS_ERR_INVALID_ARG;
     for (int i = 0; i < n; ++i)
         if (!d->x[i] || !d->gy[i] || !d->gw[i] || (d->beta[i] != 0.f && d->beta[i] != 1.f)) return MS_ERR_INVALID_ARG;
-    int rc = msw_conv1d_bwd_weight_multi(cs, n, d->x, d->gy, d->y_act, d->gw, d->gb, d->beta, workspace,
+    int rc = msw_conv1d_bwd_weight_multi(cs, n, d->x, d->gy, d->y_act, d->gw, d->gb, d->beta, d->xmax, d->gmax, workspace,
                                          workspace_bytes, (hipStream_t)stream);
     if (rc != MS_ERR_UNSUPPORTED) return rc;
     rc = msw32_bwd_weight_multi(cs, n, d->x, d->gy, d->y_act, d->gw, d->gb, d->beta, workspace, workspace_bytes,

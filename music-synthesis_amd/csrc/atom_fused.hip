@@ -210,7 +210,7 @@ template <int C, int NTP, int NW, int MODE, int NP, int DBG = 0>
 __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom_fwd(AtomP p, const float* __restrict__ X, const u32x4* __restrict__ IMG,
                                                  const float* __restrict__ b0, const float* __restrict__ b1,
                                                  float* __restrict__ Y, float* __restrict__ T, float* __restrict__ U,
-                                                 const float* __restrict__ Tm) {
+                                                 const float* __restrict__ Tm, float* __restrict__ AM) {
     constexpr bool SAVE = MODE == 1, BWD = MODE == 2;
     typedef AtomCfg<C, NTP, NW> Cfg;
     constexpr int TM = Cfg::TM, WGN = Cfg::WGN, TN = Cfg::TN, NC = Cfg::NC, ROUNDS = Cfg::ROUNDS, NT = Cfg::NT;
@@ -441,6 +441,7 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
         publish_window_max();                        // (waits for the first window)
         __syncthreads();
     }
+    float run1 = 0.f, run2 = 0.f;                    // NP = 2: largest window / second-operand magnitude over this workgroup's tiles
     // PRE: the per-tile dependent loads of the epilogues (the residual; backward: t for the derivative) are issued a GEMM
     // ahead of their use where the registers allow: with 2-3 workgroups per CU every memory round trip a tile waits for is
     // throughput lost
@@ -473,7 +474,11 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
                 }
         }
         float S1 = 1.f, iS1 = 1.f;
-        if (SC) block_scale(read_max(smax1), S1, iS1);              // (published behind the previous tile / in the prologue)
+        if (SC) {                                                    // (published behind the previous tile / in the prologue)
+            const float m1 = read_max(smax1);
+            run1 = fmaxf(run1, m1);
+            block_scale(m1, S1, iS1);
+        }
         store_x(S1);                                                 // (waits for this tile's window)
         zero_acc();
         const int nxt = tile + gridDim.x;
@@ -550,7 +555,11 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
         }
         __syncthreads();                                             // every wave is done with the x window: t overwrites it
         float S2 = 1.f, iS2 = 1.f;
-        if (SC) block_scale(read_max(smax2), S2, iS2);
+        if (SC) {
+            const float m2 = read_max(smax2);
+            run2 = fmaxf(run2, m2);
+            block_scale(m2, S2, iS2);
+        }
         // ---- second half: split (x S2) -> LDS
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -628,6 +637,16 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
         if (SC && nxt < ntiles) publish_window_max();               // (waits for the next tile's window: issued a GEMM ago)
         __syncthreads();                                             // the t tile is dead: the next window may overwrite it
     }
+    // Per-workgroup maxima for the consumers of these tensors (the weight-gradient kernel takes its block scales from them:
+    // wgrad_rows.hip): AM[0][b] = largest |first-GEMM operand| this workgroup saw (forward: x; backward: g, which bounds
+    // g lrelu'(u)), AM[1][b] = largest |second-GEMM operand| (forward: t; backward: gt lrelu'(t)).  Windows overlap, so
+    // a value may be reported by two workgroups -- the consumer takes the maximum over all MS_ATOM_AMAX_N entries, the ones
+    // behind the grid are cleared by workgroup 0.
+    if (SC && AM) {
+        if (tid == 0) { AM[blockIdx.x] = run1; AM[MS_ATOM_AMAX_N + blockIdx.x] = run2; }
+        if (blockIdx.x == 0)
+            for (int i = gridDim.x + tid; i < MS_ATOM_AMAX_N; i += NT) { AM[i] = 0.f; AM[MS_ATOM_AMAX_N + i] = 0.f; }
+    }
 }
 
 // pieces per operand element: 2 (block-scaled fp16 x 2, three products) unless MSYNTH_ATOM_NP=3 (bf16 x 3, six products:
@@ -641,7 +660,7 @@ constexpr int MAX_DEV = 64;            // per-device launch parameters (ms_commo
 
 template <int C, int NTP, int NW, int MODE, int NP>
 int launch_atom_np(AtomP p, const float* x, const void* image, const float* b0, const float* b1, float* y, float* t,
-                   float* u, const float* tm, hipStream_t s) {
+                   float* u, const float* tm, float* am, hipStream_t s) {
     p.NO = MODE == 2 ? ((NTP - 2 * p.dil) & ~3) : NTP - 4;
     if (p.NO < 4) return MS_ERR_UNSUPPORTED;
     p.tiles_per_row = (p.L + p.NO - 1) / p.NO;
@@ -667,52 +686,53 @@ int launch_atom_np(AtomP p, const float* x, const void* image, const float* b0, 
         if (dbg) {
 #define MS_ATOM_DBG(D_) if (dbg == D_) { \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, NW, 1, NP, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); \
-            hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, 1, NP, D_>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u, tm); MS_CHECK_LAUNCH(); return MS_OK; }
+            hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, 1, NP, D_>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u, tm, am); MS_CHECK_LAUNCH(); return MS_OK; }
             MS_ATOM_DBG(1) MS_ATOM_DBG(2) MS_ATOM_DBG(3) MS_ATOM_DBG(4) MS_ATOM_DBG(5)
 #undef MS_ATOM_DBG
         }
     }
     ms_note_kernel("k_atom_fwd<%d, %d, %d, %d, %d>", C, NTP, NW, MODE, NP);
-    hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, MODE, NP>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u, tm);
+    if (grid.x > MS_ATOM_AMAX_N) am = nullptr;          // (cannot happen: at most 4 workgroups on each of 256 CUs)
+    hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, MODE, NP>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u, tm, am);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }
 
 template <int C, int NTP, int NW, int MODE>
 int launch_atom_mode(const AtomP& p, const float* x, const void* image, const float* b0, const float* b1, float* y, float* t,
-                     float* u, const float* tm, hipStream_t s) {
-    if (atom_np() == 3) return launch_atom_np<C, NTP, NW, MODE, 3>(p, x, image, b0, b1, y, t, u, tm, s);
-    return launch_atom_np<C, NTP, NW, MODE, 2>(p, x, image, b0, b1, y, t, u, tm, s);
+                     float* u, const float* tm, float* am, hipStream_t s) {
+    if (atom_np() == 3) return launch_atom_np<C, NTP, NW, MODE, 3>(p, x, image, b0, b1, y, t, u, tm, nullptr, s);
+    return launch_atom_np<C, NTP, NW, MODE, 2>(p, x, image, b0, b1, y, t, u, tm, am, s);
 }
 
 // mode 0 / 1: forward (t, u: the saved activations, both or neither);  mode 2: backward data (x = g, u and tm read, t = gt out)
 template <int C, int NTP, int NW>
 int launch_atom(int mode, const AtomP& p, const float* x, const void* image, const float* b0, const float* b1, float* y,
-                float* t, float* u, const float* tm, hipStream_t s) {
-    if (mode == 2) return launch_atom_mode<C, NTP, NW, 2>(p, x, image, b0, b1, y, t, u, tm, s);
-    if (mode == 1) return launch_atom_mode<C, NTP, NW, 1>(p, x, image, b0, b1, y, t, u, tm, s);
-    return launch_atom_mode<C, NTP, NW, 0>(p, x, image, b0, b1, y, t, u, tm, s);
+                float* t, float* u, const float* tm, float* am, hipStream_t s) {
+    if (mode == 2) return launch_atom_mode<C, NTP, NW, 2>(p, x, image, b0, b1, y, t, u, tm, am, s);
+    if (mode == 1) return launch_atom_mode<C, NTP, NW, 1>(p, x, image, b0, b1, y, t, u, tm, am, s);
+    return launch_atom_mode<C, NTP, NW, 0>(p, x, image, b0, b1, y, t, u, tm, am, s);
 }
 
 int dispatch_atom(int mode, const ms_atom_desc* d, const float* x, const void* image, const float* b0, const float* b1,
-                  float* y, float* t, float* u, const float* tm, hipStream_t s) {
+                  float* y, float* t, float* u, const float* tm, float* am, hipStream_t s) {
     AtomP p = {};
     p.B = d->B; p.C = d->C; p.L = d->L; p.dil = d->dil; p.slope = d->slope;
     // tile width: the widest tile whose grid still spreads over the chip; narrow tiles when the whole problem is a few
     // dozen tiles (B = 1 inference: latency, not throughput)
     const long long cols = (long long)d->B * d->L;
     switch (d->C) {
-        case 32: return launch_atom<32, 128, 4>(mode, p, x, image, b0, b1, y, t, u, tm, s);
+        case 32: return launch_atom<32, 128, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
 #ifndef ATOM_ONLY32
         case 64:
-            if (cols < 124 * 128) return launch_atom<64, 64, 4>(mode, p, x, image, b0, b1, y, t, u, tm, s);
-            return launch_atom<64, 128, 4>(mode, p, x, image, b0, b1, y, t, u, tm, s);
+            if (cols < 124 * 128) return launch_atom<64, 64, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
+            return launch_atom<64, 128, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
         case 128:
-            if (cols < 60 * 128 && mode != 2) return launch_atom<128, 32, 4>(mode, p, x, image, b0, b1, y, t, u, tm, s);
-            return launch_atom<128, 64, 4>(mode, p, x, image, b0, b1, y, t, u, tm, s);
+            if (cols < 60 * 128 && mode != 2) return launch_atom<128, 32, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
+            return launch_atom<128, 64, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
         case 256:
-            if (cols < 60 * 64 && mode != 2) return launch_atom<256, 32, 8>(mode, p, x, image, b0, b1, y, t, u, tm, s);
-            return launch_atom<256, 64, 8>(mode, p, x, image, b0, b1, y, t, u, tm, s);
+            if (cols < 60 * 64 && mode != 2) return launch_atom<256, 32, 8>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
+            return launch_atom<256, 64, 8>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
 #endif
         default: return MS_ERR_UNSUPPORTED;
     }
@@ -765,12 +785,14 @@ int ms_residual_atom_pack_multi(const ms_atom_pack_desc* d, ms_stream_t stream) 
     return MS_OK;
 }
 
+int ms_residual_atom_publishes_amax(void) { return atom_np() == 2 ? 1 : 0; }
+
 int ms_residual_atom_fwd(const ms_atom_desc* d, const float* x, const void* image, const float* b0, const float* b1,
-                         float* y, float* t, float* y_act, ms_stream_t stream) {
+                         float* y, float* t, float* y_act, float* amax, ms_stream_t stream) {
     if (!atom_ok(d)) return d ? MS_ERR_UNSUPPORTED : MS_ERR_INVALID_ARG;
     if (!x || !image || !b0 || !b1 || !y || ((t == nullptr) != (y_act == nullptr))) return MS_ERR_INVALID_ARG;
     if ((((uintptr_t)image) & 15) || (((uintptr_t)b0) & 15) || (((uintptr_t)b1) & 15)) return MS_ERR_INVALID_ARG;
-    return dispatch_atom(t ? 1 : 0, d, x, image, b0, b1, y, t, y_act, nullptr, (hipStream_t)stream);
+    return dispatch_atom(t ? 1 : 0, d, x, image, b0, b1, y, t, y_act, nullptr, amax, (hipStream_t)stream);
 }
 
 int ms_residual_atom_bwd_supported(const ms_atom_desc* d) {
@@ -784,10 +806,10 @@ int ms_residual_atom_bwd_supported(const ms_atom_desc* d) {
 }
 
 int ms_residual_atom_bwd_data(const ms_atom_desc* d, const float* gy, const float* y_act, const float* t,
-                              const void* image_bwd, float* gt, float* gx, ms_stream_t stream) {
+                              const void* image_bwd, float* gt, float* gx, float* amax, ms_stream_t stream) {
     if (!atom_ok(d)) return d ? MS_ERR_UNSUPPORTED : MS_ERR_INVALID_ARG;
     if (!gy || !y_act || !t || !image_bwd || !gt || !gx || (((uintptr_t)image_bwd) & 15)) return MS_ERR_INVALID_ARG;
-    return dispatch_atom(2, d, gy, image_bwd, nullptr, nullptr, gx, gt, const_cast<float*>(y_act), t, (hipStream_t)stream);
+    return dispatch_atom(2, d, gy, image_bwd, nullptr, nullptr, gx, gt, const_cast<float*>(y_act), t, amax, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -76,7 +76,8 @@ int msw32_bwd_weight_multi(const ConvP* cs, int n, const float* const* x, const 
 size_t msw_multi_ws(const ConvP* cs, int n);
 int msw_conv1d_bwd_weight_multi(const ConvP* cs, int n, const float* const* x, const float* const* gy,
                                 const float* const* y_act, float* const* gw, float* const* gb,
-                                const float* beta, void* ws, size_t ws_bytes, hipStream_t s);
+                                const float* beta, const float* const* xmax, const float* const* gmax, void* ws,
+                                size_t ws_bytes, hipStream_t s);
 const char* msw_bwd_weight_name(const ConvP& p);
 int msw_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act,
                           float* gw, float* gb, float beta, void* ws, size_t ws_bytes,

@@ -46,6 +46,8 @@ struct WrMulti {
     const float* g[WR_MULTI_MAX];
     const float* gact[WR_MULTI_MAX];
     int dil[WR_MULTI_MAX], pad[WR_MULTI_MAX];
+    const float* xmax[WR_MULTI_MAX];    // per problem: MS_ATOM_AMAX_N bounds of |x| / |g| (nullptr: none) -- k_wgrad_rows3<., 2>
+    const float* gmax[WR_MULTI_MAX];
 };
 
 // Activation handling is a template parameter: a runtime `kind` compiles to scalar branches around
@@ -436,9 +438,9 @@ __device__ __forceinline__ void w3_split_quad(const float (&e)[4], uint2 (&o)[3]
     o[2] = make_uint2(l0, l1);
 }
 
-// the 8 bf16 that start E elements into the 16 elements of (lo, hi)
+// the 8 16-bit elements that start E elements into the 16 elements of (lo, hi)
 template <int E>
-__device__ __forceinline__ w3_bf16x8 w3_funnel(const uint4& lo, const uint4& hi) {
+__device__ __forceinline__ uint4 w3_funnel(const uint4& lo, const uint4& hi) {
     const unsigned d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     uint4 o;
     if (E % 2 == 0) {
@@ -449,19 +451,48 @@ __device__ __forceinline__ w3_bf16x8 w3_funnel(const uint4& lo, const uint4& hi)
         o.z = __builtin_amdgcn_alignbit(d[(E + 1) / 2 + 2], d[(E - 1) / 2 + 2], 16);
         o.w = __builtin_amdgcn_alignbit(d[(E + 1) / 2 + 3], d[(E - 1) / 2 + 3], 16);
     }
-    return __builtin_bit_cast(w3_bf16x8, o);
+    return o;
 }
 
-constexpr int W3_GRS = 208;                // bytes per gradient row: 3 pieces x 32 samples x 2 + 16
+// r04: the same kernel on block-scaled two-piece fp16 operands (NP = 2, three products per multiply into one fp32
+// accumulator: atom_fused.hip) when the caller hands in upper bounds of both tensors' magnitudes (the fused atom kernels
+// publish them): one power-of-two scale per tensor puts its largest magnitude at 2^14, the slab is written unscaled.
+typedef _Float16 w3_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 w3_f16x8 __attribute__((ext_vector_type(8)));
+
+template <int NP>
+__device__ __forceinline__ void w3_split_quad_np(const float (&e)[4], uint2 (&o)[NP]) {
+    if constexpr (NP == 3) {
+        w3_split_quad(e, o);
+    } else {
+        const w3_f32x2 v0 = {e[0], e[1]}, v1 = {e[2], e[3]};
+        const w3_f16x2 h0 = __builtin_convertvector(v0, w3_f16x2), h1 = __builtin_convertvector(v1, w3_f16x2);
+        const w3_f16x2 l0 = __builtin_convertvector(v0 - __builtin_convertvector(h0, w3_f32x2), w3_f16x2);
+        const w3_f16x2 l1 = __builtin_convertvector(v1 - __builtin_convertvector(h1, w3_f32x2), w3_f16x2);
+        o[0] = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+        o[1] = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+    }
+}
+
+// S = 2^k with m S in [2^14, 2^15) and 1 / S; 1 for a zero / denormal-range / non-finite bound (atom_fused.hip)
+__device__ __forceinline__ void w3_block_scale(float m, float& S, float& invS) {
+    const unsigned eb = (__builtin_bit_cast(unsigned, m) >> 23) & 0xFFu;
+    const bool ok = eb >= 16u && eb <= 250u;
+    S = ok ? __builtin_bit_cast(float, (268u - eb) << 23) : 1.f;
+    invS = ok ? __builtin_bit_cast(float, (eb - 14u) << 23) : 1.f;
+}
+
+template <int NP> constexpr int w3_grs() { return NP * 64 + 16; }      // bytes per gradient row: NP pieces x 32 samples x 2 + 16
 constexpr int W3_XPB = 128;                // bytes per input-row piece: 64 samples (32 + halo + funnel over-read)
-constexpr int W3_XRS = 3 * W3_XPB + 16;    // 400
+template <int NP> constexpr int w3_xrs() { return NP * W3_XPB + 16; }  // 400 / 272: odd multiples of 16 bytes
+template <int NP>
 constexpr size_t w3_lds_bytes(int BM) {
-    const size_t kloop = (size_t)2 * (BM * W3_GRS + 64 * W3_XRS);
+    const size_t kloop = (size_t)2 * (BM * w3_grs<NP>() + 64 * w3_xrs<NP>());
     const size_t merge = (size_t)4 * (BM / 64) * 3 * 16 * 64 * sizeof(float) + (size_t)2 * BM * sizeof(float);
     return kloop > merge ? kloop : merge;
 }
 
-template <int TM>
+template <int TM, int NP>
 __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restrict__ X_,
                                                     const float* __restrict__ G_,
                                                     const float* __restrict__ Gact_,
@@ -486,14 +517,19 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
         }
     }
     int by = (int)by_;
+    const float* xmax = nullptr;
+    const float* gmax = nullptr;
     if (mp.n > 0) {                                  // batched launch: this workgroup's problem
         const int prob = by / mp.tiles_m;
         by -= prob * mp.tiles_m;
         X = mp.x[prob]; G = mp.g[prob]; Gact = mp.gact[prob];
+        xmax = mp.xmax[prob]; gmax = mp.gmax[prob];
         p.dil = mp.dil[prob]; p.pad = mp.pad[prob];
         partial += (size_t)prob * mp.slab_stride;
     }
     constexpr int K = 3, BM = 64 * TM, NGU = BM / 32;
+    constexpr int W3_GRS = w3_grs<NP>(), W3_XRS = w3_xrs<NP>();
+    constexpr bool SC = NP == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5;
     const int g = __builtin_amdgcn_readfirstlane(wid >> 2), gt = tid & 255, gw = wid & 3;
@@ -508,6 +544,29 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
     const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G), 0, 0x80000000u, 0x00020000);
     const auto rsGa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Gact), 0, 0x80000000u, 0x00020000);
     const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, 0x80000000u, 0x00020000);
+
+    // NP = 2: one power-of-two scale per tensor from the published bounds (1024 entries each: two per thread, folded over the
+    // eight waves through LDS; everyone ends up with the same two scalars)
+    float Sx = 1.f, Sg = 1.f, kfin = 1.f;
+    if (SC) {
+        float mx = fmaxf(xmax[tid], xmax[tid + 512]), mg = fmaxf(gmax[tid], gmax[tid + 512]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            mg = fmaxf(mg, __shfl_xor(mg, o, 64));
+        }
+        float* red = reinterpret_cast<float*>(smem3);
+        if (lane == 0) { red[wid] = mx; red[8 + wid] = mg; }
+        __syncthreads();
+        mx = red[0]; mg = red[8];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) { mx = fmaxf(mx, red[w]); mg = fmaxf(mg, red[8 + w]); }
+        float ix, ig;
+        w3_block_scale(mx, Sx, ix);
+        w3_block_scale(mg, Sg, ig);
+        kfin = ix * ig;
+        __syncthreads();                             // (the staging buffers reuse this LDS)
+    }
 
     // staging units of this thread: gradient (row (gt >> 3) + 32 q, vector gt & 7), input (row (gt >> 4) + 16 q,
     // vector gt & 15 of the 64-sample window that starts PADA samples in front of the tile)
@@ -541,20 +600,28 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
 #pragma unroll
             for (int i = 0; i < 4; ++i) e[i] = ga[q][i] > 0.f ? gv[q][i] : gv[q][i] * p.slope;
             bs[q] += (e[0] + e[1]) + (e[2] + e[3]);
-            uint2 o3[3];
-            w3_split_quad(e, o3);
+            if (SC) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] *= Sg;
+            }
+            uint2 o3[NP];
+            w3_split_quad_np<NP>(e, o3);
             unsigned char* d = Gs + (g_row + 32 * q) * W3_GRS + g_t * 2;
 #pragma unroll
-            for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(d + pp * 64) = o3[pp];
+            for (int pp = 0; pp < NP; ++pp) *reinterpret_cast<uint2*>(d + pp * 64) = o3[pp];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float e[4] = {xv[q][0], xv[q][1], xv[q][2], xv[q][3]};
-            uint2 o3[3];
-            w3_split_quad(e, o3);
+            float e[4] = {xv[q][0], xv[q][1], xv[q][2], xv[q][3]};
+            if (SC) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] *= Sx;
+            }
+            uint2 o3[NP];
+            w3_split_quad_np<NP>(e, o3);
             unsigned char* d = Xs + (x_row + 16 * q) * W3_XRS + x_u * 2;
 #pragma unroll
-            for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(d + pp * W3_XPB) = o3[pp];
+            for (int pp = 0; pp < NP; ++pp) *reinterpret_cast<uint2*>(d + pp * W3_XPB) = o3[pp];
         }
     };
 
@@ -573,19 +640,20 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
         constexpr int PA_ = (DIL + 3) & ~3;
         constexpr int O0 = PA_ - DIL, O2 = PA_ + DIL;       // first sample of taps 0 / 2 in window coordinates (tap 1: PA_)
         constexpr int V0 = O0 / 8, NV = (O2 + 7) / 8 - V0 + 1;   // aligned 8-sample vectors the three taps touch
-        constexpr int PAI[6] = {0, 2, 1, 0, 1, 0}, PBI[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int NPR = NP == 3 ? 6 : 3;
+        constexpr int PAI[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0}, PBI[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0};
         // fragments of k-step s: the A rows and, per piece, the NV aligned vectors that hold all three taps'
         // windows (2 for dilations 1 / 3, 4 for dilation 9) -- each tap is funnelled out of two neighbours
-        w3_bf16x8 a[2][TM][3];
-        uint4 v[2][3][NV];
-        auto frag = [&](int s, w3_bf16x8 (&af)[TM][3], uint4 (&vf)[3][NV]) __attribute__((always_inline)) {
+        uint4 a[2][TM][NP];
+        uint4 v[2][NP][NV];
+        auto frag = [&](int s, uint4 (&af)[TM][NP], uint4 (&vf)[NP][NV]) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int pp = 0; pp < 3; ++pp)
-                    af[i][pp] = *reinterpret_cast<const w3_bf16x8*>(ap + i * 32 * W3_GRS + pp * 64 + s * 32);
+                for (int pp = 0; pp < NP; ++pp)
+                    af[i][pp] = *reinterpret_cast<const uint4*>(ap + i * 32 * W3_GRS + pp * 64 + s * 32);
 #pragma unroll
-            for (int pp = 0; pp < 3; ++pp)
+            for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
                 for (int k = 0; k < NV; ++k)
                     vf[pp][k] = *reinterpret_cast<const uint4*>(bp + pp * W3_XPB + (s * 16 + (V0 + k) * 8) * 2);
@@ -598,9 +666,9 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
             for (int j = 0; j < K; ++j) {
                 const int o = j * DIL - DIL + PA_;
                 const int k = o / 8 - V0;
-                w3_bf16x8 b[3];
+                uint4 b[NP];
 #pragma unroll
-                for (int pp = 0; pp < 3; ++pp) {
+                for (int pp = 0; pp < NP; ++pp) {
                     const uint4 lo = v[s][pp][k];
                     const uint4 hi = v[s][pp][k + 1 < NV ? k + 1 : k];
                     switch (o & 7) {
@@ -614,11 +682,18 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
                         default: b[pp] = w3_funnel<7>(lo, hi); break;
                     }
                 }
+                // (NP = 3: six products, smallest first; NP = 2: a_h b_l, a_l b_h, a_h b_h)
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < NPR; ++t)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i][PAI[t]], b[PBI[t]], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i) {
+                        if constexpr (NP == 3)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(w3_bf16x8, a[s][i][PAI[t]]),
+                                                                               __builtin_bit_cast(w3_bf16x8, b[PBI[t]]), acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(w3_f16x8, a[s][i][PAI[t]]),
+                                                                              __builtin_bit_cast(w3_f16x8, b[PBI[t]]), acc[i][j], 0, 0, 0);
+                    }
             }
         }
     };
@@ -691,7 +766,8 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
 #pragma unroll
                 for (int j = 0; j < K; ++j)
                     part[(size_t)m * NG + (size_t)c * K + j] =
-                        acc[i][j][r] + mrg[((gw * TM * K + i * K + j) * 16 + r) * 64 + lane];
+                        SC ? (acc[i][j][r] + mrg[((gw * TM * K + i * K + j) * 16 + r) * 64 + lane]) * kfin
+                           : acc[i][j][r] + mrg[((gw * TM * K + i * K + j) * 16 + r) * 64 + lane];
             }
     } else if (bx == 0 && gt < BM) {
         part[(size_t)p.M * NG + m0 + gt] = bsum[gt] + bsum[BM + gt];
@@ -810,22 +886,38 @@ bool wrows3_ok(const WrPlan& q, int K, int TM, bool vec, bool has_yact) {
     return true;
 }
 
-// Always 64 output channels per workgroup (TM = 1): with 128 the kernel needs more than the 256 registers a wave
-// of a 512-thread workgroup may hold (96 accumulators + fragments + the chunk in flight) and spills.  The
-// plan's grid / batching descriptor are re-derived for 64-row tiles; the slab layout does not depend on it.
-void launch_wrows3(const WrPlan& q, const float* x, const float* gy, const float* y_act, float* partial, hipStream_t s) {
-    const size_t lds = w3_lds_bytes(64);
+// NP = 3: always 64 output channels per workgroup (TM = 1): with 128 the kernel needs more than the 256 registers a wave
+// of a 512-thread workgroup may hold (96 accumulators + fragments + the chunk in flight) and spills.  The plan's grid /
+// batching descriptor are re-derived for 64-row tiles; the slab layout does not depend on it.
+// NP = 2 (every problem of a batched launch carries bounds of both operands): block-scaled fp16 x 2, three products.
+template <int TM, int NP>
+void launch_wrows3_np(const WrPlan& q, const float* x, const float* gy, const float* y_act, float* partial, hipStream_t s) {
+    const size_t lds = w3_lds_bytes<NP>(64 * TM);
     static unsigned long long attr_set = 0;
     if (ms_first_on_device(attr_set)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_rows3<1>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_rows3<TM, NP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         ms_done_on_device(attr_set);
     }
     WrMulti mp = q.mp;
-    const int tiles_m = q.p.M / 64;
+    const int tiles_m = q.p.M / (64 * TM);
     if (mp.n > 0) mp.tiles_m = tiles_m;
     const dim3 grid(q.grid.x, (unsigned)((mp.n > 0 ? mp.n : 1) * tiles_m), q.grid.z);
-    hipLaunchKernelGGL((k_wgrad_rows3<1>), grid, dim3(512), lds, s, q.p, x, gy, y_act, partial, q.stride_floats, mp);
+    ms_note_kernel("k_wgrad_rows3<%d, %d>", TM, NP);
+    hipLaunchKernelGGL((k_wgrad_rows3<TM, NP>), grid, dim3(512), lds, s, q.p, x, gy, y_act, partial, q.stride_floats, mp);
+}
+
+bool wrows3_scaled(const WrPlan& q) {
+    static const int sw = getenv("MSYNTH_WROWS3_NP") ? atoi(getenv("MSYNTH_WROWS3_NP")) : 2;      // tuning / test switch (3: bf16 x 3)
+    if (sw == 3 || q.mp.n <= 0) return false;
+    for (int i = 0; i < q.mp.n; ++i)
+        if (!q.mp.xmax[i] || !q.mp.gmax[i]) return false;
+    return true;
+}
+
+void launch_wrows3(const WrPlan& q, const float* x, const float* gy, const float* y_act, float* partial, hipStream_t s) {
+    if (wrows3_scaled(q)) launch_wrows3_np<1, 2>(q, x, gy, y_act, partial, s);
+    else launch_wrows3_np<1, 3>(q, x, gy, y_act, partial, s);
 }
 
 template <int K, int TM, bool VEC, int KPI>
@@ -882,7 +974,7 @@ const char* msw_bwd_weight_name(const ConvP& p) {
     static thread_local char buf[64];
     const WrPlan q = plan_wrows(p);
     if (wrows3_ok(q, p.K, q.tm, q.vec, p.act == MS_ACT_LRELU)) {
-        snprintf(buf, sizeof(buf), "k_wgrad_rows3<1>");
+        snprintf(buf, sizeof(buf), "k_wgrad_rows3<1, 3>");
         return buf;
     }
     snprintf(buf, sizeof(buf), "k_wgrad_rows<%d, %d, %s, %d>", p.K, q.tm, q.vec ? "true" : "false", q.p.kcols / 4);
@@ -1107,7 +1199,8 @@ size_t msw_multi_ws(const ConvP* cs, int n) {
 
 int msw_conv1d_bwd_weight_multi(const ConvP* cs, int n, const float* const* x, const float* const* gy,
                                 const float* const* y_act, float* const* gw, float* const* gb,
-                                const float* beta, void* ws, size_t ws_bytes, hipStream_t s) {
+                                const float* beta, const float* const* xmax, const float* const* gmax, void* ws,
+                                size_t ws_bytes, hipStream_t s) {
     if (msw_multi_ws(cs, n) == 0) return MS_ERR_UNSUPPORTED;
     WrPlan q = plan_wrows_multi(cs, n);
     if (!ws || ws_bytes < (size_t)q.nsplit * q.stride_floats * sizeof(float) || (((uintptr_t)ws) & 15)) return MS_ERR_UNSUPPORTED;
@@ -1118,6 +1211,7 @@ int msw_conv1d_bwd_weight_multi(const ConvP* cs, int n, const float* const* x, c
             return MS_ERR_UNSUPPORTED;
         if (beta[i] != 0.f && beta[i] != 1.f) return MS_ERR_INVALID_ARG;
         q.mp.x[i] = x[i]; q.mp.g[i] = gy[i]; q.mp.gact[i] = y_act[i];
+        q.mp.xmax[i] = xmax ? xmax[i] : nullptr; q.mp.gmax[i] = gmax ? gmax[i] : nullptr;
         o.gw[i] = gw[i]; o.gb[i] = gb[i]; o.beta[i] = beta[i];
     }
     float* partial = (float*)ws;

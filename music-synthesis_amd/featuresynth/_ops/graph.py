@@ -210,8 +210,11 @@ def atom_backward(rec, w0, w1, g, sink, i, need_wgrad=True, need_gx=True, fork=N
     if image_bwd is not None and need_gx:
         gt, gx = P.atom_bwd_data(g, u, t, image_bwd, d0.dil)
         if need_wgrad and batch is not None:
-            batch.append((i + 2, t, g, u, d1, w1.shape))
-            batch.append((i, h, gt, t, d0, w0.shape))
+            # operand bounds published by the fused launches: forward [0] = |x|, [1] = |t|; backward [0] = |g|, [1] = |gt lrelu'(t)|
+            af, ab = getattr(t, "_ms_amax", None), getattr(gt, "_ms_amax", None)
+            both = af is not None and ab is not None
+            batch.append((i + 2, t, g, u, d1, w1.shape) + ((af[1], ab[0]) if both else ()))
+            batch.append((i, h, gt, t, d0, w0.shape) + ((af[0], ab[1]) if both else ()))
         elif need_wgrad:
             gw, gb, acc = sink.pair(i + 2)
             run(lambda: sink.put(i + 2, *P.conv1d_bwd_weight(t, g, u, d1, w1.shape, gw, gb, acc)), t, g, u)
@@ -239,11 +242,12 @@ def flush_wgrad_batch(batch, sink, fork):
     if not batch:
         return
     jobs, slots, keep = [], [], []
-    for (slot, x, gy, ya, d, w_shape) in batch:
+    for job in batch:
+        (slot, x, gy, ya, d, w_shape), bounds = job[:6], job[6:]
         gw, gb, acc = sink.pair(slot)
-        jobs.append((x, gy, ya, d, w_shape, gw, gb, acc))
+        jobs.append((x, gy, ya, d, w_shape, gw, gb, acc) + tuple(bounds))
         slots.append(slot)
-        keep += [x, gy, ya]
+        keep += [x, gy, ya] + list(bounds)
 
     def go():
         for slot, (gw, gb) in zip(slots, P.conv1d_bwd_weight_multi(jobs)):

@@ -61,7 +61,11 @@ class WgradMultiDesc(ctypes.Structure):         # ms_wgrad_multi_desc
                 ("conv", ConvDesc * WGRAD_MULTI_MAX),
                 ("x", _vp * WGRAD_MULTI_MAX), ("gy", _vp * WGRAD_MULTI_MAX), ("y_act", _vp * WGRAD_MULTI_MAX),
                 ("gw", _vp * WGRAD_MULTI_MAX), ("gb", _vp * WGRAD_MULTI_MAX),
-                ("beta", _c_f * WGRAD_MULTI_MAX)]
+                ("beta", _c_f * WGRAD_MULTI_MAX),
+                ("xmax", _vp * WGRAD_MULTI_MAX), ("gmax", _vp * WGRAD_MULTI_MAX)]
+
+
+ATOM_AMAX_N = 1024
 
 
 ATOM_PACK_MAX = 16
@@ -108,9 +112,10 @@ SIGNATURES = {
     "ms_residual_atom_image_bytes": (_sz, [_c_int]),
     "ms_residual_atom_supported": (_c_int, [ctypes.POINTER(AtomDesc)]),
     "ms_residual_atom_pack_multi": (_c_int, [ctypes.POINTER(AtomPackDesc), _vp]),
-    "ms_residual_atom_fwd": (_c_int, [ctypes.POINTER(AtomDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ms_residual_atom_publishes_amax": (_c_int, []),
+    "ms_residual_atom_fwd": (_c_int, [ctypes.POINTER(AtomDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ms_residual_atom_bwd_supported": (_c_int, [ctypes.POINTER(AtomDesc)]),
-    "ms_residual_atom_bwd_data": (_c_int, [ctypes.POINTER(AtomDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ms_residual_atom_bwd_data": (_c_int, [ctypes.POINTER(AtomDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ms_conv1d_img_bytes": (_sz, [ctypes.POINTER(ConvDesc)]),
     "ms_conv1d_img_workspace_bytes": (_sz, [ctypes.POINTER(ConvDesc), _c_int]),
     "ms_conv1d_img_pack": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _c_int, _vp, _vp]),

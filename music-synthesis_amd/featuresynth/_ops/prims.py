@@ -119,14 +119,19 @@ def conv1d_bwd_weight_multi(jobs):
     for lo in range(0, len(jobs), L.WGRAD_MULTI_MAX):
         chunk = jobs[lo:lo + L.WGRAD_MULTI_MAX]
         if len(chunk) == 1:
-            x, gy, ya, d, ws_, gw, gb, acc = chunk[0]
+            x, gy, ya, d, ws_, gw, gb, acc = chunk[0][:8]
             out.append(conv1d_bwd_weight(x, gy, ya, d, ws_, gw, gb, acc))
             continue
         md = L.WgradMultiDesc()
         md.count = len(chunk)
         costs = []
-        for k, (x, gy, ya, d, w_shape, gw, gb, acc) in enumerate(chunk):
+        keep = []
+        for k, job in enumerate(chunk):
+            (x, gy, ya, d, w_shape, gw, gb, acc), bounds = job[:8], job[8:]
             L.require(gy, "conv1d grad_output"); L.require(x, "conv1d input")
+            if len(bounds) == 2 and bounds[0] is not None and bounds[1] is not None:    # bounds of |x| and |gy| (fused atoms)
+                md.xmax[k], md.gmax[k] = bounds[0].data_ptr(), bounds[1].data_ptr()
+                keep += list(bounds)
             if gw is None:
                 gw = torch.empty(tuple(w_shape), dtype=torch.float32, device=gy.device)
                 acc = False
@@ -235,18 +240,30 @@ def atom_fwd(x, image, b0, b1, dil, save):
     t = torch.empty_like(x) if save else None
     u = torch.empty_like(x) if save else None
     d = L.AtomDesc(B, C, Lg, dil, SLOPE)
+    # training: the launch's per-workgroup operand maxima ([0] of x, [1] of t) travel with t to the weight-gradient kernel,
+    # which takes its block scales from them (no extra pass over the tensors)
+    amax = _amax_buffer(x.device) if save else None
 
     def cost():
         c0 = W.conv_cost(B, C, Lg, C, 3, 1, dil, dil, 1, "fwd")
         return {"flops": 2 * c0["flops"], "bytes": 4 * x.numel() * (2 + 2 * int(save)) + 4 * 2 * (3 * C * C + C),
                 "geom": (B, C, Lg, C, 3, 1, dil, 1)}
     L.call("ms_residual_atom_fwd", cost, d, x.data_ptr(), image.data_ptr(), b0.data_ptr(), b1.data_ptr(),
-           y.data_ptr(), L.ptr(t), L.ptr(u), L.stream())
+           y.data_ptr(), L.ptr(t), L.ptr(u), L.ptr(amax), L.stream())
+    if amax is not None:
+        t._ms_amax = amax
     return y, t, u
 
 
+def _amax_buffer(device):
+    if not L.load().ms_residual_atom_publishes_amax():
+        return None
+    return torch.empty((2, L.ATOM_AMAX_N), dtype=torch.float32, device=device)
+
+
 def atom_bwd_data(g, u, t, image_bwd, dil):
-    """-> (gt, gx): gt = conv1^T(g * lrelu'(u)) (raw), gx = g + conv_d^T(gt * lrelu'(t)) -- the atom's backward data, one launch."""
+    """-> (gt, gx): gt = conv1^T(g * lrelu'(u)) (raw), gx = g + conv_d^T(gt * lrelu'(t)) -- the atom's backward data, one launch.
+    gt carries the launch's operand maxima (`gt._ms_amax`: [0] of g, [1] of gt lrelu'(t)) for the weight gradients."""
     for a, nm in ((g, "grad_output"), (u, "y_act"), (t, "t")):
         L.require(a, "residual atom " + nm)
     B, C, Lg = g.shape
@@ -256,8 +273,11 @@ def atom_bwd_data(g, u, t, image_bwd, dil):
     def cost():
         c0 = W.conv_cost(B, C, Lg, C, 3, 1, dil, dil, 1, "bwd_data")
         return {"flops": 2 * c0["flops"], "bytes": 4 * g.numel() * 5 + 4 * 2 * 3 * C * C, "geom": (B, C, Lg, C, 3, 1, dil, 1)}
+    amax = _amax_buffer(g.device)
     L.call("ms_residual_atom_bwd_data", cost, d, g.data_ptr(), u.data_ptr(), t.data_ptr(), image_bwd.data_ptr(),
-           gt.data_ptr(), gx.data_ptr(), L.stream())
+           gt.data_ptr(), gx.data_ptr(), L.ptr(amax), L.stream())
+    if amax is not None:
+        gt._ms_amax = amax
     return gt, gx
 
 
