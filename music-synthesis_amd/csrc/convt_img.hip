@@ -11,8 +11,11 @@
 // fragment-ordered images that stream from L2 into registers one chunk ahead, workgroups are persistent and prefetch the
 // next tile's window under the GEMM, results leave through buffer stores with scalar row offsets.  Unlike the atom there is
 // no halo to recompute: a tile of NTP input columns yields NTP * S output samples.
-// Arithmetic: exact 3-piece bf16 split, six products per multiply, fp32 accumulation, chunks of 16 input channels in order --
-// the same products as the paired row kernel's transposed-conv form, in another order (agreement ~1e-7, not bitwise).
+// Arithmetic (r04): block-scaled two-piece fp16 operands, three products per multiply into one fp32 accumulator
+// (atom_fused.hip): the tile's input window is scaled by the power of two that puts its largest magnitude at 2^14 (the
+// maximum of the NEXT window is published under the current tile, as in the atom kernel), the weights are packed as
+// pieces of 64 w.  The short-row K-loop kernel (convt_fwd_short.hip) shares the pack kernel and keeps the exact
+// three-piece bf16 split (np = 3 images): agreement between the schemes ~3e-7.
 #include "ms_common.h"
 #include <stdlib.h>
 
@@ -23,11 +26,30 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int XRS = 112;
+constexpr int XRS = 80;                  // bytes per LDS column of a 16-channel chunk: 2 fp16 pieces x 32 + 16
 constexpr unsigned OOB = 0xF0000000u;
+constexpr float WSCALE = 64.f;           // fp16 pieces of the weights are taken from 64 w
+
+// (a, b), scaled into fp16's range by the caller -> a = h.lo + l.lo to 22 significand bits (atom_fused.hip)
+__device__ __forceinline__ void split_pair2(float a, float b, unsigned& h, unsigned& l) {
+    const f32x2 v = {a, b};
+    const f16x2 hi = __builtin_convertvector(v, f16x2);
+    const f16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);
+    h = __builtin_bit_cast(unsigned, hi);
+    l = __builtin_bit_cast(unsigned, lo);
+}
+
+__device__ __forceinline__ void block_scale(float m, float& S, float& invS) {
+    const unsigned eb = (__builtin_bit_cast(unsigned, m) >> 23) & 0xFFu;
+    const bool ok = eb >= 16u && eb <= 250u;
+    S = ok ? __builtin_bit_cast(float, (268u - eb) << 23) : 1.f;
+    invS = ok ? __builtin_bit_cast(float, (eb - 14u) << 23) : 1.f;
+}
 
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
     const f32x2 v = {a, b};
@@ -54,7 +76,8 @@ __device__ __forceinline__ void split_quad(const float (&e)[4], uint2 (&o)[3]) {
 //   S = 8: channel cg*8 + i/4, phase half*4 + i%4;      S = 2: channel cg*32 + i, phase half
 // contraction channels chunk*16 + 8*(lane >> 5) + 0..7, tap jj -> window offset d = half + jj - 1:
 //   A = W[ci][co][phase + S/2 - d*S]          (W is (Cin, Cout, 2S))
-__global__ __launch_bounds__(256) void k_convt_pack(const float* __restrict__ W, u32x4* __restrict__ img, int Cin, int Cout, int S) {
+__global__ __launch_bounds__(256) void k_convt_pack(const float* __restrict__ W, u32x4* __restrict__ img, int Cin, int Cout, int S,
+                                                   int np) {
     const int NC = Cin / 16, NCG = Cout * S / 64;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over cg x half x chunk x jj x lane
     const size_t total = (size_t)NCG * 2 * NC * 2 * 64;
@@ -76,11 +99,11 @@ __global__ __launch_bounds__(256) void k_convt_pack(const float* __restrict__ W,
     for (int q = 0; q < 4; ++q) {
         const float a = W[((size_t)(ci0 + 2 * q) * Cout + co) * K + k];
         const float b = W[((size_t)(ci0 + 2 * q + 1) * Cout + co) * K + k];
-        split_pair(a, b, pc[0][q], pc[1][q], pc[2][q]);
+        if (np == 3) split_pair(a, b, pc[0][q], pc[1][q], pc[2][q]);
+        else { split_pair2(a * WSCALE, b * WSCALE, pc[0][q], pc[1][q]); pc[2][q] = 0u; }
     }
-    u32x4* dst = img + ((size_t)((((cg * 2 + half) * NC + chunk) * 2 + jj) * 3)) * 64 + lane;
-#pragma unroll
-    for (int pp = 0; pp < 3; ++pp) dst[pp * 64] = u32x4{pc[pp][0], pc[pp][1], pc[pp][2], pc[pp][3]};
+    u32x4* dst = img + ((size_t)((((cg * 2 + half) * NC + chunk) * 2 + jj) * np)) * 64 + lane;
+    for (int pp = 0; pp < np; ++pp) dst[pp * 64] = u32x4{pc[pp][0], pc[pp][1], pc[pp][2], pc[pp][3]};
 }
 
 struct CtP {
@@ -146,47 +169,63 @@ __global__ __launch_bounds__(256, 1) void k_convt_img(CtP p, const float* __rest
                 rx[r][cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, goff, base + cc * 4 * L, 0));
         }
     };
-    auto store_x = [&]() {
+    float* smax = reinterpret_cast<float*>(smem_ct + NC * XCS);          // [4]: per-wave |max| of the NEXT tile's window
+    auto publish_window_max = [&]() {
+        float m = 0.f;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(rx[r][cc][e]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) smax[wid] = m;
+    };
+    auto store_x = [&](float SC_) {
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = u_lcol[r] + e;
                 if (i < 0 || i >= NXA) continue;
-                const float c4[4] = {rx[r][0][e], rx[r][1][e], rx[r][2][e], rx[r][3][e]};
-                uint2 o3[3];
-                split_quad(c4, o3);
+                unsigned h0, l0, h1, l1;
+                split_pair2(rx[r][0][e] * SC_, rx[r][1][e] * SC_, h0, l0);
+                split_pair2(rx[r][2][e] * SC_, rx[r][3][e] * SC_, h1, l1);
                 unsigned char* dst = smem_ct + u_lbase[r] + i * XRS;
-#pragma unroll
-                for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<uint2*>(dst + pp * 32) = o3[pp];
+                *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(dst + 32) = make_uint2(l0, l1);
             }
         }
     };
 
     // ---- A fragments of one chunk: [half][tap jj][piece]; one chunk ahead
-    bf16x8 fa[2][2][2][3];
+    u32x4 fa[2][2][2][2];
     const int a_voff = lane * 16;
-    auto load_a = [&](int cg, int chunk, bf16x8 (&dst)[2][2][3]) {
-        const int so = ((cg * 2) * NC + chunk) * (2 * 3 * 1024);           // (cg, half 0, chunk); half 1 is NC chunks further
+    auto load_a = [&](int cg, int chunk, u32x4 (&dst)[2][2][2]) {
+        const int so = ((cg * 2) * NC + chunk) * (2 * 2 * 1024);           // (cg, half 0, chunk); half 1 is NC chunks further
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int pp = 0; pp < 3; ++pp)
-                    dst[hf][jj][pp] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                        rsI, a_voff, so + hf * NC * (2 * 3 * 1024) + (jj * 3 + pp) * 1024, 0));
+                for (int pp = 0; pp < 2; ++pp)
+                    dst[hf][jj][pp] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        rsI, a_voff, so + hf * NC * (2 * 2 * 1024) + (jj * 2 + pp) * 1024, 0));
     };
 
-    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
     int tile = blockIdx.x;
     if (tile < ntiles) load_x(tile);
+    publish_window_max();                             // (waits for the first window)
+    __syncthreads();
     for (; tile < ntiles; tile += gridDim.x) {
         int b, q0, mt;
         tile_of(tile, b, q0, mt);
         const int cg = mt * WGM + wm;
         load_a(cg, 0, fa[0]);
-        store_x();
+        float SCL, iS;
+        block_scale(fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])), SCL, iS);
+        store_x(SCL);
         const int nxt = tile + gridDim.x;
         if (nxt < ntiles) load_x(nxt);
         f32x16 acc[2][TN];
@@ -203,25 +242,28 @@ __global__ __launch_bounds__(256, 1) void k_convt_img(CtP p, const float* __rest
         for (int ch = 0; ch < NC; ++ch) {
             if (ch + 1 < NC) load_a(cg, ch + 1, fa[(ch + 1) & 1]);
             // window column offsets 0, 1, 2 (low half: taps at 0, 1; high half: 1, 2)
-            bf16x8 fb[3][TN][3];
+            u32x4 fb[3][TN][2];
 #pragma unroll
             for (int o = 0; o < 3; ++o)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int pp = 0; pp < 3; ++pp)
-                        fb[o][j][pp] = *reinterpret_cast<const bf16x8*>(Bs + ch * XCS + (j * 32 + o) * XRS + pp * 32);
+                    for (int pp = 0; pp < 2; ++pp)
+                        fb[o][j][pp] = *reinterpret_cast<const u32x4*>(Bs + ch * XCS + (j * 32 + o) * XRS + pp * 32);
             __builtin_amdgcn_sched_barrier(0);
+            // three products per multiply, smallest first: a_h b_l, a_l b_h, a_h b_h
+            constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < 3; ++t)
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[hf][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ch & 1][hf][jj][PA[t]], fb[hf + jj][j][PB[t]],
-                                                                                acc[hf][j], 0, 0, 0);
+                            acc[hf][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[ch & 1][hf][jj][PA[t]]),
+                                                                               __builtin_bit_cast(f16x8, fb[hf + jj][j][PB[t]]),
+                                                                               acc[hf][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -229,6 +271,7 @@ __global__ __launch_bounds__(256, 1) void k_convt_img(CtP p, const float* __rest
         int LS4;                                       // 4 * L * S (bytes per output channel row), opaque: see atom_fused.hip
         asm volatile("s_mov_b32 %0, %1" : "=s"(LS4) : "s"(4 * L * S));
         const int obase = b * p.Cout * LS4;
+        const float kscale = iS * (1.f / WSCALE);     // undoes the window's and the weights' scales
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = (wn * TN + j) * 32 + l31, q = q0 + n;
@@ -245,7 +288,7 @@ __global__ __launch_bounds__(256, 1) void k_convt_img(CtP p, const float* __rest
                         f32x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float t = acc[hf][j][4 * g + e] + bv;
+                            float t = fmaf(acc[hf][j][4 * g + e], kscale, bv);
                             if (p.act == MS_ACT_LRELU) t = t > 0.f ? t : t * p.slope;
                             v[e] = t;
                         }
@@ -262,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void k_convt_img(CtP p, const float* __rest
                     f32x2 v;
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
-                        float t = acc[hf][j][r] + bv;
+                        float t = fmaf(acc[hf][j][r], kscale, bv);
                         if (p.act == MS_ACT_LRELU) t = t > 0.f ? t : t * p.slope;
                         v[hf] = t;
                     }
@@ -270,6 +313,7 @@ __global__ __launch_bounds__(256, 1) void k_convt_img(CtP p, const float* __rest
                 }
             }
         }
+        if (nxt < ntiles) publish_window_max();        // (waits for the next tile's window: issued before the GEMM)
         __syncthreads();                              // the window is dead: the next one may overwrite it
     }
 }
@@ -277,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void k_convt_img(CtP p, const float* __rest
 template <int CIN, int S, int NTP, int WGM>
 int launch_ct(CtP p, const float* x, const void* image, const float* bias, float* y, hipStream_t s) {
     constexpr int NC = CIN / 16;
-    const size_t lds = (size_t)NC * (NTP + 8) * XRS;
+    const size_t lds = (size_t)NC * (NTP + 8) * XRS + 4 * sizeof(float);      // window + the scale exchange
     if (lds > 158 * 1024) return MS_ERR_UNSUPPORTED;
     p.tiles_per_row = (p.L + NTP - 1) / NTP;
     const int ncg = p.Cout * S / 64;
@@ -315,7 +359,8 @@ bool ct_ok(const ms_convt1d_desc* d) {
     // measured (tools/scratch/microbench_convt_img.py, B = 32): stride 8: 69 -> 37 us (512 -> 256), 77 -> 64 us (256 -> 128); the two
     // stride-2 layers are HBM-bound and run 20 % FASTER on the paired row kernel (42 / 28 us), and at B = 1 the pack launch
     // costs more than the kernel saves: those stay on ms_convt1d_fwd's row-tile path
-    if (d->stride != 8 || (long long)d->B * d->Lin < 1024) return false;
+    static const int s2 = getenv("MSYNTH_CONVTIMG_S2") ? atoi(getenv("MSYNTH_CONVTIMG_S2")) : 0;       // probe: stride 2 too
+    if ((d->stride != 8 && !s2) || (long long)d->B * d->Lin < 1024) return false;
     if ((long long)d->B * d->Cin * d->Lin * 4 >= (1ll << 31) || (long long)d->B * d->Cout * d->Lin * d->stride * 4 >= (1ll << 31)) return false;
     const char* sw = getenv("MSYNTH_CONVTIMG");                 // tuning / test switch (0: the row-tile kernels)
     return !(sw && atoi(sw) == 0);
@@ -333,7 +378,7 @@ extern "C" {
 
 size_t ms_convt1d_img_bytes(const ms_convt1d_desc* d) {
     if (!ct_ok(d) && !msct_short_ok(d)) return 0;
-    return (size_t)(d->Cout * d->stride / 32) * (d->Cin / 16) * 2 * 3 * 1024;
+    return (size_t)(d->Cout * d->stride / 32) * (d->Cin / 16) * 2 * 3 * 1024;      // (the larger of the two piece schemes)
 }
 
 size_t ms_convt1d_img_workspace_bytes(const ms_convt1d_desc* d) { return msct_short_ok(d) ? msct_short_ws(d) : 0; }
@@ -342,8 +387,9 @@ int ms_convt1d_img_pack(const ms_convt1d_desc* d, const float* w, void* image, m
     if (!d || !w || !image || (((uintptr_t)image) & 15)) return MS_ERR_INVALID_ARG;
     if (!ct_ok(d) && !msct_short_ok(d)) return MS_ERR_UNSUPPORTED;
     const size_t total = (size_t)(d->Cout * d->stride / 64) * 2 * (d->Cin / 16) * 2 * 64;
+    // the short-row K-loop kernel reads three bf16 pieces, the LDS-resident-window kernel two fp16 pieces of 64 w
     hipLaunchKernelGGL(k_convt_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (u32x4*)image,
-                       d->Cin, d->Cout, d->stride);
+                       d->Cin, d->Cout, d->stride, msct_short_ok(d) ? 3 : 2);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }
