@@ -158,46 +158,65 @@ def pack_atom_images(x_shape, params, backward=False):
     return images
 
 
-def pack_atom_images_aside(x_shape, params, device, with_backward=False):
-    """Every weight image of a generator pass, packed on a side stream of its own beside what the caller issues next:
-    -> (forward images, backward images or None, event behind the transposed convs' forward images, event behind everything)
-    -- the events are None when the packs ran on the caller's stream.  Order on the side stream: transposed-conv forward images
-    (the first is needed right behind the first conv), atom forward images, then -- with_backward: the backward pass of the same
-    step multiplies by the same weights -- the backward images, which are thereby off the critical path for good.
-    Keys: parameter index of the layer's (first) weight."""
+class _PackAside:
+    """The weight images of a generator pass, packed on a side stream of its own beside the caller's chain.  The side stream
+    forks where this object is made; hipGraphLaunch feeds the device in capture order (step.py), so the caller makes it first,
+    issues the head of its chain (conv0), then asks for forward() -- transposed-conv images (the first is needed right behind
+    conv0), then the atoms' -- and, once the whole forward chain is issued, for backward(): the backward pass of the same step
+    multiplies by the same weights, and its images are thereby off the critical path for good.
+    Keys of the image dicts: parameter index of the layer's (first) weight.  Events are None when the packs ran on the
+    caller's stream."""
     # (a fork + join costs ~15 us of dependency latency inside a replayed graph: only where the pass is long enough to hide a
     #  pack launch behind -- measured at B = 1: 275 us on one stream, 311 us forked)
-    def pack_all():
-        images = pack_convt_images(x_shape, params)
-        ev_t = None
-        if side is not None:
-            ev_t = torch.cuda.Event()
-            ev_t.record(side)
-        images.update(pack_atom_images(x_shape, params))
-        images_bwd = None
-        if with_backward:
-            images_bwd = pack_atom_images(x_shape, params, True)
-            images_bwd.update(pack_convt_images(x_shape, params, True))
-        return images, images_bwd, ev_t
 
-    side = None
-    if not _may_fork(device) or x_shape[0] * x_shape[2] < 256 or os.environ.get("MSYNTH_PACKASIDE", "1") == "0":
-        images, images_bwd, _ = pack_all()
-        return images, images_bwd, None, None
-    main = torch.cuda.current_stream(device)
-    key = (device.index, "pack")
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    side = _SIDE_STREAMS[key]
-    side.wait_stream(main)
-    with forked(side):
-        images, images_bwd, ev_t = pack_all()
+    def __init__(self, x_shape, params, device):
+        self.x_shape, self.params, self.device = x_shape, params, device
+        self.side = None
+        if _may_fork(device) and x_shape[0] * x_shape[2] >= 256 and os.environ.get("MSYNTH_PACKASIDE", "1") != "0":
+            key = (device.index, "pack")
+            if key not in _SIDE_STREAMS:
+                _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+            self.side = _SIDE_STREAMS[key]
+            self.side.wait_stream(torch.cuda.current_stream(device))
+
+    def _event(self):
         ev = torch.cuda.Event()
-        ev.record(side)
-    for group in (images, images_bwd or {}):
-        for t in group.values():
+        ev.record(self.side)
+        return ev
+
+    def _publish(self, images):
+        main = torch.cuda.current_stream(self.device)
+        for t in images.values():
             t.record_stream(main)       # (allocated on the side stream, read on the caller's)
-    return images, images_bwd, ev_t, ev
+
+    def forward(self):
+        """-> (images, event behind the transposed convs' images, event behind all of them)"""
+        if self.side is None:
+            images = pack_convt_images(self.x_shape, self.params)
+            images.update(pack_atom_images(self.x_shape, self.params))
+            return images, None, None
+        with forked(self.side):
+            images = pack_convt_images(self.x_shape, self.params)
+            ev_t = self._event()
+            images.update(pack_atom_images(self.x_shape, self.params))
+            ev = self._event()
+        self._publish(images)
+        return images, ev_t, ev
+
+    def backward(self):
+        """-> images of the backward pass; the caller's stream waits for them here (the side stream has had the whole
+        forward pass to finish them)."""
+        if self.side is None:
+            images = pack_atom_images(self.x_shape, self.params, True)
+            images.update(pack_convt_images(self.x_shape, self.params, True))
+            return images
+        with forked(self.side):
+            images = pack_atom_images(self.x_shape, self.params, True)
+            images.update(pack_convt_images(self.x_shape, self.params, True))
+            ev = self._event()
+        self._publish(images)
+        torch.cuda.current_stream(self.device).wait_event(ev)
+        return images
 
 
 def atom_backward(rec, w0, w1, g, sink, i, need_wgrad=True, need_gx=True, fork=None, batch=None, image_bwd=None):
@@ -265,11 +284,12 @@ def gen_forward(x, params, save):
                            (params[0].shape[1], tuple(x.shape)))
     i = 0
     tape = []
-    images, images_bwd, packed_t, packed = pack_atom_images_aside(x.shape, params, x.device, with_backward=save)
+    aside = _PackAside(x.shape, params, x.device)
     w, b = params[i], params[i + 1]; i += 2
     d, lo = P.conv_desc(x.shape, w.shape, pad=3, pad_mode=L.PAD_REFLECT, act=L.ACT_LRELU)
     h, _ = P.conv1d_fwd(x, w, b, d, lo)
     tape.append(("conv0", d, x, h))
+    images, packed_t, packed = aside.forward()
     for stride, pad in G_UPSAMPLE:
         w, b = params[i], params[i + 1]; i += 2
         dt, lo = P.convt_desc(h.shape, w.shape, stride, pad, act=L.ACT_LRELU)
@@ -291,10 +311,10 @@ def gen_forward(x, params, save):
     d, lo = P.conv_desc(h.shape, w.shape, pad=3, act=L.ACT_TANH)
     y, _ = P.conv1d_fwd(h, w, b, d, lo)
     tape.append(("last", d, h, y))
-    if images_bwd is not None:
+    if save:
         # (gen_backward: no pack launch in front of the backward chain.)  The images hold the weights as they were at THIS
         # moment and bypass save_for_backward: the parameters' version counters travel with them
-        tape.append(("images_bwd", images_bwd, _param_versions(params)))
+        tape.append(("images_bwd", aside.backward(), _param_versions(params)))
     return y, (tape if save else None)
 
 
@@ -393,14 +413,26 @@ def pack_k5_image(x_shape, params, backward=False):
     return P.conv_img_pack(d, w, backward=backward)
 
 
-def pack_k5_images_aside(x_shape, params, device):
-    """Both weight images of the k5 layer (forward, backward data), packed on the aux stream so that they travel beside
-    whatever the caller issues next (the generator forward): -> (fwd, bwd, event to wait for before the first use), or
-    (None, None, None) when the image kernel does not take the layer / streams are serialised."""
+def fork_aux(device):
+    """Fork point of the aux stream, placed BEFORE the caller issues its own chain: what is put on the aux stream later
+    (pack_k5_images_aside(forked=True), the G-step's real pass) then depends on nothing the caller issued in between.
+    -> whether the aux stream may be used at all."""
     if not _may_fork(device):
+        return False
+    aux_stream(device).wait_stream(torch.cuda.current_stream(device))
+    return True
+
+
+def pack_k5_images_aside(x_shape, params, device, forked_at=None):
+    """Both weight images of the k5 layer (forward, backward data), packed on the aux stream so that they travel beside
+    the caller's chain (the generator forward): -> (fwd, bwd, event to wait for before the first use), or
+    (None, None, None) when the image kernel does not take the layer / streams are serialised.  forked_at = the result
+    of an earlier fork_aux(): the aux stream already branched off there and is not made to wait for the caller again."""
+    if not (_may_fork(device) if forked_at is None else forked_at):
         return pack_k5_image(x_shape, params), pack_k5_image(x_shape, params, backward=True), None
     main, aux = torch.cuda.current_stream(device), aux_stream(device)
-    aux.wait_stream(main)
+    if forked_at is None:
+        aux.wait_stream(main)
     with forked(aux):
         f = pack_k5_image(x_shape, params)
         b = pack_k5_image(x_shape, params, backward=True)

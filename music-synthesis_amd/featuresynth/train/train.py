@@ -228,13 +228,20 @@ class _TrainerBase(object):
             if with_fake:
                 res['fake'] = out["fake"].cpu().numpy()
             return res
+        fake = None
+        if with_fake:
+            # the generated batch leaves in a pinned block of its own (torch's caching host allocator: no new pinning
+            # after the first steps), issued behind the step on its stream; the array handed out IS that block -- no
+            # second pass over 1 MB (and its page faults) on the host while the device waits for the next call
+            fake = torch.empty(out["fake"].shape, dtype=out["fake"].dtype, pin_memory=True)
+            fake.copy_(out["fake"], non_blocking=True)
         torch.cuda.current_stream(device).synchronize()
         loss = float(out["loss"])
         if self._runner is not None and self._runner.between:     # data-parallel plan: the slot holds the rank SUM
             loss /= _dist.world_size()
         res = {loss_key: loss}
         if with_fake:
-            res['fake'] = out["fake"].numpy().copy()   # (the pinned buffer is reused by the next step)
+            res['fake'] = fake.numpy()      # (keeps the block alive; it returns to the cache with the array)
         return res
 
     def graph_status(self):
@@ -266,6 +273,9 @@ class _TrainerBase(object):
             self._pins = {}
         host = {}
         for k, v in out.items():
+            if k == "fake":         # leaves in _result, outside the graph: a fresh pinned block per call
+                host[k] = v
+                continue
             key = (k, tuple(v.shape))
             if key not in self._pins:
                 self._pins[key] = torch.empty(tuple(v.shape), dtype=v.dtype, pin_memory=True)
