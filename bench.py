@@ -355,14 +355,20 @@ def main():
             roof = {"bound": "hbm", "achieved": by / avg_s / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        if compute_bound:
-            roof["pipe"] = ({6: "bf16 MFMA, exact 3-way operand split, 6 products per fp32 multiply, fp32 accumulate: peak = 2500 / 6",
-                             3: "fp16 MFMA, block-scaled 2-way operand split (22 significand bits), 3 products per fp32 multiply, "
-                                "fp32 accumulate: peak = 2500 / 3"}[products] if split_pipe else "fp32-input MFMA")
-            if products == 3:                                   # continuity with the r02 / r03 lines, priced on 2500 / 6
-                roof["frac_of_six_product_pipe"] = roof["achieved"] / (BF16_PEAK / 6 / 1e12)
-            roof["fp32_peak"] = F32_PEAK / 1e12                  # SURVEY 8(d)'s fp32 roofline, for continuity
-            roof["frac_of_fp32_peak"] = roof["achieved"] / roof["fp32_peak"]
+        # both legs, whichever one binds: with three products per multiply the atoms' MFMA time (flops / 833 TFLOP/s) and
+        # their HBM time (bytes / 8 TB/s) are within 15 % of each other at C = 32 .. 64
+        roof["tflops"] = fl / avg_s / 1e12
+        roof["gbps"] = by / avg_s / 1e9
+        roof["frac_of_hbm"] = roof["gbps"] / (HBM_PEAK / 1e9)
+        roof["pipe"] = ({6: "bf16 MFMA, exact 3-way operand split, 6 products per fp32 multiply, fp32 accumulate: peak = 2500 / 6",
+                         3: "fp16 MFMA, block-scaled 2-way operand split (22 significand bits), 3 products per fp32 multiply, "
+                            "fp32 accumulate: peak = 2500 / 3"}[products] if split_pipe else "fp32-input MFMA")
+        roof["pipe_peak"] = pipe_peak / 1e12
+        roof["frac_of_pipe"] = roof["tflops"] / roof["pipe_peak"]
+        if split_pipe:                                          # continuity with the r02 / r03 lines, priced on 2500 / 6
+            roof["frac_of_six_product_pipe"] = roof["tflops"] / (BF16_PEAK / 6 / 1e12)
+        roof["fp32_peak"] = F32_PEAK / 1e12                      # SURVEY 8(d)'s fp32 roofline, for continuity
+        roof["frac_of_fp32_peak"] = roof["tflops"] / roof["fp32_peak"]
         roof["traffic"] = None
         # HBM bytes per launch of that kernel from the TCC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # in separate passes, gfx950 x2 fetch correction: tools/pmc_traffic.sh), quoted only when the file was
