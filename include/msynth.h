@@ -171,6 +171,24 @@ int ms_residual_atom_bwd_data(const ms_atom_desc* d, const float* gy, const floa
                               const void* image_bwd, float* gt, float* gx, float* amax, ms_stream_t stream);
 
 /*
+ * Fused ResidualStack forward, inference (util/modules.py:391-405: `count` ResidualAtoms back to back, the generator's
+ * stacks with dilations 1, 3, 9): y = atom[count-1](... atom[0](x)) in ONE launch, nothing saved -- the values between
+ * the atoms never travel to memory (csrc/stack_fused.hip).  images[i]: atom i's forward image (ms_residual_atom_pack_multi,
+ * backward = 0; the two-piece scheme, i.e. not under MSYNTH_ATOM_NP=3), b0[i] / b1[i]: its biases; all 16-byte aligned.
+ * x and y must not alias.  ms_residual_stack_supported: 1 when the kernel takes this geometry (C in {32, 64},
+ * L % 4 == 0, sum(dil + 1) <= 16, dil[0] <= 4), else 0: the caller issues ms_residual_atom_fwd per atom.
+ */
+#define MS_STACK_MAX 3
+typedef struct ms_stack_desc {
+    int32_t B, C, L, count;
+    int32_t dil[MS_STACK_MAX];
+    float slope;      /* LeakyReLU negative slope */
+} ms_stack_desc;
+int ms_residual_stack_supported(const ms_stack_desc* d);
+int ms_residual_stack_fwd(const ms_stack_desc* d, const float* x, const void* const* images, const float* const* b0,
+                          const float* const* b1, float* y, ms_stream_t stream);
+
+/*
  * Dense k = 5 / stride 1 / padding 2 conv on short rows (L <= 64) with PRE-SPLIT weight images: the discriminator's
  * 1024 -> 1024 layer (discriminator/full.py:19) at its three scales, forward and backward data (csrc/conv5_img.hip).
  * Same operation and accuracy as ms_conv1d_fwd / ms_conv1d_bwd_data on that geometry (other summation order: ~1e-7).

@@ -302,6 +302,13 @@ def gen_forward(x, params, save):
         if packed is not None:
             torch.cuda.current_stream(x.device).wait_event(packed)
             packed = None
+        n = len(DILATIONS)
+        if not save and all(images.get(i + 4 * k) is not None for k in range(n)) and P.stack_supported(h, DILATIONS):
+            # nothing to save: the whole ResidualStack in one launch, the values between its atoms stay on chip
+            h = P.stack_fwd(h, [images[i + 4 * k] for k in range(n)], [params[i + 4 * k + 1] for k in range(n)],
+                            [params[i + 4 * k + 3] for k in range(n)], DILATIONS)
+            i += 4 * n
+            continue
         for dil in DILATIONS:
             h, rec = atom_forward(h, params[i], params[i + 1], params[i + 2], params[i + 3], dil, save,
                                   image=images.get(i))

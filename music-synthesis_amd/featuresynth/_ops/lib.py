@@ -75,6 +75,14 @@ class AtomDesc(ctypes.Structure):               # ms_atom_desc
     _fields_ = [("B", _c_int), ("C", _c_int), ("L", _c_int), ("dil", _c_int), ("slope", _c_f)]
 
 
+STACK_MAX = 3
+
+
+class StackDesc(ctypes.Structure):              # ms_stack_desc
+    _fields_ = [("B", _c_int), ("C", _c_int), ("L", _c_int), ("count", _c_int), ("dil", _c_int * STACK_MAX),
+                ("slope", _c_f)]
+
+
 class AtomPackDesc(ctypes.Structure):           # ms_atom_pack_desc
     _fields_ = [("count", _c_int), ("reserved", _c_int), ("C", _c_int * ATOM_PACK_MAX),
                 ("w0", _vp * ATOM_PACK_MAX), ("w1", _vp * ATOM_PACK_MAX), ("image", _vp * ATOM_PACK_MAX),
@@ -114,6 +122,8 @@ SIGNATURES = {
     "ms_residual_atom_pack_multi": (_c_int, [ctypes.POINTER(AtomPackDesc), _vp]),
     "ms_residual_atom_publishes_amax": (_c_int, []),
     "ms_residual_atom_fwd": (_c_int, [ctypes.POINTER(AtomDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ms_residual_stack_supported": (_c_int, [ctypes.POINTER(StackDesc)]),
+    "ms_residual_stack_fwd": (_c_int, [ctypes.POINTER(StackDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "ms_residual_atom_bwd_supported": (_c_int, [ctypes.POINTER(AtomDesc)]),
     "ms_residual_atom_bwd_data": (_c_int, [ctypes.POINTER(AtomDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ms_conv1d_img_bytes": (_sz, [ctypes.POINTER(ConvDesc)]),

@@ -1,6 +1,8 @@
 """Tensor-level wrappers of the C-ABI kernels: shape checks, output allocation, launch on the
 current stream.  No autograd here (see functional.py)."""
 import numpy as np
+import ctypes
+
 import torch
 
 from . import lib as L
@@ -253,6 +255,42 @@ def atom_fwd(x, image, b0, b1, dil, save):
     if amax is not None:
         t._ms_amax = amax
     return y, t, u
+
+
+def _stack_desc(x, dils):
+    B, C, Lg = x.shape
+    d = L.StackDesc()
+    d.B, d.C, d.L, d.count, d.slope = B, C, Lg, len(dils), SLOPE
+    for i, dl in enumerate(dils):
+        d.dil[i] = dl
+    return d
+
+
+def stack_supported(x, dils):
+    """The whole ResidualStack (len(dils) atoms) in one launch, inference only (csrc/stack_fused.hip)."""
+    return 1 <= len(dils) <= L.STACK_MAX and x.dim() == 3 and bool(L.load().ms_residual_stack_supported(ctypes.byref(_stack_desc(x, dils))))
+
+
+def stack_fwd(x, images, b0s, b1s, dils):
+    """-> y = atom[n-1](... atom[0](x)), nothing saved.  images / b0s / b1s: per atom (forward images of atom_pack)."""
+    L.require(x, "residual stack input")
+    for b in list(b0s) + list(b1s):
+        L.require(b, "bias")
+    B, C, Lg = x.shape
+    n = len(dils)
+    y = torch.empty_like(x)
+    d = _stack_desc(x, dils)
+    arr = ctypes.c_void_p * n
+    im = arr(*[t.data_ptr() for t in images])
+    pb0 = arr(*[t.data_ptr() for t in b0s])
+    pb1 = arr(*[t.data_ptr() for t in b1s])
+
+    def cost():
+        fl = sum(2 * W.conv_cost(B, C, Lg, C, 3, 1, dl, dl, 1, "fwd")["flops"] for dl in dils)
+        return {"flops": fl, "bytes": 4 * x.numel() * 2 + n * 4 * 2 * (3 * C * C + C), "geom": (B, C, Lg, C, 3, 1, tuple(dils), 1)}
+    L.call("ms_residual_stack_fwd", cost, d, x.data_ptr(), ctypes.cast(im, ctypes.c_void_p), ctypes.cast(pb0, ctypes.c_void_p),
+           ctypes.cast(pb1, ctypes.c_void_p), y.data_ptr(), L.stream())
+    return y
 
 
 def _amax_buffer(device):
