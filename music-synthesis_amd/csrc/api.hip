@@ -143,8 +143,6 @@ __global__ __launch_bounds__(256) void k_unpad_rows(const float* __restrict__ sr
 }
 
 bool pad4_applicable(const ConvP& p) {
-    const char* e = getenv("MSYNTH_PAD4");
-    if (e && atoi(e) == 0) return false;
     return p.groups == 1 && p.stride == 1 && p.Lout == p.Lin && (p.Lin & 3) != 0 && p.Lin >= 5 && p.Lin <= 256 &&
            (long long)p.B * p.Lin >= 1000 &&
            p.K == 5 && p.Cin >= 256 && p.Cout >= 256 && p.Cin % 16 == 0 && p.Cout % 16 == 0 &&

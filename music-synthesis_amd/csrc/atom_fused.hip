@@ -33,9 +33,6 @@
 #include "atom_common.h"
 #include <stdlib.h>
 #include <type_traits>
-#ifndef ATOM_LB3
-#define ATOM_LB3 0
-#endif
 
 namespace {
 
@@ -116,10 +113,6 @@ struct AtomCfg {
     static_assert(MS >= 1 && TN >= 1 && TM * WGM == MS && TN * WGN * 32 == NTP, "tile shape");
 };
 
-// DBG (tools/scratch/probe_atom.py only; 0 in the product) -- timing probes, results are garbage: 1 = weight fragments loaded
-// once (no streaming), 2 = B fragments read once per GEMM (no LDS traffic in the K loop), 3 = no global stores,
-// 4 = no x window loads / staging, 5 = no MFMAs.
-//
 // Persistent workgroups: the grid is the number of workgroups the chip holds at once; each walks the tiles
 // blockIdx.x, + gridDim.x, ...  Per tile:   [x window(t) registers -> split -> LDS] [GEMM 1] [issue the x window loads of
 // tile t + 1 into registers] [t tile -> LDS (+ stores of t)] [GEMM 2] [stores of y (and u)] -- the next tile's loads and this
@@ -140,8 +133,8 @@ struct AtomCfg {
 // equal column counts (-4 % at 128 channels, +8 % at 64 where the second GEMM body spills); a start stagger of the second
 // resident workgroup and s_setprio around the GEMMs (0 to +5 % slower); y / u / residual as 16-byte row-major vectors through a
 // per-wave LDS transpose (a quarter of the epilogue's vector-memory instructions: no change of the train step, +-1 %).
-template <int C, int NTP, int NW, int MODE, int NP, int DBG = 0>
-__global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom_fwd(AtomP p, const float* __restrict__ X, const u32x4* __restrict__ IMG,
+template <int C, int NTP, int NW, int MODE, int NP>
+__global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* __restrict__ X, const u32x4* __restrict__ IMG,
                                                  const float* __restrict__ b0, const float* __restrict__ b1,
                                                  float* __restrict__ Y, float* __restrict__ T, float* __restrict__ U,
                                                  const float* __restrict__ Tm, float* __restrict__ AM) {
@@ -198,7 +191,7 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
         const int bb = tile / p.tiles_per_row, cc0 = (tile - bb * p.tiles_per_row) * p.NO;
         const int base = 4 * bb * C * L;                            // (wave-uniform: scalar offset)
 #pragma unroll
-        for (int r = 0; r < (DBG == 4 ? 0 : ROUNDS); ++r) {
+        for (int r = 0; r < ROUNDS; ++r) {
             const int t = cc0 + u_t[r];                              // multiple of 4: all inside the row or all outside
             // (the column base rides in the lane offset: the hardware range-checks THAT part, which must not go negative)
             const unsigned goff = (t >= 0 && t < L) ? (unsigned)(u_goff[r] + 4 * cc0) : OOB;
@@ -230,7 +223,7 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
         if (!SC) return;
         float m = 0.f;
 #pragma unroll
-        for (int r = 0; r < (DBG == 4 ? 0 : ROUNDS); ++r)
+        for (int r = 0; r < ROUNDS; ++r)
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
@@ -246,7 +239,7 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
     };
     auto store_x = [&](float S) {
 #pragma unroll
-        for (int r = 0; r < (DBG == 4 ? 0 : ROUNDS); ++r) {
+        for (int r = 0; r < ROUNDS; ++r) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = u_lcol[r] + e;
@@ -307,9 +300,7 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
 #pragma unroll
         for (int ch = 0; ch < NC; ++ch) {
             const int q = g * NC + ch, qn = q + 1;
-            if (DBG == 1) {
-                if (q == 0) load_a(1);
-            } else if (qn < 2 * NC) load_a(qn);
+            if (qn < 2 * NC) load_a(qn);
             else if (more) load_a(0);
             u32x4 fb[2][TNE][NP];
             auto fragb = [&](int s, u32x4 (&dst)[TNE][NP]) {
@@ -322,13 +313,12 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
             // (C = 32: one fragment buffer -- the registers of the second one are what keeps three waves per SIMD, and
             //  with three waves the other two cover the ds_read latency)
             constexpr bool FB2 = C != 32;
-            if (FB2 && (DBG != 2 || ch == 0)) fragb(0, fb[0]);
+            if (FB2) fragb(0, fb[0]);
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
-                if (FB2 && s + 1 < 3 && (DBG != 2 || ch == 0)) fragb(s + 1, fb[(s + 1) & 1]);
-                if (!FB2 && (DBG != 2 || (ch == 0 && s == 0))) fragb(s, fb[s & 1]);
+                if (FB2 && s + 1 < 3) fragb(s + 1, fb[(s + 1) & 1]);
+                if (!FB2) fragb(s, fb[s & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (DBG == 5) continue;
                 if constexpr (NP == 3) {
                     constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};      // piece pairs, smallest products first
 #pragma unroll
@@ -379,11 +369,8 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
     // PRE: the per-tile dependent loads of the epilogues (the residual; backward: t for the derivative) are issued a GEMM
     // ahead of their use where the registers allow: with 2-3 workgroups per CU every memory round trip a tile waits for is
     // throughput lost
-#ifndef ATOM_PRE32
-#define ATOM_PRE32 0
-#endif
     // (128 channels with the registers the single accumulator freed: measured 3 % SLOWER on the train step)
-    constexpr bool PRE = C == 64 || (C == 32 && (NP == 3 || ATOM_PRE32));
+    constexpr bool PRE = C == 64 || (C == 32 && NP == 3);
     for (; tile < ntiles; tile += gridDim.x) {
         const int b = tile / p.tiles_per_row, c0 = (tile - b * p.tiles_per_row) * p.NO;
         const int no = p.NO;
@@ -434,7 +421,7 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
                 const int gc = c0 - h2 + col;
                 const bool inrow = gc >= 0 && gc < L;                // outside the row t is the second conv's ZERO padding
                 // the tile's own columns of t are stored (forward training: the saved activation; backward: the raw gt)
-                const unsigned o_t = (MODE != 0 && DBG != 3 && inrow && col >= h2 && col < h2 + no) ? (unsigned)o_lane[j] : OOB;
+                const unsigned o_t = (MODE != 0 && inrow && col >= h2 && col < h2 + no) ? (unsigned)o_lane[j] : OOB;
                 float tm[BWD ? 16 : 1];                              // backward: t itself, for the derivative
                 if (PRE_T) {
 #pragma unroll
@@ -540,7 +527,7 @@ __global__ __launch_bounds__(64 * NW, (C == 32 && ATOM_LB3) ? 3 : 2) void k_atom
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const unsigned oy = DBG == 3 ? OOB : o_y[j];
+                const unsigned oy = o_y[j];
                 float xr[16];
                 if (PRE) {
 #pragma unroll
@@ -615,16 +602,6 @@ int launch_atom_np(AtomP p, const float* x, const void* image, const float* b0, 
     const long long slots = (long long)n_cu[dev] * wgs_per_cu[dev];
     const long long ntiles = (long long)p.B * p.tiles_per_row;
     const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
-    static const int dbg = getenv("MSYNTH_ATOM_DBG") ? atoi(getenv("MSYNTH_ATOM_DBG")) : 0;       // timing probes
-    if constexpr (MODE == 1 && NW == 4 && NTP * C == 128 * 64 && NP == 2) {
-        if (dbg) {
-#define MS_ATOM_DBG(D_) if (dbg == D_) { \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, NW, 1, NP, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); \
-            hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, 1, NP, D_>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u, tm, am); MS_CHECK_LAUNCH(); return MS_OK; }
-            MS_ATOM_DBG(1) MS_ATOM_DBG(2) MS_ATOM_DBG(3) MS_ATOM_DBG(4) MS_ATOM_DBG(5)
-#undef MS_ATOM_DBG
-        }
-    }
     ms_note_kernel("k_atom_fwd<%d, %d, %d, %d, %d>", C, NTP, NW, MODE, NP);
     if (grid.x > MS_ATOM_AMAX_N) am = nullptr;          // (cannot happen: at most 4 workgroups on each of 256 CUs)
     hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, MODE, NP>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u, tm, am);
@@ -657,7 +634,6 @@ int dispatch_atom(int mode, const ms_atom_desc* d, const float* x, const void* i
     const long long cols = (long long)d->B * d->L;
     switch (d->C) {
         case 32: return launch_atom<32, 128, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
-#ifndef ATOM_ONLY32
         case 64:
             if (cols < 124 * 128) return launch_atom<64, 64, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
             return launch_atom<64, 128, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
@@ -667,7 +643,6 @@ int dispatch_atom(int mode, const ms_atom_desc* d, const float* x, const void* i
         case 256:
             if (cols < 60 * 64 && mode != 2) return launch_atom<256, 32, 8>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
             return launch_atom<256, 64, 8>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
-#endif
         default: return MS_ERR_UNSUPPORTED;
     }
 }

@@ -1100,18 +1100,13 @@ bool rows_applicable(int M, int CK, int K, int L) {
 // its 128x128 tile needs 112 KiB of LDS (one workgroup per CU, every latency exposed); two co-resident 64x128
 // workgroups measured faster (C = 128, L = 2048, B = 32: 58 vs 68 us)
 RowCfg pick_row_cfg(int M, int B, int L, bool dense = false) {
-    if (const char* e = getenv("MSYNTH_ROWCFG")) {      // tuning switch: force a tile shape
-        const int v = atoi(e);
-        if (v >= 0 && v <= 3 && (M > 32 || v == 3)) return v == 0 ? ROW_128x128 : (v == 1 ? ROW_64x128 : (v == 2 ? ROW_64x64 : ROW_32x256));
-    }
     if (M <= 32) return ROW_32x256;
     if (L < 128) return (M >= 512 && (long long)B * L >= 512) ? ROW_64x128 : ROW_64x64;   // short rows: R = 128 / L rows per tile
     const long long N = (long long)B * L;
     const char* r3 = getenv("MSYNTH_ROWS3");
     const bool split = dense && L % 4 == 0 && !(r3 && atoi(r3) == 0);
     if (M >= 128 && (N / 128) * (M / 128) >= 384 && !split) return ROW_128x128;
-    static const int t64 = getenv("MSYNTH_T64") ? atoi(getenv("MSYNTH_T64")) : 192;   // tuning switch
-    if ((N / 128) * (M / 64) < t64) return ROW_64x64;   // small batches: more, smaller workgroups
+    if ((N / 128) * (M / 64) < 192) return ROW_64x64;   // small batches: more, smaller workgroups
     return ROW_64x128;
 }
 
@@ -1178,12 +1173,10 @@ bool rows2_pick(RowCfg cfg, int K, int CC, bool has_act, int epi_s, int in_s, co
             (cfg == ROW_64x64 ? MSR2_64x64 : MSR2_32x256));
     if (in_s == 1 && msr3_supported(*tile, K, *am, epi_s, *q, 1)) return true;   // split-bf16 kernel: rows of any length
     // short rows of a length that is not a multiple of 4 (k5 conv at L = 17 / 9): whole-row staging
-    // (MSYNTH_SR=1 also sends the aligned short rows there: tuning switch)
     if (in_s == 1 && in_s_out && K == 5 && p.tiles_per_row == 1 && p.Lt == p.L) {
-        static const int sr_all = getenv("MSYNTH_SR") ? atoi(getenv("MSYNTH_SR")) : 0;
         int bm, bn;
         row_tile(cfg, &bm, &bn);
-        if (p.L < bn && (p.L % 4 != 0 || sr_all == 1) && sr_all != 2 && msr2_supported(*tile, K, CC, *am, epi_s, *q, 0)) {
+        if (p.L < bn && p.L % 4 != 0 && msr2_supported(*tile, K, CC, *am, epi_s, *q, 0)) {
             *in_s_out = 0;
             return true;
         }
@@ -1195,7 +1188,7 @@ bool rows2_pick(RowCfg cfg, int K, int CC, bool has_act, int epi_s, int in_s, co
 // it -- supported and its grid (half as many, twice as wide workgroups) still fills most of the 256 CUs -- else 0.
 int rows3p_bm(const Row2P& q, int bn, int K, int am, int epi_s, int in_s, unsigned gz) {
     if (bn != 128) return 0;                     // (q's tiling must be the 128-column one the kernel's groups own)
-    static const int min_wgs = getenv("MSYNTH_R3P_MIN") ? atoi(getenv("MSYNTH_R3P_MIN")) : 128;   // tuning switch
+    constexpr int min_wgs = 128;
     const long long ntiles = q.R == 1 ? (long long)q.B * q.tiles_per_row : (q.B + q.R - 1) / q.R;
     // (C = 256 at L = 256, B = 32: 64 workgroups of 128 rows or 128 of 64 rows both measured slower than the
     //  four-wave kernel's 256 workgroups: 61 / 44 vs 30 us -- no fallback to narrower workgroups)
@@ -1208,7 +1201,7 @@ int rows3p_bm(const Row2P& q, int bn, int K, int am, int epi_s, int in_s, unsign
 // ... and for the transposed-conv forward (two-tap form, conv_rows3.hip HS): 128 rows where that still fills the chip
 int rows3p_convt_bm(const Row2P& q, int bn, int S, unsigned gz) {
     if (bn != 128) return 0;
-    static const int min_wgs = getenv("MSYNTH_R3P_MIN") ? atoi(getenv("MSYNTH_R3P_MIN")) : 128;
+    constexpr int min_wgs = 128;
     const long long ntiles = q.R == 1 ? (long long)q.B * q.tiles_per_row : (q.B + q.R - 1) / q.R;
     for (int bm = 128; bm >= 64; bm >>= 1) {
         if (q.M < bm || !msr3p_convt_supported(bm, S, q)) continue;

@@ -885,14 +885,6 @@ int msr3p_launch(int bm, int K, int act_mode, const Row2P& p, const float* X, co
     const unsigned ntiles = p.R == 1 ? (unsigned)(p.B * p.tiles_per_row) : (unsigned)((p.B + p.R - 1) / p.R);
     const dim3 grid((ntiles + 1) / 2, (unsigned)((p.M + bm - 1) / bm), gz);
 #define MS3P(WGM_, TM_, TN_, K_, A_) return launch_pair<WGM_, TM_, TN_, K_, A_>(p, X, Xact, W, bias, res, Y, Yact, grid, s)
-    if (bm == 128 && K == 3 && act_mode == 0) {
-        static const int dbg = getenv("MSYNTH_R3P_DBG") ? atoi(getenv("MSYNTH_R3P_DBG")) : 0;     // timing probes (tools/scratch/dbg_r3p.py)
-        if (dbg == 1) return launch_pair<2, 2, 2, 3, 0, 0, false, 1>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
-        if (dbg == 2) return launch_pair<2, 2, 2, 3, 0, 0, false, 2>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
-        if (dbg == 3) return launch_pair<2, 2, 2, 3, 0, 0, false, 3>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
-        if (dbg == 4) return launch_pair<2, 2, 2, 3, 0, 0, false, 4>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
-        if (dbg == 5) return launch_pair<2, 2, 2, 3, 0, 0, false, 5>(p, X, Xact, W, bias, res, Y, Yact, grid, s);
-    }
     if (bm == 128) {
         if (K == 3 && act_mode == 0) MS3P(2, 2, 2, 3, 0);
         if (K == 3 && act_mode == 1) MS3P(2, 2, 2, 3, 1);

@@ -359,8 +359,8 @@ bool ct_ok(const ms_convt1d_desc* d) {
     // measured (tools/scratch/microbench_convt_img.py, B = 32): stride 8: 69 -> 37 us (512 -> 256), 77 -> 64 us (256 -> 128); the two
     // stride-2 layers are HBM-bound and run 20 % FASTER on the paired row kernel (42 / 28 us), and at B = 1 the pack launch
     // costs more than the kernel saves: those stay on ms_convt1d_fwd's row-tile path
-    static const int s2 = getenv("MSYNTH_CONVTIMG_S2") ? atoi(getenv("MSYNTH_CONVTIMG_S2")) : 0;       // probe: stride 2 too
-    if ((d->stride != 8 && !s2) || (long long)d->B * d->Lin < 1024) return false;
+    // (r04, fp16 x 2 images, B = 32: stride 2 on this kernel 37.7 / 30.8 us against 40.0 / 28.0 on the row kernel -- a wash)
+    if (d->stride != 8 || (long long)d->B * d->Lin < 1024) return false;
     if ((long long)d->B * d->Cin * d->Lin * 4 >= (1ll << 31) || (long long)d->B * d->Cout * d->Lin * d->stride * 4 >= (1ll << 31)) return false;
     const char* sw = getenv("MSYNTH_CONVTIMG");                 // tuning / test switch (0: the row-tile kernels)
     return !(sw && atoi(sw) == 0);

@@ -508,8 +508,7 @@ int msg_conv1d_fwd(const ConvP& p, const float* x, const float* w, const float* 
     // 4 wave units per workgroup pass; ~2048 workgroups at most, each wave then loops over units
     // ~2 waves per SIMD (2048 waves): a wave loops over `upw` units so that its loads, MFMA chains
     // and stores of consecutive units overlap
-    const char* tw = getenv("MSYNTH_GW");
-    const int target_waves = tw ? atoi(tw) : 2048;
+    const int target_waves = 2048;
     const long long total_units = (long long)nunits * p.groups;
     const int upw = (int)((total_units + target_waves - 1) / target_waves);
     const int gx = ms_ceil_div(nunits, 4 * (upw > 0 ? upw : 1));

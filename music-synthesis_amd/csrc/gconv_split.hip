@@ -903,8 +903,7 @@ int msg3_conv1d_fwd(const ConvP& p, const float* x, const float* w, const float*
     const int rb = pick_rb(p.Lout);
     const int ts = 64 / rb;
     const int spr = ms_ceil_div(p.Lout, ts), nseg = p.B * spr, nunits = ms_ceil_div(nseg, rb);
-    const char* tw = getenv("MSYNTH_GW");
-    const int target_waves = tw ? atoi(tw) : 2048;
+    const int target_waves = 2048;
     const long long total_units = (long long)nunits * p.groups;
     const int upw = (int)((total_units + target_waves - 1) / target_waves);
     const int gxn = ms_ceil_div(nunits, 4 * (upw > 0 ? upw : 1));

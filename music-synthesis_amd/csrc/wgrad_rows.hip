@@ -816,8 +816,7 @@ WrPlan plan_wrows(const ConvP& c) {
     WrP& p = q.p;
     p.B = c.B; p.CK = c.Cin; p.L = c.Lin; p.M = c.Cout; p.dil = c.dil; p.pad = c.pad;
     p.g_kind = c.act; p.x_kind = c.in_act ? MS_MOD_LRELU_FWD : MS_ACT_NONE; p.slope = c.slope;
-    static const int lt_env = getenv("MSYNTH_WLT") ? atoi(getenv("MSYNTH_WLT")) : 0;   // tuning switch: 32-column chunks
-    const int LT = (lt_env == 32 && p.L % 32 == 0) ? 32 : KMAX;
+    const int LT = KMAX;
     if (p.L >= KMAX) { p.Lt = LT; p.R = 1; p.tiles_per_row = ms_ceil_div(p.L, LT); p.nchunks = p.B * p.tiles_per_row; }
     else {
         p.Lt = p.L;
@@ -836,7 +835,6 @@ WrPlan plan_wrows(const ConvP& c) {
     p.PG = (p.kcols + 2) | 1;
     p.PX = (p.kcols + H + 2) | 1;
     q.tm = (K <= 3 && c.Cout >= 128) ? 2 : 1;
-    if (const char* e = getenv("MSYNTH_WTM")) q.tm = atoi(e) == 1 ? 1 : q.tm;   // tuning switch
     const int BM = 64 * q.tm;
     q.lds = (size_t)(2 * (BM * p.PG + CB * p.PX) + 256) * sizeof(float);   // two buffers + scratch
     if (q.lds > 150 * 1024) return q;

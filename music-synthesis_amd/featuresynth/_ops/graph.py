@@ -65,10 +65,7 @@ def forked(stream):
 def _may_fork(device):
     if not _concurrent_scales() or _on_aux(device):
         return False
-    if _FORK_DEPTH == 0:
-        return True
-    # experiment switch: nested forks on their own stream pool (one pool per depth)
-    return _FORK_DEPTH == 1 and os.environ.get("MSYNTH_NESTED_FORK") == "1"
+    return _FORK_DEPTH == 0
 
 
 class _WgradFork:
@@ -599,18 +596,14 @@ def melgan_forward(x, params, scales=2, k5_image=None):
         side = _side_streams(x.device, scales)
         # longest job first: the full-rate pass is issued before the pooled ones, which fork off an event
         # recorded ahead of it (see melgan_backward)
-        first = os.environ.get("MSYNTH_SCALE0_FIRST", "1") == "1"
         fork_ev = torch.cuda.Event()
         fork_ev.record(main)
-        if first:
-            res[0] = disc_forward(xs[0], params, k5_image)
+        res[0] = disc_forward(xs[0], params, k5_image)
         for s in range(1, scales + 1):
             st = side[s - 1]
             st.wait_event(fork_ev)
             with forked(st):
                 res[s] = disc_forward(xs[s], params, k5_image)
-        if not first:
-            res[0] = disc_forward(xs[0], params, k5_image)
         for st in side:
             main.wait_stream(st)
     else:
@@ -689,9 +682,7 @@ def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, nee
             # fork off the point before it through an event instead of waiting for the main stream's tail
             fork_ev = torch.cuda.Event()
             fork_ev.record(main)
-            first = os.environ.get("MSYNTH_SCALE0_FIRST", "1") == "1"
-            if first:
-                run_scale(0, ph, sink)
+            run_scale(0, ph, sink)
             for s in range(1, n):
                 if not grads[s][0]:
                     continue
@@ -706,8 +697,6 @@ def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, nee
                         else:
                             tmp[s] = GradSink(D_NPARAMS)      # own slabs: no cross-stream accumulation
                     run_scale(s, ph, tmp[s])
-            if not first:
-                run_scale(0, ph, sink)
             for st in side:
                 main.wait_stream(st)
             # fold the side-stream weight grads in: the parameters this phase has finished

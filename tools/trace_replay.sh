@@ -1,4 +1,6 @@
 #!/bin/bash
+# rocprofv3 kernel trace of the replayed train step -> gpurun_out/trace9/compact.csv (start, end, queue, kernel; ns) for
+# tools/trace_timeline.py (alone / overlapped time per kernel family) and tools/trace_sequence.py (one call, in order).
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/trace9

@@ -1,3 +1,7 @@
+"""Kernel sequence of one replayed trainer call (tools/trace_replay.sh writes gpurun_out/trace9/compact.csv): start, duration,
+idle gap in front, queue, kernel.  usage: trace_sequence.py compact.csv <kernels per call: 130 = D-step, 170 = G-step>
+(rocprofv3 slows the host side of hipGraphLaunch to ~10 us per node: gaps and late starts at the head of a call are
+larger than in an untraced run, where the feed rate is ~3.4 us per node -- tools/scratch/probe_launch.py)"""
 import sys, re
 rows = []
 for line in open(sys.argv[1]):

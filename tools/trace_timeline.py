@@ -1,4 +1,4 @@
-"""Timeline analysis of a rocprofv3 kernel trace of the replayed train step (tools/scratch/run9.sh writes
+"""Timeline analysis of a rocprofv3 kernel trace of the replayed train step (tools/trace_replay.sh writes
 gpurun_out/trace9/compact.csv: start, end, queue, kernel name; ns).  Steps are cut at the fused Adam kernel.
 Per step kind (D / G): wall, device-busy union, idle, and -- per kernel family -- how long it ran ALONE on the device
 (nothing else in flight) vs overlapped: the alone time is what a faster kernel would give back as wall time."""
