@@ -10,5 +10,5 @@ bash tools/pmc_one.sh k5 k5img 64 1024 32 > gpurun_out/pmc_k5.txt 2>&1
 bash tools/pmc_one.sh ctbwd ctbwd 32 256 256 128 8 > gpurun_out/pmc_ctbwd.txt 2>&1
 bash tools/pmc_one.sh gfwd fwd 64 64 2048 256 16 > gpurun_out/pmc_gfwd.txt 2>&1
 bash tools/pmc_one.sh gwgrad wgrad 64 64 2048 256 16 > gpurun_out/pmc_gwgrad.txt 2>&1
-python3 tools/pmc_ratios.py gpurun_out/pmc_atom64.txt gpurun_out/pmc_atom128.txt gpurun_out/pmc_k5.txt gpurun_out/pmc_ctbwd.txt gpurun_out/pmc_gfwd.txt gpurun_out/pmc_gwgrad.txt > gpurun_out/r03_pmc_kernels_summary.txt
-cat gpurun_out/r03_pmc_kernels_summary.txt
+python3 tools/pmc_ratios.py gpurun_out/pmc_atom64.txt gpurun_out/pmc_atom128.txt gpurun_out/pmc_k5.txt gpurun_out/pmc_ctbwd.txt gpurun_out/pmc_gfwd.txt gpurun_out/pmc_gwgrad.txt > gpurun_out/r04_pmc_kernels_summary.txt
+cat gpurun_out/r04_pmc_kernels_summary.txt
