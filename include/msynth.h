@@ -123,13 +123,15 @@ int ms_conv1d_bwd_weight_multi(const ms_wgrad_multi_desc* d, void* workspace, si
  * Fused ResidualAtom forward (util/modules.py:350-388):
  *     y = x + lrelu(conv1d(lrelu(conv1d(x, w0, b0, padding = dil, dilation = dil)), w1, b1, padding = 1))
  * both convs k = 3, C -> C channels, zero padding, in ONE launch: the intermediate activation stays on chip.
- * Same arithmetic as two ms_conv1d_fwd calls (the results agree bitwise with them).
+ * fp32 in / fp32 accumulate / fp32 out; the operands reach the 16-bit matrix pipe as block-scaled two-piece fp16 (three
+ * products per multiply, an fp32 FMA chain's accuracy; MSYNTH_ATOM_NP=3: exact three-piece bf16, bitwise equal to two
+ * ms_conv1d_fwd calls).
  *   ms_residual_atom_pack_multi  splits the fp32 weights of up to MS_ATOM_PACK_MAX atoms once into the kernel's
- *                                fragment-ordered bf16 x 3 images (ms_residual_atom_image_bytes(C) bytes each, caller-
+ *                                fragment-ordered piece images (ms_residual_atom_image_bytes(C) bytes each, caller-
  *                                owned, 16-byte aligned); call it again whenever the weights changed (once per step)
  *   ms_residual_atom_fwd         t / y_act (both or neither): training additionally stores t = lrelu(conv_d + b0) and
  *                                y_act = lrelu(conv1 + b1), the activations the backward pass of the atom needs
- *   ms_residual_atom_supported   1 when the fused kernel takes this geometry (C in {32, 64, 128}, L % 4 == 0,
+ *   ms_residual_atom_supported   1 when the fused kernel takes this geometry (C in {32, 64, 128, 256}, L % 4 == 0,
  *                                dil <= 9), else 0: the caller then issues the two convs
  * b0, b1 and image must be 16-byte aligned.
  */
