@@ -451,6 +451,22 @@ def main():
             "algorithmic_gflop_per_DG_pair": W.totals(launches)["flops"] / 1e9,
             "algorithmic_mb_per_DG_pair": W.totals(launches)["bytes"] / 1e6}
 
+    if rank == 0 and args.model == "realmelgan":
+        # step roofline of the weight-normed variant (no per-kernel leg): layer spec in featuresynth/_workload.py
+        launches = W.real_d_step_launches(B, args.mels, T) + W.real_g_step_launches(B, args.mels, T)
+        pair_s = 2 * elapsed / args.steps
+        ideal = W.roofline_seconds(launches, HBM_PEAK, F32_PEAK)
+        ideal_pipe = W.roofline_seconds(launches, HBM_PEAK, BF16_PEAK / 6)
+        ideal_hbm = W.roofline_seconds(launches, HBM_PEAK, float("inf"))
+        result["step_roofline"] = {
+            "ideal_ms_per_DG_pair": ideal * 1e3, "measured_ms_per_DG_pair": pair_s * 1e3, "frac": ideal / pair_s,
+            "frac_definition": "sum over the launches of the D+G calls of max(bytes / 8 TB/s, flops / 157.3 TFLOP/s) / measured "
+                               "(featuresynth/_workload.py: real_d_step_launches + real_g_step_launches; weight normalisation not priced)",
+            "ideal_ms_split_bf16_pipe": ideal_pipe * 1e3, "frac_split_bf16_pipe": ideal_pipe / pair_s,
+            "ideal_ms_memory_bound": ideal_hbm * 1e3, "frac_memory_bound": ideal_hbm / pair_s,
+            "algorithmic_gflop_per_DG_pair": W.totals(launches)["flops"] / 1e9,
+            "algorithmic_mb_per_DG_pair": W.totals(launches)["bytes"] / 1e6}
+
     if rank == 0 and not args.no_roofline and not args.no_gforward:
         # BASELINE config 2: generator forward only, B=1, 80-bin mel x 32 frames -> 8192 samples
         feat1 = torch.from_numpy(np.random.default_rng(1).standard_normal((1, args.mels, T)).astype(np.float32)).to(device)

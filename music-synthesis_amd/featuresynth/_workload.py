@@ -174,6 +174,98 @@ def g_step_launches(B, mels=80, T=32):
     return out
 
 
+# ---- the weight-normed MelGAN (experiment/realmelgan.py:15-181): same discriminator geometry, a generator of
+# ResnetBlocks -- shortcut1x1(x) + conv1x1(lrelu(conv_k3_dil(reflpad(lrelu(x))))) -- instead of ResidualAtoms.  Weight
+# normalisation (w = g v / |v| per output channel) is O(parameters) per pass and not priced.
+REAL_UPS = ((512, 256, 16, 8, 4), (256, 128, 16, 8, 4), (128, 64, 4, 2, 1), (64, 32, 4, 2, 1))
+
+
+def _resblock(B, C, L, d, mode, out):
+    sc = dict(B=B, Cin=C, Lin=L, Cout=C, K=1, stride=1, pad=0, dil=1, groups=1)
+    c3 = dict(B=B, Cin=C, Lin=L, Cout=C, K=3, stride=1, pad=d, dil=d, groups=1)
+    if mode in ("fwd", "fwd_train"):
+        out.append(("res%d.shortcut.fwd" % C, conv_cost(which="fwd", **sc)))
+        out.append(("res%d.conv3.fwd" % C, conv_cost(which="fwd", **c3)))
+        out.append(("res%d.conv1.fwd" % C, conv_cost(which="fwd", extra_reads=1, **sc)))
+    else:
+        out.append(("res%d.conv1.bwd_weight" % C, conv_cost(which="bwd_weight", **sc)))
+        out.append(("res%d.conv1.bwd_data" % C, conv_cost(which="bwd_data", **sc)))
+        out.append(("res%d.conv3.bwd_weight" % C, conv_cost(which="bwd_weight", act_read=True, **c3)))
+        out.append(("res%d.conv3.bwd_data" % C, conv_cost(which="bwd_data", act_read=True, **c3)))
+        out.append(("res%d.shortcut.bwd_weight" % C, conv_cost(which="bwd_weight", **sc)))
+        out.append(("res%d.shortcut.bwd_data" % C, conv_cost(which="bwd_data", extra_reads=1, **sc)))
+
+
+def real_generator_launches(B, mels, T, mode):
+    """Generator(mels, 32, 3) of experiment/realmelgan.py; mode as generator_launches."""
+    out = []
+    L = T
+    first = dict(B=B, Cin=mels, Lin=L, Cout=512, K=7, stride=1, pad=3, dil=1, groups=1)
+    stages = []
+    for cin, cout, k, s, p in REAL_UPS:
+        stages.append((cin, cout, k, s, p, L))
+        L = (L - 1) * s - 2 * p + k
+    last = dict(B=B, Cin=32, Lin=L, Cout=1, K=7, stride=1, pad=3, dil=1, groups=1)
+    if mode != "bwd":
+        out.append(("g.first.fwd", conv_cost(which="fwd", **first)))
+        for cin, cout, k, s, p, lin in stages:
+            m = convt_as_conv(B, cin, lin, cout, k, s, p)
+            out.append(("g.convT%d.fwd" % cout, conv_cost(which="bwd_data", **m)))
+            for d in (1, 3, 9):
+                _resblock(B, cout, m["Lin"], d, mode, out)
+        out.append(("g.last.fwd", conv_cost(which="fwd", **last)))
+    else:
+        out.append(("g.last.bwd_weight", conv_cost(which="bwd_weight", act_read=True, **last)))
+        out.append(("g.last.bwd_data", conv_cost(which="bwd_data", act_read=True, **last)))
+        for cin, cout, k, s, p, lin in reversed(stages):
+            m = convt_as_conv(B, cin, lin, cout, k, s, p)
+            for d in (9, 3, 1):
+                _resblock(B, cout, m["Lin"], d, "bwd", out)
+            out.append(("g.convT%d.bwd_weight" % cout, conv_cost(which="bwd_weight", act_read=True, **m)))
+            out.append(("g.convT%d.bwd_data" % cout, conv_cost(which="fwd", extra_reads=1, **m)))
+        out.append(("g.first.bwd_weight", conv_cost(which="bwd_weight", **first)))
+    return out
+
+
+def real_generator_nparam(mels):
+    """weight_v + weight_g + bias of every weight-normed layer."""
+    n = mels * 512 * 7 + 2 * 512
+    for cin, cout, k, s, p in REAL_UPS:
+        n += cin * cout * k + cin + cout                    # ConvTranspose1d: g per INPUT channel (dim 0 of its weight)
+        n += 3 * (cout * cout * 3 + 2 * (cout * cout) + 3 * 2 * cout)
+    return n + 32 * 7 + 2
+
+
+REAL_NPARAM_D = 3 * (5637953 + 16 + 64 + 256 + 1024 + 1024 + 1024 + 1)      # three independent discriminators: the headline D's tensors + one g per output channel
+
+
+def real_d_step_launches(B, mels=128, T=32):
+    L0 = T * 256
+    out = real_generator_launches(B, mels, T, "fwd")
+    for _ in range(2):
+        out += discriminator_launches(B, L0, "fwd")
+    for _ in range(2):
+        out += discriminator_launches(B, L0, "bwd", need_gx=False)
+        out += discriminator_wgrad_launches(B, L0)
+    out.append(("adam.D", {"flops": 12 * REAL_NPARAM_D, "bytes": 7 * F32 * REAL_NPARAM_D}))
+    return out
+
+
+def real_g_step_launches(B, mels=128, T=32):
+    L0 = T * 256
+    out = real_generator_launches(B, mels, T, "fwd_train")
+    out += discriminator_launches(B, L0, "fwd")
+    out += discriminator_launches(B, L0, "fwd")
+    fe = feature_elems(B, L0)
+    out.append(("loss.l1.fwd", {"flops": 3 * fe, "bytes": 2 * F32 * fe}))
+    out.append(("loss.l1.bwd", {"flops": 2 * fe, "bytes": 3 * F32 * fe}))
+    out += discriminator_launches(B, L0, "bwd", need_gx=True, feat_grads=True)
+    out += real_generator_launches(B, mels, T, "bwd")
+    n = real_generator_nparam(mels)
+    out.append(("adam.G", {"flops": 12 * n, "bytes": 7 * F32 * n}))
+    return out
+
+
 # ---- stage 1 (SURVEY.md 8(f) row 2 / BASELINE configs[4]): featuregenerator/upscale.py:85-99, featurediscriminator/upscale.py:7-27
 S1_G = ((1024, 512, 4, 2), (512, 256, 4, 2), (256, 128, 4, 2), (128, 128, 4, 2), (128, 64, 4, 2), (64, 32, 3, 1),
         (32, 1, 3, 1))          # (Cin, Cout, kH, sH) of the ConvTranspose2d stack; kW = 4, sW = 2, padding (1, 1); from 4 x 4

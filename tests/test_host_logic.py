@@ -107,6 +107,30 @@ def test_stage1_workload_spec():
     assert [m.dilation[0] for m in d.stack.main] == list(W.S1_D_DIL)
 
 
+def test_realmelgan_workload_spec():
+    """Layer spec of the weight-normed MelGAN (bench.py --model realmelgan: step_roofline) against the modules: parameter
+    counts, the ResnetBlock's three convs per block, output length."""
+    from featuresynth import _workload as W
+    from featuresynth.experiment import realmelgan as R
+    g, d = R.Generator(128, 32, 3), R.Discriminator(3, 16, 4, 4)
+    assert sum(p.numel() for p in g.parameters()) == W.real_generator_nparam(128)
+    assert sum(p.numel() for p in d.parameters()) == W.REAL_NPARAM_D
+    blocks = [m for m in g.model if isinstance(m, R.ResnetBlock)]
+    assert len(blocks) == 12 and [b.block[2].cfg[2] for b in blocks[:3]] == [1, 3, 9]
+    fwd = W.real_generator_launches(1, 128, 32, "fwd")
+    assert sum(1 for n, _ in fwd if n.startswith("res")) == 36
+    macs = 128 * 512 * 7 * 32
+    L = 32
+    for cin, cout, k, s, p in W.REAL_UPS:
+        macs += L * cin * cout * k              # every input sample meets every tap once
+        L = (L - 1) * s - 2 * p + k
+        macs += 3 * L * cout * cout * (3 + 1 + 1)
+    assert L == 8192
+    macs += L * 32 * 7
+    assert abs(W.totals(fwd)["flops"] / (2 * macs) - 1.0) < 0.01
+    assert W.totals(W.real_d_step_launches(32))["flops"] > 200e9
+
+
 def test_synthetic_inputs_are_deterministic():
     from featuresynth._synthetic import synthetic_features, synthetic_samples, synthetic_state_dict
     a, b = synthetic_samples(2, 64, rank=3), synthetic_samples(2, 64, rank=3)
