@@ -114,6 +114,10 @@ typedef struct ms_wgrad_multi_desc {
      * on block-scaled two-piece fp16 operands (three MFMA products per multiply), without on exact three-piece bf16 (six). */
     const float* xmax[MS_WGRAD_MULTI_MAX];
     const float* gmax[MS_WGRAD_MULTI_MAX];
+    /* optional (all entries or none): SIGN WORDS of the activation in place of y_act (ms_residual_atom_fwd_signs): the
+     * LeakyReLU derivative only needs "y_act > 0".  Only the batched kernels read them: MS_ERR_UNSUPPORTED otherwise (ask
+     * ms_residual_stack_signs_supported first).  y_act[i] is then ignored. */
+    const uint16_t* y_signs[MS_WGRAD_MULTI_MAX];
 } ms_wgrad_multi_desc;
 size_t ms_conv1d_bwd_weight_multi_workspace_bytes(const ms_wgrad_multi_desc* d);
 int ms_conv1d_bwd_weight_multi(const ms_wgrad_multi_desc* d, void* workspace, size_t workspace_bytes,
@@ -171,6 +175,22 @@ int ms_residual_atom_fwd(const ms_atom_desc* d, const float* x, const void* imag
 int ms_residual_atom_bwd_supported(const ms_atom_desc* d);
 int ms_residual_atom_bwd_data(const ms_atom_desc* d, const float* gy, const float* y_act, const float* t,
                               const void* image_bwd, float* gt, float* gx, float* amax, ms_stream_t stream);
+/*
+ * The same pair with SIGN WORDS (r04): the backward pass uses y_act -- and, in its data path, t -- only through
+ * "value > 0" (the LeakyReLU derivatives).  ms_residual_atom_fwd_signs stores t (fp32: the second conv's weight gradient
+ * multiplies by it) and, instead of y_act, one bit per element of y_act and of t:
+ *     signs[((b * (C / 32) + blk) * 2 + h) * L + l],  bit 15 - r  =  value[b, 32 blk + (r & 3) + 8 (r >> 2) + 4 h, l] > 0
+ * (16-bit words; ms_residual_atom_sign_words(d) = B * (C / 32) * 2 * L of them per tensor, 0 = not available: the
+ * three-piece scheme).  Per atom the forward writes 3 1/16 instead of 4 tensors, the backward reads 1 1/16 instead of 3,
+ * ms_conv1d_bwd_weight_multi (y_signs) 4 1/16 instead of 6.  16-byte aligned arrays.
+ * ms_residual_stack_signs_supported: 1 when forward, backward data AND the batched weight gradients of a stack of such
+ * atoms all take sign words (else save the fp32 activations).
+ */
+size_t ms_residual_atom_sign_words(const ms_atom_desc* d);
+int ms_residual_atom_fwd_signs(const ms_atom_desc* d, const float* x, const void* image, const float* b0, const float* b1,
+                               float* y, float* t, uint16_t* t_signs, uint16_t* y_signs, float* amax, ms_stream_t stream);
+int ms_residual_atom_bwd_data_signs(const ms_atom_desc* d, const float* gy, const uint16_t* y_signs, const uint16_t* t_signs,
+                                    const void* image_bwd, float* gt, float* gx, float* amax, ms_stream_t stream);
 
 /*
  * Fused ResidualStack forward, inference (util/modules.py:391-405: `count` ResidualAtoms back to back, the generator's
@@ -187,6 +207,7 @@ typedef struct ms_stack_desc {
     float slope;      /* LeakyReLU negative slope */
 } ms_stack_desc;
 int ms_residual_stack_supported(const ms_stack_desc* d);
+int ms_residual_stack_signs_supported(const ms_stack_desc* d);
 int ms_residual_stack_fwd(const ms_stack_desc* d, const float* x, const void* const* images, const float* const* b0,
                           const float* const* b1, float* y, ms_stream_t stream);
 

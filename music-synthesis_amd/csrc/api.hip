@@ -315,18 +315,42 @@ int ms_conv1d_bwd_weight_multi(const ms_wgrad_multi_desc* d, void* workspace, si
     if (!n) return MS_ERR_INVALID_ARG;
     for (int i = 0; i < n; ++i)
         if (!d->x[i] || !d->gy[i] || !d->gw[i] || (d->beta[i] != 0.f && d->beta[i] != 1.f)) return MS_ERR_INVALID_ARG;
-    int rc = msw_conv1d_bwd_weight_multi(cs, n, d->x, d->gy, d->y_act, d->gw, d->gb, d->beta, d->xmax, d->gmax, workspace,
+    // sign words in place of the activations: all entries or none, and only the two batched kernels read them
+    int nsig = 0;
+    for (int i = 0; i < n; ++i) nsig += d->y_signs[i] ? 1 : 0;
+    if (nsig != 0 && nsig != n) return MS_ERR_INVALID_ARG;
+    const float* ya[MS_WGRAD_MULTI_MAX];
+    for (int i = 0; i < n; ++i) ya[i] = nsig ? reinterpret_cast<const float*>(d->y_signs[i]) : d->y_act[i];
+    int rc = msw_conv1d_bwd_weight_multi(cs, n, d->x, d->gy, ya, d->gw, d->gb, d->beta, d->xmax, d->gmax, nsig ? 1 : 0, workspace,
                                          workspace_bytes, (hipStream_t)stream);
     if (rc != MS_ERR_UNSUPPORTED) return rc;
-    rc = msw32_bwd_weight_multi(cs, n, d->x, d->gy, d->y_act, d->gw, d->gb, d->beta, workspace, workspace_bytes,
+    rc = msw32_bwd_weight_multi(cs, n, d->x, d->gy, ya, d->gw, d->gb, d->beta, nsig ? 1 : 0, workspace, workspace_bytes,
                                 (hipStream_t)stream);
     if (rc != MS_ERR_UNSUPPORTED) return rc;
+    if (nsig) return MS_ERR_UNSUPPORTED;
     for (int i = 0; i < n; ++i) {       // geometry differs / unaligned operands: entry by entry
         const int r1 = ms_conv1d_bwd_weight(&d->conv[i], d->x[i], d->gy[i], d->y_act[i], d->gw[i], d->gb[i],
                                             d->beta[i], workspace, workspace_bytes, stream);
         if (r1 != MS_OK) return r1;
     }
     return MS_OK;
+}
+
+int ms_residual_stack_signs_supported(const ms_stack_desc* d) {
+    const char* sw = getenv("MSYNTH_ATOM_SIGNS");                // tuning / test switch (0: the fp32 activations are saved)
+    if (sw && atoi(sw) == 0) return 0;
+    if (!d || d->count < 1 || d->count > MS_STACK_MAX || 2 * d->count > MS_WGRAD_MULTI_MAX) return 0;
+    ConvP cs[MS_WGRAD_MULTI_MAX];
+    int n = 0;
+    for (int i = 0; i < d->count; ++i) {
+        ms_atom_desc a = {d->B, d->C, d->L, d->dil[i], d->slope};
+        if (!ms_residual_atom_sign_words(&a) || !ms_residual_atom_bwd_supported(&a)) return 0;
+        // the two weight gradients of the atom: the dilation-1 conv (input t, gradient g masked by u) and the dilated one
+        ms_conv1d_desc c1 = {d->B, d->C, d->L, d->C, 3, 1, 1, 1, 1, MS_PAD_ZERO, MS_ACT_LRELU, d->slope, MS_ACT_NONE};
+        ms_conv1d_desc c0 = {d->B, d->C, d->L, d->C, 3, 1, d->dil[i], d->dil[i], 1, MS_PAD_ZERO, MS_ACT_LRELU, d->slope, MS_ACT_NONE};
+        if (!make_conv(&c1, &cs[n++]) || !make_conv(&c0, &cs[n++])) return 0;
+    }
+    return (msw_multi_takes_signs(cs, n) || msw32_multi_takes_signs(cs, n)) ? 1 : 0;
 }
 
 size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which) {

@@ -14,6 +14,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr float WSCALE = 64.f;            // NP = 2: weights are packed as fp16 pieces of 64 w
 

@@ -121,6 +121,14 @@ struct AtomCfg {
 //  issues the next window's HBM loads BEHIND the first GEMM, so that the first wait that covers them sits a t epilogue and a
 //  chunk later; the NP = 3 form keeps r03's placement in front of the first GEMM.)
 // MODE 0: forward, inference (nothing saved);  1: forward, training (also stores t and u);
+// MASK (r04, training forward and backward data): the backward pass uses u and -- in the data path -- t only through their
+//   SIGNS (the LeakyReLU derivatives).  The training forward then stores, instead of the fp32 tensor u, one bit per element
+//   of u and of t: a 16-bit word per (batch row, 32-channel block, lane half h, column) whose bit 15 - r is "value > 0" of
+//   channel 32 blk + (r & 3) + 8 (r >> 2) + 4 h -- exactly the 16 accumulator registers a lane holds for that column, so the
+//   words leave (and, in the backward t epilogue, arrive) as ONE 2-byte access per 32 x 32 accumulator tile; the staging side
+//   of the backward reads four columns' words as one 8-byte vector.  t itself is still stored (the weight gradient of the
+//   second conv multiplies by it).  Per atom the forward writes 3 + 1/16 instead of 4 tensors, the backward reads 1 + 1/16
+//   instead of 3 (and the weight gradients, wgrad_rows.hip, 4 + 1/16 instead of 6).
 // MODE 2: BACKWARD DATA of the atom.  With g = dL/dy:   gt = conv1^T(g * lrelu'(u)),   gx = g + conv_d^T(gt * lrelu'(t)).
 //   Same two-GEMM structure with the roles mirrored: X = g, the window is multiplied by the LeakyReLU derivative taken from
 //   u (U, read) on its way into LDS; GEMM 0 is the dilation-1 conv transposed (halo 1), its raw result gt is stored (T: the
@@ -133,12 +141,14 @@ struct AtomCfg {
 // equal column counts (-4 % at 128 channels, +8 % at 64 where the second GEMM body spills); a start stagger of the second
 // resident workgroup and s_setprio around the GEMMs (0 to +5 % slower); y / u / residual as 16-byte row-major vectors through a
 // per-wave LDS transpose (a quarter of the epilogue's vector-memory instructions: no change of the train step, +-1 %).
-template <int C, int NTP, int NW, int MODE, int NP>
+template <int C, int NTP, int NW, int MODE, int NP, bool MASK = false>
 __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* __restrict__ X, const u32x4* __restrict__ IMG,
                                                  const float* __restrict__ b0, const float* __restrict__ b1,
                                                  float* __restrict__ Y, float* __restrict__ T, float* __restrict__ U,
                                                  const float* __restrict__ Tm, float* __restrict__ AM) {
+    // (MASK: U is the sign-word array of u, Tm that of t -- written by MODE 1, read by MODE 2)
     constexpr bool SAVE = MODE == 1, BWD = MODE == 2;
+    static_assert(!MASK || (MODE != 0 && NP == 2), "sign words: training forward / backward data of the two-piece scheme");
     typedef AtomCfg<C, NTP, NW> Cfg;
     constexpr int TM = Cfg::TM, WGN = Cfg::WGN, TN = Cfg::TN, NC = Cfg::NC, ROUNDS = Cfg::ROUNDS, NT = Cfg::NT;
     constexpr int XRS = xrs<NP>();
@@ -170,11 +180,17 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
     const auto rsT = __builtin_amdgcn_make_buffer_rsrc(MODE ? T - h2 : Y, 0, 0x80000000u, 0x00020000);
     const auto rsU = __builtin_amdgcn_make_buffer_rsrc(MODE ? U : Y, 0, 0x80000000u, 0x00020000);
     const auto rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BWD ? Tm - h2 : X), 0, 0x80000000u, 0x00020000);
+    // sign words (MASK): [b][C / 32][h][column] of 16 bits; the array addressed by t-tile columns starts h2 words early, as rsT
+    typedef unsigned short u16;
+    const auto rsSU = __builtin_amdgcn_make_buffer_rsrc(MASK ? reinterpret_cast<u16*>(U) : reinterpret_cast<u16*>(Y), 0, 0x80000000u, 0x00020000);
+    const auto rsST = __builtin_amdgcn_make_buffer_rsrc(
+        MASK ? reinterpret_cast<u16*>(const_cast<float*>(Tm)) - h2 : reinterpret_cast<u16*>(Y), 0, 0x80000000u, 0x00020000);
 
     // ---- tile-invariant staging units.  Unit = 4 channels x one aligned 4-sample vector; 16 consecutive lanes = 4
     // channel quads x 4 consecutive vectors (their 8-byte LDS stores fall into 16 different bank pairs).
     const int NV = (NX + sh + 3) >> 2, NV16 = (NV + 3) >> 2;
     int u_goff[ROUNDS], u_t[ROUNDS], u_lcol[ROUNDS], u_lbase[ROUNDS];
+    int u_moff[MASK && BWD ? ROUNDS : 1], u_msh[MASK && BWD ? ROUNDS : 1];   // sign words of the unit's 4 channels x 4 columns
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const int u = tid + NT * r;
@@ -185,6 +201,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
         u_goff[r] = 4 * ((chunk * 16 + 4 * cq) * L + (4 * v - sh - 1 - d));   // byte offset relative to the tile base
         u_lcol[r] = in ? 4 * v - sh : -1000;
         u_lbase[r] = chunk * XCS + cq * 8;
+        if constexpr (MASK && BWD) {
+            // channels chunk * 16 + 4 cq + 0..3: block chunk >> 1, half cq & 1, registers r0 .. r0 + 3 with r0 = 4 (2 (chunk & 1) + (cq >> 1))
+            u_moff[r] = 2 * ((((chunk >> 1) * 2 + (cq & 1)) * L) + (4 * v - sh - 1 - d));
+            u_msh[r] = 15 - 4 * (2 * (chunk & 1) + (cq >> 1));     // bit of channel + 0; channel + cc: one lower each
+        }
     }
     f32x4 rx[ROUNDS][4];
     auto load_x = [&](int tile) {
@@ -202,11 +223,21 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
     };
     // backward: the window of u (this tile; not prefetched: it would double the registers held across the GEMMs) gives
     // the LeakyReLU derivative the gradient window is multiplied by
-    f32x4 ru[BWD ? ROUNDS : 1][4];
+    f32x4 ru[BWD && !MASK ? ROUNDS : 1][4];
+    u32x2 rum[BWD && MASK ? ROUNDS : 1];             // (MASK) four columns' sign words of the unit
     auto load_u = [&](int bb, int cc0) {
         const int base = 4 * bb * C * L;
+        if constexpr (MASK) {
 #pragma unroll
-        for (int r = 0; r < (BWD ? ROUNDS : 0); ++r) {
+            for (int r = 0; r < (BWD ? ROUNDS : 0); ++r) {
+                const int t = cc0 + u_t[r];
+                const unsigned moff = (t >= 0 && t < L) ? (unsigned)(u_moff[r] + 2 * cc0) : OOB;
+                rum[r] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsSU, moff, 2 * bb * (C / 32) * 2 * L, 0));
+            }
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < (BWD && !MASK ? ROUNDS : 0); ++r) {
             const int t = cc0 + u_t[r];
             const unsigned goff = (t >= 0 && t < L) ? (unsigned)(u_goff[r] + 4 * cc0) : OOB;
 #pragma unroll
@@ -245,7 +276,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                 const int i = u_lcol[r] + e;
                 if (i < 0 || i >= NXA) continue;
                 float c4[4] = {rx[r][0][e], rx[r][1][e], rx[r][2][e], rx[r][3][e]};
-                if (BWD) {
+                if constexpr (BWD && MASK) {
+                    const unsigned pair = (e >> 1) ? rum[r].y : rum[r].x;
+                    const unsigned wd = (e & 1) ? pair >> 16 : pair;           // column e's word (bits above 15: ignored)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) c4[cc] = ((wd >> (u_msh[r] - cc)) & 1u) ? c4[cc] : c4[cc] * p.slope;
+                } else if constexpr (BWD) {
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) c4[cc] = ru[r][cc][e] > 0.f ? c4[cc] : c4[cc] * p.slope;
                 }
@@ -353,6 +389,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
     int o_lane[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) o_lane[j] = 4 * ((wn * TN + j) * 32 + l31 + 4 * h * L);
+    int o_word[MASK ? TN : 1];                       // ... and of a sign-word offset: column, lane half
+    if constexpr (MASK) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) o_word[j] = 2 * ((wn * TN + j) * 32 + l31 + h * L);
+    }
 
     int tile = blockIdx.x;
     if (tile < ntiles) load_x(tile);
@@ -379,7 +420,19 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
         if (BWD) load_u(b, c0);
         int L4;                                                      // 4 L, opaque to the optimiser: the per-channel scalar offsets
         asm volatile("s_mov_b32 %0, %1" : "=s"(L4) : "s"(4 * L));    // are then formed where they are used (2 scalar ops), not hoisted
-        constexpr bool PRE_T = BWD && C == 64;          // (C = 32: measured slower with the derivative operand hoisted)
+        const int wbase = 2 * (b * (C / 32) * 2 * L + c0);           // (MASK) byte offset of (row b, block 0, half 0, column c0)
+        unsigned tmw[MASK && BWD ? TM : 1][MASK && BWD ? TN : 1];    // (MASK) t's sign words of this lane's columns
+        if constexpr (MASK && BWD) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int gc = c0 - h2 + wcol + j * 32 + l31;
+                    const unsigned o_w = (gc >= 0 && gc < L) ? (unsigned)o_word[j] : OOB;
+                    tmw[i][j] = __builtin_amdgcn_raw_buffer_load_b16(rsST, o_w, wbase + (wm * TM + i) * 4 * L, 0);
+                }
+        }
+        constexpr bool PRE_T = BWD && C == 64 && !MASK;  // (C = 32: measured slower with the derivative operand hoisted)
         float tmp[PRE_T ? TM : 1][PRE_T ? TN : 1][16];
         if (PRE_T) {
 #pragma unroll
@@ -422,8 +475,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                 const bool inrow = gc >= 0 && gc < L;                // outside the row t is the second conv's ZERO padding
                 // the tile's own columns of t are stored (forward training: the saved activation; backward: the raw gt)
                 const unsigned o_t = (MODE != 0 && inrow && col >= h2 && col < h2 + no) ? (unsigned)o_lane[j] : OOB;
-                float tm[BWD ? 16 : 1];                              // backward: t itself, for the derivative
-                if (PRE_T) {
+                float tm[BWD && !MASK ? 16 : 1];                     // backward: t itself, for the derivative
+                unsigned sw = 0;                                     // (MASK, forward) sign word of this tile of t
+                if constexpr (MASK && BWD) {
+                } else if (PRE_T) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) tm[r] = tmp[i][j][r];
                 } else if (BWD) {
@@ -459,9 +514,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                         for (int q = 0; q < 4; ++q)
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e[q]), rsT, o_t, base + (chs + q) * L4, 0);
                     }
+                    if constexpr (MASK && SAVE) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) sw = (sw << 1) | (e[q] > 0.f ? 1u : 0u);
+                    }
                     if (BWD) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) e[q] = inrow ? (tm[4 * g + q] > 0.f ? e[q] : e[q] * p.slope) : 0.f;
+                        for (int q = 0; q < 4; ++q) {
+                            bool pos;
+                            if constexpr (MASK) pos = ((tmw[i][j] >> (15 - (4 * g + q))) & 1u) != 0;
+                            else pos = tm[4 * g + q] > 0.f;
+                            e[q] = inrow ? (pos ? e[q] : e[q] * p.slope) : 0.f;
+                        }
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -469,6 +533,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                         if (SC) tmax = fmaxf(tmax, fabsf(e[q]));
                     }
                 }
+                if constexpr (MASK && SAVE)
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)sw, rsST, o_t == OOB ? OOB : (unsigned)o_word[j],
+                                                          wbase + (wm * TM + i) * 4 * L, 0);
             }
         if (SC) {
             tmax = wave_max(tmax);
@@ -528,6 +595,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const unsigned oy = o_y[j];
+                unsigned su = 0;                                     // (MASK) sign word of this tile of u
                 float xr[16];
                 if (PRE) {
 #pragma unroll
@@ -549,11 +617,15 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                         if (SC) v *= k2;
                         v += bv[q];
                         if (!BWD) v = v > 0.f ? v : v * p.slope;
-                        if (SAVE) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsU, oy, base + (chs + q) * L4, 0);
+                        if constexpr (SAVE && MASK) su = (su << 1) | (v > 0.f ? 1u : 0u);
+                        else if (SAVE) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsU, oy, base + (chs + q) * L4, 0);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + xr[4 * g + q]), rsY, oy,
                                                               base + (chs + q) * L4, 0);
                     }
                 }
+                if constexpr (MASK && SAVE)
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)su, rsSU, oy == OOB ? OOB : (unsigned)o_word[j],
+                                                          wbase + (wm * TM + i) * 4 * L, 0);
             }
         if (SC && nxt < ntiles) publish_window_max();               // (waits for the next tile's window: issued a GEMM ago)
         __syncthreads();                                             // the t tile is dead: the next window may overwrite it
@@ -579,7 +651,7 @@ int atom_np() {
 
 constexpr int MAX_DEV = 64;            // per-device launch parameters (ms_common.h: one-time launch setup)
 
-template <int C, int NTP, int NW, int MODE, int NP>
+template <int C, int NTP, int NW, int MODE, int NP, bool MASK = false>
 int launch_atom_np(AtomP p, const float* x, const void* image, const float* b0, const float* b1, float* y, float* t,
                    float* u, const float* tm, float* am, hipStream_t s) {
     p.NO = MODE == 2 ? ((NTP - 2 * p.dil) & ~3) : NTP - 4;
@@ -587,7 +659,7 @@ int launch_atom_np(AtomP p, const float* x, const void* image, const float* b0, 
     p.tiles_per_row = (p.L + p.NO - 1) / p.NO;
     const size_t lds = (size_t)(C / 16) * (NTP + 22) * xrs<NP>() + (2 * C + 2 * NW) * sizeof(float);       // window + biases + scale exchange
     if (lds > 158 * 1024) return MS_ERR_UNSUPPORTED;
-    const void* fn = reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, NW, MODE, NP>);
+    const void* fn = reinterpret_cast<const void*>(&k_atom_fwd<C, NTP, NW, MODE, NP, MASK>);
     static int wgs_per_cu[MAX_DEV] = {}, n_cu[MAX_DEV] = {};
     const int dev = ms_current_device();
     if (!__atomic_load_n(&wgs_per_cu[dev], __ATOMIC_ACQUIRE)) {      // (idempotent: racing first calls compute the same values)
@@ -602,27 +674,33 @@ int launch_atom_np(AtomP p, const float* x, const void* image, const float* b0, 
     const long long slots = (long long)n_cu[dev] * wgs_per_cu[dev];
     const long long ntiles = (long long)p.B * p.tiles_per_row;
     const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
-    ms_note_kernel("k_atom_fwd<%d, %d, %d, %d, %d>", C, NTP, NW, MODE, NP);
+    ms_note_kernel("k_atom_fwd<%d, %d, %d, %d, %d, %s>", C, NTP, NW, MODE, NP, MASK ? "true" : "false");
     if (grid.x > MS_ATOM_AMAX_N) am = nullptr;          // (cannot happen: at most 4 workgroups on each of 256 CUs)
-    hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, MODE, NP>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u, tm, am);
+    hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, MODE, NP, MASK>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u, tm, am);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }
 
 template <int C, int NTP, int NW, int MODE>
-int launch_atom_mode(const AtomP& p, const float* x, const void* image, const float* b0, const float* b1, float* y, float* t,
+int launch_atom_mode(bool mask, const AtomP& p, const float* x, const void* image, const float* b0, const float* b1, float* y, float* t,
                      float* u, const float* tm, float* am, hipStream_t s) {
-    if (atom_np() == 3) return launch_atom_np<C, NTP, NW, MODE, 3>(p, x, image, b0, b1, y, t, u, tm, nullptr, s);
+    if (atom_np() == 3) return mask ? MS_ERR_UNSUPPORTED : launch_atom_np<C, NTP, NW, MODE, 3>(p, x, image, b0, b1, y, t, u, tm, nullptr, s);
+    if constexpr (MODE != 0) {
+        if (mask) return launch_atom_np<C, NTP, NW, MODE, 2, true>(p, x, image, b0, b1, y, t, u, tm, am, s);
+    }
     return launch_atom_np<C, NTP, NW, MODE, 2>(p, x, image, b0, b1, y, t, u, tm, am, s);
 }
 
 // mode 0 / 1: forward (t, u: the saved activations, both or neither);  mode 2: backward data (x = g, u and tm read, t = gt out)
+// mode & 4: sign words instead of the fp32 tensors u (and, backward, t) -- MASK
 template <int C, int NTP, int NW>
 int launch_atom(int mode, const AtomP& p, const float* x, const void* image, const float* b0, const float* b1, float* y,
                 float* t, float* u, const float* tm, float* am, hipStream_t s) {
-    if (mode == 2) return launch_atom_mode<C, NTP, NW, 2>(p, x, image, b0, b1, y, t, u, tm, am, s);
-    if (mode == 1) return launch_atom_mode<C, NTP, NW, 1>(p, x, image, b0, b1, y, t, u, tm, am, s);
-    return launch_atom_mode<C, NTP, NW, 0>(p, x, image, b0, b1, y, t, u, tm, am, s);
+    const bool mask = (mode & 4) != 0;
+    mode &= 3;
+    if (mode == 2) return launch_atom_mode<C, NTP, NW, 2>(mask, p, x, image, b0, b1, y, t, u, tm, am, s);
+    if (mode == 1) return launch_atom_mode<C, NTP, NW, 1>(mask, p, x, image, b0, b1, y, t, u, tm, am, s);
+    return launch_atom_mode<C, NTP, NW, 0>(false, p, x, image, b0, b1, y, t, u, tm, am, s);
 }
 
 int dispatch_atom(int mode, const ms_atom_desc* d, const float* x, const void* image, const float* b0, const float* b1,
@@ -638,10 +716,10 @@ int dispatch_atom(int mode, const ms_atom_desc* d, const float* x, const void* i
             if (cols < 124 * 128) return launch_atom<64, 64, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
             return launch_atom<64, 128, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
         case 128:
-            if (cols < 60 * 128 && mode != 2) return launch_atom<128, 32, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
+            if (cols < 60 * 128 && (mode & 3) != 2) return launch_atom<128, 32, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
             return launch_atom<128, 64, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
         case 256:
-            if (cols < 60 * 64 && mode != 2) return launch_atom<256, 32, 8>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
+            if (cols < 60 * 64 && (mode & 3) != 2) return launch_atom<256, 32, 8>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
             return launch_atom<256, 64, 8>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
         default: return MS_ERR_UNSUPPORTED;
     }
@@ -702,6 +780,33 @@ int ms_residual_atom_fwd(const ms_atom_desc* d, const float* x, const void* imag
     if (!x || !image || !b0 || !b1 || !y || ((t == nullptr) != (y_act == nullptr))) return MS_ERR_INVALID_ARG;
     if ((((uintptr_t)image) & 15) || (((uintptr_t)b0) & 15) || (((uintptr_t)b1) & 15)) return MS_ERR_INVALID_ARG;
     return dispatch_atom(t ? 1 : 0, d, x, image, b0, b1, y, t, y_act, nullptr, amax, (hipStream_t)stream);
+}
+
+size_t ms_residual_atom_sign_words(const ms_atom_desc* d) {
+    if (!atom_ok(d) || atom_np() != 2) return 0;
+    return (size_t)d->B * (d->C / 32) * 2 * d->L;
+}
+
+int ms_residual_atom_fwd_signs(const ms_atom_desc* d, const float* x, const void* image, const float* b0, const float* b1,
+                               float* y, float* t, uint16_t* t_signs, uint16_t* y_signs, float* amax, ms_stream_t stream) {
+    if (!ms_residual_atom_sign_words(d)) return d ? MS_ERR_UNSUPPORTED : MS_ERR_INVALID_ARG;
+    if (!x || !image || !b0 || !b1 || !y || !t || !t_signs || !y_signs) return MS_ERR_INVALID_ARG;
+    if ((((uintptr_t)image) & 15) || (((uintptr_t)b0) & 15) || (((uintptr_t)b1) & 15) || (((uintptr_t)t_signs) & 15) ||
+        (((uintptr_t)y_signs) & 15))
+        return MS_ERR_INVALID_ARG;
+    return dispatch_atom(1 | 4, d, x, image, b0, b1, y, t, reinterpret_cast<float*>(y_signs), reinterpret_cast<const float*>(t_signs),
+                         amax, (hipStream_t)stream);
+}
+
+int ms_residual_atom_bwd_data_signs(const ms_atom_desc* d, const float* gy, const uint16_t* y_signs, const uint16_t* t_signs,
+                                    const void* image_bwd, float* gt, float* gx, float* amax, ms_stream_t stream) {
+    if (!ms_residual_atom_sign_words(d) || !ms_residual_atom_bwd_supported(d)) return d ? MS_ERR_UNSUPPORTED : MS_ERR_INVALID_ARG;
+    if (!gy || !y_signs || !t_signs || !image_bwd || !gt || !gx || (((uintptr_t)image_bwd) & 15) ||
+        (((uintptr_t)t_signs) & 15) || (((uintptr_t)y_signs) & 15))
+        return MS_ERR_INVALID_ARG;
+    return dispatch_atom(2 | 4, d, gy, image_bwd, nullptr, nullptr, gx, gt,
+                         reinterpret_cast<float*>(const_cast<uint16_t*>(y_signs)), reinterpret_cast<const float*>(t_signs), amax,
+                         (hipStream_t)stream);
 }
 
 int ms_residual_atom_bwd_supported(const ms_atom_desc* d) {

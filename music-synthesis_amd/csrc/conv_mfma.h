@@ -69,14 +69,17 @@ int mswt2s_bwd_weight(const ConvP& p, const float* x, const float* gy, const flo
 bool msw_bwd_weight_applicable(const ConvP& p);
 size_t msw_bwd_weight_ws(const ConvP& p);
 size_t msw32_multi_ws(const ConvP* cs, int n);
+// signs: y_act[] are SIGN WORDS of the activations (atom_fused.hip, MASK), not the fp32 tensors
 int msw32_bwd_weight_multi(const ConvP* cs, int n, const float* const* x, const float* const* gy,
-                           const float* const* y_act, float* const* gw, float* const* gb, const float* beta,
+                           const float* const* y_act, float* const* gw, float* const* gb, const float* beta, int signs,
                            void* ws, size_t ws_bytes, hipStream_t s);
+bool msw32_multi_takes_signs(const ConvP* cs, int n);
+bool msw_multi_takes_signs(const ConvP* cs, int n);
 // n weight gradients of identical geometry in one launch (0 / UNSUPPORTED: the caller loops over single calls)
 size_t msw_multi_ws(const ConvP* cs, int n);
 int msw_conv1d_bwd_weight_multi(const ConvP* cs, int n, const float* const* x, const float* const* gy,
                                 const float* const* y_act, float* const* gw, float* const* gb,
-                                const float* beta, const float* const* xmax, const float* const* gmax, void* ws,
+                                const float* beta, const float* const* xmax, const float* const* gmax, int signs, void* ws,
                                 size_t ws_bytes, hipStream_t s);
 const char* msw_bwd_weight_name(const ConvP& p);
 int msw_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act,

@@ -47,6 +47,7 @@ struct WrMulti {
     const float* gact[WR_MULTI_MAX];
     int dil[WR_MULTI_MAX], pad[WR_MULTI_MAX];
     const float* xmax[WR_MULTI_MAX];    // per problem: MS_ATOM_AMAX_N bounds of |x| / |g| (nullptr: none) -- k_wgrad_rows3<., 2>
+    int signs;                          // gact[] hold SIGN WORDS of the activations (atom_fused.hip, MASK), not the fp32 tensors
     const float* gmax[WR_MULTI_MAX];
 };
 
@@ -492,7 +493,10 @@ constexpr size_t w3_lds_bytes(int BM) {
     return kloop > merge ? kloop : merge;
 }
 
-template <int TM, int NP>
+// GM: the activation whose derivative multiplies the gradient arrives as sign words -- one 16-bit word per (batch row,
+// 32-channel block, lane half, column), bit 15 - r = "positive" of channel 32 blk + (r & 3) + 8 (r >> 2) + 4 h
+// (atom_fused.hip, MASK): a thread's four columns are ONE 8-byte load where the fp32 tensor cost 16 bytes per column quad x 4.
+template <int TM, int NP, bool GM = false>
 __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restrict__ X_,
                                                     const float* __restrict__ G_,
                                                     const float* __restrict__ Gact_,
@@ -572,7 +576,10 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
     // vector gt & 15 of the 64-sample window that starts PADA samples in front of the tile)
     const int g_row = gt >> 3, g_t = 4 * (gt & 7);
     const int x_row = gt >> 4, x_u = 4 * (gt & 15);
-    w3_f32x4 gv[NGU], ga[NGU], xv[4];
+    w3_f32x4 gv[NGU], ga[GM ? 1 : NGU], xv[4];
+    uint2 gm[GM ? NGU : 1];                          // (GM) sign words of the vector's four columns
+    // (GM) row g_row of every 32-row block: lane half (g_row >> 2) & 1, register (g_row & 3) + 4 (g_row >> 3)
+    const int gm_h = (g_row >> 2) & 1, gm_sh = 15 - ((g_row & 3) + 4 * (g_row >> 3));
     float bs[NGU];
 #pragma unroll
     for (int q = 0; q < NGU; ++q) bs[q] = 0.f;
@@ -584,10 +591,12 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
         const int tg = t0 + g_t, tx = t0 - PADA + x_u;        // multiples of 4: a vector is all in or all out
         const unsigned go = (live && tg < p.L) ? 4u * (unsigned)((b * p.M + m0 + g_row) * p.L + tg) : OOB;
         const unsigned xo = (live && tx >= 0 && tx < p.L) ? 4u * (unsigned)((b * p.CK + c0 + x_row) * p.L + tx) : OOB;
+        const unsigned mo = (live && tg < p.L) ? 2u * (unsigned)(((b * (p.M / 32) + m0 / 32) * 2 + gm_h) * p.L + tg) : OOB;
 #pragma unroll
         for (int q = 0; q < NGU; ++q) {
             gv[q] = __builtin_bit_cast(w3_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, go, q * 32 * 4 * p.L, 0));
-            ga[q] = __builtin_bit_cast(w3_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsGa, go, q * 32 * 4 * p.L, 0));
+            if constexpr (GM) gm[q] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsGa, mo, q * 4 * p.L, 0));
+            else ga[q] = __builtin_bit_cast(w3_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsGa, go, q * 32 * 4 * p.L, 0));
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -598,7 +607,16 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
         for (int q = 0; q < NGU; ++q) {
             float e[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) e[i] = ga[q][i] > 0.f ? gv[q][i] : gv[q][i] * p.slope;
+            for (int i = 0; i < 4; ++i) {
+                bool pos;
+                if constexpr (GM) {
+                    const unsigned pair = (i >> 1) ? gm[q].y : gm[q].x;
+                    pos = ((((i & 1) ? pair >> 16 : pair) >> gm_sh) & 1u) != 0;
+                } else {
+                    pos = ga[q][i] > 0.f;
+                }
+                e[i] = pos ? gv[q][i] : gv[q][i] * p.slope;
+            }
             bs[q] += (e[0] + e[1]) + (e[2] + e[3]);
             if (SC) {
 #pragma unroll
@@ -888,12 +906,12 @@ bool wrows3_ok(const WrPlan& q, int K, int TM, bool vec, bool has_yact) {
 // of a 512-thread workgroup may hold (96 accumulators + fragments + the chunk in flight) and spills.  The plan's grid /
 // batching descriptor are re-derived for 64-row tiles; the slab layout does not depend on it.
 // NP = 2 (every problem of a batched launch carries bounds of both operands): block-scaled fp16 x 2, three products.
-template <int TM, int NP>
+template <int TM, int NP, bool GM = false>
 void launch_wrows3_np(const WrPlan& q, const float* x, const float* gy, const float* y_act, float* partial, hipStream_t s) {
     const size_t lds = w3_lds_bytes<NP>(64 * TM);
     static unsigned long long attr_set = 0;
     if (ms_first_on_device(attr_set)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_rows3<TM, NP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_rows3<TM, NP, GM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         ms_done_on_device(attr_set);
     }
@@ -901,8 +919,8 @@ void launch_wrows3_np(const WrPlan& q, const float* x, const float* gy, const fl
     const int tiles_m = q.p.M / (64 * TM);
     if (mp.n > 0) mp.tiles_m = tiles_m;
     const dim3 grid(q.grid.x, (unsigned)((mp.n > 0 ? mp.n : 1) * tiles_m), q.grid.z);
-    ms_note_kernel("k_wgrad_rows3<%d, %d>", TM, NP);
-    hipLaunchKernelGGL((k_wgrad_rows3<TM, NP>), grid, dim3(512), lds, s, q.p, x, gy, y_act, partial, q.stride_floats, mp);
+    ms_note_kernel("k_wgrad_rows3<%d, %d, %s>", TM, NP, GM ? "true" : "false");
+    hipLaunchKernelGGL((k_wgrad_rows3<TM, NP, GM>), grid, dim3(512), lds, s, q.p, x, gy, y_act, partial, q.stride_floats, mp);
 }
 
 bool wrows3_scaled(const WrPlan& q) {
@@ -914,6 +932,10 @@ bool wrows3_scaled(const WrPlan& q) {
 }
 
 void launch_wrows3(const WrPlan& q, const float* x, const float* gy, const float* y_act, float* partial, hipStream_t s) {
+    if (q.mp.n > 0 && q.mp.signs) {                  // (sign words only travel with the two-piece scheme: checked by the caller)
+        launch_wrows3_np<1, 2, true>(q, x, gy, y_act, partial, s);
+        return;
+    }
     if (wrows3_scaled(q)) launch_wrows3_np<1, 2>(q, x, gy, y_act, partial, s);
     else launch_wrows3_np<1, 3>(q, x, gy, y_act, partial, s);
 }
@@ -1195,12 +1217,27 @@ size_t msw_multi_ws(const ConvP* cs, int n) {
     return q.ok ? (size_t)q.nsplit * q.stride_floats * sizeof(float) : 0;
 }
 
+// does the batched split kernel take these convs with SIGN WORDS in place of the activations (k_wgrad_rows3<., 2, true>)?
+bool msw_multi_takes_signs(const ConvP* cs, int n) {
+    if (msw_multi_ws(cs, n) == 0) return false;
+    static const int sw = getenv("MSYNTH_WROWS3_NP") ? atoi(getenv("MSYNTH_WROWS3_NP")) : 2;
+    if (sw == 3) return false;
+    const WrPlan q = plan_wrows_multi(cs, n);
+    return q.ok && wrows3_ok(q, 3, q.tm, true, true);
+}
+
 int msw_conv1d_bwd_weight_multi(const ConvP* cs, int n, const float* const* x, const float* const* gy,
                                 const float* const* y_act, float* const* gw, float* const* gb,
-                                const float* beta, const float* const* xmax, const float* const* gmax, void* ws,
+                                const float* beta, const float* const* xmax, const float* const* gmax, int signs, void* ws,
                                 size_t ws_bytes, hipStream_t s) {
     if (msw_multi_ws(cs, n) == 0) return MS_ERR_UNSUPPORTED;
+    if (signs) {
+        if (!msw_multi_takes_signs(cs, n) || !xmax || !gmax) return MS_ERR_UNSUPPORTED;
+        for (int i = 0; i < n; ++i)
+            if (!xmax[i] || !gmax[i]) return MS_ERR_UNSUPPORTED;
+    }
     WrPlan q = plan_wrows_multi(cs, n);
+    q.mp.signs = signs ? 1 : 0;
     if (!ws || ws_bytes < (size_t)q.nsplit * q.stride_floats * sizeof(float) || (((uintptr_t)ws) & 15)) return MS_ERR_UNSUPPORTED;
     WrReduceMulti o;
     for (int i = 0; i < n; ++i) {
@@ -1249,7 +1286,8 @@ struct W32Multi {
     int dil[WR_MULTI_MAX], pad[WR_MULTI_MAX];
 };
 
-template <int AK>   // 1: LeakyReLU derivative on the gradient (y_act given); 0: plain gradient
+// AK: 1: LeakyReLU derivative on the gradient (y_act given); 0: plain gradient.  GM: y_act arrives as sign words (k_wgrad_rows3)
+template <int AK, bool GM = false>
 __global__ __launch_bounds__(256, 2) void k_wgrad32(W32P p, const float* __restrict__ X_,
                                                    const float* __restrict__ G_,
                                                    const float* __restrict__ Gact_,
@@ -1301,18 +1339,22 @@ __global__ __launch_bounds__(256, 2) void k_wgrad32(W32P p, const float* __restr
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     float asum = 0.f;
 
-    float4 gv[NGQ], ga[AK ? NGQ : 1], xv[NXQ];
+    float4 gv[NGQ], ga[AK && !GM ? NGQ : 1], xv[NXQ];
+    uint2 gs[GM ? NGQ : 1];                           // (GM) sign words of the piece's four columns
     auto gload = [&](int b, int ti) {
         const int t0 = ti * 64;
         const float* gb = G + (size_t)b * 32 * p.L + t0;
         const float* ab = Gact + (size_t)b * 32 * p.L + t0;
+        const unsigned short* sb = reinterpret_cast<const unsigned short*>(Gact) + (size_t)b * 2 * p.L + t0;
         const float* xb = X + (size_t)b * 32 * p.L + t0;
 #pragma unroll
         for (int q = 0; q < NGQ; ++q) {
             const bool ok = t0 + 4 * ((lane + 64 * q) & 15) < p.L;       // L % 4 == 0: all in or all out
             const int o = ok ? g_off[q] : 0;
             gv[q] = *reinterpret_cast<const float4*>(gb + o);
-            if (AK) ga[q] = *reinterpret_cast<const float4*>(ab + o);
+            // (GM) row (lane >> 4) + 4 q: lane half q & 1, register (lane >> 4) + 4 (q >> 1)
+            if constexpr (GM) gs[q] = *reinterpret_cast<const uint2*>(sb + (ok ? (q & 1) * p.L + 4 * ((lane + 64 * q) & 15) : 0));
+            else if (AK) ga[q] = *reinterpret_cast<const float4*>(ab + o);
         }
 #pragma unroll
         for (int q = 0; q < NXQ; ++q) {
@@ -1335,7 +1377,12 @@ __global__ __launch_bounds__(256, 2) void k_wgrad32(W32P p, const float* __restr
         for (int q = 0; q < NGQ; ++q) {
             const bool ok = t0 + 4 * ((lane + 64 * q) & 15) < p.L;
             float e[4] = {gv[q].x, gv[q].y, gv[q].z, gv[q].w};
-            if (AK) {
+            if constexpr (GM) {
+                const int shf = 15 - ((lane >> 4) + 4 * (q >> 1));
+                const unsigned w4[4] = {gs[q].x, gs[q].x >> 16, gs[q].y, gs[q].y >> 16};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = ((w4[i] >> shf) & 1u) ? e[i] : e[i] * p.slope;
+            } else if (AK) {
                 const float a[4] = {ga[q].x, ga[q].y, ga[q].z, ga[q].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) e[i] = a[i] > 0.f ? e[i] : e[i] * p.slope;
@@ -1457,8 +1504,10 @@ size_t msw32_multi_ws(const ConvP* cs, int n) {
     return (size_t)n * (512 / n) * (32 * 32 * 3 + 32) * sizeof(float);
 }
 
+bool msw32_multi_takes_signs(const ConvP* cs, int n) { return w32_multi_ok(cs, n); }
+
 int msw32_bwd_weight_multi(const ConvP* cs, int n, const float* const* x, const float* const* gy,
-                           const float* const* y_act, float* const* gw, float* const* gb, const float* beta,
+                           const float* const* y_act, float* const* gw, float* const* gb, const float* beta, int signs,
                            void* ws, size_t ws_bytes, hipStream_t s) {
     if (!w32_multi_ok(cs, n)) return MS_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < msw32_multi_ws(cs, n) || (((uintptr_t)ws) & 15)) return MS_ERR_UNSUPPORTED;
@@ -1488,9 +1537,11 @@ int msw32_bwd_weight_multi(const ConvP* cs, int n, const float* const* x, const 
     static unsigned long long attr_set = 0;
     if (ms_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad32<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
         ms_done_on_device(attr_set);
     }
-    hipLaunchKernelGGL(k_wgrad32<1>, dim3(n * g_per), dim3(256), lds, s, p, x[0], gy[0], y_act[0], partial, stride, mp);
+    if (signs) hipLaunchKernelGGL((k_wgrad32<1, true>), dim3(n * g_per), dim3(256), lds, s, p, x[0], gy[0], y_act[0], partial, stride, mp);
+    else hipLaunchKernelGGL(k_wgrad32<1>, dim3(n * g_per), dim3(256), lds, s, p, x[0], gy[0], y_act[0], partial, stride, mp);
     MS_CHECK_LAUNCH();
     // slabs of problem i: workgroups [i*g_per, (i+1)*g_per) -> slice stride = one slab, problem stride = g_per slabs
     const size_t wsize = 32 * 32 * 3, total = wsize + 32;

@@ -101,13 +101,15 @@ def atom_fused_ok(x_shape, w0, b0, b1, dil):
             b0.data_ptr() % 16 == 0 and b1.data_ptr() % 16 == 0 and P.atom_supported(B, C, Lg, dil))
 
 
-def atom_forward(h, w0, b0, w1, b1, dil, save, image=None):
+def atom_forward(h, w0, b0, w1, b1, dil, save, image=None, signs=False):
     """image: the atom's pre-split weight image (P.atom_pack) -> ONE fused launch, the intermediate stays on chip;
-    None -> the two row-tile conv launches.  Same results bitwise."""
+    None -> the two row-tile conv launches.
+    signs (fused, training): the record holds u as SIGN WORDS (and t carries its own): the caller has checked that the
+    whole backward pass of the stack takes them (P.stack_signs_ok)."""
     d0, lo = P.conv_desc(h.shape, w0.shape, pad=dil, dil=dil, act=L.ACT_LRELU)
     d1, _ = P.conv_desc(h.shape, w1.shape, pad=1, act=L.ACT_LRELU)
     if image is not None:
-        out, t, u = P.atom_fwd(h, image, b0, b1, dil, save)
+        out, t, u = P.atom_fwd(h, image, b0, b1, dil, save, signs=signs and save)
         return out, (d0, d1, h, t, u)
     t, _ = P.conv1d_fwd(h, w0, b0, d0, lo)
     out, u = P.conv1d_fwd(t, w1, b1, d1, lo, residual=h, want_y_act=save)
@@ -229,14 +231,18 @@ def atom_backward(rec, w0, w1, g, sink, i, need_wgrad=True, need_gx=True, fork=N
             # operand bounds published by the fused launches: forward [0] = |x|, [1] = |t|; backward [0] = |g|, [1] = |gt lrelu'(t)|
             af, ab = getattr(t, "_ms_amax", None), getattr(gt, "_ms_amax", None)
             both = af is not None and ab is not None
+            # (sign words: the derivative operand of the dilated conv's gradient is t's sign words, not t)
+            ta = t._ms_signs if P.is_signs(u) else t
             batch.append((i + 2, t, g, u, d1, w1.shape) + ((af[1], ab[0]) if both else ()))
-            batch.append((i, h, gt, t, d0, w0.shape) + ((af[0], ab[1]) if both else ()))
+            batch.append((i, h, gt, ta, d0, w0.shape) + ((af[0], ab[1]) if both else ()))
         elif need_wgrad:
             gw, gb, acc = sink.pair(i + 2)
             run(lambda: sink.put(i + 2, *P.conv1d_bwd_weight(t, g, u, d1, w1.shape, gw, gb, acc)), t, g, u)
             gw, gb, acc = sink.pair(i)
             run(lambda: sink.put(i, *P.conv1d_bwd_weight(h, gt, t, d0, w0.shape, gw, gb, acc)), h, gt, t)
         return gx
+    if P.is_signs(u):
+        raise RuntimeError("residual atom backward: the forward pass saved sign words, which only the fused backward takes")
     if need_wgrad and batch is not None:
         batch.append((i + 2, t, g, u, d1, w1.shape))
     elif need_wgrad:
@@ -306,9 +312,12 @@ def gen_forward(x, params, save):
                             [params[i + 4 * k + 3] for k in range(n)], DILATIONS)
             i += 4 * n
             continue
+        # training: where the stack's whole backward pass (fused backward data, batched weight gradients) takes them, u is
+        # saved as one sign bit per element (and t's signs beside t): a third less traffic over forward + backward
+        signs = save and all(images.get(i + 4 * k) is not None for k in range(n)) and P.stack_signs_ok(h, DILATIONS)
         for dil in DILATIONS:
             h, rec = atom_forward(h, params[i], params[i + 1], params[i + 2], params[i + 3], dil, save,
-                                  image=images.get(i))
+                                  image=images.get(i), signs=signs)
             i += 4
             tape.append(("atom", rec))
     w, b = params[i], params[i + 1]

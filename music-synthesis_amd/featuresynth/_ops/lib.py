@@ -62,7 +62,7 @@ class WgradMultiDesc(ctypes.Structure):         # ms_wgrad_multi_desc
                 ("x", _vp * WGRAD_MULTI_MAX), ("gy", _vp * WGRAD_MULTI_MAX), ("y_act", _vp * WGRAD_MULTI_MAX),
                 ("gw", _vp * WGRAD_MULTI_MAX), ("gb", _vp * WGRAD_MULTI_MAX),
                 ("beta", _c_f * WGRAD_MULTI_MAX),
-                ("xmax", _vp * WGRAD_MULTI_MAX), ("gmax", _vp * WGRAD_MULTI_MAX)]
+                ("xmax", _vp * WGRAD_MULTI_MAX), ("gmax", _vp * WGRAD_MULTI_MAX), ("y_signs", _vp * WGRAD_MULTI_MAX)]
 
 
 ATOM_AMAX_N = 1024
@@ -123,6 +123,10 @@ SIGNATURES = {
     "ms_residual_atom_publishes_amax": (_c_int, []),
     "ms_residual_atom_fwd": (_c_int, [ctypes.POINTER(AtomDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ms_residual_stack_supported": (_c_int, [ctypes.POINTER(StackDesc)]),
+    "ms_residual_stack_signs_supported": (_c_int, [ctypes.POINTER(StackDesc)]),
+    "ms_residual_atom_sign_words": (_sz, [ctypes.POINTER(AtomDesc)]),
+    "ms_residual_atom_fwd_signs": (_c_int, [ctypes.POINTER(AtomDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ms_residual_atom_bwd_data_signs": (_c_int, [ctypes.POINTER(AtomDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ms_residual_stack_fwd": (_c_int, [ctypes.POINTER(StackDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "ms_residual_atom_bwd_supported": (_c_int, [ctypes.POINTER(AtomDesc)]),
     "ms_residual_atom_bwd_data": (_c_int, [ctypes.POINTER(AtomDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1,5 +1,7 @@
 """Tensor-level wrappers of the C-ABI kernels: shape checks, output allocation, launch on the
 current stream.  No autograd here (see functional.py)."""
+import os
+
 import numpy as np
 import ctypes
 
@@ -122,6 +124,8 @@ def conv1d_bwd_weight_multi(jobs):
         chunk = jobs[lo:lo + L.WGRAD_MULTI_MAX]
         if len(chunk) == 1:
             x, gy, ya, d, ws_, gw, gb, acc = chunk[0][:8]
+            if is_signs(ya):
+                raise RuntimeError("conv1d_bwd_weight_multi: sign words only travel through the batched launch")
             out.append(conv1d_bwd_weight(x, gy, ya, d, ws_, gw, gb, acc))
             continue
         md = L.WgradMultiDesc()
@@ -140,7 +144,11 @@ def conv1d_bwd_weight_multi(jobs):
             if gb is None:
                 gb = (torch.zeros if acc else torch.empty)((d.Cout,), dtype=torch.float32, device=gy.device)
             md.conv[k] = d
-            md.x[k], md.gy[k], md.y_act[k] = x.data_ptr(), gy.data_ptr(), L.ptr(ya)
+            md.x[k], md.gy[k] = x.data_ptr(), gy.data_ptr()
+            if is_signs(ya):
+                md.y_signs[k] = ya.data_ptr()
+            else:
+                md.y_act[k] = L.ptr(ya)
             md.gw[k], md.gb[k], md.beta[k] = gw.data_ptr(), gb.data_ptr(), 1.0 if acc else 0.0
             costs.append(_ccost(d, "bwd_weight", act_read=ya is not None))
             out.append((gw, gb))
@@ -233,15 +241,46 @@ def atom_pack(jobs, backward=False):
         L.call("ms_residual_atom_pack_multi", _scost(n, 1, 1.58), d, L.stream())
 
 
-def atom_fwd(x, image, b0, b1, dil, save):
+def is_signs(t):
+    """Sign words of an activation (csrc/atom_fused.hip, MASK: int16, (B, C / 32, 2, L), bit 15 - r of word (b, blk, h, l)
+    = activation[b, 32 blk + (r & 3) + 8 (r >> 2) + 4 h, l] > 0) in place of the fp32 tensor."""
+    return t is not None and t.dtype == torch.int16
+
+
+def stack_signs_ok(x, dils):
+    """A training-mode stack of atoms may save SIGN WORDS of u (and of t, beside t itself) instead of the fp32 u: forward,
+    backward data and the batched weight gradients all take them at this geometry (MSYNTH_ATOM_SIGNS=0 / MSYNTH_WMULTI=0:
+    never)."""
+    if os.environ.get("MSYNTH_WMULTI", "1") != "1" or not (1 <= len(dils) <= L.STACK_MAX) or x.dim() != 3:
+        return False
+    return bool(L.load().ms_residual_stack_signs_supported(ctypes.byref(_stack_desc(x, dils))))
+
+
+def atom_fwd(x, image, b0, b1, dil, save, signs=False):
     """-> (y, t, u): y = x + lrelu(conv1(lrelu(conv_d(x) + b0)) + b1); t, u (the activations the backward pass needs)
-    only when save."""
+    only when save.  signs (with save): u is returned as its sign words and t carries its own (`t._ms_signs`) -- what the
+    backward pass reads instead of the two fp32 tensors wherever only the LeakyReLU derivative is needed."""
     L.require(x, "residual atom input"); L.require(b0, "bias"); L.require(b1, "bias")
     B, C, Lg = x.shape
     y = torch.empty_like(x)
     t = torch.empty_like(x) if save else None
-    u = torch.empty_like(x) if save else None
     d = L.AtomDesc(B, C, Lg, dil, SLOPE)
+    if save and signs:
+        su = torch.empty((B, C // 32, 2, Lg), dtype=torch.int16, device=x.device)
+        st = torch.empty((B, C // 32, 2, Lg), dtype=torch.int16, device=x.device)
+        amax = _amax_buffer(x.device)
+
+        def cost_s():
+            c0 = W.conv_cost(B, C, Lg, C, 3, 1, dil, dil, 1, "fwd")
+            return {"flops": 2 * c0["flops"], "bytes": 4 * x.numel() * 4 + 4 * 2 * (3 * C * C + C),
+                    "geom": (B, C, Lg, C, 3, 1, dil, 1)}
+        L.call("ms_residual_atom_fwd_signs", cost_s, d, x.data_ptr(), image.data_ptr(), b0.data_ptr(), b1.data_ptr(),
+               y.data_ptr(), t.data_ptr(), st.data_ptr(), su.data_ptr(), L.ptr(amax), L.stream())
+        t._ms_signs = st
+        if amax is not None:
+            t._ms_amax = amax
+        return y, t, su
+    u = torch.empty_like(x) if save else None
     # training: the launch's per-workgroup operand maxima ([0] of x, [1] of t) travel with t to the weight-gradient kernel,
     # which takes its block scales from them (no extra pass over the tensors)
     amax = _amax_buffer(x.device) if save else None
@@ -302,11 +341,25 @@ def _amax_buffer(device):
 def atom_bwd_data(g, u, t, image_bwd, dil):
     """-> (gt, gx): gt = conv1^T(g * lrelu'(u)) (raw), gx = g + conv_d^T(gt * lrelu'(t)) -- the atom's backward data, one launch.
     gt carries the launch's operand maxima (`gt._ms_amax`: [0] of g, [1] of gt lrelu'(t)) for the weight gradients."""
-    for a, nm in ((g, "grad_output"), (u, "y_act"), (t, "t")):
+    sg = is_signs(u)
+    for a, nm in ((g, "grad_output"), (t, "t")) + (() if sg else ((u, "y_act"),)):
         L.require(a, "residual atom " + nm)
     B, C, Lg = g.shape
     gt, gx = torch.empty_like(g), torch.empty_like(g)
     d = L.AtomDesc(B, C, Lg, dil, SLOPE)
+    if sg:
+        st = t._ms_signs
+        amax = _amax_buffer(g.device)
+
+        def cost_s():
+            c0 = W.conv_cost(B, C, Lg, C, 3, 1, dil, dil, 1, "bwd_data")
+            return {"flops": 2 * c0["flops"], "bytes": 4 * g.numel() * 5 + 4 * 2 * 3 * C * C,
+                    "geom": (B, C, Lg, C, 3, 1, dil, 1)}
+        L.call("ms_residual_atom_bwd_data_signs", cost_s, d, g.data_ptr(), u.data_ptr(), st.data_ptr(), image_bwd.data_ptr(),
+               gt.data_ptr(), gx.data_ptr(), L.ptr(amax), L.stream())
+        if amax is not None:
+            gt._ms_amax = amax
+        return gt, gx
 
     def cost():
         c0 = W.conv_cost(B, C, Lg, C, 3, 1, dil, dil, 1, "bwd_data")

@@ -84,6 +84,19 @@ def discriminator(p, x, scales=2, masks=None):
     return feats, judges
 
 
+def decode_sign_words(words):
+    """Sign words of the fused atom kernels (include/msynth.h, ms_residual_atom_fwd_signs: int16 (B, C / 32, 2, L), bit 15 - r
+    of word (b, blk, h, l) = activation[b, 32 blk + (r & 3) + 8 (r >> 2) + 4 h, l] > 0) -> CPU bool tensor (B, C, L)."""
+    w = words.detach().cpu().to(torch.int32) & 0xFFFF
+    B, NB, _, Lg = w.shape
+    out = torch.zeros((B, NB * 32, Lg), dtype=torch.bool)
+    for h in range(2):
+        for r in range(16):
+            ch = (r & 3) + 8 * (r >> 2) + 4 * h
+            out[:, ch::32, :] = ((w[:, :, h, :] >> (15 - r)) & 1).bool()
+    return out
+
+
 def generator_masks_from_tape(tape, to_bool):
     """Device-side generator tape (featuresynth._ops.graph.gen_forward) -> the masks `generator` takes.
     to_bool: tensor -> CPU bool tensor (activation > 0)."""
@@ -97,7 +110,7 @@ def generator_masks_from_tape(tape, to_bool):
         elif rec[0] == "atom":
             _, _, _, t, u = rec[1]
             masks["a%d.%d.0" % (k, a)] = to_bool(t)
-            masks["a%d.%d.1" % (k, a)] = to_bool(u)
+            masks["a%d.%d.1" % (k, a)] = decode_sign_words(u) if u.dtype == torch.int16 else to_bool(u)
             a += 1
     return masks
 

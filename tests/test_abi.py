@@ -69,5 +69,5 @@ def test_struct_layout(lib):
     assert ctypes.sizeof(lib.ConvTDesc) == 10 * 4
     assert ctypes.sizeof(lib.L1MultiDesc) == 8 + 24 * (8 + 8 + 8 + 8 + 4)     # ms_l1_multi_desc
     assert ctypes.sizeof(lib.WnMultiDesc) == 8 + 64 * (5 * 8 + 2 * 4)         # ms_wn_multi_desc
-    assert ctypes.sizeof(lib.WgradMultiDesc) == 8 + 8 * (13 * 4 + 5 * 8 + 4) + 8 * (2 * 8)    # ms_wgrad_multi_desc (+ xmax, gmax)
+    assert ctypes.sizeof(lib.WgradMultiDesc) == 8 + 8 * (13 * 4 + 5 * 8 + 4) + 8 * (3 * 8)    # ms_wgrad_multi_desc (+ xmax, gmax, y_signs)
     assert ctypes.sizeof(lib.JudgeMultiDesc) == 8 + 8 * (4 * 8 + 8)               # ms_judge_multi_desc

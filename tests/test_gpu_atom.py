@@ -256,3 +256,68 @@ def test_fused_atom_backward_at_bench_shapes(C, Lg, dil):
     assert _rel(gt, gt2) < 2e-6 and _rel(gx - g, gx2 - g) < 2e-6
     gt3, gx3 = P.atom_bwd_data(g, u, t, img, dil)
     assert torch.equal(gt3, gt) and torch.equal(gx3, gx), "launch-to-launch determinism"
+
+
+def _decode_signs(words):
+    from oracle import torch_graph as TG
+    return TG.decode_sign_words(words).cuda()
+
+
+SIGN_CASES = [("s32", 2, 32, 1032, 3), ("s32_long", 3, 32, 8192, 9), ("s64", 2, 64, 4096, 1), ("s64_ragged", 1, 64, 252, 9),
+              ("s128", 2, 128, 2048, 3), ("s128_short", 1, 128, 188, 9), ("s256", 3, 256, 256, 1), ("s256_narrow", 1, 256, 100, 9)]
+
+
+@pytest.mark.parametrize("case", SIGN_CASES, ids=[c[0] for c in SIGN_CASES])
+def test_fused_atom_sign_words(case):
+    """r04: the training forward can save u as one sign bit per element (and t's signs beside t).  Same y and t bitwise, the
+    words decode to exactly (u > 0) / (t > 0), and the backward data from the words equals the backward data from the fp32
+    tensors bitwise."""
+    from featuresynth._ops import prims as P
+    name, B, C, Lg, dil = case
+    x, w0, b0, w1, b1 = _inputs(name, B, C, Lg)
+    xt, w0t, b0t, w1t, b1t = (dev(a) for a in (x, w0, b0, w1, b1))
+    img = P.atom_image(C, xt.device); P.atom_pack([(w0t, w1t, img)])
+    imgb = P.atom_image(C, xt.device); P.atom_pack([(w0t, w1t, imgb)], backward=True)
+    y, t, u = P.atom_fwd(xt, img, b0t, b1t, dil, True)
+    ys, ts, su = P.atom_fwd(xt, img, b0t, b1t, dil, True, signs=True)
+    assert P.is_signs(su) and P.is_signs(ts._ms_signs) and tuple(su.shape) == (B, C // 32, 2, Lg)
+    assert torch.equal(ys, y) and torch.equal(ts, t)
+    assert torch.equal(_decode_signs(su), u > 0) and torch.equal(_decode_signs(ts._ms_signs), t > 0)
+    g = dev(np.random.default_rng(stable_seed(name + "g")).standard_normal((B, C, Lg)) * 1e-3)
+    gt, gx = P.atom_bwd_data(g, u, t, imgb, dil)
+    gts, gxs = P.atom_bwd_data(g, su, ts, imgb, dil)
+    assert torch.equal(gts, gt) and torch.equal(gxs, gx)
+
+
+@pytest.mark.parametrize("C,Lg,B", [(64, 4096, 2), (128, 2048, 2), (256, 256, 4), (32, 8192, 2), (32, 1024, 3)])
+def test_stack_weight_gradients_from_sign_words(C, Lg, B):
+    """The six weight gradients of a stack in one launch, LeakyReLU derivatives from sign words: bitwise what the fp32
+    activations give (k_wgrad_rows3<., 2, true>; k_wgrad32<1, true> at 32 channels)."""
+    from featuresynth._ops import graph as G
+    from featuresynth._ops import prims as P
+    rng = np.random.default_rng(stable_seed("wsig%d" % C))
+    xt = dev(rng.standard_normal((B, C, Lg)))
+    assert P.stack_signs_ok(xt, (1, 3, 9))
+    jobs_f, jobs_s = [], []
+    h = xt
+    for dil in (1, 3, 9):
+        _, w0, b0, w1, b1 = _inputs("wsig%d_%d" % (C, dil), 1, C, 8)
+        w0t, b0t, w1t, b1t = (dev(a) for a in (w0, b0, w1, b1))
+        img = P.atom_image(C, xt.device); P.atom_pack([(w0t, w1t, img)])
+        imgb = P.atom_image(C, xt.device); P.atom_pack([(w0t, w1t, imgb)], backward=True)
+        y, t, u = P.atom_fwd(h, img, b0t, b1t, dil, True)
+        ys, ts, su = P.atom_fwd(h, img, b0t, b1t, dil, True, signs=True)
+        g = dev(rng.standard_normal((B, C, Lg)) * 1e-3)
+        gt, _ = P.atom_bwd_data(g, u, t, imgb, dil)
+        gts, _ = P.atom_bwd_data(g, su, ts, imgb, dil)
+        d0, _ = P.conv_desc(h.shape, w0t.shape, pad=dil, dil=dil, act=1)
+        d1, _ = P.conv_desc(h.shape, w1t.shape, pad=1, act=1)
+        jobs_f += [(t, g, u, d1, w1t.shape, None, None, False, t._ms_amax[1], gt._ms_amax[0]),
+                   (h, gt, t, d0, w0t.shape, None, None, False, t._ms_amax[0], gt._ms_amax[1])]
+        jobs_s += [(ts, g, su, d1, w1t.shape, None, None, False, ts._ms_amax[1], gts._ms_amax[0]),
+                   (h, gts, ts._ms_signs, d0, w0t.shape, None, None, False, ts._ms_amax[0], gts._ms_amax[1])]
+        h = y
+    rf = P.conv1d_bwd_weight_multi(jobs_f)
+    rs = P.conv1d_bwd_weight_multi(jobs_s)
+    for (gw, gb), (gws, gbs) in zip(rf, rs):
+        assert torch.equal(gw, gws) and torch.equal(gb, gbs)
