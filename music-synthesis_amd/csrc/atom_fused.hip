@@ -97,6 +97,11 @@ __global__ __launch_bounds__(256) void k_atom_pack(AtomPackTable t) {
     for (int pp = 0; pp < jb.np; ++pp) dst[pp * 64] = u32x4{pc[pp][0], pc[pp][1], pc[pp][2], pc[pp][3]};
 }
 
+// m = 2 m + (v > 0): the compare sets the carry the add consumes -- two vector instructions per sign bit
+__device__ __forceinline__ void sign_push(unsigned& m, float v) {
+    asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(v) : "vcc");
+}
+
 // ---- the fused kernel ---------------------------------------------------------------------------------------
 struct AtomP {
     int B, C, L, dil, NO, tiles_per_row;           // NO: output columns per tile
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                     }
                     if constexpr (MASK && SAVE) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) sw = (sw << 1) | (e[q] > 0.f ? 1u : 0u);
+                        for (int q = 0; q < 4; ++q) sign_push(sw, e[q]);
                     }
                     if (BWD) {
 #pragma unroll
@@ -617,7 +622,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
                         if (SC) v *= k2;
                         v += bv[q];
                         if (!BWD) v = v > 0.f ? v : v * p.slope;
-                        if constexpr (SAVE && MASK) su = (su << 1) | (v > 0.f ? 1u : 0u);
+                        if constexpr (SAVE && MASK) sign_push(su, v);
                         else if (SAVE) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsU, oy, base + (chs + q) * L4, 0);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + xr[4 * g + q]), rsY, oy,
                                                               base + (chs + q) * L4, 0);

@@ -18,8 +18,9 @@ if op == "atom":      # fused residual atom, training forward + backward data: a
     b0 = torch.randn(C, device="cuda") * 0.1; b1 = torch.randn(C, device="cuda") * 0.1; g = torch.randn_like(x)
     img = P.atom_image(C, x.device); P.atom_pack([(w0, w1, img)])
     imgb = P.atom_image(C, x.device); P.atom_pack([(w0, w1, imgb)], backward=True)
+    signs = P.stack_signs_ok(x, (dil,) * 3)        # what the train step runs: sign words in place of the fp32 u (atom_fused.hip, MASK)
     for _ in range(5):
-        y, rec = G.atom_forward(x, w0, b0, w1, b1, dil, True, image=img)
+        y, rec = G.atom_forward(x, w0, b0, w1, b1, dil, True, image=img, signs=signs)
         if P.atom_bwd_supported(B, C, Lg, dil): P.atom_bwd_data(g, rec[4], rec[3], imgb, dil)
     torch.cuda.synchronize(); sys.exit(0)
 if op == "k5img":     # the k5 layer on weight images (conv5_img.hip), forward + backward data: k5img B C L
