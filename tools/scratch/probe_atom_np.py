@@ -1,7 +1,7 @@
 """r04 probe: the fused atom kernel's operand schemes / schedules at the bench shapes (B = 32).
 One process per setting (the switches are read once per process):
     MSYNTH_ATOM_NP=3                  bf16 x 3, six products (the r03 kernel)
-    MSYNTH_ATOM_NP=2 MSYNTH_ATOM_VAR=0..3   block-scaled fp16 x 2, three products; schedule variants (atom_fused.hip)
+    MSYNTH_ATOM_NP=2                  block-scaled fp16 x 2, three products (atom_fused.hip); MSYNTH_LIB=<other build> for A/Bs
 Prints time per launch and the rel-L2 distance to the two row-tile launches (bf16 x 3, exact products).
     python3 tools/scratch/probe_atom_np.py            (driver)
 """
@@ -64,9 +64,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--worker":
         worker()
         sys.exit(0)
-    settings = [("3", "0"), ("2", "0"), ("2", "1"), ("2", "2"), ("2", "3")]
-    for np_, var in settings:
-        env = dict(os.environ, MSYNTH_ATOM_NP=np_, MSYNTH_ATOM_VAR=var)
+    for np_ in ("3", "2"):
+        env = dict(os.environ, MSYNTH_ATOM_NP=np_)
         rc = subprocess.call([sys.executable, os.path.abspath(__file__), "--worker"], env=env)
         if rc:
-            print("setting NP=%s VAR=%s rc=%d" % (np_, var, rc), flush=True)
+            print("setting NP=%s rc=%d" % (np_, rc), flush=True)
