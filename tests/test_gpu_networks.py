@@ -598,3 +598,38 @@ def test_flat_adam_state_reload_keeps_captured_graphs_valid(monkeypatch):
     l_d = dt.train(*batches[4])["d_loss"]
     assert dt._runner is not old, "the trainer must re-plan when the bucket moved"
     assert abs(l_d - l0[4]) <= 1e-5 * abs(l0[4])
+
+
+def test_sign_words_train_step_equals_fp32_activations(monkeypatch):
+    """r04: the G-step saves one sign bit per element of the atoms' u (and reads t's signs) where the backward pass only
+    needs the LeakyReLU derivative.  Nothing but bookkeeping changes: after D, G, D, G at B = 4 the losses, both gradient
+    buckets and every parameter are BITWISE what MSYNTH_ATOM_SIGNS=0 (fp32 activations saved) gives; and the sign-word path
+    is really the one that runs (the library notes the instantiation)."""
+    from featuresynth._ops import lib as L
+    from featuresynth._synthetic import synthetic_features, synthetic_samples
+    B, T = 4, 8
+    out = {}
+    for mode in ("signs", "fp32"):
+        monkeypatch.setenv("MSYNTH_GRAPH", "0")
+        if mode == "fp32":
+            monkeypatch.setenv("MSYNTH_ATOM_SIGNS", "0")
+        g, d, _, _ = make_nets(dict(seed=7, bias_scale=0.02), dict(seed=8, bias_scale=0.02))
+        dt, gt, go, do = _trainers(g, d)
+        losses = []
+        for step in range(4):
+            s = dev(synthetic_samples(B, T * 256, rank=step))
+            f = dev(synthetic_features(B, 80, T, rank=step))
+            if step == 1:
+                L.profile_begin()
+            losses.append(dt.train(s, f)["d_loss"] if step % 2 == 0 else gt.train(s, f)["g_loss"])
+            if step == 1:
+                names = [c.get("kernel") or n for n, c, _ in L.profile_end()]
+                masked = sum(n.startswith("k_atom_fwd") and n.endswith("true>") for n in names)
+                assert masked == (24 if mode == "signs" else 0), (mode, masked)      # 12 training forwards + 12 backward datas
+        out[mode] = (losses, {k: host(v) for k, v in list(g.state_dict().items()) + list(d.state_dict().items())},
+                     host(go.flat_grads), host(do.flat_grads))
+        monkeypatch.delenv("MSYNTH_ATOM_SIGNS", raising=False)
+    assert out["signs"][0] == out["fp32"][0]
+    assert np.array_equal(out["signs"][2], out["fp32"][2]) and np.array_equal(out["signs"][3], out["fp32"][3])
+    for k in out["signs"][1]:
+        assert np.array_equal(out["signs"][1][k], out["fp32"][1][k]), k
