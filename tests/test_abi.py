@@ -53,6 +53,20 @@ def test_host_side_queries(lib):
     assert L.ms_convt1d_out_len(t) == 8192
     assert L.ms_audio2mel_frames(22050, 1024, 256) == 84
     assert L.ms_audio2mel_frames(100, 1024, 256) == 0
+    # r04 predicates (host arithmetic only): whole stacks in one launch at 32 / 64 channels, sign words where forward, backward
+    # data and the batched weight gradients all take them
+    def stack(B, C, Lg, dils=(1, 3, 9)):
+        d = lib.StackDesc()
+        d.B, d.C, d.L, d.count, d.slope = B, C, Lg, len(dils), 0.2
+        for i, v in enumerate(dils):
+            d.dil[i] = v
+        return d
+    assert L.ms_residual_stack_supported(stack(32, 64, 4096)) == 1 and L.ms_residual_stack_supported(stack(1, 32, 8192)) == 1
+    assert L.ms_residual_stack_supported(stack(32, 128, 2048)) == 0 and L.ms_residual_stack_supported(stack(2, 64, 64, (9, 3, 1))) == 0
+    assert L.ms_residual_atom_sign_words(lib.AtomDesc(32, 64, 4096, 3, 0.2)) == 32 * 2 * 2 * 4096
+    for B, C, Lg in ((32, 32, 8192), (32, 64, 4096), (32, 128, 2048), (32, 256, 256)):
+        assert L.ms_residual_stack_signs_supported(stack(B, C, Lg)) == 1, (B, C, Lg)
+    assert L.ms_residual_stack_signs_supported(stack(2, 64, 300)) == 0          # rows the batched weight gradient does not take
     assert L.ms_reduce_workspace_bytes(10) >= 4
     # the dispatch names a kernel for every hot-path geometry
     for args, which in (((32, 128, 2048, 128, 3, 1, 3, 3, 1, 0, 1, 0.2, 0), 0),
@@ -71,3 +85,6 @@ def test_struct_layout(lib):
     assert ctypes.sizeof(lib.WnMultiDesc) == 8 + 64 * (5 * 8 + 2 * 4)         # ms_wn_multi_desc
     assert ctypes.sizeof(lib.WgradMultiDesc) == 8 + 8 * (13 * 4 + 5 * 8 + 4) + 8 * (3 * 8)    # ms_wgrad_multi_desc (+ xmax, gmax, y_signs)
     assert ctypes.sizeof(lib.JudgeMultiDesc) == 8 + 8 * (4 * 8 + 8)               # ms_judge_multi_desc
+    assert ctypes.sizeof(lib.AtomDesc) == 5 * 4                                   # ms_atom_desc
+    assert ctypes.sizeof(lib.AtomPackDesc) == 8 + 16 * (4 + 3 * 8 + 4)               # ms_atom_pack_desc
+    assert ctypes.sizeof(lib.StackDesc) == 8 * 4                                  # ms_stack_desc
