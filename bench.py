@@ -18,12 +18,17 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 FLOPs per launch / mean DEVICE duration of the launch (the dispatches' own begin / end
                 timestamps through hipExtLaunchKernelGGL events: what rocprofv3 reports; the stream-event
                 reading around the call is kept beside it), against the ceiling of the pipe the kernel
-                runs on -- bf16 MFMA peak / 6 = 416.7 TFLOP/s for the split-bf16 kernels (six bf16
-                products per fp32 multiply), 157.3 for fp32-input MFMA, 8 TB/s for streams -- with the
-                fraction of the fp32 roofline (157.3) quoted beside it
-  step_roofline three fractions of the measured step: vs sum max(bytes/8 TB/s, flops/157.3 TFLOP/s)
-                (SURVEY 8(d)'s contract), vs sum max(bytes/8 TB/s, flops/416.7 TFLOP/s) (the pipe the
-                dense kernels now run on) and vs sum bytes/8 TB/s (pure memory-bound)
+                runs on.  The launcher of every dense kernel records, with the kernel's name, how many
+                16-bit matrix-pipe products it spends per fp32 multiply (ms_profile_record.products):
+                6 -> 2500 / 6 = 416.7 TFLOP/s (exact bf16 x 3 split), 3 -> 2500 / 3 = 833.3 (block-scaled
+                fp16 x 2 split), 0 -> 157.3 (fp32-input MFMA / vector FMA); streams: 8 TB/s
+  step_roofline fractions of the measured step: `frac` vs sum max(bytes/8 TB/s, flops/157.3 TFLOP/s) over
+                the layer spec (SURVEY 8(d)'s contract); `frac_as_run` vs the same sum over the launches
+                that really ran, each priced on the pipe its launcher recorded; three memory-bound
+                fractions (layer-granular bytes, the fused byte model of the program as scheduled, and
+                SURVEY 8(d)'s 135 MB per element per call)
+  value_exact   the same bench in a child process with the operand-scheme switches at NP=3: every fp32
+                multiply as six exact bf16 partial products (no 22-bit operand anywhere)
   cpu_baseline  the torch-functional CPU restatement of the reference graph (oracle/torch_graph.py)
                 timed on this host's cores on a bounded sample (N=1 runs only)
 """
@@ -39,7 +44,7 @@ for p in (ROOT, os.path.join(ROOT, "music-synthesis_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK = 8.0e12        # B/s   (MI355X_MICROARCH.md: HBM3E peak)
-PMC_FILE = "r04_pmc_traffic.json"      # profiles/: TCC traffic of every kernel (tools/pmc_traffic.sh), stamped with code_version()
+PMC_FILE = "r05_pmc_traffic.json"      # profiles/: TCC traffic of every kernel (tools/pmc_traffic.sh), stamped with code_version()
 F32_PEAK = 157.3e12      # FLOP/s (fp32 vector == fp32-input MFMA peak)
 WINDOW = 8192
 
@@ -66,21 +71,25 @@ def code_version():
 
 BF16_PEAK = 2500.0e12    # FLOP/s dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)
 
-# kernel templates that run fp32 arithmetic on the 16-bit matrix pipe with split operands -> partial products per multiply
-SPLIT6 = ("k_conv_rows3", "k_wgrad_rows3", "k_gconv_split", "k_wgrad_k5_split", "k_wgrad_convt8_split", "k_conv5_img",
-          "k_convt_img", "k_convt_bwd_img", "k_convt_fwd_short", "k_wgrad_convt2_short", "k_gconv_img")
+DTYPE = ("f32 storage and accumulate; multiplies on the 16-bit matrix pipe with split fp32 operands: block-scaled fp16 x 2 "
+         "(22 significand bits, 3 products per multiply) in the atoms, the k5 layer, the grouped convs, the stride-8 transposed "
+         "forward and the atom weight gradients; exact bf16 x 3 (6 products) or fp32-input MFMA elsewhere")
+DTYPE_EXACT = "f32 storage and accumulate; every multiply fp32-exact (bf16 x 3 split, 6 products, or fp32-input MFMA / vector FMA)"
 
 
-def pipe_products(template, instantiations=()):
-    """0: not a split-operand kernel; 6 / 3: products per fp32 multiply of the scheme the template's launches used."""
-    if template.startswith("k_atom_fwd") or template.startswith("k_stack_fwd"):
-        nps = set()
-        for name in instantiations:
-            args = name[name.index("<") + 1:].rstrip(">").split(",") if "<" in name else []
-            if len(args) >= 5:
-                nps.add(int(args[4]))
-        return 6 if nps == {3} else 3
-    return 6 if template.startswith(SPLIT6) else 0
+# switches that put every 22-bit (fp16 x 2) kernel back on fp32-exact arithmetic (DESIGN.md "Tuning switches")
+EXACT_ENV = {"MSYNTH_ATOM_NP": "3", "MSYNTH_C5_NP": "3", "MSYNTH_WROWS3_NP": "3", "MSYNTH_GCONV3": "0", "MSYNTH_CONVTIMG": "0"}
+
+
+def pipe_peak(products):
+    """FLOP/s ceiling of a kernel by the arithmetic its launcher recorded (ms_profile_record.products)."""
+    return BF16_PEAK / products if products else F32_PEAK
+
+
+PIPE_TEXT = {6: "bf16 MFMA, exact 3-way operand split, 6 products per fp32 multiply, fp32 accumulate: peak = 2500 / 6",
+             3: "fp16 MFMA, block-scaled 2-way operand split (22 significand bits), 3 products per fp32 multiply, "
+                "fp32 accumulate: peak = 2500 / 3",
+             0: "fp32-input MFMA / vector FMA: peak = 157.3"}
 
 
 def host_cpu_share(cap=16):
@@ -120,6 +129,34 @@ def launch_workers(args):
     return subprocess.call(cmd, env=env)
 
 
+def child_bench(args, env_extra, what):
+    """The same bench (timed region only: no roofline / CPU / config-2 legs) in a fresh child process with extra environment
+    switches -- the library reads its operand-scheme switches once per process.  The parent is idle meanwhile.
+    -> the child's JSON line as a dict, or {"error": ...}."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.update(env_extra)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--batch", str(args.batch), "--mels", str(args.mels), "--prime", str(args.prime), "--model", args.model,
+           "--no-cpu-baseline", "--no-roofline", "--no-gforward", "--no-exact", "--no-dp-overhead"]
+    log("[bench] child leg %s: %s" % (what, " ".join("%s=%s" % kv for kv in sorted(env_extra.items()))))
+    try:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    except subprocess.TimeoutExpired:
+        return {"error": "child timed out"}
+    for line in reversed(out.stdout.splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    return {"error": "child exited %d: %s" % (out.returncode, out.stderr[-400:])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +174,10 @@ def main():
     ap.add_argument("--prime", type=int, default=60,
                     help="untimed calls in front of the warm-up steps, on top of the four that load code objects and capture the "
                          "graphs (clock ramp); the profiling scripts pass 0 to keep their traces at 15 D+G pairs")
+    ap.add_argument("--no-exact", action="store_true",
+                    help="skip the value_exact leg (the same bench in a child process on fp32-exact arithmetic)")
+    ap.add_argument("--no-dp-overhead", action="store_true",
+                    help="skip the dp_overhead leg (the N = 1 step under the data-parallel control flow, child process)")
     ap.add_argument("--no-gforward", action="store_true",
                     help="skip the BASELINE config-2 leg (generator forward, B=1): keeps its B=1 dispatches out "
                          "of a rocprofv3 trace of the train step")
@@ -170,7 +211,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    _dist.init_from_env("gloo" if share else "nccl")
+    # MSYNTH_DP_FORCE=1 (the dp_overhead leg): the data-parallel control flow over a one-rank RCCL communicator
+    _dist.init_from_env("gloo" if share else "nccl", force=os.environ.get("MSYNTH_DP_FORCE") == "1")
     rank = _dist.rank()
     L.load()
     if world > 1:
@@ -265,7 +307,8 @@ def main():
         "metric": "GAN train-step audio samples/sec (22.05 kHz, 8192-sample window)",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "prime": 4 + args.prime, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": DTYPE_EXACT if all(os.environ.get(k) == v for k, v in EXACT_ENV.items()) else DTYPE,
         "data": "synthetic",
         "config": {"workload": ("stage-2 GAN train step: alternating D/G trainer calls, MelGAN "
                                 "generator + 3-scale discriminator + feature-matching loss "
@@ -308,8 +351,10 @@ def main():
         agg = {}
         for name, cost, ms in rec:
             k = cost.get("kernel") or name
-            a = agg.setdefault(k, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0, "event_ms": 0.0})
+            a = agg.setdefault(k, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0, "event_ms": 0.0, "products": 0, "pipe_s": 0.0})
             a["ms"] += ms; a["n"] += 1
+            a["products"] = max(a["products"], cost.get("products", 0))
+            a["pipe_s"] += cost.get("flops", 0) / pipe_peak(cost.get("products", 0))     # matrix / vector time at the pipe's ceiling
             a["event_ms"] += cost.get("event_ms", ms)
             a["flops"] += cost.get("flops", 0); a["bytes"] += cost.get("bytes", 0)
         tot_ms = sum(a["ms"] for a in agg.values())
@@ -332,41 +377,35 @@ def main():
         # only in tile shape / taps / fused epilogue; rocprofv3 lists them separately)
         fam = {}
         for k_, a_ in agg.items():
-            f_ = fam.setdefault(k_.split("<")[0], {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0, "event_ms": 0.0, "inst": {}})
-            for key in ("ms", "n", "flops", "bytes", "event_ms"):
+            f_ = fam.setdefault(k_.split("<")[0], {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0, "event_ms": 0.0, "pipe_s": 0.0,
+                                                   "inst": {}, "products": set()})
+            for key in ("ms", "n", "flops", "bytes", "event_ms", "pipe_s"):
                 f_[key] += a_[key]
-            f_["inst"][k_] = {"launches": a_["n"], "avg_launch_us": 1e3 * a_["ms"] / a_["n"],
+            f_["products"].add(a_["products"])
+            f_["inst"][k_] = {"launches": a_["n"], "avg_launch_us": 1e3 * a_["ms"] / a_["n"], "products": a_["products"],
                               "tflops": a_["flops"] / a_["ms"] / 1e9 if a_["ms"] else 0.0}
         k, a = sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[0]
         avg_s = a["ms"] / a["n"] / 1e3
         fl, by = a["flops"] / a["n"], a["bytes"] / a["n"]
-        # ceiling of the pipe the kernel runs on: fp32 FLOPs executed on the 16-bit matrix pipe with split operands can go no
-        # faster than its peak / (partial products per fp32 multiply): 6 for the exact three-piece bf16 split (conv_rows3.hip),
-        # 3 for the block-scaled two-piece fp16 split (atom_fused.hip, NP = 2); the fp32-input MFMA kernels no faster than
-        # the fp32 peak.  The launchers' noted names carry the scheme (k_atom_fwd's fifth template argument = pieces).
-        products = pipe_products(k, a["inst"])
-        split_pipe = products > 0
-        pipe_peak = BF16_PEAK / products if split_pipe else F32_PEAK
-        compute_bound = fl / pipe_peak >= by / HBM_PEAK
+        # ceiling of the pipe the kernel runs on, from what its launcher recorded (ms_profile_record.products): fp32 FLOPs executed
+        # on the 16-bit matrix pipe with split operands can go no faster than its peak / (partial products per fp32 multiply).
+        # A template whose instantiations differ in arithmetic is priced launch by launch (pipe_s = sum flops_i / peak_i).
+        products = max(a["products"])
+        pipe_pk = a["flops"] / a["pipe_s"] if a["pipe_s"] else F32_PEAK          # flop-weighted ceiling over the launches
+        compute_bound = a["pipe_s"] >= a["bytes"] / HBM_PEAK
         if compute_bound:
-            roof = {"bound": "mfma", "achieved": fl / avg_s / 1e12, "peak": pipe_peak / 1e12,
-                    "unit": "TFLOP/s"}
+            roof = {"bound": "mfma", "achieved": fl / avg_s / 1e12, "peak": pipe_pk / 1e12, "unit": "TFLOP/s"}
         else:
-            roof = {"bound": "hbm", "achieved": by / avg_s / 1e9, "peak": HBM_PEAK / 1e9,
-                    "unit": "GB/s"}
+            roof = {"bound": "hbm", "achieved": by / avg_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        # both legs, whichever one binds: with three products per multiply the atoms' MFMA time (flops / 833 TFLOP/s) and
-        # their HBM time (bytes / 8 TB/s) are within 15 % of each other at C = 32 .. 64
+        # both legs, whichever one binds
         roof["tflops"] = fl / avg_s / 1e12
         roof["gbps"] = by / avg_s / 1e9
         roof["frac_of_hbm"] = roof["gbps"] / (HBM_PEAK / 1e9)
-        roof["pipe"] = ({6: "bf16 MFMA, exact 3-way operand split, 6 products per fp32 multiply, fp32 accumulate: peak = 2500 / 6",
-                         3: "fp16 MFMA, block-scaled 2-way operand split (22 significand bits), 3 products per fp32 multiply, "
-                            "fp32 accumulate: peak = 2500 / 3"}[products] if split_pipe else "fp32-input MFMA")
-        roof["pipe_peak"] = pipe_peak / 1e12
+        roof["products_per_multiply"] = sorted(a["products"])
+        roof["pipe"] = PIPE_TEXT[products]
+        roof["pipe_peak"] = pipe_pk / 1e12
         roof["frac_of_pipe"] = roof["tflops"] / roof["pipe_peak"]
-        if split_pipe:                                          # continuity with the r02 / r03 lines, priced on 2500 / 6
-            roof["frac_of_six_product_pipe"] = roof["tflops"] / (BF16_PEAK / 6 / 1e12)
         roof["fp32_peak"] = F32_PEAK / 1e12                      # SURVEY 8(d)'s fp32 roofline, for continuity
         roof["frac_of_fp32_peak"] = roof["tflops"] / roof["fp32_peak"]
         roof["traffic"] = None
@@ -400,34 +439,62 @@ def main():
                      "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
                      "share_of_kernel_time": a["ms"] / tot_ms,
                      "instantiations": dict(sorted(a["inst"].items(), key=lambda kv: -kv[1]["launches"] * kv[1]["avg_launch_us"])),
-                     "families": {kf: {"ms_per_DG_pair": round(v["ms"], 4), "launches": v["n"],
-                                       "tflops": round(v["flops"] / v["ms"] / 1e9, 2) if v["ms"] else 0.0}
+                     "families": {kf: {"ms_per_DG_pair": round(v["ms"], 4), "launches": v["n"], "products": sorted(v["products"]),
+                                       "tflops": round(v["flops"] / v["ms"] / 1e9, 2) if v["ms"] else 0.0,
+                                       "gbps": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] else 0.0}
                                   for kf, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:12]}})
         result["roofline"] = roof
         launches = W.d_step_launches(B, args.mels, T) + W.g_step_launches(B, args.mels, T)
+        fused = W.fused_d_step_launches(B, args.mels, T) + W.fused_g_step_launches(B, args.mels, T)
         ideal = W.roofline_seconds(launches, HBM_PEAK, F32_PEAK)
-        ideal_pipe = W.roofline_seconds(launches, HBM_PEAK, BF16_PEAK / 6)
         ideal_hbm = W.roofline_seconds(launches, HBM_PEAK, float("inf"))
+        ideal_hbm_fused = W.roofline_seconds(fused, HBM_PEAK, float("inf"))
+        survey_bytes = W.SURVEY_MB_PER_ELEMENT_PER_CALL * 1e6 * 2 * B
+        # the launches that really ran, each on the pipe its launcher recorded
+        as_run = sum(max(c.get("bytes", 0) / HBM_PEAK, c.get("flops", 0) / pipe_peak(c.get("products", 0))) for _, c, _ in rec)
+        as_run_3 = sum(max(c.get("bytes", 0) / HBM_PEAK, c.get("flops", 0) / (BF16_PEAK / 3 if c.get("products", 0) else F32_PEAK))
+                       for _, c, _ in rec)
+        run_bytes = sum(c.get("bytes", 0) for _, c, _ in rec)
+        run_flops = sum(c.get("flops", 0) for _, c, _ in rec)
+        by_products = {}
+        for _, c, ms in rec:
+            bp = by_products.setdefault(str(c.get("products", 0)), {"launches": 0, "gflop": 0.0, "kernel_ms": 0.0})
+            bp["launches"] += 1; bp["gflop"] += c.get("flops", 0) / 1e9; bp["kernel_ms"] += ms
         pair_s = 2 * elapsed / args.steps
         result["step_roofline"] = {
             "ideal_ms_per_DG_pair": ideal * 1e3, "measured_ms_per_DG_pair": pair_s * 1e3,
             "frac": ideal / pair_s,
-            "frac_definition": "sum over launches of max(bytes / 8 TB/s, flops / 157.3 TFLOP/s) / measured (SURVEY 8(d))",
-            "ideal_ms_split_bf16_pipe": ideal_pipe * 1e3, "frac_split_bf16_pipe": ideal_pipe / pair_s,
-            "frac_split_bf16_pipe_definition": "sum max(bytes / 8 TB/s, flops / (2500 / 6 = 416.7 TFLOP/s)) / measured: "
-                                               "every FLOP priced on the pipe the dense kernels run on",
+            "frac_definition": "sum over the layer spec's launches of max(bytes / 8 TB/s, flops / 157.3 TFLOP/s) / measured (SURVEY 8(d); "
+                               "above 0.5 it says the work left the fp32 pipe, not that a roof is near)",
+            "ideal_ms_as_run": as_run * 1e3, "frac_as_run": as_run / pair_s,
+            "frac_as_run_definition": "sum over the launches of the instrumented pair of max(bytes / 8 TB/s, flops / pipe peak), the "
+                                      "pipe peak being what the launcher recorded for that kernel: 2500 / 3 (fp16 x 2), 2500 / 6 "
+                                      "(bf16 x 3) or 157.3 TFLOP/s (fp32 MFMA / vector); bytes = what that launch has to move",
+            "ideal_ms_all_split_kernels_at_3_products": as_run_3 * 1e3, "frac_all_split_kernels_at_3_products": as_run_3 / pair_s,
+            "by_products_per_multiply": by_products,
             "ideal_ms_memory_bound": ideal_hbm * 1e3, "frac_memory_bound": ideal_hbm / pair_s,
-            "frac_memory_bound_definition": "sum bytes / 8 TB/s / measured (north_star's memory-bound roofline)",
+            "frac_memory_bound_definition": "sum of the LAYER-GRANULAR bytes / 8 TB/s / measured (every conv a launch that reads its "
+                                            "input and writes its output: north_star's memory-bound roofline on SURVEY 8(d)'s byte model)",
+            "ideal_ms_memory_bound_fused": ideal_hbm_fused * 1e3, "frac_memory_bound_fused": ideal_hbm_fused / pair_s,
+            "frac_memory_bound_fused_definition": "the same on the byte model of the program as scheduled (_workload.fused_*: one launch "
+                                                  "per atom pass / inference stack, sign words, one [fake; real] discriminator pass)",
+            "ideal_ms_memory_bound_survey": survey_bytes / HBM_PEAK * 1e3, "frac_memory_bound_survey": survey_bytes / HBM_PEAK / pair_s,
+            "frac_memory_bound_survey_definition": "SURVEY 8(d)'s 135 MB per element per call x 2 B / 8 TB/s / measured",
             "algorithmic_gflop_per_DG_pair": W.totals(launches)["flops"] / 1e9,
             "algorithmic_mb_per_DG_pair": W.totals(launches)["bytes"] / 1e6,
+            "fused_mb_per_DG_pair": W.totals(fused)["bytes"] / 1e6,
+            "as_run_mb_per_DG_pair": run_bytes / 1e6, "as_run_gflop_per_DG_pair": run_flops / 1e9,
+            "launches_per_DG_pair": len(rec), "kernels_per_DG_pair": sum(c.get("kernels", 0) for _, c, _ in rec),
             "kernel_ms_per_DG_pair_eager": tot_ms}
-        # whole-pair HBM traffic from the TCC counters over the algorithmic bytes (same code_version rule as roofline.traffic)
+        # whole-pair HBM traffic from the TCC counters over the bytes the launches have to move (same code_version rule as
+        # roofline.traffic)
         sr = result["step_roofline"]
         sr["traffic_ratio"] = None
         if os.path.exists(pmc_file) and pmc.get("code_version") == ver and pmc.get("dg_pairs"):
             tot_b = sum(r_["hbm_bytes_per_launch"] * r_["dispatches"] for r_ in pmc.get("kernels", {}).values())
             sr["pmc_hbm_mb_per_DG_pair"] = tot_b / pmc["dg_pairs"] / 1e6
-            sr["traffic_ratio"] = sr["pmc_hbm_mb_per_DG_pair"] / sr["algorithmic_mb_per_DG_pair"]
+            sr["traffic_ratio"] = sr["pmc_hbm_mb_per_DG_pair"] / sr["as_run_mb_per_DG_pair"]
+            sr["traffic_ratio_vs_layer_granular"] = sr["pmc_hbm_mb_per_DG_pair"] / sr["algorithmic_mb_per_DG_pair"]
             sr["traffic_source"] = "profiles/%s (%d D+G pairs, eager, code %s)" % (PMC_FILE, pmc["dg_pairs"], ver)
 
     if rank == 0 and args.model == "twostage":
@@ -495,6 +562,40 @@ def main():
                                                   "at B=1 the chain is launch- and latency-bound, not roofline-bound"}
         log("[bench] generator forward B=1: %.1f us -> %.4g samples/s" % (us, WINDOW / (us * 1e-6)))
         del gg, y1
+
+    if rank == 0 and world == 1 and args.model == "melgan" and not args.no_exact:
+        # the same timed region with every multiply fp32-exact: what the 22-bit operand scheme buys, stated beside the headline
+        r = child_bench(args, EXACT_ENV, "value_exact")
+        if "value" in r:
+            result["value_exact"] = r["value"]
+            result["exact"] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "dtype": r["dtype"], "switches": EXACT_ENV,
+                               "headline_over_exact": value / r["value"]}
+        else:
+            result["value_exact"] = None
+            result["exact"] = r
+
+    if rank == 0 and world == 1 and args.model == "melgan" and not args.no_dp_overhead:
+        # Multi-GPU readiness measurable on one GPU: the N = 1 step under the data-parallel control flow (three graph
+        # segments per call, the stepped net's gradient bucket all-reduced in two slices over a ONE-rank RCCL communicator,
+        # both transports) against the plain single-graph step; all three as child processes in the same order on this box.
+        plain = child_bench(args, {}, "dp_overhead/plain")
+        legs = {}
+        for comm in ("torch", "abi"):
+            legs[comm] = child_bench(args, {"MSYNTH_DP_FORCE": "1", "MSYNTH_COMM": comm}, "dp_overhead/" + comm)
+        dp = {"plain_ms_per_step": plain.get("ms_per_step"), "error": plain.get("error")}
+        for comm, r in legs.items():
+            dp[comm] = ({"ms_per_step": r["ms_per_step"], "graph_segments": r["config"]["graph_segments"],
+                         "overhead_ms_per_step": r["ms_per_step"] - plain["ms_per_step"],
+                         "overhead_frac": r["ms_per_step"] / plain["ms_per_step"] - 1.0}
+                        if "ms_per_step" in r and "ms_per_step" in plain else r)
+        if "ms_per_step" in plain and all("ms_per_step" in r for r in legs.values()):
+            best = min(r["ms_per_step"] for r in legs.values())
+            # weak scaling efficiency at N = step(1) / step(N); step(N) = dp step + un-hidden all-reduce time
+            dp["unhidden_allreduce_budget_ms_per_step_for_90pct"] = plain["ms_per_step"] / 0.9 - best
+            dp["note"] = ("one rank: the collectives move no data, so this is the cost of the control flow alone (two more graph "
+                          "launches per call, event waits, the RCCL launches); at 8 GPUs the D-step exchanges 22.6 MB and the "
+                          "G-step 18.1 MB per call, the early slice under the rest of the backward pass")
+        result["dp_overhead"] = dp
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import torch_graph as TG

@@ -238,18 +238,24 @@ size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which);
  * 2 bwd_weight) -- lets a profiler line be matched to a layer.  Static string, never NULL. */
 const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which);
 
-/* Profiling aid: spelling (as rocprofv3 prints it, without the namespace) of the dense-family kernel instantiation the
- * calling THREAD's most recent ms_* call dispatched, "" when that call's launcher does not note one (then
- * ms_conv1d_kernel_name applies).  ms_last_kernel_clear() empties it.  Thread-local; not needed for normal operation. */
-const char* ms_last_kernel_name(void);
-void ms_last_kernel_clear(void);
-
-/* Profiling aid: ms_profile_kernels(1) puts the calling THREAD into profile mode -- every kernel the library launches from it is
- * then bracketed by the dispatch's own begin / end timestamps (hipExtLaunchKernelGGL start / stop events: what rocprofv3 reports as
- * the kernel's duration) and waited for; ms_profile_take() returns the number of kernels launched since the last take and their
- * summed device time in microseconds.  Not capturable into a hipGraph while on; off (0) by default. */
+/* Profiling aid (off by default; never needed for normal operation).  ms_profile_kernels(1) opens a profile session of the
+ * calling THREAD: every kernel the library launches from that thread is then bracketed by the dispatch's own begin / end
+ * timestamps (hipExtLaunchKernelGGL start / stop events: what rocprofv3 reports as the kernel's duration) and waited for, and
+ * the launchers of the templated dense families note what they dispatched.  ms_profile_take() copies the record of the calls
+ * made since the previous take into *out and resets it; ms_profile_kernels(0) closes the session.  The session is the only
+ * state involved, it is thread-local and owned by the thread that opened it; outside a session launches record nothing.  Not
+ * capturable into a hipGraph while on. */
+#define MS_PROFILE_NAME_MAX 160
+typedef struct ms_profile_record {
+    int kernels;                      /* kernel launches since the previous take */
+    int products;                     /* matrix-pipe products per fp32 multiply of the kernel noted last: 6 = exact three-piece
+                                         bf16 split, 3 = block-scaled two-piece fp16 split, 0 = fp32-input MFMA / vector FMA */
+    double device_us;                 /* summed device time of those launches */
+    char kernel[MS_PROFILE_NAME_MAX]; /* instantiation noted last, in rocprofv3's spelling without the namespace; "" when
+                                         the launcher notes none (then ms_conv1d_kernel_name applies) */
+} ms_profile_record;
 void ms_profile_kernels(int on);
-int ms_profile_take(double* device_us);
+int ms_profile_take(ms_profile_record* out);
 
 /* nn.ConvTranspose1d geometry.  w is (Cin, Cout, K).  Lout = (Lin-1)*stride - 2*pad + K */
 typedef struct ms_convt1d_desc {

@@ -4,21 +4,24 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "conv_mfma.h"
 #include "gconv_mfma.h"
 #include "conv_thin.h"
 
-static thread_local char g_last_kernel[160] = "";
+// Profile session of the calling thread (ms_profile_kernels / ms_profile_take): nothing is recorded outside one.
+static thread_local int g_prof_on = 0, g_prof_launches = 0, g_prof_products = 0;
+static thread_local double g_prof_us = 0.0;
+static thread_local char g_prof_kernel[MS_PROFILE_NAME_MAX] = "";
 
-void ms_note_kernel(const char* fmt, ...) {
+void ms_note_kernel(int products, const char* fmt, ...) {
+    if (!g_prof_on) return;
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+    vsnprintf(g_prof_kernel, sizeof(g_prof_kernel), fmt, ap);
     va_end(ap);
+    g_prof_products = products;
 }
-
-static thread_local int g_prof_on = 0, g_prof_launches = 0;
-static thread_local double g_prof_us = 0.0;
 
 bool ms_prof_on() { return g_prof_on != 0; }
 
@@ -87,18 +90,22 @@ void ms_profile_kernels(int on) {
     g_prof_on = on ? 1 : 0;
     g_prof_us = 0.0;
     g_prof_launches = 0;
+    g_prof_products = 0;
+    g_prof_kernel[0] = 0;
 }
 
-int ms_profile_take(double* device_us) {
-    const int n = g_prof_launches;
-    if (device_us) *device_us = g_prof_us;
+int ms_profile_take(ms_profile_record* out) {
+    if (!out) return MS_ERR_INVALID_ARG;
+    out->kernels = g_prof_launches;
+    out->products = g_prof_products;
+    out->device_us = g_prof_us;
+    memcpy(out->kernel, g_prof_kernel, sizeof(out->kernel));
     g_prof_us = 0.0;
     g_prof_launches = 0;
-    return n;
+    g_prof_products = 0;
+    g_prof_kernel[0] = 0;
+    return MS_OK;
 }
-
-const char* ms_last_kernel_name(void) { return g_last_kernel; }
-void ms_last_kernel_clear(void) { g_last_kernel[0] = 0; }
 
 const char* ms_status_string(int status) {
     switch (status) {

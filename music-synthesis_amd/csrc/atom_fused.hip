@@ -679,7 +679,7 @@ int launch_atom_np(AtomP p, const float* x, const void* image, const float* b0, 
     const long long slots = (long long)n_cu[dev] * wgs_per_cu[dev];
     const long long ntiles = (long long)p.B * p.tiles_per_row;
     const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
-    ms_note_kernel("k_atom_fwd<%d, %d, %d, %d, %d, %s>", C, NTP, NW, MODE, NP, MASK ? "true" : "false");
+    ms_note_kernel(NP == 2 ? 3 : 6, "k_atom_fwd<%d, %d, %d, %d, %d, %s>", C, NTP, NW, MODE, NP, MASK ? "true" : "false");
     if (grid.x > MS_ATOM_AMAX_N) am = nullptr;          // (cannot happen: at most 4 workgroups on each of 256 CUs)
     hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, MODE, NP, MASK>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u, tm, am);
     MS_CHECK_LAUNCH();

@@ -468,7 +468,7 @@ int c5_launch_np(const C5P& p, const float* X, const float* Xact, const void* im
         ms_done_on_device(attr_set);
     }
     const dim3 grid((unsigned)((p.B + p.R - 1) / p.R), (unsigned)(p.M / 64), (unsigned)p.nsplit);
-    ms_note_kernel("k_conv5_img<%d, %d>", MODE, NP);
+    ms_note_kernel(NP == 2 ? 3 : 6, "k_conv5_img<%d, %d>", MODE, NP);
     hipLaunchKernelGGL((k_conv5_img<MODE, NP>), grid, dim3(512), lds, s, p, X, Xact, (const u32x4*)image, bias, add, Y, slabs);
     MS_CHECK_LAUNCH();
     if (p.nsplit > 1) {

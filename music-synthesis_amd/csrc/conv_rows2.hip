@@ -469,7 +469,7 @@ int launch_inst(const Row2P& p, const float* X, const float* Xact, const float* 
     }
     Row2P pp = p;
     pp.scratch_off = (int)fl;
-    ms_note_kernel("k_conv_rows2<%d, %d, %d, %d, %d, %d, %d, %d, %d>", WGM, WGN, TM, TN, K, CC, AM, EPI_S, IN_S);
+    ms_note_kernel(0, "k_conv_rows2<%d, %d, %d, %d, %d, %d, %d, %d, %d>", WGM, WGN, TM, TN, K, CC, AM, EPI_S, IN_S);
     hipLaunchKernelGGL((k_conv_rows2<WGM, WGN, TM, TN, K, CC, AM, EPI_S, IN_S>), grid, dim3(256), lds, s, pp, X, Xact,
                        W, bias, res, Y, Yact);
     MS_CHECK_LAUNCH();

@@ -775,7 +775,7 @@ int launch_pair(const Row2P& p, const float* X, const float* Xact, const float* 
     }
     Row2P pp = p;
     pp.scratch_off = (int)by;
-    ms_note_kernel("k_conv_rows3p<%d, %d, %d, %d, %d, %d, %s>", WGM, TM, TN, K, AM, HS, INA ? "true" : "false");
+    ms_note_kernel(6, "k_conv_rows3p<%d, %d, %d, %d, %d, %d, %s>", WGM, TM, TN, K, AM, HS, INA ? "true" : "false");
     hipLaunchKernelGGL((k_conv_rows3p<WGM, TM, TN, K, AM, HS, INA, DBG>), grid, dim3(512), lds, s, pp, X, Xact, W, bias, res,
                        Y, Yact);
     MS_CHECK_LAUNCH();
@@ -805,7 +805,7 @@ int launch_inst(const Row2P& p, const float* X, const float* Xact, const float* 
     }
     Row2P pp = p;
     pp.scratch_off = (int)by;
-    ms_note_kernel("k_conv_rows3<%d, %d, %d, %d, %d, %d, %s>", WGM, WGN, TM, TN, K, AM, VEC ? "true" : "false");
+    ms_note_kernel(6, "k_conv_rows3<%d, %d, %d, %d, %d, %d, %s>", WGM, WGN, TM, TN, K, AM, VEC ? "true" : "false");
     hipLaunchKernelGGL((k_conv_rows3<WGM, WGN, TM, TN, K, AM, VEC>), grid, dim3(256), lds, s, pp, X, Xact, W, bias,
                        res, Y, Yact);
     MS_CHECK_LAUNCH();

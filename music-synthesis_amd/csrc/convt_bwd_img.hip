@@ -354,7 +354,7 @@ int cb_launch(const CbP& p, const float* gy, const float* ya, const void* image,
         ms_done_on_device(attr_set);
     }
     const dim3 grid((unsigned)((p.B + p.R - 1) / p.R), (unsigned)(p.M / (64 * TM)), (unsigned)p.nsplit);
-    ms_note_kernel("k_convt_bwd_img<%d, %d>", S, TM);
+    ms_note_kernel(6, "k_convt_bwd_img<%d, %d>", S, TM);
     hipLaunchKernelGGL((k_convt_bwd_img<S, TM>), grid, dim3(512), lds, s, p, gy, ya, (const u32x4*)image, gx, slabs);
     MS_CHECK_LAUNCH();
     if (p.nsplit > 1) {

@@ -297,7 +297,7 @@ int msct_short_fwd(const ms_convt1d_desc* d, const float* x, const void* image, 
         ms_done_on_device(attr_set);
     }
     const dim3 grid((unsigned)((p.B + p.R - 1) / p.R), (unsigned)(p.Cout / 64), (unsigned)p.nsplit);
-    ms_note_kernel("k_convt_fwd_short");
+    ms_note_kernel(6, "k_convt_fwd_short");
     hipLaunchKernelGGL(k_convt_fwd_short, grid, dim3(512), lds, s, p, x, (const u32x4*)image, bias, y, slabs);
     MS_CHECK_LAUNCH();
     if (p.nsplit > 1) {

@@ -342,7 +342,7 @@ int launch_ct(CtP p, const float* x, const void* image, const float* bias, float
     const long long ntiles = (long long)p.B * p.tiles_per_row * p.mtiles;
     const long long slots = (long long)n_cu[dev] * wgs_per_cu[dev];
     const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
-    ms_note_kernel("k_convt_img<%d, %d, %d, %d>", CIN, S, NTP, WGM);
+    ms_note_kernel(3, "k_convt_img<%d, %d, %d, %d>", CIN, S, NTP, WGM);
     hipLaunchKernelGGL((k_convt_img<CIN, S, NTP, WGM>), grid, dim3(256), lds, s, p, x, (const u32x4*)image, bias, y);
     MS_CHECK_LAUNCH();
     return MS_OK;

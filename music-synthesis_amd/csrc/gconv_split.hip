@@ -910,8 +910,11 @@ int msg3_conv1d_fwd(const ConvP& p, const float* x, const float* w, const float*
     const dim3 grid(gxn, p.groups);
     const bool vec = p.Lin % 4 == 0 && p.pad % 4 == 0 && (((uintptr_t)x) & 15) == 0;
     const bool vout = p.Lout % 4 == 0 && (((uintptr_t)y) & 15) == 0;
-#define MS_G3(RBV, V, VO) \
-    hipLaunchKernelGGL((k_gconv_split_fwd<RBV, V, VO>), grid, dim3(256), 0, s, p, spr, nseg, nunits, x, w, bias, y)
+#define MS_G3(RBV, V, VO)                                                                                                    \
+    do {                                                                                                                     \
+        ms_note_kernel(3, "k_gconv_split_fwd<%d, %s, %s>", RBV, V ? "true" : "false", VO ? "true" : "false");               \
+        hipLaunchKernelGGL((k_gconv_split_fwd<RBV, V, VO>), grid, dim3(256), 0, s, p, spr, nseg, nunits, x, w, bias, y); \
+    } while (0)
 #define MS_G3V(RBV)                                   \
     do {                                              \
         if (vec && vout) MS_G3(RBV, true, true);      \
@@ -946,6 +949,7 @@ int msg3_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, cons
     float* partial = (float*)ws;
     const bool vec = p.Lin % 4 == 0 && p.pad % 4 == 0 && p.Lout % 4 == 0 && (((uintptr_t)x) & 15) == 0 &&
                      (((uintptr_t)gy) & 15) == 0 && (!y_act || (((uintptr_t)y_act) & 15) == 0);
+    ms_note_kernel(3, "k_gconv_split_wgrad<%s>", vec ? "true" : "false");
     if (vec) hipLaunchKernelGGL((k_gconv_split_wgrad<true>), dim3(gxn, p.groups), dim3(256), 0, s, p, x, gy, y_act, partial, stride);
     else hipLaunchKernelGGL((k_gconv_split_wgrad<false>), dim3(gxn, p.groups), dim3(256), 0, s, p, x, gy, y_act, partial, stride);
     MS_CHECK_LAUNCH();
@@ -972,8 +976,11 @@ int msg3_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, co
     const dim3 grid(gxn, p.groups);
     const bool vec = p.Lout % 4 == 0 && (((uintptr_t)gy) & 15) == 0 && (!y_act || (((uintptr_t)y_act) & 15) == 0);
     const bool vout = p.Lin % 4 == 0 && (((uintptr_t)gx) & 15) == 0 && (!gx_add || (((uintptr_t)gx_add) & 15) == 0);
-#define MS_B3(V, VO) \
-    hipLaunchKernelGGL((k_gconv_split_bwd_data<V, VO>), grid, dim3(256), 0, s, p, tiles, nunits, gy, y_act, w, gx_add, gx)
+#define MS_B3(V, VO)                                                                                                              \
+    do {                                                                                                                          \
+        ms_note_kernel(3, "k_gconv_split_bwd_data<%s, %s>", V ? "true" : "false", VO ? "true" : "false");                        \
+        hipLaunchKernelGGL((k_gconv_split_bwd_data<V, VO>), grid, dim3(256), 0, s, p, tiles, nunits, gy, y_act, w, gx_add, gx); \
+    } while (0)
     if (vec && vout) MS_B3(true, true);
     else if (vec) MS_B3(true, false);
     else if (vout) MS_B3(false, true);

@@ -11,10 +11,12 @@
         if (hipGetLastError() != hipSuccess) return MS_ERR_LAUNCH; \
     } while (0)
 
-// Profiling aid: the launchers of the templated dense families note the instantiation they dispatched, in the
-// spelling rocprofv3 prints ("k_conv_rows3p<2, 2, 2, 3, 0, 0, false>"); ms_last_kernel_name() hands it to the
-// caller so that a profiler line can be matched to a layer without re-deriving the dispatch (thread-local).
-void ms_note_kernel(const char* fmt, ...);
+// Profiling aid: while the calling thread is in a profile session (ms_profile_kernels) the launchers of the templated dense
+// families note the instantiation they dispatched, in the spelling rocprofv3 prints ("k_conv_rows3p<2, 2, 2, 3, 0, 0, false>"),
+// and the arithmetic it runs: `products` = matrix-pipe products per fp32 multiply -- 6 (exact three-piece bf16 split), 3
+// (block-scaled two-piece fp16 split), 0 (fp32-input MFMA or vector FMA).  ms_profile_take() hands both to the caller, so a
+// profiler line is matched to a layer and priced on the right pipe without re-deriving the dispatch.  No-op outside a session.
+void ms_note_kernel(int products, const char* fmt, ...);
 
 // Profiling aid (ms_profile_kernels / ms_profile_take, api.hip): while a thread is in profile mode every kernel launch of the
 // library carries a start / stop event pair (hipExtLaunchKernelGGL: the events take the dispatch's own begin / end timestamps,

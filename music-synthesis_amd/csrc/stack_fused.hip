@@ -386,7 +386,7 @@ int launch_stack(StackP p, const float* x, float* y, hipStream_t s) {
     const long long slots = (long long)n_cu[dev] * wgs_per_cu[dev];
     const long long ntiles = (long long)p.B * p.tiles_per_row;
     const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
-    ms_note_kernel("k_stack_fwd<%d, %d, %d>", C, NTP, NW);
+    ms_note_kernel(3, "k_stack_fwd<%d, %d, %d>", C, NTP, NW);
     hipLaunchKernelGGL((k_stack_fwd<C, NTP, NW>), grid, dim3(64 * NW), lds, s, p, x, y);
     MS_CHECK_LAUNCH();
     return MS_OK;

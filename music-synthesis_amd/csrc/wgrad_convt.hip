@@ -244,6 +244,7 @@ int mswt8_bwd_weight(const ConvP& p, const float* x, const float* gy, const floa
         ms_done_on_device(attr_set);
     }
     float* partial = (float*)ws;
+    ms_note_kernel(6, "k_wgrad_convt8_split");
     hipLaunchKernelGGL(k_wgrad_convt8_split, dim3(p.Cout / TCI, p.Cin / TCO, nz), dim3(NT), 2 * IMG, s, q, x, gy,
                        y_act, partial);
     MS_CHECK_LAUNCH();

@@ -247,7 +247,7 @@ int mswt2s_bwd_weight(const ConvP& p, const float* x, const float* gy, const flo
     q.zstride = (long long)p.Cout * p.Cin * 4;
     const int nz = (q.nsteps + q.sps - 1) / q.sps;
     float* partial = (float*)ws;
-    ms_note_kernel("k_wgrad_convt2_short");
+    ms_note_kernel(6, "k_wgrad_convt2_short");
     hipLaunchKernelGGL(k_wgrad_convt2_short, dim3(p.Cout / BM, p.Cin * 4 / BN, nz), dim3(NT), 0, s, q, x, gy, y_act, partial);
     MS_CHECK_LAUNCH();
     return msm_wgrad_reduce(partial, (size_t)q.zstride, nz, (size_t)q.zstride, 0, gw, nullptr, beta, s);

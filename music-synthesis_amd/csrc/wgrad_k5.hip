@@ -287,6 +287,7 @@ int msw5_bwd_weight(const ConvP& p, const float* x, const float* gy, const float
         ms_done_on_device(attr_set);
     }
     float* partial = (float*)ws;
+    ms_note_kernel(6, "k_wgrad_k5_split<%s>", vec ? "true" : "false");
     if (vec) hipLaunchKernelGGL((k_wgrad_k5_split<true>), grid, dim3(256), 2 * IMG, s, q, x, gy, y_act, partial);
     else hipLaunchKernelGGL((k_wgrad_k5_split<false>), grid, dim3(256), 2 * IMG, s, q, x, gy, y_act, partial);
     MS_CHECK_LAUNCH();

@@ -919,7 +919,7 @@ void launch_wrows3_np(const WrPlan& q, const float* x, const float* gy, const fl
     const int tiles_m = q.p.M / (64 * TM);
     if (mp.n > 0) mp.tiles_m = tiles_m;
     const dim3 grid(q.grid.x, (unsigned)((mp.n > 0 ? mp.n : 1) * tiles_m), q.grid.z);
-    ms_note_kernel("k_wgrad_rows3<%d, %d, %s>", TM, NP, GM ? "true" : "false");
+    ms_note_kernel(NP == 2 ? 3 : 6, "k_wgrad_rows3<%d, %d, %s>", TM, NP, GM ? "true" : "false");
     hipLaunchKernelGGL((k_wgrad_rows3<TM, NP, GM>), grid, dim3(512), lds, s, q.p, x, gy, y_act, partial, q.stride_floats, mp);
 }
 

@@ -107,6 +107,14 @@ class WnMultiDesc(ctypes.Structure):            # ms_wn_multi_desc
                 ("rows", _c_int * WN_MULTI_MAX), ("cols", _c_int * WN_MULTI_MAX)]
 
 
+PROFILE_NAME_MAX = 160
+
+
+class ProfileRecord(ctypes.Structure):          # ms_profile_record
+    _fields_ = [("kernels", _c_int), ("products", _c_int), ("device_us", ctypes.c_double),
+                ("kernel", ctypes.c_char * PROFILE_NAME_MAX)]
+
+
 # name -> (restype, argtypes); every symbol include/msynth.h declares
 SIGNATURES = {
     "ms_version": (_c_int, []),
@@ -138,10 +146,8 @@ SIGNATURES = {
     "ms_conv1d_workspace_bytes": (_sz, [ctypes.POINTER(ConvDesc), _c_int]),
     "ms_conv1d_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvDesc), _c_int]),
     "ms_convt1d_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvTDesc), _c_int]),
-    "ms_last_kernel_name": (ctypes.c_char_p, []),
-    "ms_last_kernel_clear": (None, []),
     "ms_profile_kernels": (None, [_c_int]),
-    "ms_profile_take": (_c_int, [ctypes.POINTER(ctypes.c_double)]),
+    "ms_profile_take": (_c_int, [ctypes.POINTER(ProfileRecord)]),
     "ms_convt1d_out_len": (_c_int, [ctypes.POINTER(ConvTDesc)]),
     "ms_convt1d_fwd": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ms_convt1d_bwd_data": (_c_int, [ctypes.POINTER(ConvTDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -310,15 +316,16 @@ def call(name, cost_fn, *args):
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     lib = load()
-    lib.ms_last_kernel_clear()
+    rec = ProfileRecord()
+    lib.ms_profile_take(ctypes.byref(rec))          # (drops what an unrecorded call may have left)
     e0.record()
     rc = fn(*args)
     e1.record()
     check(rc, name)
     cost = cost_fn() if cost_fn else {}
-    noted = lib.ms_last_kernel_name().decode()
-    if noted:                   # the instantiation the launcher really dispatched (split-K aware)
+    check(lib.ms_profile_take(ctypes.byref(rec)), "ms_profile_take")
+    noted = rec.kernel.decode()
+    if noted:                   # the instantiation the launcher really dispatched (split-K aware) and its arithmetic
         cost["kernel"] = noted
-    dev_us = ctypes.c_double(0.0)
-    nk = lib.ms_profile_take(ctypes.byref(dev_us))
-    PROFILE.append((name, cost, e0, e1, dev_us.value, nk))
+    cost["products"] = int(rec.products)
+    PROFILE.append((name, cost, e0, e1, float(rec.device_us), int(rec.kernels)))

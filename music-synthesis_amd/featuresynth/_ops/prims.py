@@ -272,7 +272,8 @@ def atom_fwd(x, image, b0, b1, dil, save, signs=False):
 
         def cost_s():
             c0 = W.conv_cost(B, C, Lg, C, 3, 1, dil, dil, 1, "fwd")
-            return {"flops": 2 * c0["flops"], "bytes": 4 * x.numel() * 4 + 4 * 2 * (3 * C * C + C),
+            # moves x (read), y and t (written) and two sign-word tensors of 1 / 32 of an fp32 tensor each
+            return {"flops": 2 * c0["flops"], "bytes": int(4 * x.numel() * (3 + 1 / 16)) + 4 * 2 * (3 * C * C + C),
                     "geom": (B, C, Lg, C, 3, 1, dil, 1)}
         L.call("ms_residual_atom_fwd_signs", cost_s, d, x.data_ptr(), image.data_ptr(), b0.data_ptr(), b1.data_ptr(),
                y.data_ptr(), t.data_ptr(), st.data_ptr(), su.data_ptr(), L.ptr(amax), L.stream())
@@ -353,7 +354,8 @@ def atom_bwd_data(g, u, t, image_bwd, dil):
 
         def cost_s():
             c0 = W.conv_cost(B, C, Lg, C, 3, 1, dil, dil, 1, "bwd_data")
-            return {"flops": 2 * c0["flops"], "bytes": 4 * g.numel() * 5 + 4 * 2 * 3 * C * C,
+            # moves g (read), gt and gx (written) and the sign words of u and t (1 / 32 of an fp32 tensor each)
+            return {"flops": 2 * c0["flops"], "bytes": int(4 * g.numel() * (3 + 1 / 16)) + 4 * 2 * 3 * C * C,
                     "geom": (B, C, Lg, C, 3, 1, dil, 1)}
         L.call("ms_residual_atom_bwd_data_signs", cost_s, d, g.data_ptr(), u.data_ptr(), st.data_ptr(), image_bwd.data_ptr(),
                gt.data_ptr(), gx.data_ptr(), L.ptr(amax), L.stream())

@@ -174,6 +174,80 @@ def g_step_launches(B, mels=80, T=32):
     return out
 
 
+# ---- the byte model of the program AS SCHEDULED (r05): the layer-granular model above prices every conv as a launch of its
+# own (SURVEY.md 8(d)'s contract: 96 atom convs per pair reading and writing whole tensors).  What runs fuses each ResidualAtom
+# into one launch per pass (csrc/atom_fused.hip: the value between its two convs never leaves the chip), whole stacks into one
+# launch where nothing is saved (csrc/stack_fused.hip, <= 64 channels), keeps the LeakyReLU masks of a training atom as one bit
+# per element (sign words: 1 / 32 of an fp32 tensor each for u and t), runs the discriminator once over [fake; real] in the
+# D-step and fuses the 18-map L1 loss with its gradient.  Same FLOPs, fewer necessary bytes.
+SIGN_WORDS = 1.0 / 32        # one sign-word tensor relative to the fp32 tensor it stands for
+STACK_FUSED_MAX_C = 64       # P.stack_supported: the one-launch inference stack takes 32 / 64 channels
+
+
+def _atom_fused(B, C, L, d, mode, out):
+    n = B * C * L
+    c0 = conv_cost(B, C, L, C, 3, 1, d, d, 1, "fwd")
+    fl, wb = 2 * c0["flops"], F32 * 2 * (3 * C * C + C)
+    if mode == "fwd":            # x in, y out
+        out.append(("atom%d.fwd" % C, {"flops": fl, "bytes": int(F32 * n * 2) + wb}))
+    elif mode == "fwd_train":    # x in; y, t out; sign words of u and t
+        out.append(("atom%d.fwd_train" % C, {"flops": fl, "bytes": int(F32 * n * (3 + 2 * SIGN_WORDS)) + wb}))
+    else:                        # g in, sign words of u and t in; gt, gx out -- then the two weight gradients
+        out.append(("atom%d.bwd_data" % C, {"flops": fl, "bytes": int(F32 * n * (3 + 2 * SIGN_WORDS)) + wb}))
+        for nm in ("conv1", "conv0"):       # operands (t, g) / (x, gt) + one sign-word tensor; gw out
+            out.append(("atom%d.%s.bwd_weight" % (C, nm),
+                        {"flops": c0["flops"], "bytes": int(F32 * n * (2 + SIGN_WORDS)) + wb // 2}))
+
+
+def fused_generator_launches(B, mels, T, mode):
+    """generator_launches with the atoms / stacks as the fused launches that run."""
+    out = []
+    for name, c in generator_launches(B, mels, T, mode):
+        if not name.startswith("atom"):
+            out.append((name, c))
+    # atoms: same walk as generator_launches
+    L = T
+    atoms = []
+    for cin, cout, k, s, p in G_UPS:
+        L = (L - 1) * s - 2 * p + k
+        if mode == "fwd" and cout <= STACK_FUSED_MAX_C:
+            n = B * cout * L
+            fl = sum(2 * conv_cost(B, cout, L, cout, 3, 1, d, d, 1, "fwd")["flops"] for d in (1, 3, 9))
+            atoms.append(("stack%d.fwd" % cout, {"flops": fl, "bytes": F32 * n * 2 + 3 * F32 * 2 * (3 * cout * cout + cout)}))
+            continue
+        for d in ((1, 3, 9) if mode != "bwd" else (9, 3, 1)):
+            _atom_fused(B, cout, L, d, mode, atoms)
+    return out + atoms
+
+
+def fused_d_step_launches(B, mels=80, T=32):
+    L0 = T * 256
+    out = fused_generator_launches(B, mels, T, "fwd")
+    out += discriminator_launches(2 * B, L0, "fwd")                      # one pass over [fake; real]
+    out += discriminator_launches(2 * B, L0, "bwd", need_gx=False)
+    out += discriminator_wgrad_launches(2 * B, L0)
+    nparam = 5637953
+    out.append(("adam.D", {"flops": 12 * nparam, "bytes": 7 * F32 * nparam}))
+    return out
+
+
+def fused_g_step_launches(B, mels=80, T=32):
+    L0 = T * 256
+    out = fused_generator_launches(B, mels, T, "fwd_train")
+    out += discriminator_launches(B, L0, "fwd")
+    out += discriminator_launches(B, L0, "fwd")
+    fe = feature_elems(B, L0)
+    out.append(("loss.l1.fwd_bwd", {"flops": 5 * fe, "bytes": 3 * F32 * fe}))      # r, f in; d loss / d f out: one pass
+    out += discriminator_launches(B, L0, "bwd", need_gx=True, feat_grads=True)
+    out += fused_generator_launches(B, mels, T, "bwd")
+    nparam = 4519937 + (mels - 80) * 512 * 7
+    out.append(("adam.G", {"flops": 12 * nparam, "bytes": 7 * F32 * nparam}))
+    return out
+
+
+SURVEY_MB_PER_ELEMENT_PER_CALL = 135.0      # SURVEY.md 8(d): mean necessary bytes per batch element per trainer call
+
+
 # ---- the weight-normed MelGAN (SURVEY.md 8(f) row 1, experiment/realmelgan.py:15-181): same discriminator geometry, a generator of
 # ResnetBlocks -- shortcut1x1(x) + conv1x1(lrelu(conv_k3_dil(reflpad(lrelu(x))))) -- instead of ResidualAtoms.  Weight
 # normalisation (w = g v / |v| per output channel) is O(parameters) per pass and not priced.

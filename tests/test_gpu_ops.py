@@ -4,6 +4,8 @@ against the golden fixtures (imported reference) and the CPU oracle on seeded in
 Tolerances: all arithmetic is fp32; forward results must be within 1e-4 rel-L2 of the
 reference (the north-star bound for the generator output; single ops land at ~1e-6),
 gradients within 1e-3 rel-L2 per tensor."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -582,9 +584,15 @@ def test_profile_mode_reports_device_time():
     y, _ = P.conv1d_fwd(x, w, None, d, lo)
     rec = L.profile_end()
     assert len(rec) == 1 and rec[0][1]["kernels"] >= 1
+    # the record names what was dispatched and the arithmetic it ran (products per fp32 multiply: 0 / 3 / 6)
+    assert rec[0][1]["kernel"].startswith("k_conv_") and rec[0][1]["products"] in (0, 3, 6)
     assert 0.5e-3 < rec[0][2] < 5.0 and rec[0][2] <= rec[0][1]["event_ms"] * 1.05       # milliseconds; device <= event reading
     assert torch.equal(y, ref)
-    assert L.load().ms_profile_take(None) == 0           # off again: nothing is counted
+    P.conv1d_fwd(x, w, None, d, lo)
+    after = L.ProfileRecord()
+    assert L.load().ms_profile_take(ctypes.byref(after)) == 0
+    assert after.kernels == 0 and after.kernel == b"" and after.device_us == 0.0     # session closed: launches record nothing
+    assert L.load().ms_profile_take(None) < 0                                        # the record is an out-parameter
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):                            # and launches are capturable again
         y2, _ = P.conv1d_fwd(x, w, None, d, lo)
