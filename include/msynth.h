@@ -92,6 +92,43 @@ int ms_conv1d_bwd_weight(const ms_conv1d_desc* d, const float* x, const float* g
                          size_t workspace_bytes, ms_stream_t stream);
 
 /*
+ * One conv layer applied, with the SAME weights, to up to MS_CONV_PARTS_MAX inputs of different batch size / length -- the
+ * reference's multi-scale discriminator runs one FullDiscriminator on x, pool(x), pool(pool(x)) (discriminator/melgan.py:13-27,
+ * full.py:13-22).  Three calls of ms_conv1d_* give the same results; here the parts share ONE launch where a kernel takes them
+ * (the grouped k41 / stride-4 layers, the 1024 -> 1024 k5 layer on its weight image): the pooled scales are too small to fill
+ * the chip on their own, and the weight gradient of the shared parameters is summed over the parts by the launch's one
+ * reduction instead of by extra adds.  Where no parts kernel applies the entry points run the parts one after the other on
+ * `stream` (ms_conv1d_parts_launches tells which).  d->B and d->Lin are ignored: they are taken per part.
+ *   fwd         y[i] = act(conv(x[i], w) + bias);   image: the layer's forward weight image (ms_conv1d_img_pack) or NULL
+ *   bwd_data    gx[i] = conv_backward_input(gy[i] * act'(y_act[i]), w) (+ gx_add[i]);   image_bwd likewise
+ *   bwd_weight  gw = beta gw + sum_i conv_backward_weight(x[i], gy[i] * act'(y_act[i])), gb likewise
+ * Pointers of unused roles / parts may be NULL.
+ */
+#define MS_CONV_PARTS_MAX 3
+typedef struct ms_conv1d_parts {
+    int32_t count;                               /* 1 .. MS_CONV_PARTS_MAX */
+    int32_t reserved;
+    int32_t B[MS_CONV_PARTS_MAX];                /* batch rows of part i */
+    int32_t Lin[MS_CONV_PARTS_MAX];              /* input length of part i */
+    const float* x[MS_CONV_PARTS_MAX];           /* fwd, bwd_weight: (B[i], Cin, Lin[i]) */
+    float* y[MS_CONV_PARTS_MAX];                 /* fwd: (B[i], Cout, Lout[i]) */
+    const float* gy[MS_CONV_PARTS_MAX];          /* bwd_data, bwd_weight: gradient w.r.t. the output */
+    const float* y_act[MS_CONV_PARTS_MAX];       /* bwd_data, bwd_weight: the saved output (ignored when d->act is NONE) */
+    const float* gx_add[MS_CONV_PARTS_MAX];      /* bwd_data: optional addend */
+    float* gx[MS_CONV_PARTS_MAX];                /* bwd_data: (B[i], Cin, Lin[i]) */
+} ms_conv1d_parts;
+/* which: 0 fwd, 1 bwd_data, 2 bwd_weight.  -> number of kernel launch groups the call issues: 1 = one launch takes all
+ * parts, count = part by part; < 0: an ms_status error (invalid description). */
+int ms_conv1d_parts_launches(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, int which, int with_image);
+size_t ms_conv1d_parts_workspace_bytes(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, int which, int with_image);
+int ms_conv1d_parts_fwd(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, const float* w, const float* bias,
+                        const void* image, void* workspace, size_t workspace_bytes, ms_stream_t stream);
+int ms_conv1d_parts_bwd_data(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, const float* w, const void* image_bwd,
+                             void* workspace, size_t workspace_bytes, ms_stream_t stream);
+int ms_conv1d_parts_bwd_weight(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, float* gw, float* gb, float beta,
+                               void* workspace, size_t workspace_bytes, ms_stream_t stream);
+
+/*
  * `count` independent ms_conv1d_bwd_weight calls in one entry.  The six k3 convs of a ResidualStack
  * (util/modules.py:391-405: same channels and length, dilations 1/3/9) are issued as ONE launch pair when
  * their geometry agrees -- a single layer's weight gradient leaves every workgroup a contraction too short

@@ -296,6 +296,121 @@ int ms_conv1d_bwd_weight(const ms_conv1d_desc* d, const float* x, const float* g
                                         workspace_bytes, s);
 }
 
+// ---- one layer over several inputs (ms_conv1d_parts): a parts kernel where one applies, else part by part
+namespace {
+
+bool parts_ok(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, ConvP* c) {
+    if (!d || !parts || parts->count < 1 || parts->count > MS_CONV_PARTS_MAX) return false;
+    ms_conv1d_desc d0 = *d;
+    for (int i = 0; i < parts->count; ++i) {
+        d0.B = parts->B[i]; d0.Lin = parts->Lin[i];
+        ConvP p;
+        if (!make_conv(&d0, &p)) return false;
+        if (i == 0) *c = p;
+    }
+    return true;
+}
+
+ms_conv1d_desc part_desc(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, int i) {
+    ms_conv1d_desc di = *d;
+    di.B = parts->B[i]; di.Lin = parts->Lin[i];
+    return di;
+}
+
+// 1: a parts kernel takes the call; 0: part by part
+int parts_kernel(const ConvP& c, const ms_conv1d_parts* parts, int which, bool with_image) {
+    if (parts->count < 2 || c.in_act) return 0;
+    if (which == 0) return (with_image && ms5_parts_applicable(c, parts, false)) || msg3_parts_fwd_applicable(c, parts);
+    if (which == 1) return (with_image && ms5_parts_applicable(c, parts, true)) || msg3_parts_bwd_data_applicable(c, parts);
+    return msg3_parts_bwd_weight_applicable(c, parts);
+}
+
+}  // namespace
+
+int ms_conv1d_parts_launches(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, int which, int with_image) {
+    ConvP c;
+    if (!parts_ok(d, parts, &c) || which < 0 || which > 2) return MS_ERR_INVALID_ARG;
+    return parts_kernel(c, parts, which, with_image != 0) ? 1 : parts->count;
+}
+
+size_t ms_conv1d_parts_workspace_bytes(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, int which, int with_image) {
+    ConvP c;
+    if (!parts_ok(d, parts, &c) || which < 0 || which > 2) return 0;
+    if (parts_kernel(c, parts, which, with_image != 0)) return which == 2 ? msg3_parts_bwd_weight_ws(c, parts) : 0;
+    size_t n = 0;
+    for (int i = 0; i < parts->count; ++i) {
+        const ms_conv1d_desc di = part_desc(d, parts, i);
+        size_t m = ms_conv1d_workspace_bytes(&di, which);
+        if (with_image && which < 2 && ms_conv1d_img_bytes(&di)) m = ms_conv1d_img_workspace_bytes(&di, which);
+        if (m > n) n = m;
+    }
+    return n;
+}
+
+int ms_conv1d_parts_fwd(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, const float* w, const float* bias,
+                        const void* image, void* workspace, size_t workspace_bytes, ms_stream_t stream) {
+    ConvP c;
+    if (!parts_ok(d, parts, &c) || (!w && !image)) return MS_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (parts->count >= 2 && !c.in_act) {
+        if (image && ms5_parts_applicable(c, parts, false)) return ms5_parts_fwd(c, parts, image, bias, s);
+        if (w && msg3_parts_fwd_applicable(c, parts)) return msg3_parts_fwd(c, parts, w, bias, s);
+    }
+    for (int i = 0; i < parts->count; ++i) {
+        const ms_conv1d_desc di = part_desc(d, parts, i);
+        int rc;
+        if (image && ms_conv1d_img_bytes(&di))
+            rc = ms_conv1d_img_fwd(&di, parts->x[i], image, bias, parts->y[i], workspace, workspace_bytes, stream);
+        else if (w)
+            rc = ms_conv1d_fwd(&di, parts->x[i], w, bias, nullptr, parts->y[i], nullptr, workspace, workspace_bytes, stream);
+        else
+            rc = MS_ERR_UNSUPPORTED;
+        if (rc != MS_OK) return rc;
+    }
+    return MS_OK;
+}
+
+int ms_conv1d_parts_bwd_data(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, const float* w, const void* image_bwd,
+                             void* workspace, size_t workspace_bytes, ms_stream_t stream) {
+    ConvP c;
+    if (!parts_ok(d, parts, &c) || (!w && !image_bwd)) return MS_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (parts->count >= 2 && !c.in_act) {
+        if (image_bwd && ms5_parts_applicable(c, parts, true)) return ms5_parts_bwd_data(c, parts, image_bwd, s);
+        if (w && msg3_parts_bwd_data_applicable(c, parts)) return msg3_parts_bwd_data(c, parts, w, s);
+    }
+    for (int i = 0; i < parts->count; ++i) {
+        const ms_conv1d_desc di = part_desc(d, parts, i);
+        const float* ya = d->act == MS_ACT_NONE ? nullptr : parts->y_act[i];
+        int rc;
+        if (image_bwd && ms_conv1d_img_bytes(&di))
+            rc = ms_conv1d_img_bwd_data(&di, parts->gy[i], ya, image_bwd, parts->gx_add[i], parts->gx[i], workspace,
+                                        workspace_bytes, stream);
+        else if (w)
+            rc = ms_conv1d_bwd_data(&di, parts->gy[i], ya, w, parts->gx_add[i], parts->gx[i], workspace, workspace_bytes, stream);
+        else
+            rc = MS_ERR_UNSUPPORTED;
+        if (rc != MS_OK) return rc;
+    }
+    return MS_OK;
+}
+
+int ms_conv1d_parts_bwd_weight(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, float* gw, float* gb, float beta,
+                               void* workspace, size_t workspace_bytes, ms_stream_t stream) {
+    ConvP c;
+    if (!parts_ok(d, parts, &c) || !gw || (beta != 0.f && beta != 1.f)) return MS_ERR_INVALID_ARG;
+    if (parts->count >= 2 && !c.in_act && msg3_parts_bwd_weight_applicable(c, parts))
+        return msg3_parts_bwd_weight(c, parts, gw, gb, beta, workspace, workspace_bytes, (hipStream_t)stream);
+    for (int i = 0; i < parts->count; ++i) {             // the parts' gradients accumulate in order on the one stream
+        const ms_conv1d_desc di = part_desc(d, parts, i);
+        const float* ya = d->act == MS_ACT_NONE ? nullptr : parts->y_act[i];
+        const int rc = ms_conv1d_bwd_weight(&di, parts->x[i], parts->gy[i], ya, gw, gb, i == 0 ? beta : 1.f, workspace,
+                                            workspace_bytes, stream);
+        if (rc != MS_OK) return rc;
+    }
+    return MS_OK;
+}
+
 static int multi_convs(const ms_wgrad_multi_desc* d, ConvP* cs) {
     if (!d || d->count <= 0 || d->count > MS_WGRAD_MULTI_MAX) return 0;
     for (int i = 0; i < d->count; ++i)

@@ -136,19 +136,21 @@ struct C5P {
     long long zstride;        // floats per slab
 };
 
+extern __shared__ __attribute__((aligned(16))) unsigned char smem5[];
+
 // MODE 0: forward (X = x); MODE 1: backward data (X = gy, multiplied on load by act'(Xact) when Xact != nullptr)
+// bx: the workgroup's batch-row tile (blockIdx.x in a single launch, its offset within the part's range in a parts launch)
 template <int MODE, int NP>
-__global__ __launch_bounds__(512, 2) void k_conv5_img(C5P p, const float* __restrict__ X, const float* __restrict__ Xact,
-                                                     const u32x4* __restrict__ IMG, const float* __restrict__ bias,
-                                                     const float* __restrict__ add, float* __restrict__ Y,
-                                                     float* __restrict__ slabs) {
+__device__ __forceinline__ void conv5_body(const C5P& p, const float* __restrict__ X, const float* __restrict__ Xact,
+                                           const u32x4* __restrict__ IMG, const float* __restrict__ bias,
+                                           const float* __restrict__ add, float* __restrict__ Y,
+                                           float* __restrict__ slabs, int bx) {
     constexpr int XRS = xrs<NP>();
     constexpr bool SC = NP == 2;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem5[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;                   // 2 x 4 waves: 32 rows x 64 columns each
-    const int L = p.L, b0 = blockIdx.x * p.R, m0 = blockIdx.y * 64;
+    const int L = p.L, b0 = bx * p.R, m0 = blockIdx.y * 64;
     const int cbeg = blockIdx.z * p.cks;
     const int cend = cbeg + p.cks < p.CK ? cbeg + p.cks : p.CK;
     const int nchunks = (cend - cbeg) / 16;
@@ -385,6 +387,51 @@ __global__ __launch_bounds__(512, 2) void k_conv5_img(C5P p, const float* __rest
         }
 }
 
+template <int MODE, int NP>
+__global__ __launch_bounds__(512, 2) void k_conv5_img(C5P p, const float* __restrict__ X, const float* __restrict__ Xact,
+                                                     const u32x4* __restrict__ IMG, const float* __restrict__ bias,
+                                                     const float* __restrict__ add, float* __restrict__ Y,
+                                                     float* __restrict__ slabs) {
+    conv5_body<MODE, NP>(p, X, Xact, IMG, bias, add, Y, slabs, blockIdx.x);
+}
+
+// The layer over up to three inputs of different batch size / row length in ONE launch (the shared discriminator's three
+// scales: rows of 32 / 17 / 9 samples, reference discriminator/melgan.py:13-27).  Batch-row tiles [bx0[i], bx0[i + 1]) belong
+// to part i and run exactly as a launch of their own would, with that part's tile geometry; no split-K (the parts together
+// fill the chip: 16 x (8 + 5 + 3) = 256 workgroups at B = 64), so every tile applies its epilogue itself and there is no
+// slab traffic and no finish kernel.
+struct C5Parts {
+    int count, bx0[MS_CONV_PARTS_MAX + 1];
+    int B[MS_CONV_PARTS_MAX], L[MS_CONV_PARTS_MAX], R[MS_CONV_PARTS_MAX], SS[MS_CONV_PARTS_MAX], PX[MS_CONV_PARTS_MAX],
+        NV[MS_CONV_PARTS_MAX], NVG[MS_CONV_PARTS_MAX];
+    const float* X[MS_CONV_PARTS_MAX];
+    const float* Xact[MS_CONV_PARTS_MAX];
+    const float* add[MS_CONV_PARTS_MAX];
+    float* Y[MS_CONV_PARTS_MAX];
+};
+
+template <int MODE, int NP>
+__global__ __launch_bounds__(512, 2) void k_conv5_img_parts(C5P p, C5Parts q, const u32x4* __restrict__ IMG,
+                                                           const float* __restrict__ bias) {
+    // (the part's fields are picked with compile-time indices: a run-time index into the pointer arrays of a by-value kernel
+    //  argument crashes this compiler's kernel-argument promotion)
+    int bx0 = 0;
+    const float* X = q.X[0];
+    const float* Xact = q.Xact[0];
+    const float* add = q.add[0];
+    float* Y = q.Y[0];
+    p.B = q.B[0]; p.L = q.L[0]; p.R = q.R[0]; p.SS = q.SS[0]; p.PX = q.PX[0]; p.NV = q.NV[0]; p.NVG = q.NVG[0];
+#pragma unroll
+    for (int k = 1; k < MS_CONV_PARTS_MAX; ++k)
+        if (k < q.count && (int)blockIdx.x >= q.bx0[k]) {
+            bx0 = q.bx0[k];
+            X = q.X[k]; Xact = q.Xact[k]; add = q.add[k]; Y = q.Y[k];
+            p.B = q.B[k]; p.L = q.L[k]; p.R = q.R[k]; p.SS = q.SS[k]; p.PX = q.PX[k]; p.NV = q.NV[k]; p.NVG = q.NVG[k];
+        }
+    // (nsplit == 1: the slab pointer is never used; a literal nullptr there crashes the compiler's inliner, ROCm 7.2)
+    conv5_body<MODE, NP>(p, X, Xact, IMG, bias, add, Y, Y, (int)blockIdx.x - bx0);
+}
+
 // y = act(sum_z slab_z + bias[channel]) (+ add), slabs summed in slice order
 __global__ __launch_bounds__(256) void k_conv5_finish(const float* __restrict__ slabs, int ns, long long zstride,
                                                      const float* __restrict__ bias, int M, int L, int act, float slope,
@@ -489,6 +536,48 @@ int c5_launch(const C5P& p, const float* X, const float* Xact, const void* image
     return c5_launch_np<MODE, 2>(p, X, Xact, image, bias, add, Y, ws, ws_bytes, s);
 }
 
+bool c5_parts_geometry(const ConvP& c, const ms_conv1d_parts* parts, bool backward, C5P* p, C5Parts* q) {
+    if (!parts || parts->count < 2 || parts->count > MS_CONV_PARTS_MAX) return false;
+    q->count = parts->count;
+    q->bx0[0] = 0;
+    for (int i = 0; i < parts->count; ++i) {
+        ConvP ci = c;
+        ci.B = parts->B[i]; ci.Lin = ci.Lout = parts->Lin[i];
+        C5P pi;
+        if (ci.B <= 0 || ci.Lin <= 0 || !c5_geometry(ci, backward, &pi)) return false;
+        if (i == 0) *p = pi;
+        q->B[i] = pi.B; q->L[i] = pi.L; q->R[i] = pi.R; q->SS[i] = pi.SS; q->PX[i] = pi.PX; q->NV[i] = pi.NV; q->NVG[i] = pi.NVG;
+        q->bx0[i + 1] = q->bx0[i] + (pi.B + pi.R - 1) / pi.R;
+    }
+    for (int i = parts->count; i < MS_CONV_PARTS_MAX; ++i) {
+        q->B[i] = q->L[i] = q->R[i] = q->SS[i] = q->PX[i] = q->NV[i] = q->NVG[i] = 0;
+        q->bx0[i + 1] = q->bx0[parts->count];
+        q->X[i] = q->Xact[i] = q->add[i] = nullptr; q->Y[i] = nullptr;
+    }
+    p->nsplit = 1;
+    p->cks = p->CK;
+    // without split-K the tiles alone must occupy the chip: at least one workgroup for every second CU
+    return q->bx0[parts->count] * (p->M / 64) >= 128;
+}
+
+template <int MODE, int NP>
+int c5_parts_launch_np(const C5P& p, const C5Parts& q, const void* image, const float* bias, hipStream_t s) {
+    int pxmax = 0;
+    for (int i = 0; i < q.count; ++i) pxmax = q.PX[i] > pxmax ? q.PX[i] : pxmax;
+    const size_t lds = (size_t)2 * pxmax * xrs<NP>() + 2 * R_MAX * sizeof(float);
+    static unsigned long long attr_set = 0;
+    if (ms_first_on_device(attr_set)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_img_parts<MODE, NP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PX_MAX * xrs<NP>() + 2 * R_MAX * sizeof(float));
+        ms_done_on_device(attr_set);
+    }
+    const dim3 grid((unsigned)q.bx0[q.count], (unsigned)(p.M / 64), 1);
+    ms_note_kernel(NP == 2 ? 3 : 6, "k_conv5_img_parts<%d, %d>", MODE, NP);
+    hipLaunchKernelGGL((k_conv5_img_parts<MODE, NP>), grid, dim3(512), lds, s, p, q, (const u32x4*)image, bias);
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
 bool to_convp(const ms_conv1d_desc* d, ConvP* p) {
     if (!d || d->B <= 0 || d->Cin <= 0 || d->Lin <= 0 || d->Cout <= 0 || d->K <= 0 || d->stride <= 0 || d->pad < 0 || d->dil <= 0 ||
         d->groups <= 0)
@@ -501,6 +590,38 @@ bool to_convp(const ms_conv1d_desc* d, ConvP* p) {
 }
 
 }  // namespace
+
+// parts launches of the k5 layer (api.hip: ms_conv1d_parts_*); c: the layer with any B / Lin
+bool ms5_parts_applicable(const ConvP& c, const ms_conv1d_parts* parts, bool backward) {
+    C5P p;
+    C5Parts q;
+    return c5_enabled() && c5_parts_geometry(c, parts, backward, &p, &q);
+}
+
+int ms5_parts_fwd(const ConvP& c, const ms_conv1d_parts* parts, const void* image, const float* bias, hipStream_t s) {
+    C5P p;
+    C5Parts q;
+    if (!c5_parts_geometry(c, parts, false, &p, &q)) return MS_ERR_UNSUPPORTED;
+    if (!image || (((uintptr_t)image) & 15) || (bias && (((uintptr_t)bias) & 15))) return MS_ERR_INVALID_ARG;
+    for (int i = 0; i < q.count; ++i) {
+        if (!parts->x[i] || !parts->y[i]) return MS_ERR_INVALID_ARG;
+        q.X[i] = parts->x[i]; q.Xact[i] = nullptr; q.add[i] = nullptr; q.Y[i] = parts->y[i];
+    }
+    return c5_np() == 3 ? c5_parts_launch_np<0, 3>(p, q, image, bias, s) : c5_parts_launch_np<0, 2>(p, q, image, bias, s);
+}
+
+int ms5_parts_bwd_data(const ConvP& c, const ms_conv1d_parts* parts, const void* image_bwd, hipStream_t s) {
+    C5P p;
+    C5Parts q;
+    if (!c5_parts_geometry(c, parts, true, &p, &q)) return MS_ERR_UNSUPPORTED;
+    if (!image_bwd || (((uintptr_t)image_bwd) & 15)) return MS_ERR_INVALID_ARG;
+    for (int i = 0; i < q.count; ++i) {
+        if (!parts->gy[i] || !parts->gx[i]) return MS_ERR_INVALID_ARG;
+        q.X[i] = parts->gy[i]; q.Xact[i] = c.act == MS_ACT_NONE ? nullptr : parts->y_act[i]; q.add[i] = parts->gx_add[i];
+        q.Y[i] = parts->gx[i];
+    }
+    return c5_np() == 3 ? c5_parts_launch_np<1, 3>(p, q, image_bwd, nullptr, s) : c5_parts_launch_np<1, 2>(p, q, image_bwd, nullptr, s);
+}
 
 extern "C" {
 

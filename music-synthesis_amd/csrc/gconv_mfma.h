@@ -34,3 +34,17 @@ bool msg3_bwd_data_applicable(const ConvP& p);
 const char* msg3_bwd_data_name(const ConvP& p);
 int msg3_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, const float* w,
                          const float* gx_add, float* gx, hipStream_t s);
+
+// parts launches (gconv_split.hip): one layer over the discriminator's scales, include/msynth.h ms_conv1d_parts
+bool msg3_parts_fwd_applicable(const ConvP& c, const ms_conv1d_parts* parts);
+int msg3_parts_fwd(const ConvP& c, const ms_conv1d_parts* parts, const float* w, const float* bias, hipStream_t s);
+bool msg3_parts_bwd_data_applicable(const ConvP& c, const ms_conv1d_parts* parts);
+int msg3_parts_bwd_data(const ConvP& c, const ms_conv1d_parts* parts, const float* w, hipStream_t s);
+bool msg3_parts_bwd_weight_applicable(const ConvP& c, const ms_conv1d_parts* parts);
+size_t msg3_parts_bwd_weight_ws(const ConvP& c, const ms_conv1d_parts* parts);
+int msg3_parts_bwd_weight(const ConvP& c, const ms_conv1d_parts* parts, float* gw, float* gb, float beta, void* ws,
+                          size_t ws_bytes, hipStream_t s);
+// the k5 layer over the scales (conv5_img.hip)
+bool ms5_parts_applicable(const ConvP& c, const ms_conv1d_parts* parts, bool backward);
+int ms5_parts_fwd(const ConvP& c, const ms_conv1d_parts* parts, const void* image, const float* bias, hipStream_t s);
+int ms5_parts_bwd_data(const ConvP& c, const ms_conv1d_parts* parts, const void* image_bwd, hipStream_t s);

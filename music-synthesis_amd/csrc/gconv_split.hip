@@ -104,14 +104,20 @@ struct GF {
 // (ds_read2_b64), LeakyReLU is mul + max.  (A software-pipelined variant -- next unit split and written to a
 // second LDS image between the tap-group steps, two register sets of loads in flight -- measured 5-10 %
 // SLOWER at 4-8 units per wave: its longer prologue costs more than the in-wave overlap returns; removed.)
+// All kernels of this file take their LDS from ONE dynamic array: a "parts" kernel (below) runs the bodies of up to three
+// instantiations in one launch, one per workgroup range, and they must not each own a static allocation.
+extern __shared__ __attribute__((aligned(16))) unsigned char g3_smem[];
+
+// bx / nbx: this workgroup's index and the number of workgroups that share the (part of the) problem -- blockIdx.x and
+// gridDim.x in a single launch, offsets into a workgroup range in a parts launch.
 template <int RB, bool VEC, bool VOUT>
-__global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, int nseg, int nunits,
-                                                           const float* __restrict__ x,
-                                                           const float* __restrict__ w,
-                                                           const float* __restrict__ bias,
-                                                           float* __restrict__ y) {
+__device__ __forceinline__ void gconv_fwd_body(const ConvP& p, int spr, int nseg, int nunits,
+                                               const float* __restrict__ x,
+                                               const float* __restrict__ w,
+                                               const float* __restrict__ bias,
+                                               float* __restrict__ y, int bx, int nbx) {
     using C = GF<RB>;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * C::WAVE_BYTES];
+    unsigned char* const lds = g3_smem;               // 4 * C::WAVE_BYTES
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = blockIdx.y;
     const int n = lane & 15, kg = lane >> 4;
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, in
         it_qs[i] = act ? 4 * Q + sg : -4;
         it_c[i] = act ? (unsigned)(ci * p.Lin + 4 * Q) * 4u : 0xF0000000u;
     }
-    const int wstride = gridDim.x * 4;
+    const int wstride = nbx * 4;
     const int sstride = wstride * RB;
     const int dsb = sstride / spr, dst = sstride - dsb * spr;     // segment index += sstride, in (b, ts) form
     struct Cur { int seg, b, ts; };
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, in
         *reinterpret_cast<uint2*>(d + C::PIECE_BYTES) = make_uint2(l0, l1);
     };
 
-    int unit = blockIdx.x * 4 + wid;
+    int unit = bx * 4 + wid;
     Cur ld, ep;
     ld.seg = unit * RB; ld.b = ld.seg / spr; ld.ts = ld.seg - ld.b * spr;
     ep = ld;
@@ -344,6 +350,55 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, in
     }
 }
 
+template <int RB, bool VEC, bool VOUT>
+__global__ __launch_bounds__(256, 2) void k_gconv_split_fwd(ConvP p, int spr, int nseg, int nunits,
+                                                           const float* __restrict__ x,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ bias,
+                                                           float* __restrict__ y) {
+    gconv_fwd_body<RB, VEC, VOUT>(p, spr, nseg, nunits, x, w, bias, y, blockIdx.x, gridDim.x);
+}
+
+// The SAME layer (weights, bias) over up to three inputs of different batch size / length in one launch: the shared
+// discriminator on x, pool(x), pool(pool(x)) (reference discriminator/melgan.py:13-27).  Workgroups [bx0[i], bx0[i + 1]) run
+// part i exactly as a launch of its own would.  Part 0 is the full-rate scale (16-byte shaped: checked by the launcher),
+// the pooled parts have odd lengths and take the dword paths.
+struct G3Parts {
+    ConvP p;                         // the layer; B / Lin / Lout are taken per part
+    int count, bx0[MS_CONV_PARTS_MAX + 1];
+    int B[MS_CONV_PARTS_MAX], Lin[MS_CONV_PARTS_MAX], Lout[MS_CONV_PARTS_MAX];
+    int u0[MS_CONV_PARTS_MAX], u1[MS_CONV_PARTS_MAX], u2[MS_CONV_PARTS_MAX];       // per-part launch integers of the pass
+    const float* a[MS_CONV_PARTS_MAX];
+    const float* b[MS_CONV_PARTS_MAX];
+    const float* c[MS_CONV_PARTS_MAX];
+    float* o[MS_CONV_PARTS_MAX];
+};
+
+__device__ __forceinline__ int g3_part_of(const G3Parts& q, int bx) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < MS_CONV_PARTS_MAX; ++k)
+        if (k < q.count && bx >= q.bx0[k]) i = k;
+    return __builtin_amdgcn_readfirstlane(i);
+}
+
+__device__ __forceinline__ ConvP g3_part_conv(const G3Parts& q, int i) {
+    ConvP p = q.p;
+    p.B = q.B[i]; p.Lin = q.Lin[i]; p.Lout = q.Lout[i];
+    return p;
+}
+
+template <int RB0, int RB1, int RB2>
+__global__ __launch_bounds__(256, 2) void k_gconv_split_fwd_parts(G3Parts q, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias) {
+    const int bx = blockIdx.x, i = g3_part_of(q, bx);
+    const ConvP p = g3_part_conv(q, i);
+    const int rbx = bx - q.bx0[i], nbx = q.bx0[i + 1] - q.bx0[i];
+    if (i == 0) gconv_fwd_body<RB0, true, true>(p, q.u0[0], q.u1[0], q.u2[0], q.a[0], w, bias, q.o[0], rbx, nbx);
+    else if (i == 1) gconv_fwd_body<RB1, false, false>(p, q.u0[1], q.u1[1], q.u2[1], q.a[1], w, bias, q.o[1], rbx, nbx);
+    else gconv_fwd_body<RB2, false, false>(p, q.u0[2], q.u1[2], q.u2[2], q.a[2], w, bias, q.o[2], rbx, nbx);
+}
+
 // ---------------------------------------------------------------- backward weight
 // gw[co, ci, k] = sum_{b, t} gp[b, co, t] * x[b, g*4 + ci, 4t + k - pad]   (gp = gy * act'(y_act))
 // Per group and input channel: M = co (16), N = tap k (3 tiles of 16: 41 taps + 7 discarded columns), the MFMA
@@ -366,12 +421,14 @@ constexpr int W_WAVE = 3 * (WG_PIECE + WX_PIECE);     // (sized for three pieces
 constexpr int WNP = 2;                        // pieces per operand element: block-scaled fp16 x 2 (r04)
 constexpr int NKT = 3;                        // 16-tap column tiles
 
+// slab: the workgroup's slab index (blockIdx.x in a single launch; the workgroup's index over ALL parts in a parts launch,
+// whose slabs the one deterministic reduce then sums: the weight gradient of the shared layer over every scale)
 template <bool VEC>
-__global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const float* __restrict__ x,
-                                                             const float* __restrict__ gy,
-                                                             const float* __restrict__ y_act,
-                                                             float* __restrict__ partial, size_t partial_stride) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * W_WAVE];
+__device__ __forceinline__ void gconv_wgrad_body(const ConvP& p, const float* __restrict__ x,
+                                                 const float* __restrict__ gy,
+                                                 const float* __restrict__ y_act,
+                                                 float* __restrict__ partial, size_t partial_stride, int bx, int nbx, int slab) {
+    unsigned char* const lds = g3_smem;               // 4 * W_WAVE
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = blockIdx.y;
     const int kind = y_act ? p.act : MS_ACT_NONE;
@@ -402,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const flo
 
     const int tiles = (p.Lout + WU - 1) / WU;
     const int nunits = p.B * tiles;
-    const int ustride = gridDim.x * 4;
+    const int ustride = nbx * 4;
     const int db = ustride / tiles, dt = ustride - db * tiles;     // unit += ustride, in (b, tile) form
 
     // interior units (all 64 outputs and all 300 inputs inside their rows): lane-constant byte offsets + a
@@ -487,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const flo
     // transposing read: lane 4q + p of a 16-lane group supplies row q (output t), column quad p (4 taps)
     const unsigned b_rd = (unsigned)(uintptr_t)ximg + 64 * kg + 8 * ((lane & 15) >> 2) + 8 * (lane & 3);
 
-    int unit = blockIdx.x * 4 + wid;
+    int unit = bx * 4 + wid;
     int b = unit / tiles, ti = unit - b * tiles;
     if (unit < nunits) gload(b, ti);
     for (; unit < nunits; unit += ustride) {
@@ -642,7 +699,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const flo
         if ((lane & 15) == 0) redb[wid * 16 + co0 + 4 * i] = v;
     }
     __syncthreads();
-    float* part = partial + (size_t)blockIdx.x * partial_stride;
+    float* part = partial + (size_t)slab * partial_stride;
     const int J = GCG * GK;
     {
         const int c = wid;
@@ -661,6 +718,23 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const flo
     }
     if (wid == 0 && lane < 16 && lane < p.Og)
         part[(size_t)p.Cout * J + g * p.Og + lane] = (redb[lane] + redb[16 + lane]) + (redb[32 + lane] + redb[48 + lane]);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad(ConvP p, const float* __restrict__ x,
+                                                             const float* __restrict__ gy,
+                                                             const float* __restrict__ y_act,
+                                                             float* __restrict__ partial, size_t partial_stride) {
+    gconv_wgrad_body<VEC>(p, x, gy, y_act, partial, partial_stride, blockIdx.x, gridDim.x, blockIdx.x);
+}
+
+// parts: a = x, b = gy, c = y_act
+__global__ __launch_bounds__(256, 2) void k_gconv_split_wgrad_parts(G3Parts q, float* __restrict__ partial, size_t partial_stride) {
+    const int bx = blockIdx.x, i = g3_part_of(q, bx);
+    const ConvP p = g3_part_conv(q, i);
+    const int rbx = bx - q.bx0[i], nbx = q.bx0[i + 1] - q.bx0[i];
+    if (i == 0) gconv_wgrad_body<true>(p, q.a[0], q.b[0], q.c[0], partial, partial_stride, rbx, nbx, bx);
+    else gconv_wgrad_body<false>(p, q.a[i], q.b[i], q.c[i], partial, partial_stride, rbx, nbx, bx);
 }
 
 // ---------------------------------------------------------------- backward data (16 outputs per group)
@@ -683,20 +757,20 @@ constexpr int B_WAVE = 2 * B_PIECE;         // two fp16 pieces (r04)
 constexpr int BJ = 6;                         // MFMA steps: taps 2J, 2J+1
 
 template <bool VEC, bool VOUT>
-__global__ __launch_bounds__(256, 2) void k_gconv_split_bwd_data(ConvP p, int tiles, int nunits,
-                                                                const float* __restrict__ gy,
-                                                                const float* __restrict__ y_act,
-                                                                const float* __restrict__ w,
-                                                                const float* __restrict__ gx_add,
-                                                                float* __restrict__ gx) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * B_WAVE];
+__device__ __forceinline__ void gconv_bwd_data_body(const ConvP& p, int tiles, int nunits,
+                                                    const float* __restrict__ gy,
+                                                    const float* __restrict__ y_act,
+                                                    const float* __restrict__ w,
+                                                    const float* __restrict__ gx_add,
+                                                    float* __restrict__ gx, int bx, int nbx) {
+    unsigned char* const lds = g3_smem;               // 4 * B_WAVE
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = blockIdx.y;
     const int kind = y_act ? p.act : MS_ACT_NONE;
     unsigned char* img = lds + wid * B_WAVE;
     const int n = lane & 15, kg = lane >> 4;
     const int oct = kg >> 1, tp = kg & 1;
-    const int wstride = gridDim.x * 4;
+    const int wstride = nbx * 4;
     const int db = wstride / tiles, dt = wstride - db * tiles;
 
     // staging item of this lane: co quad cq, position quad pq
@@ -739,7 +813,7 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_bwd_data(ConvP p, int ti
             }
         }
     };
-    int unit = blockIdx.x * 4 + wid;
+    int unit = bx * 4 + wid;
     int b = unit / tiles, ti = unit - b * tiles;
     if (unit < nunits) gload(b, ti);
 
@@ -873,6 +947,25 @@ __global__ __launch_bounds__(256, 2) void k_gconv_split_bwd_data(ConvP p, int ti
     }
 }
 
+template <bool VEC, bool VOUT>
+__global__ __launch_bounds__(256, 2) void k_gconv_split_bwd_data(ConvP p, int tiles, int nunits,
+                                                                const float* __restrict__ gy,
+                                                                const float* __restrict__ y_act,
+                                                                const float* __restrict__ w,
+                                                                const float* __restrict__ gx_add,
+                                                                float* __restrict__ gx) {
+    gconv_bwd_data_body<VEC, VOUT>(p, tiles, nunits, gy, y_act, w, gx_add, gx, blockIdx.x, gridDim.x);
+}
+
+// parts: a = gy, b = y_act, c = gx_add, o = gx; u0 = tiles, u1 = nunits
+__global__ __launch_bounds__(256, 2) void k_gconv_split_bwd_data_parts(G3Parts q, const float* __restrict__ w) {
+    const int bx = blockIdx.x, i = g3_part_of(q, bx);
+    const ConvP p = g3_part_conv(q, i);
+    const int rbx = bx - q.bx0[i], nbx = q.bx0[i + 1] - q.bx0[i];
+    if (i == 0) gconv_bwd_data_body<true, true>(p, q.u0[0], q.u1[0], q.a[0], q.b[0], w, q.c[0], q.o[0], rbx, nbx);
+    else gconv_bwd_data_body<false, false>(p, q.u0[i], q.u1[i], q.a[i], q.b[i], w, q.c[i], q.o[i], rbx, nbx);
+}
+
 int pick_rb(int Lout) {
     if (Lout <= 16) return 4;
     if (Lout <= 32) return 2;
@@ -898,6 +991,10 @@ bool msg3_fwd_applicable(const ConvP& p) {
 
 const char* msg3_fwd_name(const ConvP&) { return "k_gconv_split_fwd"; }
 
+template <int RB>
+constexpr size_t g3_fwd_lds() { return 4 * (size_t)GF<RB>::WAVE_BYTES; }
+static size_t g3_fwd_lds_rt(int rb) { return rb == 1 ? g3_fwd_lds<1>() : (rb == 2 ? g3_fwd_lds<2>() : g3_fwd_lds<4>()); }
+
 int msg3_conv1d_fwd(const ConvP& p, const float* x, const float* w, const float* bias, float* y,
                     hipStream_t s) {
     const int rb = pick_rb(p.Lout);
@@ -913,7 +1010,8 @@ int msg3_conv1d_fwd(const ConvP& p, const float* x, const float* w, const float*
 #define MS_G3(RBV, V, VO)                                                                                                    \
     do {                                                                                                                     \
         ms_note_kernel(3, "k_gconv_split_fwd<%d, %s, %s>", RBV, V ? "true" : "false", VO ? "true" : "false");               \
-        hipLaunchKernelGGL((k_gconv_split_fwd<RBV, V, VO>), grid, dim3(256), 0, s, p, spr, nseg, nunits, x, w, bias, y); \
+        hipLaunchKernelGGL((k_gconv_split_fwd<RBV, V, VO>), grid, dim3(256), g3_fwd_lds<RBV>(), s, p, spr, nseg, nunits, x, w, \
+                           bias, y);                                                                                         \
     } while (0)
 #define MS_G3V(RBV)                                   \
     do {                                              \
@@ -927,6 +1025,82 @@ int msg3_conv1d_fwd(const ConvP& p, const float* x, const float* w, const float*
     else MS_G3V(4);
 #undef MS_G3V
 #undef MS_G3
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+// ---- parts launches: one layer over the discriminator's scales (G3Parts)
+namespace {
+
+bool g3_parts_table(const ConvP& c, const ms_conv1d_parts* parts, G3Parts* q) {
+    if (!parts || parts->count < 2 || parts->count > MS_CONV_PARTS_MAX) return false;
+    q->p = c;
+    q->count = parts->count;
+    for (int i = 0; i < parts->count; ++i) {
+        if (parts->B[i] <= 0 || parts->Lin[i] <= 0) return false;
+        const int eff = parts->Lin[i] + 2 * c.pad - c.dil * (c.K - 1) - 1;
+        if (eff < 0) return false;
+        q->B[i] = parts->B[i]; q->Lin[i] = parts->Lin[i]; q->Lout[i] = eff / c.stride + 1;
+    }
+    for (int i = parts->count; i < MS_CONV_PARTS_MAX; ++i) {
+        q->B[i] = q->Lin[i] = q->Lout[i] = q->u0[i] = q->u1[i] = q->u2[i] = 0;
+        q->a[i] = q->b[i] = q->c[i] = nullptr; q->o[i] = nullptr;
+    }
+    return true;
+}
+
+ConvP g3_host_part(const ConvP& c, const G3Parts& q, int i) {
+    ConvP p = c;
+    p.B = q.B[i]; p.Lin = q.Lin[i]; p.Lout = q.Lout[i];
+    return p;
+}
+
+bool al16(const void* a) { return (((uintptr_t)a) & 15) == 0; }
+
+}  // namespace
+
+// Forward: every part must be a geometry the single launch takes; part 0 16-byte shaped (the instantiations of a parts kernel
+// are <RB0, vec, vec>, <RB1, dword, dword>, <RB2, dword, dword>); the RB triples are those of the three scales of 2^k-sample
+// windows (8192 -> 2048 / 1025 / 513 ... 32 / 17 / 9) -- anything else runs part by part.
+bool msg3_parts_fwd_applicable(const ConvP& c, const ms_conv1d_parts* parts) {
+    G3Parts q;
+    if (!g3_parts_table(c, parts, &q) || q.count != 3) return false;
+    for (int i = 0; i < q.count; ++i)
+        if (!msg3_fwd_applicable(g3_host_part(c, q, i)) || !parts->x[i] || !parts->y[i]) return false;
+    if (q.Lin[0] % 4 || c.pad % 4 || q.Lout[0] % 4 || !al16(parts->x[0]) || !al16(parts->y[0])) return false;
+    const int r0 = pick_rb(q.Lout[0]), r1 = pick_rb(q.Lout[1]), r2 = pick_rb(q.Lout[2]);
+    return (r0 == 1 && r1 == 1 && r2 == 1) || (r0 == 1 && r1 == 4 && r2 == 1) || (r0 == 2 && r1 == 2 && r2 == 4);
+}
+
+int msg3_parts_fwd(const ConvP& c, const ms_conv1d_parts* parts, const float* w, const float* bias, hipStream_t s) {
+    G3Parts q;
+    if (!g3_parts_table(c, parts, &q)) return MS_ERR_INVALID_ARG;
+    int rb[MS_CONV_PARTS_MAX], nunits[MS_CONV_PARTS_MAX];
+    long long total_units = 0;
+    size_t lds = 0;
+    for (int i = 0; i < q.count; ++i) {
+        rb[i] = pick_rb(q.Lout[i]);
+        const int ts = 64 / rb[i];
+        const int spr = ms_ceil_div(q.Lout[i], ts), nseg = q.B[i] * spr;
+        nunits[i] = ms_ceil_div(nseg, rb[i]);
+        q.u0[i] = spr; q.u1[i] = nseg; q.u2[i] = nunits[i];
+        q.a[i] = parts->x[i]; q.o[i] = parts->y[i];
+        total_units += (long long)nunits[i] * c.groups;
+        if (g3_fwd_lds_rt(rb[i]) > lds) lds = g3_fwd_lds_rt(rb[i]);
+    }
+    const int upw = (int)((total_units + 2047) / 2048);             // ~2 waves per SIMD, `upw` units per wave
+    q.bx0[0] = 0;
+    for (int i = 0; i < q.count; ++i) q.bx0[i + 1] = q.bx0[i] + ms_ceil_div(nunits[i], 4 * (upw > 0 ? upw : 1));
+    for (int i = q.count; i < MS_CONV_PARTS_MAX; ++i) q.bx0[i + 1] = q.bx0[q.count];
+    const dim3 grid(q.bx0[q.count], c.groups);
+    ms_note_kernel(3, "k_gconv_split_fwd_parts<%d, %d, %d>", rb[0], rb[1], rb[2]);
+#define MS_G3P(A, B_, C_) \
+    hipLaunchKernelGGL((k_gconv_split_fwd_parts<A, B_, C_>), grid, dim3(256), lds, s, q, w, bias)
+    if (rb[0] == 1 && rb[1] == 1 && rb[2] == 1) MS_G3P(1, 1, 1);
+    else if (rb[0] == 1 && rb[1] == 4 && rb[2] == 1) MS_G3P(1, 4, 1);
+    else if (rb[0] == 2 && rb[1] == 2 && rb[2] == 4) MS_G3P(2, 2, 4);
+    else return MS_ERR_UNSUPPORTED;
+#undef MS_G3P
     MS_CHECK_LAUNCH();
     return MS_OK;
 }
@@ -950,10 +1124,73 @@ int msg3_conv1d_bwd_weight(const ConvP& p, const float* x, const float* gy, cons
     const bool vec = p.Lin % 4 == 0 && p.pad % 4 == 0 && p.Lout % 4 == 0 && (((uintptr_t)x) & 15) == 0 &&
                      (((uintptr_t)gy) & 15) == 0 && (!y_act || (((uintptr_t)y_act) & 15) == 0);
     ms_note_kernel(3, "k_gconv_split_wgrad<%s>", vec ? "true" : "false");
-    if (vec) hipLaunchKernelGGL((k_gconv_split_wgrad<true>), dim3(gxn, p.groups), dim3(256), 0, s, p, x, gy, y_act, partial, stride);
-    else hipLaunchKernelGGL((k_gconv_split_wgrad<false>), dim3(gxn, p.groups), dim3(256), 0, s, p, x, gy, y_act, partial, stride);
+    if (vec) hipLaunchKernelGGL((k_gconv_split_wgrad<true>), dim3(gxn, p.groups), dim3(256), 4 * W_WAVE, s, p, x, gy, y_act, partial, stride);
+    else hipLaunchKernelGGL((k_gconv_split_wgrad<false>), dim3(gxn, p.groups), dim3(256), 4 * W_WAVE, s, p, x, gy, y_act, partial, stride);
     MS_CHECK_LAUNCH();
     return msg_reduce_slabs(p, partial, stride, gxn, gw, gb, beta, s);      // one slab per workgroup
+}
+
+// Weight gradient of the shared layer over all parts: workgroup columns are dealt to the parts in proportion to their
+// wave units, every workgroup writes one slab, ONE reduce sums them all -- the sum over the scales that
+// discriminator/melgan.py:13-27 implies for the shared parameters costs nothing extra.
+namespace {
+int g3_wgrad_parts_columns(const ConvP& c, const G3Parts& q, int* cols) {
+    const size_t slab = ((size_t)c.Cout * GCG * GK + c.Cout) * sizeof(float);
+    long long chunks[MS_CONV_PARTS_MAX], total = 0;
+    for (int i = 0; i < q.count; ++i) {
+        chunks[i] = ms_ceil_div(q.B[i] * ms_ceil_div(q.Lout[i], WU), 4);
+        total += chunks[i];
+    }
+    int gx = ms_ceil_div(512, c.groups);                 // ~2 workgroups per CU over all parts
+    const size_t cap = (size_t)32 << 20;
+    while (gx > q.count && (size_t)gx * slab > cap) --gx;
+    if (gx < q.count) gx = q.count;
+    int sum = 0;
+    for (int i = 0; i < q.count; ++i) {
+        long long n = (chunks[i] * gx + total - 1) / total;
+        if (n < 1) n = 1;
+        if (n > chunks[i]) n = chunks[i];
+        cols[i] = (int)n;
+        sum += cols[i];
+    }
+    return sum;
+}
+}  // namespace
+
+bool msg3_parts_bwd_weight_applicable(const ConvP& c, const ms_conv1d_parts* parts) {
+    G3Parts q;
+    if (!g3_parts_table(c, parts, &q)) return false;
+    for (int i = 0; i < q.count; ++i)
+        if (!msg3_bwd_weight_applicable(g3_host_part(c, q, i)) || !parts->x[i] || !parts->gy[i]) return false;
+    return q.Lin[0] % 4 == 0 && c.pad % 4 == 0 && q.Lout[0] % 4 == 0 && al16(parts->x[0]) && al16(parts->gy[0]) &&
+           (!parts->y_act[0] || al16(parts->y_act[0]));
+}
+
+size_t msg3_parts_bwd_weight_ws(const ConvP& c, const ms_conv1d_parts* parts) {
+    G3Parts q;
+    int cols[MS_CONV_PARTS_MAX];
+    if (!g3_parts_table(c, parts, &q)) return 0;
+    return (size_t)g3_wgrad_parts_columns(c, q, cols) * ((size_t)c.Cout * GCG * GK + c.Cout) * sizeof(float);
+}
+
+int msg3_parts_bwd_weight(const ConvP& c, const ms_conv1d_parts* parts, float* gw, float* gb, float beta, void* ws,
+                          size_t ws_bytes, hipStream_t s) {
+    G3Parts q;
+    int cols[MS_CONV_PARTS_MAX];
+    if (!g3_parts_table(c, parts, &q)) return MS_ERR_INVALID_ARG;
+    const int gxn = g3_wgrad_parts_columns(c, q, cols);
+    const size_t stride = (size_t)c.Cout * GCG * GK + c.Cout;
+    if (!ws || ws_bytes < (size_t)gxn * stride * sizeof(float)) return MS_ERR_WORKSPACE;
+    q.bx0[0] = 0;
+    for (int i = 0; i < q.count; ++i) {
+        q.bx0[i + 1] = q.bx0[i] + cols[i];
+        q.a[i] = parts->x[i]; q.b[i] = parts->gy[i]; q.c[i] = c.act == MS_ACT_NONE ? nullptr : parts->y_act[i];
+    }
+    for (int i = q.count; i < MS_CONV_PARTS_MAX; ++i) q.bx0[i + 1] = q.bx0[q.count];
+    ms_note_kernel(3, "k_gconv_split_wgrad_parts");
+    hipLaunchKernelGGL(k_gconv_split_wgrad_parts, dim3(gxn, c.groups), dim3(256), 4 * W_WAVE, s, q, (float*)ws, stride);
+    MS_CHECK_LAUNCH();
+    return msg_reduce_slabs(c, (float*)ws, stride, gxn, gw, gb, beta, s);
 }
 
 bool msg3_bwd_data_applicable(const ConvP& p) {
@@ -979,13 +1216,47 @@ int msg3_conv1d_bwd_data(const ConvP& p, const float* gy, const float* y_act, co
 #define MS_B3(V, VO)                                                                                                              \
     do {                                                                                                                          \
         ms_note_kernel(3, "k_gconv_split_bwd_data<%s, %s>", V ? "true" : "false", VO ? "true" : "false");                        \
-        hipLaunchKernelGGL((k_gconv_split_bwd_data<V, VO>), grid, dim3(256), 0, s, p, tiles, nunits, gy, y_act, w, gx_add, gx); \
+        hipLaunchKernelGGL((k_gconv_split_bwd_data<V, VO>), grid, dim3(256), 4 * B_WAVE, s, p, tiles, nunits, gy, y_act, w, gx_add, \
+                           gx);                                                                                                   \
     } while (0)
     if (vec && vout) MS_B3(true, true);
     else if (vec) MS_B3(true, false);
     else if (vout) MS_B3(false, true);
     else MS_B3(false, false);
 #undef MS_B3
+    MS_CHECK_LAUNCH();
+    return MS_OK;
+}
+
+bool msg3_parts_bwd_data_applicable(const ConvP& c, const ms_conv1d_parts* parts) {
+    G3Parts q;
+    if (!g3_parts_table(c, parts, &q)) return false;
+    for (int i = 0; i < q.count; ++i)
+        if (!msg3_bwd_data_applicable(g3_host_part(c, q, i)) || !parts->gy[i] || !parts->gx[i]) return false;
+    return q.Lout[0] % 4 == 0 && q.Lin[0] % 4 == 0 && al16(parts->gy[0]) && al16(parts->gx[0]) &&
+           (!parts->y_act[0] || al16(parts->y_act[0])) && (!parts->gx_add[0] || al16(parts->gx_add[0]));
+}
+
+int msg3_parts_bwd_data(const ConvP& c, const ms_conv1d_parts* parts, const float* w, hipStream_t s) {
+    G3Parts q;
+    if (!g3_parts_table(c, parts, &q)) return MS_ERR_INVALID_ARG;
+    int nunits[MS_CONV_PARTS_MAX];
+    long long total_units = 0;
+    for (int i = 0; i < q.count; ++i) {
+        const int Lq = ms_ceil_div(q.Lin[i], GS);
+        const int tiles = ms_ceil_div(Lq, BQ);
+        nunits[i] = q.B[i] * tiles;
+        q.u0[i] = tiles; q.u1[i] = nunits[i]; q.u2[i] = 0;
+        q.a[i] = parts->gy[i]; q.b[i] = c.act == MS_ACT_NONE ? nullptr : parts->y_act[i]; q.c[i] = parts->gx_add[i];
+        q.o[i] = parts->gx[i];
+        total_units += (long long)nunits[i] * c.groups;
+    }
+    const int upw = (int)((total_units + 2047) / 2048);
+    q.bx0[0] = 0;
+    for (int i = 0; i < q.count; ++i) q.bx0[i + 1] = q.bx0[i] + ms_ceil_div(nunits[i], 4 * (upw > 0 ? upw : 1));
+    for (int i = q.count; i < MS_CONV_PARTS_MAX; ++i) q.bx0[i + 1] = q.bx0[q.count];
+    ms_note_kernel(3, "k_gconv_split_bwd_data_parts");
+    hipLaunchKernelGGL(k_gconv_split_bwd_data_parts, dim3(q.bx0[q.count], c.groups), dim3(256), 4 * B_WAVE, s, q, w);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }

@@ -587,6 +587,114 @@ def _concurrent_scales():
     return os.environ.get("MSYNTH_STREAMS", "1") != "0"
 
 
+def _parts_mode():
+    """Every layer of the shared discriminator ONCE per pass over all scales (ms_conv1d_parts_*: one launch where a parts
+    kernel takes the layer, part by part on one stream otherwise).  MSYNTH_DPARTS=0: one pass per scale on forked streams
+    (the r01-r04 schedule), kept for A/B runs."""
+    return os.environ.get("MSYNTH_DPARTS", "1") != "0"
+
+
+def melgan_forward_parts(x, params, scales=2, k5_image=None):
+    """MelGanDiscriminator (reference discriminator/melgan.py:13-27): the ONE FullDiscriminator on x, pool(x), pool(pool(x)),
+    layer by layer over all scales -- the weights are shared by construction, so a layer's three scales are one piece of
+    work for the device.  -> (features[scale][6], judgements[scale], ctx) like melgan_forward."""
+    if len(params) != D_NPARAMS:
+        raise RuntimeError("discriminator expects %d parameter tensors, got %d" % (D_NPARAMS, len(params)))
+    L.require(x, "discriminator input")
+    if x.dim() != 3 or x.shape[1] != 1:
+        raise RuntimeError("discriminator input must be (B, 1, L), got %s" % (tuple(x.shape),))
+    xs = [x]
+    for s in range(scales):
+        xs.append(P.avg_pool_fwd(xs[-1]))
+    n = len(xs)
+    if k5_image is None:
+        k5_image = pack_k5_image(x.shape, params)
+    feats, tapes = [[] for _ in range(n)], [[] for _ in range(n)]
+    hs = xs
+    for li, (stride, pad, groups) in enumerate(D_LAYERS):
+        w, b = params[2 * li], params[2 * li + 1]
+        ds = [P.conv_desc(h.shape, w.shape, stride=stride, pad=pad, groups=groups, act=L.ACT_LRELU)[0] for h in hs]
+        img = k5_image if (li == 5 and k5_image is not None and P.conv_img_bytes(ds[0])) else None
+        ys = P.conv1d_parts_fwd(hs, w, b, ds[0], image=img)
+        for s in range(n):
+            tapes[s].append((ds[s], hs[s], ys[s]))
+            feats[s].append(ys[s])
+        hs = ys
+    w, b = params[12], params[13]
+    djs = [P.conv_desc(h.shape, w.shape, pad=1)[0] for h in hs]
+    js = P.conv1d_parts_fwd(hs, w, b, djs[0])
+    for s in range(n):
+        tapes[s].append((djs[s], hs[s], js[s]))
+    return feats, js, (tapes, xs)
+
+
+def melgan_backward_parts(ctx, params, g_feats, g_judges, sink=None, need_gx=True, need_wgrad=True, cut=None,
+                          k5_image_bwd=None):
+    """Backward of melgan_forward_parts, layer by layer over all scales: backward data of a layer's scales is one launch,
+    and so is its weight gradient -- summed over the scales by the launch's own reduction.  The gradients may cover fewer
+    batch rows than the forward pass saved (the G-step runs one pass over [fake; real] and differentiates the fake half):
+    the leading rows of the saved tensors are used.  cut: called once the head's parameters (k5 layer + judge conv) are final."""
+    tapes, xs = ctx
+    n = len(tapes)
+    sink = sink if sink is not None else GradSink(D_NPARAMS)
+    k5_bwd = k5_image_bwd if k5_image_bwd is not None else pack_k5_image(xs[0].shape, params, backward=True)
+
+    def own(s, li):
+        return g_feats[s][li] if (g_feats is not None and g_feats[s] is not None and li >= 0) else None
+
+    def wgrad(slot, live, xs_, gys, yas, d, w_shape):
+        gw, gb, acc = sink.pair(slot)
+        sink.put(slot, *P.conv1d_parts_bwd_weight([xs_[s] for s in live], [gys[s] for s in live],
+                                                  None if yas is None else [yas[s] for s in live], d, w_shape, gw, gb, acc))
+
+    g = [None] * n
+    # judge conv: g = total gradient w.r.t. feature 5 (judge path + the loss's own term on that feature)
+    live = [s for s in range(n) if g_judges is not None and g_judges[s] is not None]
+    if live:
+        dj = tapes[live[0]][6][0]
+        h5 = [tapes[s][6][1] for s in range(n)]
+        if need_wgrad:
+            wgrad(12, live, h5, g_judges, None, dj, params[12].shape)
+        outs = P.conv1d_parts_bwd_data([g_judges[s] for s in live], None, params[12], dj, [h5[s].shape for s in live],
+                                       gx_adds=[own(s, 5) for s in live])
+        for s, o in zip(live, outs):
+            g[s] = o
+    for s in range(n):
+        if g[s] is None:
+            g[s] = own(s, 5)
+    for li in range(5, -1, -1):
+        live = [s for s in range(n) if g[s] is not None]
+        prev = [own(s, li - 1) if li > 0 else None for s in range(n)]
+        if live:
+            d = tapes[live[0]][li][0]
+            hin = [tapes[s][li][1] for s in range(n)]
+            h = [tapes[s][li][2] for s in range(n)]
+            if need_wgrad:
+                wgrad(2 * li, live, hin, g, h, d, params[2 * li].shape)
+            if li > 0 or need_gx:
+                img = k5_bwd if (li == 5 and k5_bwd is not None and P.conv_img_bytes(d)) else None
+                outs = P.conv1d_parts_bwd_data([g[s] for s in live], [h[s] for s in live], params[2 * li], d,
+                                               [hin[s].shape for s in live], gx_adds=[prev[s] for s in live], image_bwd=img)
+                for s, o in zip(live, outs):
+                    g[s] = o
+            else:
+                for s in live:
+                    g[s] = None
+        for s in range(n):
+            if s not in live:
+                g[s] = prev[s]
+        if li == 5 and cut is not None:
+            cut()
+    gx_next = None
+    for s in range(n - 1, -1, -1):
+        gx = g[s]
+        if gx_next is not None and need_gx:
+            B = gx_next.shape[0]
+            gx = P.avg_pool_bwd(gx_next, (B,) + tuple(xs[s].shape[1:]), gx_add=gx)
+        gx_next = gx
+    return (gx_next if need_gx else None), sink
+
+
 def melgan_forward(x, params, scales=2, k5_image=None):
     """MelGanDiscriminator: the shared discriminator on x, pool(x), pool(pool(x)).
 
@@ -594,6 +702,8 @@ def melgan_forward(x, params, scales=2, k5_image=None):
     run at L = 17 / 9 and cannot fill 256 CUs on their own), so they are issued on side HIP
     streams forked from / joined to the caller's stream -- under hipGraph capture they become
     parallel branches of the graph."""
+    if _parts_mode():
+        return melgan_forward_parts(x, params, scales, k5_image)
     xs = [x]
     for s in range(scales):
         xs.append(P.avg_pool_fwd(xs[-1]))
@@ -654,6 +764,8 @@ def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, nee
     """cut: optional callback.  When given, every scale's head (judge + k5 layer, disc_backward phase
     "head") runs first, all streams join, cut() is called -- at that point sink slots D_HEAD_PARAM.. are
     final -- and the tails follow.  Without it each scale runs head and tail back to back."""
+    if _parts_mode():
+        return melgan_backward_parts(ctx, params, g_feats, g_judges, sink, need_gx, need_wgrad, cut, k5_image_bwd)
     tapes, xs = ctx
     n = len(tapes)
     sink = sink if sink is not None else GradSink(D_NPARAMS)

@@ -53,6 +53,15 @@ class JudgeMultiDesc(ctypes.Structure):         # ms_judge_multi_desc
                 ("n", ctypes.c_int64 * JUDGE_MULTI_MAX)]
 
 
+CONV_PARTS_MAX = 3
+
+
+class ConvParts(ctypes.Structure):              # ms_conv1d_parts
+    _fields_ = [("count", _c_int), ("reserved", _c_int), ("B", _c_int * CONV_PARTS_MAX), ("Lin", _c_int * CONV_PARTS_MAX),
+                ("x", _vp * CONV_PARTS_MAX), ("y", _vp * CONV_PARTS_MAX), ("gy", _vp * CONV_PARTS_MAX),
+                ("y_act", _vp * CONV_PARTS_MAX), ("gx_add", _vp * CONV_PARTS_MAX), ("gx", _vp * CONV_PARTS_MAX)]
+
+
 WGRAD_MULTI_MAX = 8
 
 
@@ -123,6 +132,11 @@ SIGNATURES = {
     "ms_conv1d_fwd": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ms_conv1d_bwd_data": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ms_conv1d_bwd_weight": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _c_f, _vp, _sz, _vp]),
+    "ms_conv1d_parts_launches": (_c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvParts), _c_int, _c_int]),
+    "ms_conv1d_parts_workspace_bytes": (_sz, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvParts), _c_int, _c_int]),
+    "ms_conv1d_parts_fwd": (_c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvParts), _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ms_conv1d_parts_bwd_data": (_c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvParts), _vp, _vp, _vp, _sz, _vp]),
+    "ms_conv1d_parts_bwd_weight": (_c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvParts), _vp, _vp, _c_f, _vp, _sz, _vp]),
     "ms_conv1d_bwd_weight_multi_workspace_bytes": (_sz, [ctypes.POINTER(WgradMultiDesc)]),
     "ms_conv1d_bwd_weight_multi": (_c_int, [ctypes.POINTER(WgradMultiDesc), _vp, _sz, _vp]),
     "ms_residual_atom_image_bytes": (_sz, [_c_int]),

@@ -166,6 +166,116 @@ def conv1d_bwd_weight_multi(jobs):
     return out
 
 
+# ---- one layer, shared weights, several inputs (the discriminator's scales): ms_conv1d_parts_*
+def _part_desc(d, B, Lin):
+    return L.ConvDesc(B, d.Cin, Lin, d.Cout, d.K, d.stride, d.pad, d.dil, d.groups, d.pad_mode, d.act, d.slope, d.in_act)
+
+
+def _parts_cost(d, shapes, which, name, **kw):
+    """shapes: [(B, Lin)] of the parts."""
+    def cost():
+        cs = [W.conv_cost(B, d.Cin, Lin, d.Cout, d.K, d.stride, d.pad, d.dil, d.groups, which, **kw) for B, Lin in shapes]
+        nw = 4 * (d.Cout * (d.Cin // d.groups) * d.K + d.Cout)
+        return {"flops": sum(c["flops"] for c in cs), "bytes": sum(c["bytes"] for c in cs) - (len(cs) - 1) * nw,   # weights once
+                "geom": ("parts", tuple(shapes), d.Cin, d.Cout, d.K, d.stride, d.dil, d.groups),
+                "kernel": L.load().ms_conv1d_kernel_name(_part_desc(d, *shapes[0]), _WHICH[which]).decode(), "parts": len(cs)}
+    return cost
+
+
+def conv1d_parts_fwd(xs, w, b, d, image=None):
+    """The layer d (its B / Lin are ignored) on every tensor of xs with the same weights -> [y_i].  One launch where a
+    parts kernel takes the geometry (grouped k41 layers; the k5 layer on its weight image), else one call per part."""
+    if not 1 <= len(xs) <= L.CONV_PARTS_MAX:
+        raise RuntimeError("conv1d_parts: 1 .. %d parts" % L.CONV_PARTS_MAX)
+    L.require(w, "conv1d weight")
+    if b is not None:
+        L.require(b, "conv1d bias")
+    parts = L.ConvParts()
+    parts.count = len(xs)
+    ys, shapes = [], []
+    for i, x in enumerate(xs):
+        L.require(x, "conv1d input")
+        if x.dim() != 3 or x.shape[1] != d.Cin:
+            raise RuntimeError("conv1d_parts: input %d is %s, expected (B, %d, L)" % (i, tuple(x.shape), d.Cin))
+        B, Lin = int(x.shape[0]), int(x.shape[2])
+        lo = L.load().ms_conv1d_out_len(_part_desc(d, B, Lin))
+        if lo <= 0:
+            raise RuntimeError("conv1d_parts: invalid geometry for part %d: %s" % (i, tuple(x.shape)))
+        y = torch.empty((B, d.Cout, lo), dtype=torch.float32, device=x.device)
+        parts.B[i], parts.Lin[i], parts.x[i], parts.y[i] = B, Lin, x.data_ptr(), y.data_ptr()
+        ys.append(y); shapes.append((B, Lin))
+    lib = L.load()
+    nws = lib.ms_conv1d_parts_workspace_bytes(d, parts, 0, 1 if image is not None else 0)
+    ws = L.workspace(nws, xs[0].device)
+    L.call("ms_conv1d_parts_fwd", _parts_cost(d, shapes, "fwd", "fwd"), d, parts, w.data_ptr(), L.ptr(b), L.ptr(image),
+           L.ptr(ws), nws, L.stream())
+    return ys
+
+
+def conv1d_parts_bwd_data(gys, y_acts, w, d, in_shapes, gx_adds=None, image_bwd=None):
+    """Input gradients of the layer for every part: gys[i] (B_i, Cout, Lout_i) -> (B_i, Cin, in_shapes[i][-1]).  y_acts[i]: the
+    saved outputs (may hold MORE batch rows than gys[i]: the leading ones are used).  gx_adds[i]: optional addends."""
+    n = len(gys)
+    parts = L.ConvParts()
+    parts.count = n
+    gxs, shapes = [], []
+    for i in range(n):
+        gy = L.require(gys[i], "conv1d grad_output")
+        B, Lin = int(gy.shape[0]), int(in_shapes[i][-1])
+        ya = y_acts[i] if (y_acts is not None and d.act != L.ACT_NONE) else None
+        if ya is not None:
+            L.require(ya, "conv1d saved output")
+            if ya.shape[0] < B or tuple(ya.shape[1:]) != tuple(gy.shape[1:]):
+                raise RuntimeError("conv1d_parts: saved output %s does not cover gradient %s" % (tuple(ya.shape), tuple(gy.shape)))
+        ga = gx_adds[i] if gx_adds is not None else None
+        gx = torch.empty((B, d.Cin, Lin), dtype=torch.float32, device=gy.device)
+        if ga is not None:
+            L.require(ga, "conv1d gx_add")
+            if ga.shape != gx.shape:
+                raise RuntimeError("conv1d_parts: gx_add %s != input gradient %s" % (tuple(ga.shape), tuple(gx.shape)))
+        parts.B[i], parts.Lin[i] = B, Lin
+        parts.gy[i], parts.y_act[i], parts.gx_add[i], parts.gx[i] = gy.data_ptr(), L.ptr(ya), L.ptr(ga), gx.data_ptr()
+        gxs.append(gx); shapes.append((B, Lin))
+    lib = L.load()
+    nws = lib.ms_conv1d_parts_workspace_bytes(d, parts, 1, 1 if image_bwd is not None else 0)
+    ws = L.workspace(nws, gys[0].device)
+    L.call("ms_conv1d_parts_bwd_data", _parts_cost(d, shapes, "bwd_data", "bwd_data", act_read=d.act != L.ACT_NONE,
+                                                   extra_reads=int(gx_adds is not None and any(g is not None for g in gx_adds))),
+           d, parts, w.data_ptr(), L.ptr(image_bwd), L.ptr(ws), nws, L.stream())
+    return gxs
+
+
+def conv1d_parts_bwd_weight(xs, gys, y_acts, d, w_shape, gw=None, gb=None, accumulate=False):
+    """gw (+)= sum over the parts of the layer's weight gradient; xs[i] / y_acts[i] may hold more batch rows than gys[i]."""
+    n = len(gys)
+    dev_ = gys[0].device
+    if gw is None:
+        gw = torch.empty(tuple(w_shape), dtype=torch.float32, device=dev_)
+        accumulate = False
+    if gb is None:
+        gb = (torch.zeros if accumulate else torch.empty)((d.Cout,), dtype=torch.float32, device=dev_)
+    parts = L.ConvParts()
+    parts.count = n
+    shapes = []
+    for i in range(n):
+        gy, x = L.require(gys[i], "conv1d grad_output"), L.require(xs[i], "conv1d input")
+        B, Lin = int(gy.shape[0]), int(x.shape[2])
+        if x.shape[0] < B or x.shape[1] != d.Cin:
+            raise RuntimeError("conv1d_parts: input %s does not cover gradient %s" % (tuple(x.shape), tuple(gy.shape)))
+        ya = y_acts[i] if (y_acts is not None and d.act != L.ACT_NONE) else None
+        if ya is not None and (ya.shape[0] < B or tuple(ya.shape[1:]) != tuple(gy.shape[1:])):
+            raise RuntimeError("conv1d_parts: saved output %s does not cover gradient %s" % (tuple(ya.shape), tuple(gy.shape)))
+        parts.B[i], parts.Lin[i] = B, Lin
+        parts.x[i], parts.gy[i], parts.y_act[i] = x.data_ptr(), gy.data_ptr(), L.ptr(ya)
+        shapes.append((B, Lin))
+    lib = L.load()
+    nws = lib.ms_conv1d_parts_workspace_bytes(d, parts, 2, 0)
+    ws = L.workspace(nws, dev_)
+    L.call("ms_conv1d_parts_bwd_weight", _parts_cost(d, shapes, "bwd_weight", "bwd_weight", act_read=d.act != L.ACT_NONE),
+           d, parts, gw.data_ptr(), gb.data_ptr(), 1.0 if accumulate else 0.0, L.ptr(ws), nws, L.stream())
+    return gw, gb
+
+
 # ---- dense k5 conv on short rows with pre-split weight images (csrc/conv5_img.hip)
 def conv_img_bytes(d):
     """Bytes of the weight image the image kernel wants for this conv geometry; 0 = not taken."""

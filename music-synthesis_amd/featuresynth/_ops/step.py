@@ -73,26 +73,39 @@ def g_step(gen_params, disc_params, samples, features, scales=2, weight=10.0, cu
            loss_slot=None):
     """-> (g_loss, fake); generator gradients accumulate into its bucket."""
     dev = samples.device
-    # the real path neither depends on the generator nor needs gradients: it runs on a forked stream
-    # (a parallel branch of the captured graph) beside G and D(fake)
     main = torch.cuda.current_stream(dev)
     side = G.aux_stream(dev)
-    # the branch forks here and is filled after the generator forward (capture order = launch order, see d_step)
+    # the aux branch forks here and is filled after the generator forward (capture order = launch order, see d_step)
     fork_real = G.fork_aux(dev)
     fake, tape = G.gen_forward(features, gen_params, save=True)
-    # one pair of weight images for both discriminator passes and the backward, packed on the aux stream (where the
-    # real pass follows them) beside the generator forward
+    # one pair of weight images for the discriminator pass(es) and the backward, packed on the aux stream beside the
+    # generator forward
     k5, k5b, k5ev = G.pack_k5_images_aside(samples.shape, disc_params, dev, forked_at=fork_real)
-    if fork_real:
-        with G.forked(side):
-            r_feats, r_judges, _ = G.melgan_forward(samples, disc_params, scales, k5_image=k5)
+    rows = None
+    if G._parts_mode():
+        # ONE discriminator pass over [fake; real], as in the D-step (samples are independent): every layer runs once over
+        # both halves and all scales; the backward pass differentiates the fake half (the leading rows of what was saved)
+        if k5ev is not None:
+            main.wait_event(k5ev)
+        B = fake.shape[0]
+        feats, judges, ctx = G.melgan_forward(torch.cat([fake, samples], 0), disc_params, scales, k5_image=k5)
+        f_feats = [[t[:B] for t in grp] for grp in feats]
+        r_feats = [[t[B:] for t in grp] for grp in feats]
+        f_judges = [j[:B] for j in judges]
+        rows = slice(0, B)
     else:
-        r_feats, r_judges, _ = G.melgan_forward(samples, disc_params, scales, k5_image=k5)
-    if k5ev is not None:
-        main.wait_event(k5ev)
-    f_feats, f_judges, ctx = G.melgan_forward(fake, disc_params, scales, k5_image=k5)
-    if fork_real:
-        main.wait_stream(side)
+        # the real path neither depends on the generator nor needs gradients: it runs on a forked stream
+        # (a parallel branch of the captured graph) beside G and D(fake)
+        if fork_real:
+            with G.forked(side):
+                r_feats, r_judges, _ = G.melgan_forward(samples, disc_params, scales, k5_image=k5)
+        else:
+            r_feats, r_judges, _ = G.melgan_forward(samples, disc_params, scales, k5_image=k5)
+        if k5ev is not None:
+            main.wait_event(k5ev)
+        f_feats, f_judges, ctx = G.melgan_forward(fake, disc_params, scales, k5_image=k5)
+        if fork_real:
+            main.wait_stream(side)
     S, Lyr = len(f_feats), len(f_feats[0])
     rf = [t for grp in r_feats for t in grp]
     ff = [t for grp in f_feats for t in grp]
@@ -110,7 +123,7 @@ def g_step(gen_params, disc_params, samples, features, scales=2, weight=10.0, cu
     g_feats = [g_ff[Lyr * s:Lyr * s + Lyr] for s in range(S)]
     gx, _ = G.melgan_backward(ctx, disc_params, g_feats, g_fj, None, need_gx=True, need_wgrad=False, k5_image_bwd=k5b)
     if debug is not None:
-        debug.update(fake=fake, gen_tape=tape, disc_ctx=ctx, r_feats=r_feats, f_feats=f_feats,
+        debug.update(fake=fake, gen_tape=tape, disc_ctx=ctx, disc_rows=rows, r_feats=r_feats, f_feats=f_feats,
                      f_judges=f_judges, g_fake=gx)
     G.gen_backward(tape, gen_params, gx, _slots(gen_params), cut=cut)
     return loss, fake

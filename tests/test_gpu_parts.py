@@ -1,0 +1,186 @@
+"""ms_conv1d_parts_*: one conv layer with shared weights over the discriminator's three scales in one launch
+(reference discriminator/melgan.py:13-27: the same FullDiscriminator on x, pool(x), pool(pool(x))).
+
+Checked against the single-part entry points (the launches they replace) and against float64 torch on the CPU,
+at the layer geometries of discriminator/full.py:13-22 and at lengths no parts kernel takes (part-by-part path)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+# (Cin, Cout, K, stride, pad, groups) of FullDiscriminator.main[1..5]
+GROUPED = [(16, 64, 41, 4, 20, 4), (64, 256, 41, 4, 20, 16), (256, 1024, 41, 4, 20, 64), (1024, 1024, 41, 4, 20, 256)]
+K5 = (1024, 1024, 5, 1, 2, 1)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def _scale_lengths(L0, depth):
+    """Input lengths of layer `depth` (0 = first grouped layer) at the three scales of an L0-sample window."""
+    out = []
+    L = L0
+    for s in range(3):
+        if s:
+            L = L // 2 + 1                     # avg_pool1d(4, 2, 2)
+        l = L
+        for _ in range(depth):
+            l = (l + 40 - 41) // 4 + 1
+        out.append(l)
+    return out
+
+
+def _inputs(geo, B, lens, seed):
+    Cin, Cout, K, stride, pad, groups = geo
+    rng = np.random.default_rng(seed)
+    xs = [dev(rng.standard_normal((B, Cin, l))) for l in lens]
+    w = dev(rng.standard_normal((Cout, Cin // groups, K)) * (1.0 / np.sqrt(K * Cin // groups)))
+    b = dev(rng.standard_normal((Cout,)) * 0.1)
+    return xs, w, b
+
+
+def _desc(geo, x, w):
+    from featuresynth._ops import lib as L
+    from featuresynth._ops import prims as P
+    Cin, Cout, K, stride, pad, groups = geo
+    return P.conv_desc(x.shape, w.shape, stride=stride, pad=pad, groups=groups, act=L.ACT_LRELU)
+
+
+def _launches(d, tensors, which, image=False):
+    from featuresynth._ops import lib as L
+    parts = L.ConvParts()
+    parts.count = len(tensors)
+    for i, t in enumerate(tensors):
+        parts.B[i], parts.Lin[i] = t.shape[0], t.shape[2]
+        parts.x[i] = parts.y[i] = parts.gy[i] = parts.y_act[i] = parts.gx[i] = t.data_ptr()      # (16-byte aligned stand-ins)
+    return L.load().ms_conv1d_parts_launches(d, parts, which, 1 if image else 0)
+
+
+@pytest.mark.parametrize("layer", [0, 1, 2, 3])
+@pytest.mark.parametrize("B,L0", [(3, 8192), (64, 8192), (2, 3000)], ids=["b3", "b64", "offgrid"])
+def test_grouped_layer_over_three_scales(layer, B, L0):
+    """Forward, backward data and weight gradient of a grouped k41 layer over the three scales: the parts call equals the
+    three single calls it replaces -- bitwise for forward and backward data (same work units, same arithmetic), to
+    summation order for the weight gradient (one reduction over all scales' slabs instead of three accumulations) -- and
+    float64 torch.  At the window sizes of the reference (8192 samples) it is ONE launch; other lengths run part by part."""
+    import torch.nn.functional as F
+    from featuresynth._ops import lib as L
+    from featuresynth._ops import prims as P
+    geo = GROUPED[layer]
+    if B == 64 and layer < 2:
+        B = 16          # (keeps the float64 CPU reference of the wide maps in seconds)
+    lens = _scale_lengths(L0, layer)
+    xs, w, b = _inputs(geo, B, lens, 100 + layer)
+    d, _ = _desc(geo, xs[0], w)
+    one = L0 == 8192
+    assert _launches(d, xs, 0) == (1 if one else 3)
+    ys = P.conv1d_parts_fwd(xs, w, b, d)
+    gys = [dev(np.random.default_rng(7 + i).standard_normal(tuple(y.shape))) for i, y in enumerate(ys)]
+    adds = [dev(np.random.default_rng(17 + i).standard_normal(tuple(x.shape))) for i, x in enumerate(xs)]
+    gxs = P.conv1d_parts_bwd_data(gys, ys, w, d, [x.shape for x in xs], gx_adds=adds)
+    gw, gb = P.conv1d_parts_bwd_weight(xs, gys, ys, d, w.shape)
+    gw_sum, gb_sum = None, None
+    for i, x in enumerate(xs):
+        di, lo = _desc(geo, x, w)
+        y1, _ = P.conv1d_fwd(x, w, b, di, lo)
+        assert torch.equal(ys[i], y1), ("forward", i)
+        gx1 = P.conv1d_bwd_data(gys[i], y1, w, di, gx_add=adds[i])
+        assert torch.equal(gxs[i], gx1), ("backward data", i)
+        gw_sum, gb_sum = P.conv1d_bwd_weight(x, gys[i], y1, di, w.shape, gw_sum, gb_sum, accumulate=i > 0)
+    assert rel(gw, gw_sum) < 2e-6 and rel(gb, gb_sum) < 2e-6, (rel(gw, gw_sum), rel(gb, gb_sum))
+    # float64 reference (CPU)
+    Cin, Cout, K, stride, pad, groups = geo
+    wd, bd = w.double().cpu().requires_grad_(True), b.double().cpu().requires_grad_(True)
+    tot = 0
+    for i, x in enumerate(xs):
+        xd = x.double().cpu().requires_grad_(True)
+        yr = F.leaky_relu(F.conv1d(xd, wd, bd, stride=stride, padding=pad, groups=groups), 0.2)
+        assert rel(ys[i].cpu(), yr.detach()) < 1e-6, ("forward vs float64", i, rel(ys[i].cpu(), yr.detach()))
+        # the device differentiates LeakyReLU by the sign of ITS saved output
+        pre_grad = gys[i].double().cpu() * torch.where(ys[i].cpu() > 0, 1.0, 0.2).double()
+        pre = F.conv1d(xd, wd, bd, stride=stride, padding=pad, groups=groups)
+        (gxr,) = torch.autograd.grad(pre, xd, pre_grad, retain_graph=True)
+        assert rel(gxs[i].cpu() - adds[i].cpu(), gxr) < 2e-6, ("backward data vs float64", i)
+        tot = tot + (pre * pre_grad).sum()
+    gwr, gbr = torch.autograd.grad(tot, (wd, bd))
+    assert rel(gw.cpu(), gwr) < 2e-6 and rel(gb.cpu(), gbr) < 2e-6, (rel(gw.cpu(), gwr), rel(gb.cpu(), gbr))
+    # accumulate form: beta = 1 adds to what the slots hold
+    gw2, gb2 = P.conv1d_parts_bwd_weight(xs, gys, ys, d, w.shape, gw.clone(), gb.clone(), accumulate=True)
+    assert rel(gw2, 2 * gw) < 1e-6 and rel(gb2, 2 * gb) < 1e-6
+
+
+@pytest.mark.parametrize("B,rows", [(64, 64), (64, 32), (6, 6)], ids=["b64", "b64_grad32", "small"])
+def test_k5_layer_over_three_scales(B, rows):
+    """The 1024 -> 1024 k5 layer on its weight image over rows of 32 / 17 / 9 samples: one launch without split-K slabs at
+    the batch sizes of the train step, against the per-scale image launches (1e-6: other slice grouping) and float64; the
+    backward pass may cover only the leading rows of what the forward saved (G-step: the fake half of [fake; real])."""
+    import torch.nn.functional as F
+    from featuresynth._ops import lib as L
+    from featuresynth._ops import prims as P
+    lens = [32, 17, 9]
+    xs, w, b = _inputs(K5, B, lens, 55)
+    d, _ = _desc(K5, xs[0], w)
+    assert P.conv_img_bytes(d) > 0
+    img, imgb = P.conv_img_pack(d, w), P.conv_img_pack(d, w, backward=True)
+    assert _launches(d, xs, 0, image=True) == (1 if B >= 32 else 3)
+    ys = P.conv1d_parts_fwd(xs, w, b, d, image=img)
+    gys = [dev(np.random.default_rng(3 + i).standard_normal((rows,) + tuple(y.shape[1:]))) for i, y in enumerate(ys)]
+    adds = [dev(np.random.default_rng(13 + i).standard_normal((rows,) + tuple(x.shape[1:]))) for i, x in enumerate(xs)]
+    gxs = P.conv1d_parts_bwd_data(gys, ys, w, d, [x.shape for x in xs], gx_adds=adds, image_bwd=imgb)
+    wd, bd = w.double().cpu(), b.double().cpu()
+    for i, x in enumerate(xs):
+        di, lo = _desc(K5, x, w)
+        y1 = P.conv1d_img_fwd(x, img, b, di, lo)
+        assert rel(ys[i], y1) < 1e-6, ("forward vs single image launch", i, rel(ys[i], y1))
+        yr = F.leaky_relu(F.conv1d(x.double().cpu(), wd, bd, padding=2), 0.2)
+        assert rel(ys[i].cpu(), yr) < 1e-6, ("forward vs float64", i, rel(ys[i].cpu(), yr))
+        dr, _ = _desc(K5, x[:rows], w)
+        gx1 = P.conv1d_img_bwd_data(gys[i], ys[i][:rows].contiguous(), imgb, dr, gx_add=adds[i])
+        assert rel(gxs[i], gx1) < 1e-6, ("backward data vs single image launch", i, rel(gxs[i], gx1))
+        pre_grad = gys[i].double().cpu() * torch.where(ys[i][:rows].cpu() > 0, 1.0, 0.2).double()
+        gxr = F.conv_transpose1d(pre_grad, wd, padding=2)
+        assert rel(gxs[i].cpu() - adds[i].cpu(), gxr) < 2e-6, ("backward data vs float64", i)
+    # run-to-run determinism of the one-launch form
+    ys2 = P.conv1d_parts_fwd(xs, w, b, d, image=img)
+    assert all(torch.equal(a, c) for a, c in zip(ys, ys2))
+
+
+def test_parts_mode_equals_per_scale_passes(monkeypatch):
+    """The discriminator pass layer-by-layer over all scales (the default) against one pass per scale on forked streams
+    (MSYNTH_DPARTS=0, the r01-r04 schedule): same features and judgements (bitwise where the kernels are the same work units:
+    everything but the k5 layer's slice grouping), same input gradient and parameter gradients to summation order."""
+    from featuresynth._ops import graph as G
+    from featuresynth._synthetic import module_param_shapes, synthetic_samples, synthetic_state_dict
+    import featuresynth as fs
+    dmod = fs.MelGanDiscriminator()
+    sd = synthetic_state_dict(module_param_shapes(dmod), seed=8, bias_scale=0.02)
+    params = [dev(v) for v in sd.values()]
+    x = dev(synthetic_samples(4, 8192, rank=3))
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MSYNTH_DPARTS", mode)
+        feats, judges, ctx = G.melgan_forward(x, params)
+        g_feats = [[torch.full_like(t, 1e-3) for t in grp] for grp in feats]
+        g_judges = [torch.full_like(j, -0.25) for j in judges]
+        gx, sink = G.melgan_backward(ctx, params, g_feats, g_judges, None, need_gx=True, need_wgrad=True)
+        torch.cuda.synchronize()
+        res[mode] = (feats, judges, gx, sink.t)
+    fa, ja, gxa, ga = res["1"]
+    fb, jb, gxb, gb = res["0"]
+    for s in range(3):
+        assert rel(ja[s], jb[s]) < 1e-6
+        for li in range(6):
+            if li < 5:
+                assert torch.equal(fa[s][li], fb[s][li]), (s, li)
+            else:
+                assert rel(fa[s][li], fb[s][li]) < 1e-6, (s, li)
+    assert rel(gxa, gxb) < 1e-5, rel(gxa, gxb)
+    for i, (a, c) in enumerate(zip(ga, gb)):
+        assert rel(a, c) < 1e-5, (i, rel(a, c))
