@@ -26,6 +26,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // a 16-byte access at any 4-byte aligned address
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -155,10 +156,13 @@ __device__ __forceinline__ void gconv_fwd_body(const ConvP& p, int spr, int nseg
     // Inputs are read through a buffer descriptor: a quad that lies outside its row (the zero padding) or
     // behind the last segment carries an out-of-range offset and the hardware range check returns 0.0f.
     constexpr unsigned OOB = 0xF0000000u;
-    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x80000000u, 0x00020000);
+    // (true size: the unaligned quad across the END of the tensor's last row must not touch memory behind the tensor -- the
+    //  range check returns 0.0 for those dwords)
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 4u * (unsigned)(p.B * p.Cin * p.Lin), 0x00020000);
     auto gload = [&](auto& xr, const Cur& c) {
-        if (RB == 1 && VEC) {
-            // interior unit (every quad inside its row): lane-constant offsets + scalar unit base, no vector math
+        if (RB == 1) {
+            // interior unit (every quad inside its row): lane-constant offsets + scalar unit base, no vector math (rows of
+            // any length: a quad that is not 16-byte aligned is one unaligned 16-byte access, which the memory pipe takes)
             const int s0 = c.ts * (C::TS * GS) - p.pad;
             if (c.seg < nseg && s0 >= 0 && s0 + 4 * C::NQR <= p.Lin) {
                 const unsigned ub = (unsigned)__builtin_amdgcn_readfirstlane(((c.b * p.Cin + g * GCG) * p.Lin + s0) * 4);
@@ -182,12 +186,14 @@ __device__ __forceinline__ void gconv_fwd_body(const ConvP& p, int spr, int nseg
                 xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                       rsX, ok ? (rowoff + (unsigned)sidx) * 4u : OOB, 0, 0));
             } else {
+                // rows whose length is not a multiple of 4: the quad is still ONE (unaligned) 16-byte load; sidx is a multiple of
+                // 4, so a quad is wholly in front of its row or starts inside it, and only the quad across the row END holds
+                // samples of the next row, which are cleared
+                const bool ok = segok && sidx >= 0 && sidx < p.Lin;
+                xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      rsX, ok ? (rowoff + (unsigned)sidx) * 4u : OOB, 0, 0));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool ok = segok && sidx + e >= 0 && sidx + e < p.Lin;
-                    xr[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                             rsX, ok ? (rowoff + (unsigned)(sidx + e)) * 4u : OOB, 0, 0));
-                }
+                for (int e = 1; e < 4; ++e) xr[i][e] = sidx + e < p.Lin ? xr[i][e] : 0.f;
             }
         }
     };
@@ -319,6 +325,8 @@ __device__ __forceinline__ void gconv_fwd_body(const ConvP& p, int spr, int nseg
                 }
                 if (VOUT) {
                     *reinterpret_cast<float4*>(yr + (size_t)r * p.Lout) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if (t + 3 < p.Lout) {          // any row length: one unaligned 16-byte store inside the row
+                    *reinterpret_cast<f32x4u*>(yr + (size_t)r * p.Lout) = (f32x4u){v[0], v[1], v[2], v[3]};
                 } else {
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
@@ -453,9 +461,11 @@ __device__ __forceinline__ void gconv_wgrad_body(const ConvP& p, const float* __
         x_c[i] = act ? (unsigned)(ci * p.Lin + 4 * Q) : 0x3C000000u;      // (elements; x4 = out of range)
     }
     constexpr unsigned OOB = 0xF0000000u;
-    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x80000000u, 0x00020000);
-    const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy), 0, 0x80000000u, 0x00020000);
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(y_act ? y_act : gy), 0, 0x80000000u, 0x00020000);
+    // (true sizes: see the forward kernel)
+    const unsigned g_bytes = 4u * (unsigned)(p.B * p.Cout * p.Lout);
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 4u * (unsigned)(p.B * p.Cin * p.Lin), 0x00020000);
+    const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy), 0, g_bytes, 0x00020000);
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(y_act ? y_act : gy), 0, g_bytes, 0x00020000);
 
     const int tiles = (p.Lout + WU - 1) / WU;
     const int nunits = p.B * tiles;
@@ -472,7 +482,7 @@ __device__ __forceinline__ void gconv_wgrad_body(const ConvP& p, const float* __
         const int t0 = ti * WU, u0 = t0 * GS - p.pad;
         const unsigned gbase = (unsigned)((b * p.Cout + g * p.Og) * p.Lout + t0);
         const unsigned xbase = (unsigned)((b * p.Cin + g * GCG) * p.Lin);
-        if (VEC && t0 + WU <= p.Lout && u0 >= 0 && u0 + 4 * WXQ <= p.Lin) {
+        if (t0 + WU <= p.Lout && u0 >= 0 && u0 + 4 * WXQ <= p.Lin) {      // interior unit, rows of any length (unaligned 16-byte loads)
             const unsigned gs = (unsigned)__builtin_amdgcn_readfirstlane((int)(gbase * 4u));
             const unsigned xs = (unsigned)__builtin_amdgcn_readfirstlane((int)((xbase + (unsigned)u0) * 4u));
 #pragma unroll
@@ -495,14 +505,14 @@ __device__ __forceinline__ void gconv_wgrad_body(const ConvP& p, const float* __
                 const unsigned vo = ok ? off * 4u : OOB;
                 gv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vo, 0, 0));
                 ga[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0));
-            } else {
+            } else {         // any row length: unaligned 16-byte loads, the samples behind the row end cleared
+                const bool ok = co < p.Og && t0 + 4 * tq < p.Lout;
+                const unsigned vo = ok ? off * 4u : OOB;
+                gv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vo, 0, 0));
+                ga[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool ok = co < p.Og && t0 + 4 * tq + e < p.Lout;
-                    const unsigned vo = ok ? (off + e) * 4u : OOB;
-                    gv[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsG, vo, 0, 0));
-                    ga[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, vo, 0, 0));
-                }
+                for (int e = 1; e < 4; ++e)
+                    if (t0 + 4 * tq + e >= p.Lout) { gv[i][e] = 0.f; ga[i][e] = 0.f; }
             }
         }
 #pragma unroll
@@ -513,13 +523,12 @@ __device__ __forceinline__ void gconv_wgrad_body(const ConvP& p, const float* __
                 const bool ok = x_c[i] < 0x3C000000u && sidx >= 0 && sidx < p.Lin;
                 xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                       rsX, ok ? (xbase + x_c[i] + (unsigned)u0) * 4u : OOB, 0, 0));
-            } else {
+            } else {         // (u0 is a multiple of 4: a quad lies wholly in front of the row or starts inside it)
+                const bool ok = x_c[i] < 0x3C000000u && sidx >= 0 && sidx < p.Lin;
+                xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      rsX, ok ? (xbase + x_c[i] + (unsigned)u0) * 4u : OOB, 0, 0));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool ok = x_c[i] < 0x3C000000u && sidx + e >= 0 && sidx + e < p.Lin;
-                    xv[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                             rsX, ok ? (xbase + x_c[i] + (unsigned)(u0 + e)) * 4u : OOB, 0, 0));
-                }
+                for (int e = 1; e < 4; ++e) xv[i][e] = sidx + e < p.Lin ? xv[i][e] : 0.f;
             }
         }
     };
@@ -777,8 +786,9 @@ __device__ __forceinline__ void gconv_bwd_data_body(const ConvP& p, int tiles, i
     const int cq = lane & 3, pq = lane >> 2;
     unsigned char* wr = img + (cq >> 1) * BOCT + (4 * pq) * 16 + (cq & 1) * 8;       // + j * 16 (position), + piece
     constexpr unsigned OOB = 0xF0000000u;
-    const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy), 0, 0x80000000u, 0x00020000);
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(y_act ? y_act : gy), 0, 0x80000000u, 0x00020000);
+    const unsigned g_bytes = 4u * (unsigned)(p.B * p.Cout * p.Lout);            // (true sizes: see the forward kernel)
+    const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy), 0, g_bytes, 0x00020000);
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(y_act ? y_act : gy), 0, g_bytes, 0x00020000);
     unsigned g_c[4];                              // interior units: byte offset of row 4 cq + k, position quad pq
 #pragma unroll
     for (int k = 0; k < 4; ++k) g_c[k] = (unsigned)((4 * cq + k) * p.Lout + 4 * pq) * 4u;
@@ -786,7 +796,7 @@ __device__ __forceinline__ void gconv_bwd_data_body(const ConvP& p, int tiles, i
     auto gload = [&](int b, int ti) {
         const int ws = ti * BQ - 8;                                   // first staged gradient position
         const unsigned base = (unsigned)((b * p.Cout + g * 16) * p.Lout);
-        if (VEC && ws >= 0 && ws + BNP <= p.Lout) {
+        if (ws >= 0 && ws + BNP <= p.Lout) {                   // interior unit, rows of any length (unaligned 16-byte loads)
             const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((base + (unsigned)ws) * 4u));
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -803,13 +813,13 @@ __device__ __forceinline__ void gconv_bwd_data_body(const ConvP& p, int tiles, i
                 const unsigned vo = (t >= 0 && t < p.Lout) ? (off + (unsigned)t) * 4u : OOB;
                 gv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vo, 0, 0));
                 ga[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0));
-            } else {
+            } else {         // any row length (t is a multiple of 4: only the quad across the row end needs clearing)
+                const unsigned vo = (t >= 0 && t < p.Lout) ? (off + (unsigned)t) * 4u : OOB;
+                gv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vo, 0, 0));
+                ga[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned vo = (t + e >= 0 && t + e < p.Lout) ? (off + (unsigned)(t + e)) * 4u : OOB;
-                    gv[k][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsG, vo, 0, 0));
-                    ga[k][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, vo, 0, 0));
-                }
+                for (int e = 1; e < 4; ++e)
+                    if (t + e >= p.Lout) { gv[k][e] = 0.f; ga[k][e] = 0.f; }
             }
         }
     };
@@ -932,6 +942,13 @@ __device__ __forceinline__ void gconv_bwd_data_body(const ConvP& p, int tiles, i
                 f32x4 v = acc[tq];
                 if (gx_add) v += addv[tq];
                 *reinterpret_cast<f32x4*>(gx + rowoff + sidx) = v;
+            } else if (sidx + 3 < p.Lin) {                 // any row length: unaligned 16-byte accesses inside the row
+                f32x4 v = acc[tq];
+                if (gx_add) {
+                    const f32x4u a4 = *reinterpret_cast<const f32x4u*>(gx_add + rowoff + sidx);
+                    v += (f32x4){a4[0], a4[1], a4[2], a4[3]};
+                }
+                *reinterpret_cast<f32x4u*>(gx + rowoff + sidx) = (f32x4u){v[0], v[1], v[2], v[3]};
             } else {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
@@ -1060,8 +1077,8 @@ bool al16(const void* a) { return (((uintptr_t)a) & 15) == 0; }
 }  // namespace
 
 // Forward: every part must be a geometry the single launch takes; part 0 16-byte shaped (the instantiations of a parts kernel
-// are <RB0, vec, vec>, <RB1, dword, dword>, <RB2, dword, dword>); the RB triples are those of the three scales of 2^k-sample
-// windows (8192 -> 2048 / 1025 / 513 ... 32 / 17 / 9) -- anything else runs part by part.
+// are <RB0, vec, vec>, <RB1, dword, dword>, <RB2, dword, dword>); the RB triples are those of the three scales of an 8192-sample
+// window (outputs 2048 / 1025 / 513 ... 32 / 17 / 9) -- anything else runs part by part.
 bool msg3_parts_fwd_applicable(const ConvP& c, const ms_conv1d_parts* parts) {
     G3Parts q;
     if (!g3_parts_table(c, parts, &q) || q.count != 3) return false;
@@ -1069,7 +1086,8 @@ bool msg3_parts_fwd_applicable(const ConvP& c, const ms_conv1d_parts* parts) {
         if (!msg3_fwd_applicable(g3_host_part(c, q, i)) || !parts->x[i] || !parts->y[i]) return false;
     if (q.Lin[0] % 4 || c.pad % 4 || q.Lout[0] % 4 || !al16(parts->x[0]) || !al16(parts->y[0])) return false;
     const int r0 = pick_rb(q.Lout[0]), r1 = pick_rb(q.Lout[1]), r2 = pick_rb(q.Lout[2]);
-    return (r0 == 1 && r1 == 1 && r2 == 1) || (r0 == 1 && r1 == 4 && r2 == 1) || (r0 == 2 && r1 == 2 && r2 == 4);
+    return (r0 == 1 && r1 == 1 && r2 == 2) || (r0 == 1 && r1 == 2 && r2 == 4) || (r0 == 1 && r1 == 4 && r2 == 1) ||
+           (r0 == 2 && r1 == 2 && r2 == 4);
 }
 
 int msg3_parts_fwd(const ConvP& c, const ms_conv1d_parts* parts, const float* w, const float* bias, hipStream_t s) {
@@ -1096,9 +1114,10 @@ int msg3_parts_fwd(const ConvP& c, const ms_conv1d_parts* parts, const float* w,
     ms_note_kernel(3, "k_gconv_split_fwd_parts<%d, %d, %d>", rb[0], rb[1], rb[2]);
 #define MS_G3P(A, B_, C_) \
     hipLaunchKernelGGL((k_gconv_split_fwd_parts<A, B_, C_>), grid, dim3(256), lds, s, q, w, bias)
-    if (rb[0] == 1 && rb[1] == 1 && rb[2] == 1) MS_G3P(1, 1, 1);
-    else if (rb[0] == 1 && rb[1] == 4 && rb[2] == 1) MS_G3P(1, 4, 1);
-    else if (rb[0] == 2 && rb[1] == 2 && rb[2] == 4) MS_G3P(2, 2, 4);
+    if (rb[0] == 1 && rb[1] == 1 && rb[2] == 2) MS_G3P(1, 1, 2);              // 2048 / 1025 / 513 outputs
+    else if (rb[0] == 1 && rb[1] == 2 && rb[2] == 4) MS_G3P(1, 2, 4);         // 512 / 257 / 129
+    else if (rb[0] == 1 && rb[1] == 4 && rb[2] == 1) MS_G3P(1, 4, 1);         // 128 / 65 / 33
+    else if (rb[0] == 2 && rb[1] == 2 && rb[2] == 4) MS_G3P(2, 2, 4);         // 32 / 17 / 9
     else return MS_ERR_UNSUPPORTED;
 #undef MS_G3P
     MS_CHECK_LAUNCH();

@@ -642,10 +642,20 @@ def melgan_backward_parts(ctx, params, g_feats, g_judges, sink=None, need_gx=Tru
     def own(s, li):
         return g_feats[s][li] if (g_feats is not None and g_feats[s] is not None and li >= 0) else None
 
+    # the weight gradients only need the chain's gradients, never the other way round: they run on a side stream beside the
+    # backward-data chain (MSYNTH_DWGSTREAM=0: on the caller's stream)
+    fork = _WgradFork(xs[0].device) if (need_wgrad and os.environ.get("MSYNTH_DWGSTREAM", "1") != "0") else None
+
     def wgrad(slot, live, xs_, gys, yas, d, w_shape):
         gw, gb, acc = sink.pair(slot)
-        sink.put(slot, *P.conv1d_parts_bwd_weight([xs_[s] for s in live], [gys[s] for s in live],
-                                                  None if yas is None else [yas[s] for s in live], d, w_shape, gw, gb, acc))
+        a, b_, c = [xs_[s] for s in live], [gys[s] for s in live], (None if yas is None else [yas[s] for s in live])
+
+        def go():
+            sink.put(slot, *P.conv1d_parts_bwd_weight(a, b_, c, d, w_shape, gw, gb, acc))
+        if fork is not None:
+            fork.run(go, *(a + b_ + (c or [])))
+        else:
+            go()
 
     g = [None] * n
     # judge conv: g = total gradient w.r.t. feature 5 (judge path + the loss's own term on that feature)
@@ -684,7 +694,11 @@ def melgan_backward_parts(ctx, params, g_feats, g_judges, sink=None, need_gx=Tru
             if s not in live:
                 g[s] = prev[s]
         if li == 5 and cut is not None:
+            if fork is not None:
+                fork.join()             # the head's parameter gradients are final on the caller's stream
             cut()
+    if fork is not None:
+        fork.join()
     gx_next = None
     for s in range(n - 1, -1, -1):
         gx = g[s]
