@@ -320,9 +320,10 @@ ms_conv1d_desc part_desc(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, 
 // 1: a parts kernel takes the call; 0: part by part
 int parts_kernel(const ConvP& c, const ms_conv1d_parts* parts, int which, bool with_image) {
     if (parts->count < 2 || c.in_act) return 0;
+    if (msd_parts_applicable(c, parts, which)) return 1;
     if (which == 0) return (with_image && ms5_parts_applicable(c, parts, false)) || msg3_parts_fwd_applicable(c, parts);
     if (which == 1) return (with_image && ms5_parts_applicable(c, parts, true)) || msg3_parts_bwd_data_applicable(c, parts);
-    return msg3_parts_bwd_weight_applicable(c, parts);
+    return msw5_parts_applicable(c, parts) || msg3_parts_bwd_weight_applicable(c, parts);
 }
 
 }  // namespace
@@ -336,7 +337,11 @@ int ms_conv1d_parts_launches(const ms_conv1d_desc* d, const ms_conv1d_parts* par
 size_t ms_conv1d_parts_workspace_bytes(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, int which, int with_image) {
     ConvP c;
     if (!parts_ok(d, parts, &c) || which < 0 || which > 2) return 0;
-    if (parts_kernel(c, parts, which, with_image != 0)) return which == 2 ? msg3_parts_bwd_weight_ws(c, parts) : 0;
+    if (parts_kernel(c, parts, which, with_image != 0)) {
+        if (which != 2) return 0;
+        if (msd_parts_applicable(c, parts, which)) return msd_parts_bwd_weight_ws(c, parts);
+        return msw5_parts_applicable(c, parts) ? msw5_parts_ws(c, parts) : msg3_parts_bwd_weight_ws(c, parts);
+    }
     size_t n = 0;
     for (int i = 0; i < parts->count; ++i) {
         const ms_conv1d_desc di = part_desc(d, parts, i);
@@ -353,6 +358,10 @@ int ms_conv1d_parts_fwd(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, c
     if (!parts_ok(d, parts, &c) || (!w && !image)) return MS_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (parts->count >= 2 && !c.in_act) {
+        if (w && msd_parts_applicable(c, parts, 0)) {
+            const int rc = msd_parts_fwd(c, parts, w, bias, s);
+            if (rc != MS_ERR_UNSUPPORTED) return rc;
+        }
         if (image && ms5_parts_applicable(c, parts, false)) return ms5_parts_fwd(c, parts, image, bias, s);
         if (w && msg3_parts_fwd_applicable(c, parts)) return msg3_parts_fwd(c, parts, w, bias, s);
     }
@@ -376,6 +385,10 @@ int ms_conv1d_parts_bwd_data(const ms_conv1d_desc* d, const ms_conv1d_parts* par
     if (!parts_ok(d, parts, &c) || (!w && !image_bwd)) return MS_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (parts->count >= 2 && !c.in_act) {
+        if (w && msd_parts_applicable(c, parts, 1)) {
+            const int rc = msd_parts_bwd_data(c, parts, w, s);
+            if (rc != MS_ERR_UNSUPPORTED) return rc;
+        }
         if (image_bwd && ms5_parts_applicable(c, parts, true)) return ms5_parts_bwd_data(c, parts, image_bwd, s);
         if (w && msg3_parts_bwd_data_applicable(c, parts)) return msg3_parts_bwd_data(c, parts, w, s);
     }
@@ -399,6 +412,12 @@ int ms_conv1d_parts_bwd_weight(const ms_conv1d_desc* d, const ms_conv1d_parts* p
                                void* workspace, size_t workspace_bytes, ms_stream_t stream) {
     ConvP c;
     if (!parts_ok(d, parts, &c) || !gw || (beta != 0.f && beta != 1.f)) return MS_ERR_INVALID_ARG;
+    if (parts->count >= 2 && !c.in_act && msd_parts_applicable(c, parts, 2)) {
+        const int rc = msd_parts_bwd_weight(c, parts, gw, gb, beta, workspace, workspace_bytes, (hipStream_t)stream);
+        if (rc != MS_ERR_UNSUPPORTED) return rc;
+    }
+    if (parts->count >= 2 && !c.in_act && msw5_parts_applicable(c, parts))
+        return msw5_parts_bwd_weight(c, parts, gw, gb, beta, workspace, workspace_bytes, (hipStream_t)stream);
     if (parts->count >= 2 && !c.in_act && msg3_parts_bwd_weight_applicable(c, parts))
         return msg3_parts_bwd_weight(c, parts, gw, gb, beta, workspace, workspace_bytes, (hipStream_t)stream);
     for (int i = 0; i < parts->count; ++i) {             // the parts' gradients accumulate in order on the one stream

@@ -48,3 +48,15 @@ int msg3_parts_bwd_weight(const ConvP& c, const ms_conv1d_parts* parts, float* g
 bool ms5_parts_applicable(const ConvP& c, const ms_conv1d_parts* parts, bool backward);
 int ms5_parts_fwd(const ConvP& c, const ms_conv1d_parts* parts, const void* image, const float* bias, hipStream_t s);
 int ms5_parts_bwd_data(const ConvP& c, const ms_conv1d_parts* parts, const void* image_bwd, hipStream_t s);
+// the k5 layer's weight gradient over the scales (wgrad_k5.hip)
+bool msw5_parts_applicable(const ConvP& c, const ms_conv1d_parts* parts);
+size_t msw5_parts_ws(const ConvP& c, const ms_conv1d_parts* parts);
+int msw5_parts_bwd_weight(const ConvP& c, const ms_conv1d_parts* parts, float* gw, float* gb, float beta, void* ws,
+                          size_t ws_bytes, hipStream_t s);
+// the discriminator's first conv (1 -> 16, k15) and judge conv (1024 -> 1, k3) over the scales (disc_parts.hip)
+bool msd_parts_applicable(const ConvP& c, const ms_conv1d_parts* parts, int which);
+size_t msd_parts_bwd_weight_ws(const ConvP& c, const ms_conv1d_parts* parts);
+int msd_parts_fwd(const ConvP& c, const ms_conv1d_parts* parts, const float* w, const float* bias, hipStream_t s);
+int msd_parts_bwd_data(const ConvP& c, const ms_conv1d_parts* parts, const float* w, hipStream_t s);
+int msd_parts_bwd_weight(const ConvP& c, const ms_conv1d_parts* parts, float* gw, float* gb, float beta, void* ws,
+                         size_t ws_bytes, hipStream_t s);

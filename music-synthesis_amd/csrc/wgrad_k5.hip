@@ -42,10 +42,19 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsign
     l = __builtin_bit_cast(unsigned, lo);
 }
 
+// The contraction runs over OCTETS of 8 consecutive outputs.  The octets of up to MS_CONV_PARTS_MAX inputs ("parts": the
+// shared discriminator's three scales, reference discriminator/melgan.py:13-27) form one index space -- part i owns octets
+// [o0[i], o0[i + 1]), NO[i] per batch row -- so that the weight gradient of the shared layer over all scales is ONE launch
+// and one slab reduction.
 struct W5P {
-    int B, M, C, L, NO, nsteps, sps, act;     // NO octets per row, nsteps = ceil(B * NO / 4), sps steps per slab
+    int M, C, nsteps, sps, act;               // nsteps = ceil(total octets / 4), sps steps per slab
     float slope;
     size_t stride;                            // floats per slab
+    int count, o0[MS_CONV_PARTS_MAX + 1];
+    int B[MS_CONV_PARTS_MAX], L[MS_CONV_PARTS_MAX], NO[MS_CONV_PARTS_MAX];
+    const float* x[MS_CONV_PARTS_MAX];
+    const float* gy[MS_CONV_PARTS_MAX];
+    const float* ya[MS_CONV_PARTS_MAX];       // saved outputs (activation derivative) or nullptr
 };
 
 constexpr int TCO = 64, TCI = 64;
@@ -55,57 +64,59 @@ constexpr int IMG = 3 * (A_PIECE + B_PIECE);
 constexpr int EPI_FLOATS = 32 * TCI * 5;     // half a tile staged for the coalesced slab write
 static_assert(2 * IMG >= EPI_FLOATS * 4, "epilogue staging fits the images");
 
+// VEC: one part whose rows are 16-byte shaped (aligned vectors, all-or-nothing); otherwise rows of any length through
+// unaligned 16- / 8-byte loads whose out-of-row samples are cleared (the conditions are wave-uniform: a wave stages one octet
+// slot per step)
 template <bool VEC>
-__global__ __launch_bounds__(256, 2) void k_wgrad_k5_split(W5P p, const float* __restrict__ x,
-                                                          const float* __restrict__ gy,
-                                                          const float* __restrict__ y_act,
-                                                          float* __restrict__ partial) {
+__global__ __launch_bounds__(256, 2) void k_wgrad_k5_split(W5P p, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem5[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int m0 = blockIdx.x * TCO, c0 = blockIdx.y * TCI, z = blockIdx.z;
-    const int kind = y_act ? p.act : MS_ACT_NONE;
-    const int r64 = tid & 63, oc = tid >> 6;            // staging item: row (co / ci) r64 of octet slot oc
+    const int kind = p.ya[0] ? p.act : MS_ACT_NONE;
+    const int r64 = tid & 63, oc = __builtin_amdgcn_readfirstlane(tid >> 6);   // staging item: row (co / ci) r64 of octet slot oc
     constexpr unsigned OOB = 0xF0000000u;
-    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x80000000u, 0x00020000);
-    const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy), 0, 0x80000000u, 0x00020000);
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(y_act ? y_act : gy), 0, 0x80000000u, 0x00020000);
 
     float gv[8], ga[8], xv[12];
     auto gload = [&](int step) {
         const int o = 4 * step + oc;
-        const int b = o / p.NO, t0 = (o - b * p.NO) * 8;
-        const bool ov = b < p.B;
-        const unsigned grow = (unsigned)((b * p.M + m0 + r64) * p.L);
-        const unsigned xrow = (unsigned)((b * p.C + c0 + r64) * p.L);
-        if (VEC) {                                       // L % 4 == 0: aligned 16- / 8-byte loads, all-or-nothing
+        // the octet's part (compile-time indices into the by-value tables: see conv5_img.hip)
+        int ob = 0, Bp = p.B[0], L = p.L[0], NO = p.NO[0];
+        const float* xp = p.x[0];
+        const float* gp = p.gy[0];
+        const float* ap = p.ya[0];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const unsigned vo = (ov && t0 + 4 * j < p.L) ? (grow + (unsigned)(t0 + 4 * j)) * 4u : OOB;
-                const f32x4 g4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vo, 0, 0));
-                const f32x4 a4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { gv[4 * j + e] = g4[e]; ga[4 * j + e] = a4[e]; }
+        for (int k = 1; k < MS_CONV_PARTS_MAX; ++k)
+            if (k < p.count && o >= p.o0[k]) {
+                ob = p.o0[k]; Bp = p.B[k]; L = p.L[k]; NO = p.NO[k];
+                xp = p.x[k]; gp = p.gy[k]; ap = p.ya[k];
             }
+        // (true sizes: the unaligned loads across the end of a tensor's last row read 0.0 behind it)
+        const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xp), 0, 4u * (unsigned)(Bp * p.C * L), 0x00020000);
+        const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gp), 0, 4u * (unsigned)(Bp * p.M * L), 0x00020000);
+        const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ap ? ap : gp), 0, 4u * (unsigned)(Bp * p.M * L), 0x00020000);
+        const int ol = o - ob;
+        const int b = ol / NO, t0 = (ol - b * NO) * 8;
+        const bool ov = b < Bp;
+        const unsigned grow = (unsigned)((b * p.M + m0 + r64) * L);
+        const unsigned xrow = (unsigned)((b * p.C + c0 + r64) * L);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int t = t0 - 2 + 2 * j;
-                const unsigned vo = (ov && t >= 0 && t < p.L) ? (xrow + (unsigned)t) * 4u : OOB;
-                const f32x2 v2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsX, vo, 0, 0));
-                xv[2 * j] = v2[0]; xv[2 * j + 1] = v2[1];
-            }
-        } else {
+        for (int j = 0; j < 2; ++j) {
+            const unsigned vo = (ov && t0 + 4 * j < L) ? (grow + (unsigned)(t0 + 4 * j)) * 4u : OOB;
+            const f32x4 g4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vo, 0, 0));
+            const f32x4 a4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, 0, 0));
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const unsigned vo = (ov && t0 + e < p.L) ? (grow + (unsigned)(t0 + e)) * 4u : OOB;
-                gv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsG, vo, 0, 0));
-                ga[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, vo, 0, 0));
+            for (int e = 0; e < 4; ++e) {
+                const bool in = VEC || t0 + 4 * j + e < L;
+                gv[4 * j + e] = in ? g4[e] : 0.f; ga[4 * j + e] = in ? a4[e] : 0.f;
             }
+        }
 #pragma unroll
-            for (int e = 0; e < 12; ++e) {
-                const int t = t0 - 2 + e;
-                const unsigned vo = (ov && t >= 0 && t < p.L) ? (xrow + (unsigned)t) * 4u : OOB;
-                xv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, vo, 0, 0));
-            }
+        for (int j = 0; j < 6; ++j) {
+            const int t = t0 - 2 + 2 * j;                  // (even: a pair lies wholly in front of the row or starts inside it)
+            const unsigned vo = (ov && t >= 0 && t < L) ? (xrow + (unsigned)t) * 4u : OOB;
+            const f32x2 v2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsX, vo, 0, 0));
+            xv[2 * j] = v2[0];
+            xv[2 * j + 1] = (VEC || t + 1 < L) ? v2[1] : 0.f;
         }
     };
     float bsum = 0.f;
@@ -246,38 +257,39 @@ int pick_nsplit(const ConvP& p, int nsteps) {
     return ns < 1 ? 1 : ns;
 }
 
-}  // namespace
-
-bool msw5_applicable(const ConvP& p) {
-    const char* e = getenv("MSYNTH_WGRAD5");          // tuning / test switch (0: fp32-MFMA row-tile kernel)
-    if (e && atoi(e) == 0) return false;
+bool w5_geometry(const ConvP& p) {
     return p.groups == 1 && p.stride == 1 && p.dil == 1 && p.K == 5 && p.pad == 2 && p.Lout == p.Lin &&
            p.pad_mode == MS_PAD_ZERO && !p.in_act && p.Cout % TCO == 0 && p.Cin % TCI == 0 && p.Cout >= 256 &&
            p.Cin >= 256 && p.Lin <= 64 && (long long)p.B * p.Cout * p.Lin * 4 < (1ll << 31) &&
            (long long)p.B * p.Cin * p.Lin * 4 < (1ll << 31);
 }
 
-size_t msw5_ws(const ConvP& p) {
-    const int NO = (p.Lin + 7) / 8, nsteps = (p.B * NO + 3) / 4;
-    return (size_t)pick_nsplit(p, nsteps) * ((size_t)p.Cout * p.Cin * 5 + p.Cout) * sizeof(float);
+bool w5_enabled() {
+    const char* e = getenv("MSYNTH_WGRAD5");          // tuning / test switch (0: fp32-MFMA row-tile kernel)
+    return !(e && atoi(e) == 0);
 }
 
-const char* msw5_name(const ConvP&) { return "k_wgrad_k5_split"; }
+// table of `n` parts (B[i], L[i]) of the layer c; pointers filled by the caller
+void w5_table(const ConvP& c, int n, const int* B, const int* L, W5P* q) {
+    q->M = c.Cout; q->C = c.Cin; q->act = c.act; q->slope = c.slope;
+    q->stride = (size_t)c.Cout * c.Cin * 5 + c.Cout;
+    q->count = n;
+    q->o0[0] = 0;
+    for (int i = 0; i < MS_CONV_PARTS_MAX; ++i) {
+        const bool on = i < n;
+        q->B[i] = on ? B[i] : 0; q->L[i] = on ? L[i] : 1; q->NO[i] = on ? (L[i] + 7) / 8 : 1;
+        q->o0[i + 1] = q->o0[i] + q->B[i] * q->NO[i];
+        q->x[i] = q->gy[i] = q->ya[i] = nullptr;
+    }
+    q->nsteps = (q->o0[n] + 3) / 4;
+    const int ns = pick_nsplit(c, q->nsteps);
+    q->sps = (q->nsteps + ns - 1) / ns;
+}
 
-int msw5_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act, float* gw, float* gb,
-                    float beta, void* ws, size_t ws_bytes, hipStream_t s) {
-    if (!ws || ws_bytes < msw5_ws(p) || (((uintptr_t)ws) & 15)) return MS_ERR_WORKSPACE;
-    W5P q;
-    q.B = p.B; q.M = p.Cout; q.C = p.Cin; q.L = p.Lin; q.NO = (p.Lin + 7) / 8;
-    q.nsteps = (p.B * q.NO + 3) / 4;
-    const int ns = pick_nsplit(p, q.nsteps);
-    q.sps = (q.nsteps + ns - 1) / ns;
-    q.act = p.act; q.slope = p.slope;
-    q.stride = (size_t)p.Cout * p.Cin * 5 + p.Cout;
+int w5_launch(const ConvP& c, const W5P& q, bool vec, float* gw, float* gb, float beta, void* ws, size_t ws_bytes, hipStream_t s) {
     const int nz = (q.nsteps + q.sps - 1) / q.sps;
-    const dim3 grid(p.Cout / TCO, p.Cin / TCI, nz);
-    const bool vec = p.Lin % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)gy) & 15) == 0 &&
-                     (!y_act || (((uintptr_t)y_act) & 15) == 0);
+    if (!ws || ws_bytes < (size_t)nz * q.stride * sizeof(float) || (((uintptr_t)ws) & 15)) return MS_ERR_WORKSPACE;
+    const dim3 grid(c.Cout / TCO, c.Cin / TCI, nz);
     static unsigned long long attr_set = 0;
     if (ms_first_on_device(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_k5_split<true>),
@@ -288,8 +300,58 @@ int msw5_bwd_weight(const ConvP& p, const float* x, const float* gy, const float
     }
     float* partial = (float*)ws;
     ms_note_kernel(6, "k_wgrad_k5_split<%s>", vec ? "true" : "false");
-    if (vec) hipLaunchKernelGGL((k_wgrad_k5_split<true>), grid, dim3(256), 2 * IMG, s, q, x, gy, y_act, partial);
-    else hipLaunchKernelGGL((k_wgrad_k5_split<false>), grid, dim3(256), 2 * IMG, s, q, x, gy, y_act, partial);
+    if (vec) hipLaunchKernelGGL((k_wgrad_k5_split<true>), grid, dim3(256), 2 * IMG, s, q, partial);
+    else hipLaunchKernelGGL((k_wgrad_k5_split<false>), grid, dim3(256), 2 * IMG, s, q, partial);
     MS_CHECK_LAUNCH();
-    return msm_wgrad_reduce(partial, q.stride, nz, (size_t)p.Cout * p.Cin * 5, p.Cout, gw, gb, beta, s);
+    return msm_wgrad_reduce(partial, q.stride, nz, (size_t)c.Cout * c.Cin * 5, c.Cout, gw, gb, beta, s);
+}
+
+}  // namespace
+
+bool msw5_applicable(const ConvP& p) { return w5_enabled() && w5_geometry(p); }
+
+size_t msw5_ws(const ConvP& p) {
+    W5P q;
+    w5_table(p, 1, &p.B, &p.Lin, &q);
+    return (size_t)((q.nsteps + q.sps - 1) / q.sps) * q.stride * sizeof(float);
+}
+
+const char* msw5_name(const ConvP&) { return "k_wgrad_k5_split"; }
+
+int msw5_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act, float* gw, float* gb,
+                    float beta, void* ws, size_t ws_bytes, hipStream_t s) {
+    W5P q;
+    w5_table(p, 1, &p.B, &p.Lin, &q);
+    q.x[0] = x; q.gy[0] = gy; q.ya[0] = y_act;
+    const bool vec = p.Lin % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)gy) & 15) == 0 &&
+                     (!y_act || (((uintptr_t)y_act) & 15) == 0);
+    return w5_launch(p, q, vec, gw, gb, beta, ws, ws_bytes, s);
+}
+
+// ---- the layer's weight gradient over all parts in one launch (api.hip: ms_conv1d_parts_bwd_weight)
+bool msw5_parts_applicable(const ConvP& c, const ms_conv1d_parts* parts) {
+    if (!w5_enabled() || !parts || parts->count < 2 || parts->count > MS_CONV_PARTS_MAX) return false;
+    for (int i = 0; i < parts->count; ++i) {
+        ConvP p = c;
+        p.B = parts->B[i]; p.Lin = p.Lout = parts->Lin[i];
+        if (p.B <= 0 || p.Lin <= 0 || !w5_geometry(p)) return false;
+    }
+    return true;
+}
+
+size_t msw5_parts_ws(const ConvP& c, const ms_conv1d_parts* parts) {
+    W5P q;
+    w5_table(c, parts->count, parts->B, parts->Lin, &q);
+    return (size_t)((q.nsteps + q.sps - 1) / q.sps) * q.stride * sizeof(float);
+}
+
+int msw5_parts_bwd_weight(const ConvP& c, const ms_conv1d_parts* parts, float* gw, float* gb, float beta, void* ws,
+                          size_t ws_bytes, hipStream_t s) {
+    W5P q;
+    w5_table(c, parts->count, parts->B, parts->Lin, &q);
+    for (int i = 0; i < parts->count; ++i) {
+        if (!parts->x[i] || !parts->gy[i]) return MS_ERR_INVALID_ARG;
+        q.x[i] = parts->x[i]; q.gy[i] = parts->gy[i]; q.ya[i] = c.act == MS_ACT_NONE ? nullptr : parts->y_act[i];
+    }
+    return w5_launch(c, q, false, gw, gb, beta, ws, ws_bytes, s);
 }

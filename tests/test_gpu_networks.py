@@ -97,7 +97,8 @@ def test_discriminator_forward_golden(golden):
     fd = d.disc
     with torch.no_grad():
         f1, j1 = fd(dev(synthetic_samples(2, 3000, rank=5)))
-    assert len(f1) == 6 and torch.equal(j1, judges[0])
+    # (the one-scale module runs the per-scale kernels, the three-scale one the parts kernels: summation order)
+    assert len(f1) == 6 and rel_l2(host(j1), host(judges[0])) < 1e-5
 
 
 def _trainers(g, d, optim_kind="flat"):

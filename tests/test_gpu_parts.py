@@ -46,11 +46,11 @@ def _inputs(geo, B, lens, seed):
     return xs, w, b
 
 
-def _desc(geo, x, w):
+def _desc(geo, x, w, act=None):
     from featuresynth._ops import lib as L
     from featuresynth._ops import prims as P
     Cin, Cout, K, stride, pad, groups = geo
-    return P.conv_desc(x.shape, w.shape, stride=stride, pad=pad, groups=groups, act=L.ACT_LRELU)
+    return P.conv_desc(x.shape, w.shape, stride=stride, pad=pad, groups=groups, act=L.ACT_LRELU if act is None else act)
 
 
 def _launches(d, tensors, which, image=False):
@@ -150,12 +150,99 @@ def test_k5_layer_over_three_scales(B, rows):
     # run-to-run determinism of the one-launch form
     ys2 = P.conv1d_parts_fwd(xs, w, b, d, image=img)
     assert all(torch.equal(a, c) for a, c in zip(ys, ys2))
+    # weight gradient over the three scales: one launch (the octets of all parts form one contraction), against the three
+    # accumulated single calls and float64
+    assert _launches(d, gys, 2) == 1
+    gw, gb = P.conv1d_parts_bwd_weight(xs, gys, ys, d, w.shape)
+    gw_s, gb_s = None, None
+    for i, x in enumerate(xs):
+        dr, _ = _desc(K5, x[:rows], w)
+        gw_s, gb_s = P.conv1d_bwd_weight(x[:rows].contiguous(), gys[i], ys[i][:rows].contiguous(), dr, w.shape, gw_s, gb_s,
+                                         accumulate=i > 0)
+    assert rel(gw, gw_s) < 2e-6 and rel(gb, gb_s) < 2e-6, (rel(gw, gw_s), rel(gb, gb_s))
+    gwr = torch.zeros_like(wd)
+    gbr = torch.zeros_like(bd)
+    for i, x in enumerate(xs):
+        pre_grad = gys[i].double().cpu() * torch.where(ys[i][:rows].cpu() > 0, 1.0, 0.2).double()
+        xd = F.pad(x[:rows].double().cpu(), (2, 2))
+        # gw[co, ci, k] = sum_{b, t} pre_grad[b, co, t] x[b, ci, t + k - 2]
+        for k in range(5):
+            gwr[:, :, k] += torch.einsum("bot,bit->oi", pre_grad, xd[:, :, k:k + x.shape[2]])
+        gbr += pre_grad.sum((0, 2))
+    assert rel(gw.cpu(), gwr) < 2e-6 and rel(gb.cpu(), gbr) < 2e-6, (rel(gw.cpu(), gwr), rel(gb.cpu(), gbr))
+    gw2, _ = P.conv1d_parts_bwd_weight(xs, gys, ys, d, w.shape)
+    assert torch.equal(gw, gw2)
+
+
+FIRST = (1, 16, 15, 1, 7, 1)          # discriminator/full.py:14 (+ LeakyReLU)
+JUDGE = (1024, 1, 3, 1, 1, 1)        # discriminator/full.py:22 (no activation)
+
+
+@pytest.mark.parametrize("which", ["first", "judge"])
+@pytest.mark.parametrize("B,rows,L0", [(64, 64, 8192), (64, 32, 8192), (3, 3, 8192), (2, 2, 3000)],
+                         ids=["b64", "b64_grad32", "b3", "offgrid"])
+def test_thin_layers_over_three_scales(which, B, rows, L0):
+    """The first conv (1 -> 16, k15, LeakyReLU) and the judge conv (1024 -> 1, k3) over the three scales, every pass as ONE
+    launch (csrc/disc_parts.hip) for rows of any length: against the per-scale entry points (1e-6: other summation order)
+    and float64 torch; deterministic; the backward passes may cover only the leading batch rows of what was saved."""
+    import torch.nn.functional as F
+    from featuresynth._ops import lib as L
+    from featuresynth._ops import prims as P
+    geo = FIRST if which == "first" else JUDGE
+    act = L.ACT_LRELU if which == "first" else L.ACT_NONE
+    if which == "first":
+        lens = _scale_lengths(L0, 0)
+    else:
+        lens = [l for l in _scale_lengths(L0, 4)]            # rows of 32 / 17 / 9 samples behind the four stride-4 layers
+    Cin, Cout, K, stride, pad, groups = geo
+    xs, w, b = _inputs(geo, B, lens, 77)
+    d, _ = _desc(geo, xs[0], w, act)
+    assert _launches(d, xs, 0) == 1 and _launches(d, xs, 1) == 1 and _launches(d, xs, 2) == 1
+    ys = P.conv1d_parts_fwd(xs, w, b, d)
+    ys_again = P.conv1d_parts_fwd(xs, w, b, d)
+    gys = [dev(np.random.default_rng(5 + i).standard_normal((rows,) + tuple(y.shape[1:]))) for i, y in enumerate(ys)]
+    adds = [dev(np.random.default_rng(25 + i).standard_normal((rows,) + tuple(x.shape[1:]))) for i, x in enumerate(xs)]
+    ya = ys if which == "first" else None
+    gxs = P.conv1d_parts_bwd_data(gys, ya, w, d, [x.shape for x in xs], gx_adds=adds)
+    gw, gb = P.conv1d_parts_bwd_weight(xs, gys, ya, d, w.shape)
+    gw2, gb2 = P.conv1d_parts_bwd_weight(xs, gys, ya, d, w.shape)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    wd, bd = w.double().cpu(), b.double().cpu()
+    gw_s = gb_s = None
+    gwr, gbr = torch.zeros_like(wd), torch.zeros_like(bd)
+    for i, x in enumerate(xs):
+        assert torch.equal(ys[i], ys_again[i])
+        di, lo = _desc(geo, x, w, act)
+        y1, _ = P.conv1d_fwd(x, w, b, di, lo)
+        assert rel(ys[i], y1) < 1e-6, ("forward vs per-scale launch", i, rel(ys[i], y1))
+        pre = F.conv1d(x.double().cpu(), wd, bd, padding=pad)
+        yr = F.leaky_relu(pre, 0.2) if which == "first" else pre
+        assert rel(ys[i].cpu(), yr) < 1e-6, ("forward vs float64", i, rel(ys[i].cpu(), yr))
+        xr = x[:rows].contiguous()
+        dr, _ = _desc(geo, xr, w, act)
+        yar = ys[i][:rows].contiguous() if which == "first" else None
+        gx1 = P.conv1d_bwd_data(gys[i], yar, w, dr, gx_add=adds[i])
+        assert rel(gxs[i], gx1) < 1e-6, ("backward data vs per-scale launch", i, rel(gxs[i], gx1))
+        gw_s, gb_s = P.conv1d_bwd_weight(xr, gys[i], yar, dr, w.shape, gw_s, gb_s, accumulate=i > 0)
+        pg = gys[i].double().cpu()
+        if which == "first":
+            pg = pg * torch.where(ys[i][:rows].cpu() > 0, 1.0, 0.2).double()
+        gxr = F.conv_transpose1d(pg, wd, padding=pad)
+        assert rel(gxs[i].cpu() - adds[i].cpu(), gxr) < 2e-6, ("backward data vs float64", i)
+        xp = F.pad(xr.double().cpu(), (pad, pad))
+        for k in range(K):
+            gwr[:, :, k] += torch.einsum("bot,bit->oi", pg, xp[:, :, k:k + x.shape[2]])
+        gbr += pg.sum((0, 2))
+    assert rel(gw, gw_s) < 2e-6 and rel(gb, gb_s) < 2e-5, (rel(gw, gw_s), rel(gb, gb_s))
+    assert rel(gw.cpu(), gwr) < 2e-6 and rel(gb.cpu(), gbr) < 2e-5, (rel(gw.cpu(), gwr), rel(gb.cpu(), gbr))
+    gw3, gb3 = P.conv1d_parts_bwd_weight(xs, gys, ya, d, w.shape, gw.clone(), gb.clone(), accumulate=True)
+    assert rel(gw3, 2 * gw) < 1e-6 and rel(gb3, 2 * gb) < 1e-6
 
 
 def test_parts_mode_equals_per_scale_passes(monkeypatch):
     """The discriminator pass layer-by-layer over all scales (the default) against one pass per scale on forked streams
-    (MSYNTH_DPARTS=0, the r01-r04 schedule): same features and judgements (bitwise where the kernels are the same work units:
-    everything but the k5 layer's slice grouping), same input gradient and parameter gradients to summation order."""
+    (MSYNTH_DPARTS=0, the r01-r04 schedule): same features, judgements, input gradient and parameter gradients to summation order (the
+    first conv, the judge conv and the k5 layer run other kernels; the grouped layers the same work units)."""
     from featuresynth._ops import graph as G
     from featuresynth._synthetic import module_param_shapes, synthetic_samples, synthetic_state_dict
     import featuresynth as fs
@@ -175,12 +262,9 @@ def test_parts_mode_equals_per_scale_passes(monkeypatch):
     fa, ja, gxa, ga = res["1"]
     fb, jb, gxb, gb = res["0"]
     for s in range(3):
-        assert rel(ja[s], jb[s]) < 1e-6
+        assert rel(ja[s], jb[s]) < 1e-5, (s, rel(ja[s], jb[s]))          # (small sums of cancelling terms)
         for li in range(6):
-            if li < 5:
-                assert torch.equal(fa[s][li], fb[s][li]), (s, li)
-            else:
-                assert rel(fa[s][li], fb[s][li]) < 1e-6, (s, li)
+            assert rel(fa[s][li], fb[s][li]) < 2e-6, (s, li, rel(fa[s][li], fb[s][li]))
     assert rel(gxa, gxb) < 1e-5, rel(gxa, gxb)
     for i, (a, c) in enumerate(zip(ga, gb)):
         assert rel(a, c) < 1e-5, (i, rel(a, c))
