@@ -294,6 +294,12 @@ typedef struct ms_profile_record {
 void ms_profile_kernels(int on);
 int ms_profile_take(ms_profile_record* out);
 
+/* Debug aid for test harnesses (no reference counterpart, never called by the product path): installs handlers for SIGSEGV /
+ * SIGBUS / SIGABRT / SIGFPE / SIGILL that write the NATIVE backtrace of the faulting thread to stderr and re-raise with the
+ * default action -- a fault inside the HIP runtime (e.g. in hipGraphLaunch) otherwise leaves only interpreter frames.
+ * Process-wide by nature (signal dispositions); the handler that was installed before (e.g. Python's faulthandler) runs next. */
+int ms_debug_install_crash_handler(void);
+
 /* nn.ConvTranspose1d geometry.  w is (Cin, Cout, K).  Lout = (Lin-1)*stride - 2*pad + K */
 typedef struct ms_convt1d_desc {
     int32_t B, Cin, Lin, Cout, K, stride, pad;

@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include "conv_mfma.h"
 #include "gconv_mfma.h"
 #include "conv_thin.h"
@@ -105,6 +108,36 @@ int ms_profile_take(ms_profile_record* out) {
     g_prof_products = 0;
     g_prof_kernel[0] = 0;
     return MS_OK;
+}
+
+// Debug aid (tests/conftest.py): native frames on a fatal signal.  A hipGraphLaunch / kernel-launch fault inside the runtime
+// leaves Python's faulthandler with Python frames only (profiles/r03_forked_replay_segfault.txt); this handler writes the
+// native backtrace of the faulting thread to stderr (async-signal-safe calls only), then re-raises with the default action.
+static struct sigaction g_prev_action[32];
+
+static void ms_crash_handler(int sig) {
+    static const char head[] = "\n[msynth] fatal signal: native backtrace of the faulting thread\n";
+    (void)!write(2, head, sizeof(head) - 1);
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    // hand on to whoever was installed before (Python's faulthandler prints the interpreter frames and re-raises)
+    if (sig > 0 && sig < 32) sigaction(sig, &g_prev_action[sig], nullptr);
+    else signal(sig, SIG_DFL);
+    raise(sig);
+}
+
+int ms_debug_install_crash_handler(void) {
+    void* warm[4];
+    (void)backtrace(warm, 4);              // (loads libgcc's unwinder now, not inside the handler)
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = ms_crash_handler;
+    sa.sa_flags = SA_NODEFER | SA_RESETHAND;
+    sigemptyset(&sa.sa_mask);
+    int rc = 0;
+    for (int sig : {SIGSEGV, SIGBUS, SIGABRT, SIGFPE, SIGILL}) rc |= sigaction(sig, &sa, &g_prev_action[sig]);
+    return rc == 0 ? MS_OK : MS_ERR_INVALID_ARG;
 }
 
 const char* ms_status_string(int status) {
@@ -338,7 +371,10 @@ size_t ms_conv1d_parts_workspace_bytes(const ms_conv1d_desc* d, const ms_conv1d_
     ConvP c;
     if (!parts_ok(d, parts, &c) || which < 0 || which > 2) return 0;
     if (parts_kernel(c, parts, which, with_image != 0)) {
-        if (which != 2) return 0;
+        if (which != 2) {
+            if (msd_parts_applicable(c, parts, which)) return 0;
+            return (with_image && ms5_parts_applicable(c, parts, which == 1)) ? ms5_parts_ws(c, parts, which == 1) : 0;
+        }
         if (msd_parts_applicable(c, parts, which)) return msd_parts_bwd_weight_ws(c, parts);
         return msw5_parts_applicable(c, parts) ? msw5_parts_ws(c, parts) : msg3_parts_bwd_weight_ws(c, parts);
     }
@@ -362,7 +398,8 @@ int ms_conv1d_parts_fwd(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, c
             const int rc = msd_parts_fwd(c, parts, w, bias, s);
             if (rc != MS_ERR_UNSUPPORTED) return rc;
         }
-        if (image && ms5_parts_applicable(c, parts, false)) return ms5_parts_fwd(c, parts, image, bias, s);
+        if (image && ms5_parts_applicable(c, parts, false))
+            return ms5_parts_fwd(c, parts, image, bias, workspace, workspace_bytes, s);
         if (w && msg3_parts_fwd_applicable(c, parts)) return msg3_parts_fwd(c, parts, w, bias, s);
     }
     for (int i = 0; i < parts->count; ++i) {
@@ -389,7 +426,8 @@ int ms_conv1d_parts_bwd_data(const ms_conv1d_desc* d, const ms_conv1d_parts* par
             const int rc = msd_parts_bwd_data(c, parts, w, s);
             if (rc != MS_ERR_UNSUPPORTED) return rc;
         }
-        if (image_bwd && ms5_parts_applicable(c, parts, true)) return ms5_parts_bwd_data(c, parts, image_bwd, s);
+        if (image_bwd && ms5_parts_applicable(c, parts, true))
+            return ms5_parts_bwd_data(c, parts, image_bwd, workspace, workspace_bytes, s);
         if (w && msg3_parts_bwd_data_applicable(c, parts)) return msg3_parts_bwd_data(c, parts, w, s);
     }
     for (int i = 0; i < parts->count; ++i) {

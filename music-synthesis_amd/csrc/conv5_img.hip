@@ -140,13 +140,19 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem5[];
 
 // MODE 0: forward (X = x); MODE 1: backward data (X = gy, multiplied on load by act'(Xact) when Xact != nullptr)
 // bx: the workgroup's batch-row tile (blockIdx.x in a single launch, its offset within the part's range in a parts launch)
-template <int MODE, int NP>
+// PRE (NP = 2, parts launches): the activations arrive ALREADY split -- k_conv5_presplit wrote them once as fp16 pieces in
+// exactly the order an LDS column holds them (P: [batch row][chunk][sample][piece][16 channels], 64 bytes per column), with the
+// rows' sticky chunk scales beside them (Pinv: [batch row][chunk]) -- so staging a chunk is two 16-byte copies per thread
+// instead of eight loads, a lane-shuffle maximum, 32 multiplies and 16 splits: the operand split is out of the K loop.
+template <int MODE, int NP, bool PRE = false>
 __device__ __forceinline__ void conv5_body(const C5P& p, const float* __restrict__ X, const float* __restrict__ Xact,
                                            const u32x4* __restrict__ IMG, const float* __restrict__ bias,
                                            const float* __restrict__ add, float* __restrict__ Y,
-                                           float* __restrict__ slabs, int bx) {
+                                           float* __restrict__ slabs, int bx, const u32x4* __restrict__ P = nullptr,
+                                           const float* __restrict__ Pinv = nullptr) {
     constexpr int XRS = xrs<NP>();
     constexpr bool SC = NP == 2;
+    static_assert(!PRE || NP == 2, "pre-split operands are fp16 pieces");
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;                   // 2 x 4 waves: 32 rows x 64 columns each
@@ -180,8 +186,33 @@ __device__ __forceinline__ void conv5_body(const C5P& p, const float* __restrict
         u_lbase[k] = (r * p.SS + 2 + 4 * v) * XRS + cq * 8;
         u_r[k] = (r < p.R && (u & (16 * p.NVG - 1)) == 0) ? r : -1;           // the lane that publishes the row's 1 / scale
     }
+    // PRE: copy items (two rounds of 512): item = (column of the tile, 16-byte quarter of its 64 pre-split bytes)
+    const int NCH = p.CK / 16;
+    unsigned q_goff[2];
+    int q_lds[2];
+    u32x4 rp[2];
+    float rinv = 1.f;
+    const auto rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(PRE ? P : IMG), 0,
+                                                        PRE ? 64u * (unsigned)(p.B * NCH * L) : 16u, 0x00020000);
+    if (PRE) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + 512 * k, col = i >> 2, qq = i & 3;
+            const int r = col / L, l = col - r * L;
+            const bool ok = r < p.R && b0 + r < p.B;
+            q_goff[k] = ok ? 64u * (unsigned)(((b0 + r) * NCH) * L + l) + 16u * qq : OOB;        // + chunk * L * 64 (scalar)
+            q_lds[k] = ok ? (r * p.SS + 2 + l) * XRS + qq * 16 : -1;
+        }
+    }
     f32x4 rx[2][4], rxa[MODE == 1 ? 2 : 1][4];
     auto load_x = [&](int c0, bool live) {
+        if (PRE) {
+            const int so = live ? (c0 / 16) * L * 64 : 0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) rp[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, q_goff[k], so, 0));
+            if (tid < p.R) rinv = (live && b0 + tid < p.B) ? Pinv[(size_t)(b0 + tid) * NCH + c0 / 16] : 1.f;
+            return;
+        }
         const int so = live ? 4 * c0 * L : 0;
 #pragma unroll
         for (int k = 0; k < 2; ++k)
@@ -198,6 +229,13 @@ __device__ __forceinline__ void conv5_body(const C5P& p, const float* __restrict
     // their partial sums into the running sums only where a scale has moved.
     float Scur[2] = {0.f, 0.f};
     auto store_x = [&](unsigned char* buf, float* inv_out) {
+        if (PRE) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (q_lds[k] >= 0) *reinterpret_cast<u32x4*>(buf + q_lds[k]) = rp[k];
+            if (tid < p.R) inv_out[tid] = rinv;
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (SC) {
@@ -337,21 +375,29 @@ __device__ __forceinline__ void conv5_body(const C5P& p, const float* __restrict
                                                                          __builtin_bit_cast(bf16x8, fb[t & 1][j][PB[s]]), acc[j], 0, 0, 0);
             } else {
                 const f16x8 ah = __builtin_bit_cast(f16x8, fa[t][0]), al = __builtin_bit_cast(f16x8, fa[t][1]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const f16x8 bh = __builtin_bit_cast(f16x8, fb[t & 1][j][0]), bl = __builtin_bit_cast(f16x8, fb[t & 1][j][1]);
-                    cm[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, cm[j], 0, 0, 0);
-                    cm[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, cm[j], 0, 0, 0);
-                    cm[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, cm[j], 0, 0, 0);
-                }
+                const f16x8 bh0 = __builtin_bit_cast(f16x8, fb[t & 1][0][0]), bl0 = __builtin_bit_cast(f16x8, fb[t & 1][0][1]);
+                const f16x8 bh1 = __builtin_bit_cast(f16x8, fb[t & 1][1][0]), bl1 = __builtin_bit_cast(f16x8, fb[t & 1][1][1]);
+                // (the two column tiles' accumulator chains interleaved: dependent MFMAs sit one issue apart)
+                cm[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl0, cm[0], 0, 0, 0);
+                cm[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl1, cm[1], 0, 0, 0);
+                cm[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh0, cm[0], 0, 0, 0);
+                cm[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh1, cm[1], 0, 0, 0);
+                cm[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh0, cm[0], 0, 0, 0);
+                cm[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh1, cm[1], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            load_a_tap(a_next, t);                                     // this tap's registers are free: the next chunk's tap
-            if (t == 1 && more) store_x(Xn, sinv + ((ch & 1) ^ 1) * R_MAX);   // chunk ch+1: registers -> the other buffer
-            if (t == 2) load_x(cbeg + (ch + 2) * 16, ch + 2 < nchunks);
+#ifndef MS_C5_PROBE
+#define MS_C5_PROBE 0
+#endif
+            // (timing probes, never in a shipped build: 1 = no weight-fragment loads, 2 = no activation staging, 4 = no barrier)
+            if (!(MS_C5_PROBE & 1)) load_a_tap(a_next, t);             // this tap's registers are free: the next chunk's tap
+            if (!(MS_C5_PROBE & 2)) {
+                if (t == 1 && more) store_x(Xn, sinv + ((ch & 1) ^ 1) * R_MAX);   // chunk ch+1: registers -> the other buffer
+                if (t == 2) load_x(cbeg + (ch + 2) * 16, ch + 2 < nchunks);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        if (!(MS_C5_PROBE & 4)) __syncthreads();
     }
     if (SC) fold();
 
@@ -408,9 +454,86 @@ struct C5Parts {
     const float* Xact[MS_CONV_PARTS_MAX];
     const float* add[MS_CONV_PARTS_MAX];
     float* Y[MS_CONV_PARTS_MAX];
+    u32x4* P[MS_CONV_PARTS_MAX];          // pre-split activations of the part (k_conv5_presplit), PRE launches
+    float* Pinv[MS_CONV_PARTS_MAX];       // 1 / scale per (batch row, chunk)
 };
 
-template <int MODE, int NP>
+// One pass over the layer's input ahead of a PRE launch: workgroup = one batch row of one part.  Per 16-channel chunk the
+// row's largest magnitude (raw gradient for MODE 1: it bounds the masked one) -> the STICKY power-of-two scale exactly as the
+// in-kernel staging chooses it (it moves only when the chunk maximum times the current scale leaves [2^8, 2^15)) -> the
+// values (MODE 1: times the LeakyReLU derivative at Xact), scaled and split into fp16 pieces, 64 bytes per (chunk, sample).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_conv5_presplit(C5P p, C5Parts q, float slope) {
+    __shared__ unsigned mx[256];
+    __shared__ float sc[256];
+    int b0w = 0, B = q.B[0], L = q.L[0];
+    const float* X = q.X[0];
+    const float* Xact = q.Xact[0];
+    u32x4* P = q.P[0];
+    float* Pinv = q.Pinv[0];
+    int wg0 = 0;
+#pragma unroll
+    for (int k = 1; k < MS_CONV_PARTS_MAX; ++k) {
+        wg0 += q.B[k - 1];
+        if (k < q.count && (int)blockIdx.x >= wg0) { b0w = wg0; B = q.B[k]; L = q.L[k]; X = q.X[k]; Xact = q.Xact[k]; P = q.P[k]; Pinv = q.Pinv[k]; }
+    }
+    const int b = (int)blockIdx.x - b0w, tid = threadIdx.x;
+    const int NC = p.CK / 16;
+    if (b >= B) return;
+    const bool masked = MODE == 1 && Xact != nullptr;
+    const float* row = X + (size_t)b * p.CK * L;
+    const float* rowa = (masked ? Xact : X) + (size_t)b * p.CK * L;
+    for (int c = tid; c < NC; c += 256) mx[c] = 0u;
+    __syncthreads();
+    // chunk maxima: a flat coalesced sweep (the row's CK * L floats are contiguous and 16-byte aligned for CK % 4 == 0)
+    const int nv = p.CK * L / 4, cv = 4 * L;                  // 16-byte vectors per row / per chunk
+    for (int v = tid; v < nv; v += 256) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(row + 4 * v);
+        const float m = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+        atomicMax(&mx[v / cv], __builtin_bit_cast(unsigned, m));         // (non-negative floats order like their bits)
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float S = 0.f;
+        for (int c = 0; c < NC; ++c) {
+            const float m = __builtin_bit_cast(float, mx[c]);
+            const float ms = m * S;
+            if (!(ms >= 256.f && ms < 32768.f) && m > 0.f) {
+                float inv;
+                block_scale(m * 4.f, S, inv);
+            }
+            if (S == 0.f) S = 1.f;
+            sc[c] = S;
+            Pinv[(size_t)b * NC + c] = 1.f / S;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < NC * L; i += 256) {
+        const int c = i / L, l = i - c * L;
+        const float S = sc[c];
+        const float* xr = row + (size_t)(16 * c) * L + l;
+        const float* ar = rowa + (size_t)(16 * c) * L + l;
+        unsigned hh[8], ll[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float a = xr[(size_t)(2 * k) * L], bq = xr[(size_t)(2 * k + 1) * L];
+            if (masked) {
+                a = ar[(size_t)(2 * k) * L] > 0.f ? a : a * slope;
+                bq = ar[(size_t)(2 * k + 1) * L] > 0.f ? bq : bq * slope;
+            }
+            unsigned o[2];
+            split_pair<2>(a * S, bq * S, o);
+            hh[k] = o[0]; ll[k] = o[1];
+        }
+        u32x4* dst = P + ((size_t)(b * NC + c) * L + l) * 4;
+        dst[0] = u32x4{hh[0], hh[1], hh[2], hh[3]};
+        dst[1] = u32x4{hh[4], hh[5], hh[6], hh[7]};
+        dst[2] = u32x4{ll[0], ll[1], ll[2], ll[3]};
+        dst[3] = u32x4{ll[4], ll[5], ll[6], ll[7]};
+    }
+}
+
+template <int MODE, int NP, bool PRE>
 __global__ __launch_bounds__(512, 2) void k_conv5_img_parts(C5P p, C5Parts q, const u32x4* __restrict__ IMG,
                                                            const float* __restrict__ bias) {
     // (the part's fields are picked with compile-time indices: a run-time index into the pointer arrays of a by-value kernel
@@ -420,16 +543,18 @@ __global__ __launch_bounds__(512, 2) void k_conv5_img_parts(C5P p, C5Parts q, co
     const float* Xact = q.Xact[0];
     const float* add = q.add[0];
     float* Y = q.Y[0];
+    const u32x4* P = q.P[0];
+    const float* Pinv = q.Pinv[0];
     p.B = q.B[0]; p.L = q.L[0]; p.R = q.R[0]; p.SS = q.SS[0]; p.PX = q.PX[0]; p.NV = q.NV[0]; p.NVG = q.NVG[0];
 #pragma unroll
     for (int k = 1; k < MS_CONV_PARTS_MAX; ++k)
         if (k < q.count && (int)blockIdx.x >= q.bx0[k]) {
             bx0 = q.bx0[k];
-            X = q.X[k]; Xact = q.Xact[k]; add = q.add[k]; Y = q.Y[k];
+            X = q.X[k]; Xact = q.Xact[k]; add = q.add[k]; Y = q.Y[k]; P = q.P[k]; Pinv = q.Pinv[k];
             p.B = q.B[k]; p.L = q.L[k]; p.R = q.R[k]; p.SS = q.SS[k]; p.PX = q.PX[k]; p.NV = q.NV[k]; p.NVG = q.NVG[k];
         }
     // (nsplit == 1: the slab pointer is never used; a literal nullptr there crashes the compiler's inliner, ROCm 7.2)
-    conv5_body<MODE, NP>(p, X, Xact, IMG, bias, add, Y, Y, (int)blockIdx.x - bx0);
+    conv5_body<MODE, NP, PRE>(p, X, PRE ? nullptr : Xact, IMG, bias, add, Y, Y, (int)blockIdx.x - bx0, P, Pinv);
 }
 
 // y = act(sum_z slab_z + bias[channel]) (+ add), slabs summed in slice order
@@ -554,28 +679,68 @@ bool c5_parts_geometry(const ConvP& c, const ms_conv1d_parts* parts, bool backwa
         q->bx0[i + 1] = q->bx0[parts->count];
         q->X[i] = q->Xact[i] = q->add[i] = nullptr; q->Y[i] = nullptr;
     }
+    for (int i = 0; i < MS_CONV_PARTS_MAX; ++i) { q->P[i] = nullptr; q->Pinv[i] = nullptr; }
     p->nsplit = 1;
     p->cks = p->CK;
     // without split-K the tiles alone must occupy the chip: at least one workgroup for every second CU
     return q->bx0[parts->count] * (p->M / 64) >= 128;
 }
 
-template <int MODE, int NP>
-int c5_parts_launch_np(const C5P& p, const C5Parts& q, const void* image, const float* bias, hipStream_t s) {
+// workspace of a PRE launch: the parts' pre-split activations and scale tables (256-byte aligned blocks)
+size_t c5_pre_bytes(const C5P& p, const C5Parts& q, size_t* offP, size_t* offS) {
+    size_t o = 0;
+    for (int i = 0; i < q.count; ++i) {
+        if (offP) offP[i] = o;
+        o += ((size_t)q.B[i] * (p.CK / 16) * q.L[i] * 64 + 255) & ~(size_t)255;
+    }
+    for (int i = 0; i < q.count; ++i) {
+        if (offS) offS[i] = o;
+        o += ((size_t)q.B[i] * (p.CK / 16) * sizeof(float) + 255) & ~(size_t)255;
+    }
+    return o;
+}
+
+bool c5_pre_enabled() {
+    const char* sw = getenv("MSYNTH_C5_PRE");                 // tuning / test switch (0: operands split inside the K loop)
+    return c5_np() == 2 && !(sw && atoi(sw) == 0);
+}
+
+template <int MODE, int NP, bool PRE>
+int c5_parts_launch_np(const C5P& p, C5Parts& q, const void* image, const float* bias, void* ws, size_t ws_bytes, hipStream_t s) {
     int pxmax = 0;
     for (int i = 0; i < q.count; ++i) pxmax = q.PX[i] > pxmax ? q.PX[i] : pxmax;
     const size_t lds = (size_t)2 * pxmax * xrs<NP>() + 2 * R_MAX * sizeof(float);
     static unsigned long long attr_set = 0;
     if (ms_first_on_device(attr_set)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_img_parts<MODE, NP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_img_parts<MODE, NP, PRE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PX_MAX * xrs<NP>() + 2 * R_MAX * sizeof(float));
         ms_done_on_device(attr_set);
     }
+    if (PRE) {
+        size_t offP[MS_CONV_PARTS_MAX], offS[MS_CONV_PARTS_MAX];
+        const size_t need = c5_pre_bytes(p, q, offP, offS);
+        if (!ws || ws_bytes < need || (((uintptr_t)ws) & 255)) return MS_ERR_WORKSPACE;
+        int rows = 0;
+        for (int i = 0; i < q.count; ++i) {
+            q.P[i] = (u32x4*)((char*)ws + offP[i]);
+            q.Pinv[i] = (float*)((char*)ws + offS[i]);
+            rows += q.B[i];
+        }
+        hipLaunchKernelGGL((k_conv5_presplit<MODE>), dim3(rows), dim3(256), 0, s, p, q, p.slope);
+        MS_CHECK_LAUNCH();
+    }
     const dim3 grid((unsigned)q.bx0[q.count], (unsigned)(p.M / 64), 1);
-    ms_note_kernel(NP == 2 ? 3 : 6, "k_conv5_img_parts<%d, %d>", MODE, NP);
-    hipLaunchKernelGGL((k_conv5_img_parts<MODE, NP>), grid, dim3(512), lds, s, p, q, (const u32x4*)image, bias);
+    ms_note_kernel(NP == 2 ? 3 : 6, "k_conv5_img_parts<%d, %d, %s>", MODE, NP, PRE ? "true" : "false");
+    hipLaunchKernelGGL((k_conv5_img_parts<MODE, NP, PRE>), grid, dim3(512), lds, s, p, q, (const u32x4*)image, bias);
     MS_CHECK_LAUNCH();
     return MS_OK;
+}
+
+template <int MODE>
+int c5_parts_launch(const C5P& p, C5Parts& q, const void* image, const float* bias, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (c5_np() == 3) return c5_parts_launch_np<MODE, 3, false>(p, q, image, bias, ws, ws_bytes, s);
+    if (c5_pre_enabled() && p.CK <= 4096) return c5_parts_launch_np<MODE, 2, true>(p, q, image, bias, ws, ws_bytes, s);
+    return c5_parts_launch_np<MODE, 2, false>(p, q, image, bias, ws, ws_bytes, s);
 }
 
 bool to_convp(const ms_conv1d_desc* d, ConvP* p) {
@@ -598,7 +763,15 @@ bool ms5_parts_applicable(const ConvP& c, const ms_conv1d_parts* parts, bool bac
     return c5_enabled() && c5_parts_geometry(c, parts, backward, &p, &q);
 }
 
-int ms5_parts_fwd(const ConvP& c, const ms_conv1d_parts* parts, const void* image, const float* bias, hipStream_t s) {
+size_t ms5_parts_ws(const ConvP& c, const ms_conv1d_parts* parts, bool backward) {
+    C5P p;
+    C5Parts q;
+    if (!c5_parts_geometry(c, parts, backward, &p, &q) || !c5_pre_enabled() || p.CK > 4096) return 0;
+    return c5_pre_bytes(p, q, nullptr, nullptr);
+}
+
+int ms5_parts_fwd(const ConvP& c, const ms_conv1d_parts* parts, const void* image, const float* bias, void* ws, size_t ws_bytes,
+                  hipStream_t s) {
     C5P p;
     C5Parts q;
     if (!c5_parts_geometry(c, parts, false, &p, &q)) return MS_ERR_UNSUPPORTED;
@@ -607,10 +780,11 @@ int ms5_parts_fwd(const ConvP& c, const ms_conv1d_parts* parts, const void* imag
         if (!parts->x[i] || !parts->y[i]) return MS_ERR_INVALID_ARG;
         q.X[i] = parts->x[i]; q.Xact[i] = nullptr; q.add[i] = nullptr; q.Y[i] = parts->y[i];
     }
-    return c5_np() == 3 ? c5_parts_launch_np<0, 3>(p, q, image, bias, s) : c5_parts_launch_np<0, 2>(p, q, image, bias, s);
+    return c5_parts_launch<0>(p, q, image, bias, ws, ws_bytes, s);
 }
 
-int ms5_parts_bwd_data(const ConvP& c, const ms_conv1d_parts* parts, const void* image_bwd, hipStream_t s) {
+int ms5_parts_bwd_data(const ConvP& c, const ms_conv1d_parts* parts, const void* image_bwd, void* ws, size_t ws_bytes,
+                       hipStream_t s) {
     C5P p;
     C5Parts q;
     if (!c5_parts_geometry(c, parts, true, &p, &q)) return MS_ERR_UNSUPPORTED;
@@ -620,7 +794,7 @@ int ms5_parts_bwd_data(const ConvP& c, const ms_conv1d_parts* parts, const void*
         q.X[i] = parts->gy[i]; q.Xact[i] = c.act == MS_ACT_NONE ? nullptr : parts->y_act[i]; q.add[i] = parts->gx_add[i];
         q.Y[i] = parts->gx[i];
     }
-    return c5_np() == 3 ? c5_parts_launch_np<1, 3>(p, q, image_bwd, nullptr, s) : c5_parts_launch_np<1, 2>(p, q, image_bwd, nullptr, s);
+    return c5_parts_launch<1>(p, q, image_bwd, nullptr, ws, ws_bytes, s);
 }
 
 extern "C" {

@@ -46,8 +46,11 @@ int msg3_parts_bwd_weight(const ConvP& c, const ms_conv1d_parts* parts, float* g
                           size_t ws_bytes, hipStream_t s);
 // the k5 layer over the scales (conv5_img.hip)
 bool ms5_parts_applicable(const ConvP& c, const ms_conv1d_parts* parts, bool backward);
-int ms5_parts_fwd(const ConvP& c, const ms_conv1d_parts* parts, const void* image, const float* bias, hipStream_t s);
-int ms5_parts_bwd_data(const ConvP& c, const ms_conv1d_parts* parts, const void* image_bwd, hipStream_t s);
+size_t ms5_parts_ws(const ConvP& c, const ms_conv1d_parts* parts, bool backward);
+int ms5_parts_fwd(const ConvP& c, const ms_conv1d_parts* parts, const void* image, const float* bias, void* ws, size_t ws_bytes,
+                  hipStream_t s);
+int ms5_parts_bwd_data(const ConvP& c, const ms_conv1d_parts* parts, const void* image_bwd, void* ws, size_t ws_bytes,
+                       hipStream_t s);
 // the k5 layer's weight gradient over the scales (wgrad_k5.hip)
 bool msw5_parts_applicable(const ConvP& c, const ms_conv1d_parts* parts);
 size_t msw5_parts_ws(const ConvP& c, const ms_conv1d_parts* parts);

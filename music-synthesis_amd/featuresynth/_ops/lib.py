@@ -160,6 +160,7 @@ SIGNATURES = {
     "ms_conv1d_workspace_bytes": (_sz, [ctypes.POINTER(ConvDesc), _c_int]),
     "ms_conv1d_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvDesc), _c_int]),
     "ms_convt1d_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvTDesc), _c_int]),
+    "ms_debug_install_crash_handler": (_c_int, []),
     "ms_profile_kernels": (None, [_c_int]),
     "ms_profile_take": (_c_int, [ctypes.POINTER(ProfileRecord)]),
     "ms_convt1d_out_len": (_c_int, [ctypes.POINTER(ConvTDesc)]),

@@ -14,6 +14,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fatal signal during the GPU tests must leave NATIVE frames (a fault inside hipGraphLaunch shows only interpreter
+    # frames in Python's faulthandler): one occurrence then suffices for a diagnosis -- faults are never re-provoked
+    import faulthandler
+    faulthandler.enable()
+    try:
+        from featuresynth._ops import lib as L
+        if os.path.exists(L.LIB_PATH):
+            L.load().ms_debug_install_crash_handler()
+    except Exception as e:          # (CPU-only runs without the library: the ABI tests report that themselves)
+        sys.stderr.write("conftest: native crash handler not installed: %r\n" % (e,))
 
 
 @pytest.fixture(scope="session")

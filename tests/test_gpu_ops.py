@@ -598,3 +598,42 @@ def test_profile_mode_reports_device_time():
         y2, _ = P.conv1d_fwd(x, w, None, d, lo)
     g.replay(); torch.cuda.synchronize()
     assert torch.equal(y2, ref)
+
+
+def test_side_stream_tracking_under_capture():
+    """graph.join_side_streams / begin_step (the r04 audit of the forked-replay fault): forks are tracked per
+    trainer step -- begin_step() drops what earlier steps left -- and under hipGraph capture a stream that is NOT part of the
+    capture is neither waited for (recording an event on a non-capturing stream and waiting for it from the capturing one
+    is not a captured dependency: it invalidates the capture) nor left in the set; a fork that IS part of the capture is joined."""
+    from featuresynth._ops import graph as G
+    device = torch.device("cuda", torch.cuda.current_device())
+    stale, side, cap = (torch.cuda.Stream(device=device) for _ in range(3))
+    x = torch.ones(1024, device=device)
+    torch.cuda.synchronize()
+    G.begin_step()
+    assert not G._FORKED_SINCE_JOIN
+    stale.wait_stream(torch.cuda.current_stream(device))
+    with G.forked(stale):                                  # an eager step forks to `stale` and never joins explicitly
+        w = x * 3
+    assert stale in G._FORKED_SINCE_JOIN
+    torch.cuda.current_stream(device).wait_stream(stale)
+    G.begin_step()                                         # the next step starts clean
+    assert not G._FORKED_SINCE_JOIN
+    G._FORKED_SINCE_JOIN.add(stale)                        # ... and if a stale stream were still tracked during a capture:
+    g = torch.cuda.CUDAGraph()
+    cap.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(cap):
+        g.capture_begin()
+        side.wait_stream(cap)
+        with G.forked(side):                               # a fork that belongs to this capture
+            y = x * 2
+        assert side in G._FORKED_SINCE_JOIN
+        G.join_side_streams(device)
+        z = y + 1
+        g.capture_end()
+    assert stale not in G._FORKED_SINCE_JOIN and side not in G._FORKED_SINCE_JOIN
+    torch.cuda.current_stream(device).wait_stream(cap)
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(z.min()) == 3.0 and float(z.max()) == 3.0 and float(w.max()) == 3.0
+    G.begin_step()
