@@ -78,7 +78,7 @@ DTYPE_EXACT = "f32 storage and accumulate; every multiply fp32-exact (bf16 x 3 s
 
 
 # switches that put every 22-bit (fp16 x 2) kernel back on fp32-exact arithmetic (DESIGN.md "Tuning switches")
-EXACT_ENV = {"MSYNTH_ATOM_NP": "3", "MSYNTH_C5_NP": "3", "MSYNTH_WROWS3_NP": "3", "MSYNTH_GCONV3": "0", "MSYNTH_CONVTIMG": "0"}
+EXACT_ENV = {"MSYNTH_ATOM_NP": "3", "MSYNTH_C5_NP": "3", "MSYNTH_W5_NP": "3", "MSYNTH_WROWS3_NP": "3", "MSYNTH_GCONV3": "0", "MSYNTH_CONVTIMG": "0"}
 
 
 def pipe_peak(products):

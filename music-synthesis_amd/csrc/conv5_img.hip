@@ -458,74 +458,80 @@ struct C5Parts {
     float* Pinv[MS_CONV_PARTS_MAX];       // 1 / scale per (batch row, chunk)
 };
 
-// One pass over the layer's input ahead of a PRE launch: workgroup = one batch row of one part.  Per 16-channel chunk the
-// row's largest magnitude (raw gradient for MODE 1: it bounds the masked one) -> the STICKY power-of-two scale exactly as the
-// in-kernel staging chooses it (it moves only when the chunk maximum times the current scale leaves [2^8, 2^15)) -> the
-// values (MODE 1: times the LeakyReLU derivative at Xact), scaled and split into fp16 pieces, 64 bytes per (chunk, sample).
-template <int MODE>
-__global__ __launch_bounds__(256) void k_conv5_presplit(C5P p, C5Parts q, float slope) {
-    __shared__ unsigned mx[256];
-    __shared__ float sc[256];
-    int b0w = 0, B = q.B[0], L = q.L[0];
-    const float* X = q.X[0];
-    const float* Xact = q.Xact[0];
-    u32x4* P = q.P[0];
-    float* Pinv = q.Pinv[0];
+// Two small passes over the layer's input ahead of a PRE launch; workgroup = (batch row of a part, block of PB_CH channels):
+//   k_conv5_rowmax    the block's largest magnitude (raw gradient for MODE 1: it bounds the masked one) -> pm[row][block]
+//   k_conv5_presplit  the row's power-of-two scale (its largest magnitude at 2^12: ONE scale per batch row -- every output
+//                     column sums over one batch row only, so the scale factors out of the whole contraction and the K
+//                     loop never folds), then the values (MODE 1: times the LeakyReLU derivative at Xact), scaled and split
+//                     into fp16 pieces, 64 bytes per (16-channel chunk, sample)
+// An element within 2^16 of its batch row's largest magnitude keeps 22 significand bits; smaller ones an absolute error below
+// 2^-37 of that maximum.
+constexpr int PB_CH = 128;                 // channels per pre-pass workgroup
+
+struct C5Pre { int row0, B, L; const float* X; const float* Xact; u32x4* P; float* Pinv; };
+__device__ __forceinline__ C5Pre c5_pre_part(const C5Parts& q, int row) {
+    C5Pre r{0, q.B[0], q.L[0], q.X[0], q.Xact[0], q.P[0], q.Pinv[0]};
     int wg0 = 0;
 #pragma unroll
     for (int k = 1; k < MS_CONV_PARTS_MAX; ++k) {
         wg0 += q.B[k - 1];
-        if (k < q.count && (int)blockIdx.x >= wg0) { b0w = wg0; B = q.B[k]; L = q.L[k]; X = q.X[k]; Xact = q.Xact[k]; P = q.P[k]; Pinv = q.Pinv[k]; }
+        if (k < q.count && row >= wg0) r = C5Pre{wg0, q.B[k], q.L[k], q.X[k], q.Xact[k], q.P[k], q.Pinv[k]};
     }
-    const int b = (int)blockIdx.x - b0w, tid = threadIdx.x;
-    const int NC = p.CK / 16;
-    if (b >= B) return;
-    const bool masked = MODE == 1 && Xact != nullptr;
-    const float* row = X + (size_t)b * p.CK * L;
-    const float* rowa = (masked ? Xact : X) + (size_t)b * p.CK * L;
-    for (int c = tid; c < NC; c += 256) mx[c] = 0u;
-    __syncthreads();
-    // chunk maxima: a flat coalesced sweep (the row's CK * L floats are contiguous and 16-byte aligned for CK % 4 == 0)
-    const int nv = p.CK * L / 4, cv = 4 * L;                  // 16-byte vectors per row / per chunk
-    for (int v = tid; v < nv; v += 256) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(row + 4 * v);
-        const float m = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
-        atomicMax(&mx[v / cv], __builtin_bit_cast(unsigned, m));         // (non-negative floats order like their bits)
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_conv5_rowmax(C5P p, C5Parts q, float* __restrict__ pm) {
+    __shared__ float red[4];
+    const C5Pre r = c5_pre_part(q, blockIdx.x);
+    const int b = (int)blockIdx.x - r.row0, tid = threadIdx.x;
+    // the block's PB_CH * L floats are contiguous and start 16-byte aligned
+    const float* src = r.X + ((size_t)b * p.CK + (size_t)blockIdx.y * PB_CH) * r.L;
+    float m = 0.f;
+    for (int v = tid; v < PB_CH * r.L / 4; v += 256) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(src + 4 * v);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))));
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
-    if (tid == 0) {
-        float S = 0.f;
-        for (int c = 0; c < NC; ++c) {
-            const float m = __builtin_bit_cast(float, mx[c]);
-            const float ms = m * S;
-            if (!(ms >= 256.f && ms < 32768.f) && m > 0.f) {
-                float inv;
-                block_scale(m * 4.f, S, inv);
-            }
-            if (S == 0.f) S = 1.f;
-            sc[c] = S;
-            Pinv[(size_t)b * NC + c] = 1.f / S;
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < NC * L; i += 256) {
-        const int c = i / L, l = i - c * L;
-        const float S = sc[c];
+    if (tid == 0) pm[(size_t)blockIdx.x * gridDim.y + blockIdx.y] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_conv5_presplit(C5P p, C5Parts q, const float* __restrict__ pm, float slope) {
+    const C5Pre r = c5_pre_part(q, blockIdx.x);
+    const int b = (int)blockIdx.x - r.row0, tid = threadIdx.x, L = r.L;
+    const int NC = p.CK / 16, c0 = blockIdx.y * (PB_CH / 16);
+    float m = 0.f;
+    for (int k = 0; k < (int)gridDim.y; ++k) m = fmaxf(m, pm[(size_t)blockIdx.x * gridDim.y + k]);
+    float S, inv;
+    block_scale(m * 4.f, S, inv);
+    if (tid < PB_CH / 16) r.Pinv[(size_t)b * NC + c0 + tid] = inv;
+    const bool masked = MODE == 1 && r.Xact != nullptr;
+    const float* row = r.X + (size_t)b * p.CK * L;
+    const float* rowa = (masked ? r.Xact : r.X) + (size_t)b * p.CK * L;
+    for (int i = tid; i < (PB_CH / 16) * L; i += 256) {
+        const int cl = i / L, l = i - cl * L, c = c0 + cl;
         const float* xr = row + (size_t)(16 * c) * L + l;
         const float* ar = rowa + (size_t)(16 * c) * L + l;
+        float xv[16], av[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) xv[k] = xr[(size_t)k * L];
+        if (masked) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) av[k] = ar[(size_t)k * L];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) xv[k] = av[k] > 0.f ? xv[k] : xv[k] * slope;
+        }
         unsigned hh[8], ll[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            float a = xr[(size_t)(2 * k) * L], bq = xr[(size_t)(2 * k + 1) * L];
-            if (masked) {
-                a = ar[(size_t)(2 * k) * L] > 0.f ? a : a * slope;
-                bq = ar[(size_t)(2 * k + 1) * L] > 0.f ? bq : bq * slope;
-            }
             unsigned o[2];
-            split_pair<2>(a * S, bq * S, o);
+            split_pair<2>(xv[2 * k] * S, xv[2 * k + 1] * S, o);
             hh[k] = o[0]; ll[k] = o[1];
         }
-        u32x4* dst = P + ((size_t)(b * NC + c) * L + l) * 4;
+        u32x4* dst = r.P + ((size_t)(b * NC + c) * L + l) * 4;
         dst[0] = u32x4{hh[0], hh[1], hh[2], hh[3]};
         dst[1] = u32x4{hh[4], hh[5], hh[6], hh[7]};
         dst[2] = u32x4{ll[0], ll[1], ll[2], ll[3]};
@@ -687,8 +693,12 @@ bool c5_parts_geometry(const ConvP& c, const ms_conv1d_parts* parts, bool backwa
 }
 
 // workspace of a PRE launch: the parts' pre-split activations and scale tables (256-byte aligned blocks)
-size_t c5_pre_bytes(const C5P& p, const C5Parts& q, size_t* offP, size_t* offS) {
+size_t c5_pre_bytes(const C5P& p, const C5Parts& q, size_t* offP, size_t* offS, size_t* offM = nullptr) {
     size_t o = 0;
+    int rows = 0;
+    for (int i = 0; i < q.count; ++i) rows += q.B[i];
+    if (offM) *offM = o;
+    o += ((size_t)rows * (p.CK / PB_CH) * sizeof(float) + 255) & ~(size_t)255;
     for (int i = 0; i < q.count; ++i) {
         if (offP) offP[i] = o;
         o += ((size_t)q.B[i] * (p.CK / 16) * q.L[i] * 64 + 255) & ~(size_t)255;
@@ -717,8 +727,8 @@ int c5_parts_launch_np(const C5P& p, C5Parts& q, const void* image, const float*
         ms_done_on_device(attr_set);
     }
     if (PRE) {
-        size_t offP[MS_CONV_PARTS_MAX], offS[MS_CONV_PARTS_MAX];
-        const size_t need = c5_pre_bytes(p, q, offP, offS);
+        size_t offP[MS_CONV_PARTS_MAX], offS[MS_CONV_PARTS_MAX], offM;
+        const size_t need = c5_pre_bytes(p, q, offP, offS, &offM);
         if (!ws || ws_bytes < need || (((uintptr_t)ws) & 255)) return MS_ERR_WORKSPACE;
         int rows = 0;
         for (int i = 0; i < q.count; ++i) {
@@ -726,7 +736,11 @@ int c5_parts_launch_np(const C5P& p, C5Parts& q, const void* image, const float*
             q.Pinv[i] = (float*)((char*)ws + offS[i]);
             rows += q.B[i];
         }
-        hipLaunchKernelGGL((k_conv5_presplit<MODE>), dim3(rows), dim3(256), 0, s, p, q, p.slope);
+        float* pm = (float*)((char*)ws + offM);
+        const dim3 pgrid((unsigned)rows, (unsigned)(p.CK / PB_CH));
+        hipLaunchKernelGGL(k_conv5_rowmax, pgrid, dim3(256), 0, s, p, q, pm);
+        MS_CHECK_LAUNCH();
+        hipLaunchKernelGGL((k_conv5_presplit<MODE>), pgrid, dim3(256), 0, s, p, q, pm, p.slope);
         MS_CHECK_LAUNCH();
     }
     const dim3 grid((unsigned)q.bx0[q.count], (unsigned)(p.M / 64), 1);
@@ -739,7 +753,7 @@ int c5_parts_launch_np(const C5P& p, C5Parts& q, const void* image, const float*
 template <int MODE>
 int c5_parts_launch(const C5P& p, C5Parts& q, const void* image, const float* bias, void* ws, size_t ws_bytes, hipStream_t s) {
     if (c5_np() == 3) return c5_parts_launch_np<MODE, 3, false>(p, q, image, bias, ws, ws_bytes, s);
-    if (c5_pre_enabled() && p.CK <= 4096) return c5_parts_launch_np<MODE, 2, true>(p, q, image, bias, ws, ws_bytes, s);
+    if (c5_pre_enabled() && p.CK % PB_CH == 0) return c5_parts_launch_np<MODE, 2, true>(p, q, image, bias, ws, ws_bytes, s);
     return c5_parts_launch_np<MODE, 2, false>(p, q, image, bias, ws, ws_bytes, s);
 }
 
@@ -766,7 +780,7 @@ bool ms5_parts_applicable(const ConvP& c, const ms_conv1d_parts* parts, bool bac
 size_t ms5_parts_ws(const ConvP& c, const ms_conv1d_parts* parts, bool backward) {
     C5P p;
     C5Parts q;
-    if (!c5_parts_geometry(c, parts, backward, &p, &q) || !c5_pre_enabled() || p.CK > 4096) return 0;
+    if (!c5_parts_geometry(c, parts, backward, &p, &q) || !c5_pre_enabled() || p.CK % PB_CH) return 0;
     return c5_pre_bytes(p, q, nullptr, nullptr);
 }
 
