@@ -678,9 +678,12 @@ int launch_atom_np(AtomP p, const float* x, const void* image, const float* b0, 
     }
     const long long slots = (long long)n_cu[dev] * wgs_per_cu[dev];
     const long long ntiles = (long long)p.B * p.tiles_per_row;
-    const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
+    // a launch that publishes operand maxima has one slot per workgroup in the caller's table: the persistent grid (whose tile
+    // loop works with any workgroup count) is clamped to it, whatever the occupancy query and the CU count say
+    long long nwg = ntiles < slots ? ntiles : slots;
+    if (am && nwg > MS_ATOM_AMAX_N) nwg = MS_ATOM_AMAX_N;
+    const dim3 grid((unsigned)nwg);
     ms_note_kernel(NP == 2 ? 3 : 6, "k_atom_fwd<%d, %d, %d, %d, %d, %s>", C, NTP, NW, MODE, NP, MASK ? "true" : "false");
-    if (grid.x > MS_ATOM_AMAX_N) am = nullptr;          // (cannot happen: at most 4 workgroups on each of 256 CUs)
     hipLaunchKernelGGL((k_atom_fwd<C, NTP, NW, MODE, NP, MASK>), grid, dim3(64 * NW), lds, s, p, x, (const u32x4*)image, b0, b1, y, t, u, tm, am);
     MS_CHECK_LAUNCH();
     return MS_OK;

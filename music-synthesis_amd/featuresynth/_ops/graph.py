@@ -104,16 +104,16 @@ def atom_fused_ok(x_shape, w0, b0, b1, dil):
 def atom_forward(h, w0, b0, w1, b1, dil, save, image=None, signs=False):
     """image: the atom's pre-split weight image (P.atom_pack) -> ONE fused launch, the intermediate stays on chip;
     None -> the two row-tile conv launches.
-    signs (fused, training): the record holds u as SIGN WORDS (and t carries its own): the caller has checked that the
-    whole backward pass of the stack takes them (P.stack_signs_ok)."""
+    signs (fused, training): the record holds u as SIGN WORDS and t's in its AtomAux: the caller has checked that the
+    whole backward pass of the stack takes them (P.stack_signs_ok).  Record: (d0, d1, h, t, u, aux)."""
     d0, lo = P.conv_desc(h.shape, w0.shape, pad=dil, dil=dil, act=L.ACT_LRELU)
     d1, _ = P.conv_desc(h.shape, w1.shape, pad=1, act=L.ACT_LRELU)
     if image is not None:
-        out, t, u = P.atom_fwd(h, image, b0, b1, dil, save, signs=signs and save)
-        return out, (d0, d1, h, t, u)
+        out, t, u, aux = P.atom_fwd(h, image, b0, b1, dil, save, signs=signs and save)
+        return out, (d0, d1, h, t, u, aux)
     t, _ = P.conv1d_fwd(h, w0, b0, d0, lo)
     out, u = P.conv1d_fwd(t, w1, b1, d1, lo, residual=h, want_y_act=save)
-    return out, (d0, d1, h, t, u)
+    return out, (d0, d1, h, t, u, None)
 
 
 def pack_convt_images(x_shape, params, backward=False):
@@ -223,16 +223,16 @@ def atom_backward(rec, w0, w1, g, sink, i, need_wgrad=True, need_gx=True, fork=N
     batch: list collecting the weight-grad jobs (slot, x, gy, y_act, desc, w_shape) instead of running them
     (the caller issues a stack's six jobs as one launch, flush_wgrad_batch).
     image_bwd: the atom's backward weight image -> both backward-data convs in ONE fused launch (atom_fused.hip)."""
-    d0, d1, h, t, u = rec
+    d0, d1, h, t, u, aux = rec
     run = fork.run if fork is not None else (lambda fn, *ts: fn())
     if image_bwd is not None and need_gx:
-        gt, gx = P.atom_bwd_data(g, u, t, image_bwd, d0.dil)
+        gt, gx, ab = P.atom_bwd_data(g, u, t, image_bwd, d0.dil, t_signs=aux.t_signs if aux is not None else None)
         if need_wgrad and batch is not None:
             # operand bounds published by the fused launches: forward [0] = |x|, [1] = |t|; backward [0] = |g|, [1] = |gt lrelu'(t)|
-            af, ab = getattr(t, "_ms_amax", None), getattr(gt, "_ms_amax", None)
+            af = aux.amax if aux is not None else None
             both = af is not None and ab is not None
             # (sign words: the derivative operand of the dilated conv's gradient is t's sign words, not t)
-            ta = t._ms_signs if P.is_signs(u) else t
+            ta = aux.t_signs if P.is_signs(u) else t
             batch.append((i + 2, t, g, u, d1, w1.shape) + ((af[1], ab[0]) if both else ()))
             batch.append((i, h, gt, ta, d0, w0.shape) + ((af[0], ab[1]) if both else ()))
         elif need_wgrad:

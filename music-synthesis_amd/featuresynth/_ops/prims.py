@@ -366,10 +366,20 @@ def stack_signs_ok(x, dils):
     return bool(L.load().ms_residual_stack_signs_supported(ctypes.byref(_stack_desc(x, dils))))
 
 
+class AtomAux:
+    """What a training-mode fused atom forward leaves for the backward pass BESIDE the activations t and u: the sign words of t
+    (when u is saved as sign words too) and the launch's operand bounds ([0] of x, [1] of t) for the batched weight gradients.
+    Carried in the tape record, never as attributes of tensors (a view / contiguous() of t would silently drop those)."""
+    __slots__ = ("t_signs", "amax")
+
+    def __init__(self, t_signs=None, amax=None):
+        self.t_signs, self.amax = t_signs, amax
+
+
 def atom_fwd(x, image, b0, b1, dil, save, signs=False):
-    """-> (y, t, u): y = x + lrelu(conv1(lrelu(conv_d(x) + b0)) + b1); t, u (the activations the backward pass needs)
-    only when save.  signs (with save): u is returned as its sign words and t carries its own (`t._ms_signs`) -- what the
-    backward pass reads instead of the two fp32 tensors wherever only the LeakyReLU derivative is needed."""
+    """-> (y, t, u, aux): y = x + lrelu(conv1(lrelu(conv_d(x) + b0)) + b1); t, u (the activations the backward pass needs)
+    and aux (AtomAux) only when save, else None.  signs (with save): u is returned as its sign words and aux.t_signs holds
+    t's -- what the backward pass reads instead of the two fp32 tensors wherever only the LeakyReLU derivative is needed."""
     L.require(x, "residual atom input"); L.require(b0, "bias"); L.require(b1, "bias")
     B, C, Lg = x.shape
     y = torch.empty_like(x)
@@ -387,13 +397,10 @@ def atom_fwd(x, image, b0, b1, dil, save, signs=False):
                     "geom": (B, C, Lg, C, 3, 1, dil, 1)}
         L.call("ms_residual_atom_fwd_signs", cost_s, d, x.data_ptr(), image.data_ptr(), b0.data_ptr(), b1.data_ptr(),
                y.data_ptr(), t.data_ptr(), st.data_ptr(), su.data_ptr(), L.ptr(amax), L.stream())
-        t._ms_signs = st
-        if amax is not None:
-            t._ms_amax = amax
-        return y, t, su
+        return y, t, su, AtomAux(st, amax)
     u = torch.empty_like(x) if save else None
-    # training: the launch's per-workgroup operand maxima ([0] of x, [1] of t) travel with t to the weight-gradient kernel,
-    # which takes its block scales from them (no extra pass over the tensors)
+    # training: the launch's per-workgroup operand maxima ([0] of x, [1] of t) go to the weight-gradient kernel, which takes its
+    # block scales from them (no extra pass over the tensors)
     amax = _amax_buffer(x.device) if save else None
 
     def cost():
@@ -402,9 +409,7 @@ def atom_fwd(x, image, b0, b1, dil, save, signs=False):
                 "geom": (B, C, Lg, C, 3, 1, dil, 1)}
     L.call("ms_residual_atom_fwd", cost, d, x.data_ptr(), image.data_ptr(), b0.data_ptr(), b1.data_ptr(),
            y.data_ptr(), L.ptr(t), L.ptr(u), L.ptr(amax), L.stream())
-    if amax is not None:
-        t._ms_amax = amax
-    return y, t, u
+    return y, t, u, (AtomAux(None, amax) if save else None)
 
 
 def _stack_desc(x, dils):
@@ -449,39 +454,36 @@ def _amax_buffer(device):
     return torch.empty((2, L.ATOM_AMAX_N), dtype=torch.float32, device=device)
 
 
-def atom_bwd_data(g, u, t, image_bwd, dil):
-    """-> (gt, gx): gt = conv1^T(g * lrelu'(u)) (raw), gx = g + conv_d^T(gt * lrelu'(t)) -- the atom's backward data, one launch.
-    gt carries the launch's operand maxima (`gt._ms_amax`: [0] of g, [1] of gt lrelu'(t)) for the weight gradients."""
+def atom_bwd_data(g, u, t, image_bwd, dil, t_signs=None):
+    """-> (gt, gx, amax): gt = conv1^T(g * lrelu'(u)) (raw), gx = g + conv_d^T(gt * lrelu'(t)) -- the atom's backward data, one
+    launch; amax = the launch's operand maxima ([0] of g, [1] of gt lrelu'(t)) for the weight gradients, or None.
+    u as sign words (atom_fwd(..., signs=True)) needs t_signs, the forward's AtomAux.t_signs."""
     sg = is_signs(u)
     for a, nm in ((g, "grad_output"), (t, "t")) + (() if sg else ((u, "y_act"),)):
         L.require(a, "residual atom " + nm)
     B, C, Lg = g.shape
     gt, gx = torch.empty_like(g), torch.empty_like(g)
     d = L.AtomDesc(B, C, Lg, dil, SLOPE)
+    amax = _amax_buffer(g.device)
     if sg:
-        st = t._ms_signs
-        amax = _amax_buffer(g.device)
+        if not is_signs(t_signs):
+            raise RuntimeError("residual atom backward: u is sign words, t's sign words (AtomAux.t_signs) are required")
 
         def cost_s():
             c0 = W.conv_cost(B, C, Lg, C, 3, 1, dil, dil, 1, "bwd_data")
             # moves g (read), gt and gx (written) and the sign words of u and t (1 / 32 of an fp32 tensor each)
             return {"flops": 2 * c0["flops"], "bytes": int(4 * g.numel() * (3 + 1 / 16)) + 4 * 2 * 3 * C * C,
                     "geom": (B, C, Lg, C, 3, 1, dil, 1)}
-        L.call("ms_residual_atom_bwd_data_signs", cost_s, d, g.data_ptr(), u.data_ptr(), st.data_ptr(), image_bwd.data_ptr(),
+        L.call("ms_residual_atom_bwd_data_signs", cost_s, d, g.data_ptr(), u.data_ptr(), t_signs.data_ptr(), image_bwd.data_ptr(),
                gt.data_ptr(), gx.data_ptr(), L.ptr(amax), L.stream())
-        if amax is not None:
-            gt._ms_amax = amax
-        return gt, gx
+        return gt, gx, amax
 
     def cost():
         c0 = W.conv_cost(B, C, Lg, C, 3, 1, dil, dil, 1, "bwd_data")
         return {"flops": 2 * c0["flops"], "bytes": 4 * g.numel() * 5 + 4 * 2 * 3 * C * C, "geom": (B, C, Lg, C, 3, 1, dil, 1)}
-    amax = _amax_buffer(g.device)
     L.call("ms_residual_atom_bwd_data", cost, d, g.data_ptr(), u.data_ptr(), t.data_ptr(), image_bwd.data_ptr(),
            gt.data_ptr(), gx.data_ptr(), L.ptr(amax), L.stream())
-    if amax is not None:
-        gt._ms_amax = amax
-    return gt, gx
+    return gt, gx, amax
 
 
 def convt_desc(x_shape, w_shape, stride, pad, act=L.ACT_NONE, in_act=L.ACT_NONE):

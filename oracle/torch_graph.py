@@ -108,7 +108,7 @@ def generator_masks_from_tape(tape, to_bool):
             k, a = k + 1, 0
             masks["ct%d" % k] = to_bool(rec[3])
         elif rec[0] == "atom":
-            _, _, _, t, u = rec[1]
+            t, u = rec[1][3], rec[1][4]
             masks["a%d.%d.0" % (k, a)] = to_bool(t)
             masks["a%d.%d.1" % (k, a)] = decode_sign_words(u) if u.dtype == torch.int16 else to_bool(u)
             a += 1

@@ -150,7 +150,7 @@ def test_fused_atom_block_scaling(C, Lg, scale):
     g = dev(np.random.default_rng(7).standard_normal(x.shape).astype(np.float32) * scale * 1e-3)
     imgb = P.atom_image(C, xt.device)
     P.atom_pack([(w0t, w1t, imgb)], backward=True)
-    gt, gx = P.atom_bwd_data(g, rec[4], rec[3], imgb, 3)
+    gt, gx, _ = P.atom_bwd_data(g, rec[4], rec[3], imgb, 3)
     import torch.nn.functional as F
     gd = g.double() * torch.where(rec[4] > 0, 1.0, 0.2).double()
     gt_r = F.conv_transpose1d(gd, w1t.double(), padding=1)
@@ -208,12 +208,12 @@ def test_fused_atom_backward_vs_oracle_and_unfused(case):
     xt, w0t, b0t, w1t, b1t = (dev(a) for a in (x, w0, b0, w1, b1))
     assert P.atom_bwd_supported(B, C, Lg, dil)
     y, rec = G.atom_forward(xt, w0t, b0t, w1t, b1t, dil, True, image=None)
-    d0, d1, _, t, u = rec
+    d0, d1, _, t, u, _ = rec
     g = np.random.default_rng(stable_seed(name) + 1).standard_normal((B, C, Lg)).astype(np.float32)
     gt_d = dev(g)
     img = P.atom_image(C, xt.device)
     P.atom_pack([(w0t, w1t, img)], backward=True)
-    gt, gx = P.atom_bwd_data(gt_d, u, t, img, dil)
+    gt, gx, _ = P.atom_bwd_data(gt_d, u, t, img, dil)
     # oracle
     gp1 = O.act_bwd(host(u), g, 1)
     gt_ref = O.conv1d_bwd_data(gp1, w1, x.shape, 1, 1, 1, 1, O.PAD_ZERO)
@@ -237,11 +237,11 @@ def test_fused_atom_backward_at_bench_shapes(C, Lg, dil):
     x, w0, b0, w1, b1 = _inputs("bench_%d" % C, 32, C, Lg)
     xt, w0t, b0t, w1t, b1t = (dev(a) for a in (x, w0, b0, w1, b1))
     y, rec = G.atom_forward(xt, w0t, b0t, w1t, b1t, dil, True, image=None)
-    d0, d1, _, t, u = rec
+    d0, d1, _, t, u, _ = rec
     g = dev(np.random.default_rng(5).standard_normal((32, C, Lg)).astype(np.float32) * 1e-6)
     img = P.atom_image(C, xt.device)
     P.atom_pack([(w0t, w1t, img)], backward=True)
-    gt, gx = P.atom_bwd_data(g, u, t, img, dil)
+    gt, gx, _ = P.atom_bwd_data(g, u, t, img, dil)
     gt2 = P.conv1d_bwd_data(g, u, w1t, d1)
     gx2 = P.conv1d_bwd_data(gt2, t, w0t, d0, gx_add=g)
     names = [L.load().ms_conv1d_kernel_name(dd, 1).decode() for dd in (d0, d1)]
@@ -254,7 +254,7 @@ def test_fused_atom_backward_at_bench_shapes(C, Lg, dil):
     print("C=%d backward vs float64: fused gt %.2e gx-g %.2e | two launches gt %.2e gx-g %.2e" % ((C,) + e_f + e_u))
     assert max(e_f) < 1e-6 and max(e_u) < 1e-6
     assert _rel(gt, gt2) < 2e-6 and _rel(gx - g, gx2 - g) < 2e-6
-    gt3, gx3 = P.atom_bwd_data(g, u, t, img, dil)
+    gt3, gx3, _ = P.atom_bwd_data(g, u, t, img, dil)
     assert torch.equal(gt3, gt) and torch.equal(gx3, gx), "launch-to-launch determinism"
 
 
@@ -278,15 +278,17 @@ def test_fused_atom_sign_words(case):
     xt, w0t, b0t, w1t, b1t = (dev(a) for a in (x, w0, b0, w1, b1))
     img = P.atom_image(C, xt.device); P.atom_pack([(w0t, w1t, img)])
     imgb = P.atom_image(C, xt.device); P.atom_pack([(w0t, w1t, imgb)], backward=True)
-    y, t, u = P.atom_fwd(xt, img, b0t, b1t, dil, True)
-    ys, ts, su = P.atom_fwd(xt, img, b0t, b1t, dil, True, signs=True)
-    assert P.is_signs(su) and P.is_signs(ts._ms_signs) and tuple(su.shape) == (B, C // 32, 2, Lg)
+    y, t, u, _ = P.atom_fwd(xt, img, b0t, b1t, dil, True)
+    ys, ts, su, aux = P.atom_fwd(xt, img, b0t, b1t, dil, True, signs=True)
+    assert P.is_signs(su) and P.is_signs(aux.t_signs) and tuple(su.shape) == (B, C // 32, 2, Lg)
     assert torch.equal(ys, y) and torch.equal(ts, t)
-    assert torch.equal(_decode_signs(su), u > 0) and torch.equal(_decode_signs(ts._ms_signs), t > 0)
+    assert torch.equal(_decode_signs(su), u > 0) and torch.equal(_decode_signs(aux.t_signs), t > 0)
     g = dev(np.random.default_rng(stable_seed(name + "g")).standard_normal((B, C, Lg)) * 1e-3)
-    gt, gx = P.atom_bwd_data(g, u, t, imgb, dil)
-    gts, gxs = P.atom_bwd_data(g, su, ts, imgb, dil)
+    gt, gx, _ = P.atom_bwd_data(g, u, t, imgb, dil)
+    gts, gxs, _ = P.atom_bwd_data(g, su, ts, imgb, dil, t_signs=aux.t_signs)
     assert torch.equal(gts, gt) and torch.equal(gxs, gx)
+    with pytest.raises(RuntimeError):
+        P.atom_bwd_data(g, su, ts, imgb, dil)             # sign words of u without t's: refused, not guessed
 
 
 @pytest.mark.parametrize("C,Lg,B", [(64, 4096, 2), (128, 2048, 2), (256, 256, 4), (32, 8192, 2), (32, 1024, 3)])
@@ -305,17 +307,17 @@ def test_stack_weight_gradients_from_sign_words(C, Lg, B):
         w0t, b0t, w1t, b1t = (dev(a) for a in (w0, b0, w1, b1))
         img = P.atom_image(C, xt.device); P.atom_pack([(w0t, w1t, img)])
         imgb = P.atom_image(C, xt.device); P.atom_pack([(w0t, w1t, imgb)], backward=True)
-        y, t, u = P.atom_fwd(h, img, b0t, b1t, dil, True)
-        ys, ts, su = P.atom_fwd(h, img, b0t, b1t, dil, True, signs=True)
+        y, t, u, af = P.atom_fwd(h, img, b0t, b1t, dil, True)
+        ys, ts, su, afs = P.atom_fwd(h, img, b0t, b1t, dil, True, signs=True)
         g = dev(rng.standard_normal((B, C, Lg)) * 1e-3)
-        gt, _ = P.atom_bwd_data(g, u, t, imgb, dil)
-        gts, _ = P.atom_bwd_data(g, su, ts, imgb, dil)
+        gt, _, ab = P.atom_bwd_data(g, u, t, imgb, dil)
+        gts, _, abs_ = P.atom_bwd_data(g, su, ts, imgb, dil, t_signs=afs.t_signs)
         d0, _ = P.conv_desc(h.shape, w0t.shape, pad=dil, dil=dil, act=1)
         d1, _ = P.conv_desc(h.shape, w1t.shape, pad=1, act=1)
-        jobs_f += [(t, g, u, d1, w1t.shape, None, None, False, t._ms_amax[1], gt._ms_amax[0]),
-                   (h, gt, t, d0, w0t.shape, None, None, False, t._ms_amax[0], gt._ms_amax[1])]
-        jobs_s += [(ts, g, su, d1, w1t.shape, None, None, False, ts._ms_amax[1], gts._ms_amax[0]),
-                   (h, gts, ts._ms_signs, d0, w0t.shape, None, None, False, ts._ms_amax[0], gts._ms_amax[1])]
+        jobs_f += [(t, g, u, d1, w1t.shape, None, None, False, af.amax[1], ab[0]),
+                   (h, gt, t, d0, w0t.shape, None, None, False, af.amax[0], ab[1])]
+        jobs_s += [(ts, g, su, d1, w1t.shape, None, None, False, afs.amax[1], abs_[0]),
+                   (h, gts, afs.t_signs, d0, w0t.shape, None, None, False, afs.amax[0], abs_[1])]
         h = y
     rf = P.conv1d_bwd_weight_multi(jobs_f)
     rs = P.conv1d_bwd_weight_multi(jobs_s)

@@ -21,7 +21,7 @@ if op == "atom":      # fused residual atom, training forward + backward data: a
     signs = P.stack_signs_ok(x, (dil,) * 3)        # what the train step runs: sign words in place of the fp32 u (atom_fused.hip, MASK)
     for _ in range(5):
         y, rec = G.atom_forward(x, w0, b0, w1, b1, dil, True, image=img, signs=signs)
-        if P.atom_bwd_supported(B, C, Lg, dil): P.atom_bwd_data(g, rec[4], rec[3], imgb, dil)
+        if P.atom_bwd_supported(B, C, Lg, dil): P.atom_bwd_data(g, rec[4], rec[3], imgb, dil, t_signs=rec[5].t_signs if rec[5] is not None else None)
     torch.cuda.synchronize(); sys.exit(0)
 if op == "k5img":     # the k5 layer on weight images (conv5_img.hip), forward + backward data: k5img B C L
     B, C, Lg = map(int, sys.argv[2:5])

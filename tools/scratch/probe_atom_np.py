@@ -52,7 +52,7 @@ def worker():
                 d0, d1, _, tt, uu = rec2
                 g = torch.randn_like(x) * 1e-6          # gradient-sized magnitudes
                 imgb = P.atom_image(C, x.device); P.atom_pack([(w0, w1, imgb)], backward=True)
-                gt, gx = P.atom_bwd_data(g, uu, tt, imgb, dil)
+                gt, gx, _ = P.atom_bwd_data(g, uu, tt, imgb, dil)
                 gt2 = P.conv1d_bwd_data(g, uu, w1, d1)
                 gx2 = P.conv1d_bwd_data(gt2, tt, w0, d0, gx_add=g)
                 t = timeit(lambda: P.atom_bwd_data(g, uu, tt, imgb, dil))
