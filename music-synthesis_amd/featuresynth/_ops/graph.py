@@ -49,7 +49,7 @@ _FORKED_SINCE_JOIN = set()     # side streams work was issued on since the last 
 @contextlib.contextmanager
 def forked(stream):
     """`with torch.cuda.stream(stream)` that also counts the fork level: code issued inside must not
-    fork again (melgan_forward / melgan_backward / _WgradFork check `_may_fork`).  Forks are kept ONE
+    fork again (_WgradFork / _PackAside / fork_aux check `_may_fork`).  Forks are kept ONE
     level deep under hipGraph capture: a fork inside a fork crashed graph instantiation on ROCm 7.2
     ("Streams inside the graph")."""
     global _FORK_DEPTH
@@ -278,7 +278,8 @@ def flush_wgrad_batch(batch, sink, fork):
     batch.clear()
 
 
-def gen_forward(x, params, save):
+def gen_forward(x, params, save, out=None):
+    """out: optional preallocated (B, 1, 256 T) buffer for the waveform (e.g. the leading half of a [fake; real] batch)."""
     if len(params) != G_NPARAMS:
         raise RuntimeError("generator expects %d parameter tensors, got %d" % (G_NPARAMS, len(params)))
     L.require(x, "generator input")
@@ -322,7 +323,7 @@ def gen_forward(x, params, save):
             tape.append(("atom", rec))
     w, b = params[i], params[i + 1]
     d, lo = P.conv_desc(h.shape, w.shape, pad=3, act=L.ACT_TANH)
-    y, _ = P.conv1d_fwd(h, w, b, d, lo)
+    y, _ = P.conv1d_fwd(h, w, b, d, lo, out=out)
     tape.append(("last", d, h, y))
     if save:
         # (gen_backward: no pack launch in front of the backward chain.)  The images hold the weights as they were at THIS
@@ -457,80 +458,7 @@ def pack_k5_images_aside(x_shape, params, device, forked_at=None):
     return f, b, ev
 
 
-def disc_forward(x, params, k5_image=None):
-    """One FullDiscriminator pass -> (features[6], judgement, tape)."""
-    if len(params) != D_NPARAMS:
-        raise RuntimeError("discriminator expects %d parameter tensors, got %d" % (D_NPARAMS, len(params)))
-    L.require(x, "discriminator input")
-    if x.dim() != 3 or x.shape[1] != 1:
-        raise RuntimeError("discriminator input must be (B, 1, L), got %s" % (tuple(x.shape),))
-    feats, tape = [], []
-    h = x
-    for li, (stride, pad, groups) in enumerate(D_LAYERS):
-        w, b = params[2 * li], params[2 * li + 1]
-        d, lo = P.conv_desc(h.shape, w.shape, stride=stride, pad=pad, groups=groups, act=L.ACT_LRELU)
-        hin = h
-        if li == 5 and k5_image is not None and P.conv_img_bytes(d):
-            h = P.conv1d_img_fwd(hin, k5_image, b, d, lo)
-        else:
-            h, _ = P.conv1d_fwd(hin, w, b, d, lo)
-        tape.append((d, hin, h))
-        feats.append(h)
-    w, b = params[12], params[13]
-    dj, lo = P.conv_desc(h.shape, w.shape, pad=1)
-    j, _ = P.conv1d_fwd(h, w, b, dj, lo)
-    tape.append((dj, h, j))
-    return feats, j, tape
-
-
 D_HEAD_PARAM = 10      # first parameter of the discriminator's "head" (main.5 = the 1024 -> 1024 k5 conv, then judge)
-
-
-def disc_backward(tape, params, g_feats, g_judge, sink, need_gx=True, need_wgrad=True, phase=None, g_in=None,
-                  k5_image_bwd=None):
-    """g_feats: list of 6 (entries may be None) or None; g_judge may be None (treated as zero).
-    Parameter grads go to `sink` (GradSink of 14); returns d loss / d x (or None).
-
-    phase None: the whole pass.  phase "head": judge conv + the k5 layer only (93 % of the gradient bytes;
-    they are the FIRST thing the backward produces) -> returns the gradient w.r.t. feature 4;
-    phase "tail": layers 4..0, continuing from g_in.  (The split lets the data-parallel trainer all-reduce
-    the head's gradients while the tail still runs, train.py.)"""
-    dj, h5, _ = tape[6]
-
-    def own(li):  # the loss's own gradient on feature li (feature-matching term), if any
-        return g_feats[li] if (g_feats is not None and li >= 0) else None
-
-    if phase != "tail":
-        # g = total gradient w.r.t. feature 5 (judge path + its own loss term)
-        if g_judge is not None:
-            if need_wgrad:
-                gw, gb, acc = sink.pair(12)
-                sink.put(12, *P.conv1d_bwd_weight(h5, g_judge, None, dj, params[12].shape, gw, gb, acc))
-            g = P.conv1d_bwd_data(g_judge, None, params[12], dj, gx_add=own(5))
-        else:
-            g = own(5)
-        layers = (5,) if phase == "head" else range(5, -1, -1)
-    else:
-        g = g_in
-        layers = range(4, -1, -1)
-    for li in layers:
-        d, hin, h = tape[li]
-        prev = own(li - 1) if li > 0 else None
-        if g is None:           # nothing flows through this layer
-            g = prev
-            continue
-        if need_wgrad:
-            gw, gb, acc = sink.pair(2 * li)
-            sink.put(2 * li, *P.conv1d_bwd_weight(hin, g, h, d, params[2 * li].shape, gw, gb, acc))
-        if li == 5 and k5_image_bwd is not None and P.conv_img_bytes(d):
-            g = P.conv1d_img_bwd_data(g, h, k5_image_bwd, d, gx_add=prev)
-        elif li > 0:
-            g = P.conv1d_bwd_data(g, h, params[2 * li], d, gx_add=prev)
-        elif need_gx:
-            g = P.conv1d_bwd_data(g, h, params[0], d)
-        else:
-            g = None
-    return g
 
 
 _SIDE_STREAMS = {}
@@ -587,17 +515,12 @@ def _concurrent_scales():
     return os.environ.get("MSYNTH_STREAMS", "1") != "0"
 
 
-def _parts_mode():
-    """Every layer of the shared discriminator ONCE per pass over all scales (ms_conv1d_parts_*: one launch where a parts
-    kernel takes the layer, part by part on one stream otherwise).  MSYNTH_DPARTS=0: one pass per scale on forked streams
-    (the r01-r04 schedule), kept for A/B runs."""
-    return os.environ.get("MSYNTH_DPARTS", "1") != "0"
-
-
-def melgan_forward_parts(x, params, scales=2, k5_image=None):
+def melgan_forward(x, params, scales=2, k5_image=None):
     """MelGanDiscriminator (reference discriminator/melgan.py:13-27): the ONE FullDiscriminator on x, pool(x), pool(pool(x)),
     layer by layer over all scales -- the weights are shared by construction, so a layer's three scales are one piece of
-    work for the device.  -> (features[scale][6], judgements[scale], ctx) like melgan_forward."""
+    work for the device (ms_conv1d_parts_*: one launch where a parts kernel takes the layer, part by part on the caller's
+    stream otherwise; r01-r04 ran one pass per scale on forked streams).  -> (features[scale][6], judgements[scale], ctx);
+    scales = 0: the single FullDiscriminator (discriminator/full.py:24-40)."""
     if len(params) != D_NPARAMS:
         raise RuntimeError("discriminator expects %d parameter tensors, got %d" % (D_NPARAMS, len(params)))
     L.require(x, "discriminator input")
@@ -628,9 +551,9 @@ def melgan_forward_parts(x, params, scales=2, k5_image=None):
     return feats, js, (tapes, xs)
 
 
-def melgan_backward_parts(ctx, params, g_feats, g_judges, sink=None, need_gx=True, need_wgrad=True, cut=None,
+def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, need_wgrad=True, cut=None,
                           k5_image_bwd=None):
-    """Backward of melgan_forward_parts, layer by layer over all scales: backward data of a layer's scales is one launch,
+    """Backward of melgan_forward, layer by layer over all scales: backward data of a layer's scales is one launch,
     and so is its weight gradient -- summed over the scales by the launch's own reduction.  The gradients may cover fewer
     batch rows than the forward pass saved (the G-step runs one pass over [fake; real] and differentiates the fake half):
     the leading rows of the saved tensors are used.  cut: called once the head's parameters (k5 layer + judge conv) are final."""
@@ -705,163 +628,5 @@ def melgan_backward_parts(ctx, params, g_feats, g_judges, sink=None, need_gx=Tru
         if gx_next is not None and need_gx:
             B = gx_next.shape[0]
             gx = P.avg_pool_bwd(gx_next, (B,) + tuple(xs[s].shape[1:]), gx_add=gx)
-        gx_next = gx
-    return (gx_next if need_gx else None), sink
-
-
-def melgan_forward(x, params, scales=2, k5_image=None):
-    """MelGanDiscriminator: the shared discriminator on x, pool(x), pool(pool(x)).
-
-    The three scale passes are independent; the pooled scales are tiny (their 1024-channel layers
-    run at L = 17 / 9 and cannot fill 256 CUs on their own), so they are issued on side HIP
-    streams forked from / joined to the caller's stream -- under hipGraph capture they become
-    parallel branches of the graph."""
-    if _parts_mode():
-        return melgan_forward_parts(x, params, scales, k5_image)
-    xs = [x]
-    for s in range(scales):
-        xs.append(P.avg_pool_fwd(xs[-1]))
-    res = [None] * (scales + 1)
-    if k5_image is None:
-        k5_image = pack_k5_image(x.shape, params)          # (on the caller's stream, ahead of the forks)
-    if scales > 0 and _may_fork(x.device):   # forks are kept one level deep
-        main = torch.cuda.current_stream(x.device)
-        side = _side_streams(x.device, scales)
-        # longest job first: the full-rate pass is issued before the pooled ones, which fork off an event
-        # recorded ahead of it (see melgan_backward)
-        fork_ev = torch.cuda.Event()
-        fork_ev.record(main)
-        res[0] = disc_forward(xs[0], params, k5_image)
-        for s in range(1, scales + 1):
-            st = side[s - 1]
-            st.wait_event(fork_ev)
-            with forked(st):
-                res[s] = disc_forward(xs[s], params, k5_image)
-        for st in side:
-            main.wait_stream(st)
-    else:
-        for s in range(scales + 1):
-            res[s] = disc_forward(xs[s], params, k5_image)
-    feats = [r[0] for r in res]
-    judges = [r[1] for r in res]
-    tapes = [r[2] for r in res]
-    return feats, judges, (tapes, xs)
-
-
-def _scale_has_grad(g_feats, g_judges, s):
-    gf = None if g_feats is None else g_feats[s]
-    gj = None if g_judges is None else g_judges[s]
-    return gj is not None or (gf is not None and any(t is not None for t in gf)), gf, gj
-
-
-def _flat_view(sink, params):
-    """(flat tensor spanning the sink's destination slots, per-parameter offsets, length) when the slots
-    are consecutive 16-byte aligned views of one buffer (a FlatAdam gradient bucket) that already hold
-    values to accumulate into; else (None, None, 0)."""
-    if len(sink.t) != len(params) or any(t is None for t in sink.t) or not all(sink.acc):
-        return None, None, 0
-    offs, total = [], 0
-    base = sink.t[0]
-    for t, p in zip(sink.t, params):
-        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != p.shape or \
-                t.untyped_storage().data_ptr() != base.untyped_storage().data_ptr() or \
-                t.storage_offset() - base.storage_offset() != total:
-            return None, None, 0
-        offs.append(total)
-        total += (p.numel() + 3) // 4 * 4
-    if base.storage_offset() + total > base.untyped_storage().nbytes() // 4:
-        return None, None, 0
-    return base.as_strided((total,), (1,)), offs, total
-
-
-def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, need_wgrad=True, cut=None, k5_image_bwd=None):
-    """cut: optional callback.  When given, every scale's head (judge + k5 layer, disc_backward phase
-    "head") runs first, all streams join, cut() is called -- at that point sink slots D_HEAD_PARAM.. are
-    final -- and the tails follow.  Without it each scale runs head and tail back to back."""
-    if _parts_mode():
-        return melgan_backward_parts(ctx, params, g_feats, g_judges, sink, need_gx, need_wgrad, cut, k5_image_bwd)
-    tapes, xs = ctx
-    n = len(tapes)
-    sink = sink if sink is not None else GradSink(D_NPARAMS)
-    gxs = [None] * n
-    phases = (None,) if cut is None else ("head", "tail")
-    mid = [None] * n                                   # gradient w.r.t. feature 4 between the two phases
-    tmp = [None] * n
-    flat_tmp = [None] * n
-    grads = [_scale_has_grad(g_feats, g_judges, s) for s in range(n)]
-    fork = n > 1 and _may_fork(xs[0].device)
-    dev = xs[0].device
-    # when the destination slots are one flat bucket (FlatAdam), every side scale writes into a private
-    # bucket of the same layout, folded in afterwards with ONE add (per phase) instead of one per parameter
-    flat_main, offs, total = (_flat_view(sink, params) if (need_wgrad and fork) else (None, None, 0))
-
-    # (ahead of the forks: all scales read it; the hand-scheduled step packs it at its start, off the critical path)
-    k5_bwd = k5_image_bwd if k5_image_bwd is not None else pack_k5_image(xs[0].shape, params, backward=True)
-
-    def run_scale(s, ph, dest):
-        has, gf, gj = grads[s]
-        if not has:
-            return
-        out = disc_backward(tapes[s], params, gf, gj, dest, need_gx=need_gx, need_wgrad=need_wgrad,
-                            phase=ph, g_in=mid[s], k5_image_bwd=k5_bwd)
-        if ph == "head":
-            mid[s] = out
-        else:
-            gxs[s] = out
-
-    for ph in phases:
-        if fork:
-            main = torch.cuda.current_stream(dev)
-            side = _side_streams(dev, n - 1)
-            # the full-rate scale has the most work: it is issued FIRST (longest job first), the side scales
-            # fork off the point before it through an event instead of waiting for the main stream's tail
-            fork_ev = torch.cuda.Event()
-            fork_ev.record(main)
-            run_scale(0, ph, sink)
-            for s in range(1, n):
-                if not grads[s][0]:
-                    continue
-                st = side[s - 1]
-                st.wait_event(fork_ev)
-                with forked(st):
-                    if tmp[s] is None:
-                        if flat_main is not None:
-                            flat_tmp[s] = torch.zeros_like(flat_main)
-                            views = [flat_tmp[s][o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
-                            tmp[s] = GradSink(D_NPARAMS, views, [False] * D_NPARAMS)
-                        else:
-                            tmp[s] = GradSink(D_NPARAMS)      # own slabs: no cross-stream accumulation
-                    run_scale(s, ph, tmp[s])
-            for st in side:
-                main.wait_stream(st)
-            # fold the side-stream weight grads in: the parameters this phase has finished
-            lo, hi = {None: (0, D_NPARAMS), "head": (D_HEAD_PARAM, D_NPARAMS), "tail": (0, D_HEAD_PARAM)}[ph]
-            for s in range(1, n):
-                if tmp[s] is None or not need_wgrad:
-                    continue
-                if flat_tmp[s] is not None:
-                    a, b = offs[lo], (total if hi == D_NPARAMS else offs[hi])
-                    P.add_(flat_main[a:b], flat_tmp[s][a:b])
-                    for i in range(lo, hi):
-                        sink.acc[i] = True
-                    continue
-                for i in range(lo, hi):
-                    if tmp[s].t[i] is None:
-                        continue
-                    if sink.t[i] is None:
-                        sink.t[i] = tmp[s].t[i]
-                    else:
-                        P.add_(sink.t[i], tmp[s].t[i])
-                    sink.acc[i] = True
-        else:
-            for s in range(n - 1, -1, -1):
-                run_scale(s, ph, sink)
-        if ph == "head":
-            cut()
-    gx_next = None
-    for s in range(n - 1, -1, -1):
-        gx = gxs[s]
-        if gx_next is not None and need_gx:
-            gx = P.avg_pool_bwd(gx_next, xs[s].shape, gx_add=gx)
         gx_next = gx
     return (gx_next if need_gx else None), sink

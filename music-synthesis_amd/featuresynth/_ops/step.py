@@ -31,6 +31,14 @@ def _one(device):
     return t
 
 
+def _both_buffer(samples):
+    """(2 B, 1, L) buffer whose trailing half already holds the real samples (one copy instead of a concatenation of both halves)."""
+    B = samples.shape[0]
+    both = torch.empty((2 * B,) + tuple(samples.shape[1:]), dtype=samples.dtype, device=samples.device)
+    both[B:].copy_(samples)
+    return both
+
+
 def _slots(params):
     """Gradient destinations = the parameters' FlatAdam bucket views (zeroed by zero_grad: accumulate)."""
     slots = [F_._bound_slot(p) for p in params]
@@ -47,7 +55,9 @@ def d_step(gen_params, disc_params, samples, features, scales=2, cut=None, debug
     # 0.59 ms of host time per launch) and the caller synchronises after every step: whatever the generator forward --
     # the head of the critical path -- does not need is issued AFTER it, on a branch forked before it
     forked_at = G.fork_aux(dev)
-    fake, _ = G.gen_forward(features, gen_params, save=False)
+    # [fake; real] is ONE buffer: the generator's last conv writes its leading half, the samples are copied behind it
+    both = _both_buffer(samples)
+    fake, _ = G.gen_forward(features, gen_params, save=False, out=both[:samples.shape[0]])
     k5f, k5b, k5ev = G.pack_k5_images_aside(samples.shape, disc_params, dev, forked_at=forked_at)
     B = fake.shape[0]
     if k5ev is not None:
@@ -56,7 +66,6 @@ def d_step(gen_params, disc_params, samples, features, scales=2, cut=None, debug
     # judgements are the same and the shared weights' gradients are summed in-kernel.  (r03 tried the real half of the
     # forward on the aux stream under the generator, both halves writing into shared full-batch buffers: 3.71 vs 3.66 ms
     # per step -- the half-batch passes cost more than the overlap returns; dropped.)
-    both = torch.cat([fake, samples], 0)
     _, judges, ctx = G.melgan_forward(both, disc_params, scales, k5_image=k5f)
     loss = F_.disc_loss_cat_fwd(judges, B)
     if loss_slot is not None:          # data parallel: the value travels with the gradient slice behind the cut
@@ -74,38 +83,24 @@ def g_step(gen_params, disc_params, samples, features, scales=2, weight=10.0, cu
     """-> (g_loss, fake); generator gradients accumulate into its bucket."""
     dev = samples.device
     main = torch.cuda.current_stream(dev)
-    side = G.aux_stream(dev)
     # the aux branch forks here and is filled after the generator forward (capture order = launch order, see d_step)
     fork_real = G.fork_aux(dev)
-    fake, tape = G.gen_forward(features, gen_params, save=True)
+    both = _both_buffer(samples)
+    fake, tape = G.gen_forward(features, gen_params, save=True, out=both[:samples.shape[0]])
     # one pair of weight images for the discriminator pass(es) and the backward, packed on the aux stream beside the
     # generator forward
     k5, k5b, k5ev = G.pack_k5_images_aside(samples.shape, disc_params, dev, forked_at=fork_real)
-    rows = None
-    if G._parts_mode():
-        # ONE discriminator pass over [fake; real], as in the D-step (samples are independent): every layer runs once over
-        # both halves and all scales; the backward pass differentiates the fake half (the leading rows of what was saved)
-        if k5ev is not None:
-            main.wait_event(k5ev)
-        B = fake.shape[0]
-        feats, judges, ctx = G.melgan_forward(torch.cat([fake, samples], 0), disc_params, scales, k5_image=k5)
-        f_feats = [[t[:B] for t in grp] for grp in feats]
-        r_feats = [[t[B:] for t in grp] for grp in feats]
-        f_judges = [j[:B] for j in judges]
-        rows = slice(0, B)
-    else:
-        # the real path neither depends on the generator nor needs gradients: it runs on a forked stream
-        # (a parallel branch of the captured graph) beside G and D(fake)
-        if fork_real:
-            with G.forked(side):
-                r_feats, r_judges, _ = G.melgan_forward(samples, disc_params, scales, k5_image=k5)
-        else:
-            r_feats, r_judges, _ = G.melgan_forward(samples, disc_params, scales, k5_image=k5)
-        if k5ev is not None:
-            main.wait_event(k5ev)
-        f_feats, f_judges, ctx = G.melgan_forward(fake, disc_params, scales, k5_image=k5)
-        if fork_real:
-            main.wait_stream(side)
+    # ONE discriminator pass over [fake; real], as in the D-step (samples are independent): every layer runs once over both
+    # halves and all scales; the backward pass differentiates the fake half (the leading rows of what was saved).  (r01-r04 ran
+    # the real half on a forked stream beside the generator forward, one pass per scale.)
+    if k5ev is not None:
+        main.wait_event(k5ev)
+    B = fake.shape[0]
+    feats, judges, ctx = G.melgan_forward(both, disc_params, scales, k5_image=k5)
+    f_feats = [[t[:B] for t in grp] for grp in feats]
+    r_feats = [[t[B:] for t in grp] for grp in feats]
+    f_judges = [j[:B] for j in judges]
+    rows = slice(0, B)
     S, Lyr = len(f_feats), len(f_feats[0])
     rf = [t for grp in r_feats for t in grp]
     ff = [t for grp in f_feats for t in grp]

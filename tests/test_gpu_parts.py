@@ -239,32 +239,35 @@ def test_thin_layers_over_three_scales(which, B, rows, L0):
     assert rel(gw3, 2 * gw) < 1e-6 and rel(gb3, 2 * gb) < 1e-6
 
 
-def test_parts_mode_equals_per_scale_passes(monkeypatch):
-    """The discriminator pass layer-by-layer over all scales (the default) against one pass per scale on forked streams
-    (MSYNTH_DPARTS=0, the r01-r04 schedule): same features, judgements, input gradient and parameter gradients to summation order (the
-    first conv, the judge conv and the k5 layer run other kernels; the grouped layers the same work units)."""
+def test_three_scale_pass_equals_one_scale_passes():
+    """The discriminator pass layer-by-layer over all scales (parts launches) against the SAME layers applied to each scale on
+    its own (scales = 0: the parts entry points then run the per-scale kernels): same features, judgements, input gradient
+    and parameter gradients to summation order."""
     from featuresynth._ops import graph as G
+    from featuresynth._ops import prims as P
     from featuresynth._synthetic import module_param_shapes, synthetic_samples, synthetic_state_dict
     import featuresynth as fs
     dmod = fs.MelGanDiscriminator()
     sd = synthetic_state_dict(module_param_shapes(dmod), seed=8, bias_scale=0.02)
     params = [dev(v) for v in sd.values()]
     x = dev(synthetic_samples(4, 8192, rank=3))
-    res = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("MSYNTH_DPARTS", mode)
-        feats, judges, ctx = G.melgan_forward(x, params)
-        g_feats = [[torch.full_like(t, 1e-3) for t in grp] for grp in feats]
-        g_judges = [torch.full_like(j, -0.25) for j in judges]
-        gx, sink = G.melgan_backward(ctx, params, g_feats, g_judges, None, need_gx=True, need_wgrad=True)
-        torch.cuda.synchronize()
-        res[mode] = (feats, judges, gx, sink.t)
-    fa, ja, gxa, ga = res["1"]
-    fb, jb, gxb, gb = res["0"]
+    feats, judges, ctx = G.melgan_forward(x, params)
+    g_feats = [[torch.full_like(t, 1e-3) for t in grp] for grp in feats]
+    g_judges = [torch.full_like(j, -0.25) for j in judges]
+    gx, sink = G.melgan_backward(ctx, params, g_feats, g_judges, None, need_gx=True, need_wgrad=True)
+    # one scale at a time
+    xs = [x, P.avg_pool_fwd(x)]
+    xs.append(P.avg_pool_fwd(xs[1]))
+    gws, gxs = None, []
     for s in range(3):
-        assert rel(ja[s], jb[s]) < 1e-5, (s, rel(ja[s], jb[s]))          # (small sums of cancelling terms)
+        f1, j1, c1 = G.melgan_forward(xs[s], params, scales=0)
+        assert rel(j1[0], judges[s]) < 1e-5, (s, rel(j1[0], judges[s]))          # (small sums of cancelling terms)
         for li in range(6):
-            assert rel(fa[s][li], fb[s][li]) < 2e-6, (s, li, rel(fa[s][li], fb[s][li]))
-    assert rel(gxa, gxb) < 1e-5, rel(gxa, gxb)
-    for i, (a, c) in enumerate(zip(ga, gb)):
+            assert rel(f1[0][li], feats[s][li]) < 2e-6, (s, li, rel(f1[0][li], feats[s][li]))
+        gx1, sk = G.melgan_backward(c1, params, [g_feats[s]], [g_judges[s]], None, need_gx=True, need_wgrad=True)
+        gxs.append(gx1)
+        gws = [t.clone() for t in sk.t] if gws is None else [a + t for a, t in zip(gws, sk.t)]
+    tot = gxs[0] + P.avg_pool_bwd(gxs[1] + P.avg_pool_bwd(gxs[2], xs[1].shape), xs[0].shape)
+    assert rel(gx, tot) < 1e-5, rel(gx, tot)
+    for i, (a, c) in enumerate(zip(sink.t, gws)):
         assert rel(a, c) < 1e-5, (i, rel(a, c))
