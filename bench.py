@@ -77,7 +77,7 @@ DTYPE = ("f32 storage and accumulate; multiplies on the 16-bit matrix pipe with 
 DTYPE_EXACT = "f32 storage and accumulate; every multiply fp32-exact (bf16 x 3 split, 6 products, or fp32-input MFMA / vector FMA)"
 
 
-# switches that put every 22-bit (fp16 x 2) kernel back on fp32-exact arithmetic (DESIGN.md "Tuning switches")
+# switches that put every 22-bit (fp16 x 2) kernel back on fp32-exact arithmetic (DESIGN_HISTORY.md "Tuning switches")
 EXACT_ENV = {"MSYNTH_ATOM_NP": "3", "MSYNTH_C5_NP": "3", "MSYNTH_W5_NP": "3", "MSYNTH_WROWS3_NP": "3", "MSYNTH_GCONV3": "0", "MSYNTH_CONVTIMG": "0"}
 
 

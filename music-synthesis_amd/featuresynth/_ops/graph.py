@@ -51,7 +51,7 @@ def forked(stream):
     """`with torch.cuda.stream(stream)` that also counts the fork level: code issued inside must not
     fork again (_WgradFork / _PackAside / fork_aux check `_may_fork`).  Forks are kept ONE
     level deep under hipGraph capture: a fork inside a fork crashed graph instantiation on ROCm 7.2
-    ("Streams inside the graph")."""
+    (DESIGN_HISTORY.md section 4, "Streams inside the graph")."""
     global _FORK_DEPTH
     _FORK_DEPTH += 1
     _FORKED_SINCE_JOIN.add(stream)

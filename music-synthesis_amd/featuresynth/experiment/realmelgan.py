@@ -223,7 +223,7 @@ class Discriminator(nn.Module):
         """realmelgan.py:163-181: three independent discriminators on x, pool(x), pool(pool(x)), issued back to back on the
         caller's stream.  (r01-r03 carried an opt-in variant with the pooled discriminators on forked streams, +3 % under
         hipGraph replay; its replay died once inside hipGraphLaunch and no cause could be proven from that one stack --
-        DESIGN.md section 4, "Streams inside the graph" lists what was audited and fixed -- so r04 removed it: a switch that
+        DESIGN_HISTORY.md section 4, "Streams inside the graph" lists what was audited and fixed -- so r04 removed it: a switch that
         can take the process down is not shipped.)"""
         _derive_weights(self)
         discs = list(self.model.values())

@@ -265,7 +265,7 @@ class _TrainerBase(object):
         Only in the FINAL segment of a multi-segment step: the host reads the pinned buffers (and the next
         trainer call overwrites the static inputs) as soon as the stream has drained, which must mean the whole
         step has -- a device-to-host copy node in an earlier segment of a pool-sharing capture sequence is the
-        one topology that crashed hipGraphLaunch on ROCm 7.2 ("graph faults")."""
+        one topology that crashed hipGraphLaunch on ROCm 7.2 (DESIGN_HISTORY.md section 6, "graph faults")."""
         if self._runner is not None and not self._runner.in_final_segment():
             raise RuntimeError("train step: host copies belong to the last graph segment (segment %d of %d)"
                                % (self._runner.segment, len(self._runner.between) + 1))

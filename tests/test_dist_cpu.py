@@ -137,7 +137,7 @@ def test_single_process_helpers_are_noops():
 
 
 def test_host_copies_only_in_the_final_segment():
-    """Constraint recorded in DESIGN.md section 6 ("graph faults"): the device-to-host result copies of a
+    """Constraint recorded in DESIGN_HISTORY.md section 6 ("graph faults"): the device-to-host result copies of a
     multi-segment train step belong to its LAST segment; _to_host refuses anything else (on an eager call and
     under capture alike -- the guard sits in front of any device work)."""
     from featuresynth.train.train import _GraphedStep, _TrainerBase

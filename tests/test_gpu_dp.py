@@ -136,7 +136,7 @@ def test_two_ranks_match_global_batch(tmp_path):
     mean_losses = r0["losses"]
     assert abs(mean_losses[0] - losses[0]) <= 1e-5 * abs(losses[0])          # d_loss, same params
     for i, (a, b) in enumerate(zip(mean_losses[1:], losses[1:]), 1):
-        # after Adam updates (DESIGN.md "Adam sensitivity"): d_loss ~ 6 stays tight, g_loss is a
+        # after Adam updates (DESIGN_HISTORY.md "Adam sensitivity"): d_loss ~ 6 stays tight, g_loss is a
         # small number near zero whose judge term moves at the +-lr scale PER UPDATE already made: the
         # single-process value itself moves by 4e-4 at call 6 between two kernel generations of identical
         # accuracy (tools/scratch/dbg_dp.py with MSYNTH_GCONV3/CONVT3/PAD4 = 0 vs default: -0.003496 vs -0.003921), so
@@ -149,7 +149,7 @@ def test_two_ranks_match_global_batch(tmp_path):
         if k.endswith("weight"):
             assert rel_l2(r0[k], v) < 1e-2, k
     # ---- the real gate: all-reduced flat gradient bucket x 1/world vs the global-batch bucket, no Adam in the way
-    # (the trajectory checks above are smoke checks only: DESIGN.md "Adam sensitivity")
+    # (the trajectory checks above are smoke checks only: DESIGN_HISTORY.md "Adam sensitivity")
     b0, b1 = np.load(str(tmp_path / "buckets0.npz")), np.load(str(tmp_path / "buckets1.npz"))
     assert np.array_equal(b0["sums"], b1["sums"]), "ranks hold different all-reduced buckets"
     assert np.array_equal(b0["losses"], b1["losses"])

@@ -227,7 +227,7 @@ def test_train_steps_vs_reference_fixture(golden, tag, optim_kind):
     every generator gradient) -- directly, not through the oracle.  `small`: B = 2, 2048-sample windows, D,G,D,G;
     `cfg3`: B = 1 at BASELINE config 3's 8192-sample window, D,G.  Tolerances are those the CPU oracle is held to against
     the same fixture (tests/test_oracle_golden.py::test_train_steps_small): the reference here ran in float32, and its own
-    float32 / float64 runs differ by more than this from the second D-step on (DESIGN.md "Adam sensitivity")."""
+    float32 / float64 runs differ by more than this from the second D-step on (DESIGN_HISTORY.md "Adam sensitivity")."""
     from featuresynth._synthetic import strided_sample, synthetic_features, synthetic_samples
     z = golden("train")
     B, T, nsteps = [int(v) for v in z[tag + "/cfg"]]
@@ -315,7 +315,7 @@ def test_reference_order_path_matches_native(monkeypatch):
     a, b = results["native"], results["generic"]
     # the D-step runs on identical parameters: same loss.  The native path sums the shared
     # discriminator's weight grads in a different order (one pass over [fake; real]); after the Adam
-    # update, rounding-level gradient entries may step the other way (DESIGN.md "Adam sensitivity"),
+    # update, rounding-level gradient entries may step the other way (DESIGN_HISTORY.md "Adam sensitivity"),
     # so post-update quantities are compared at the +-lr level.
     assert abs(a[0] - b[0]) < 1e-6
     assert abs(a[1] - b[1]) < 1e-2 * abs(b[1])

@@ -1,4 +1,4 @@
-"""The contract of the block-scaled two-piece fp16 operand scheme (csrc/atom_fused.hip header, DESIGN.md section 4h), per kernel
+"""The contract of the block-scaled two-piece fp16 operand scheme (csrc/atom_fused.hip header, DESIGN.md section 3), per kernel
 family that uses it: a block of operand values is scaled by a power of two so that its largest magnitude sits at 2^12 .. 2^15
 and every value is split into two fp16 pieces.  What the comments claim, and what is held here PER ELEMENT against float64:
 

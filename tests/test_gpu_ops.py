@@ -601,7 +601,7 @@ def test_profile_mode_reports_device_time():
 
 
 def test_side_stream_tracking_under_capture():
-    """graph.join_side_streams / begin_step (the r04 audit of the forked-replay fault): forks are tracked per
+    """graph.join_side_streams / begin_step (the r04 audit of the forked-replay fault, DESIGN_HISTORY.md section 6b): forks are tracked per
     trainer step -- begin_step() drops what earlier steps left -- and under hipGraph capture a stream that is NOT part of the
     capture is neither waited for (recording an event on a non-capturing stream and waiting for it from the capturing one
     is not a captured dependency: it invalidates the capture) nor left in the set; a fork that IS part of the capture is joined."""

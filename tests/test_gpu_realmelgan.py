@@ -477,7 +477,7 @@ def test_realmelgan_replay_gradients_bitwise(monkeypatch):
     """hipGraph capture and replay of the weight-normed variant's train steps reproduce the eager execution bitwise: with
     lr = 0 (parameters fixed) every one of D,G,D,G,D,G -- call 1 eager, call 2 captured, later calls replayed -- yields the
     same loss and the same flat gradient bucket as the eager run.  (r03 also ran the three discriminators on forked streams
-    here; that variant was removed in r04)  Trainers are dropped between the runs: their graphs must
+    here; that variant was removed in r04, DESIGN_HISTORY.md section 4.)  Trainers are dropped between the runs: their graphs must
     go when they go (no reference cycle through the graphed step), not whenever the cycle collector fires."""
     import gc
     import weakref
