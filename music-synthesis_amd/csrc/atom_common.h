@@ -16,7 +16,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr float WSCALE = 64.f;            // NP = 2: weights are packed as fp16 pieces of 64 w
+// NP = 2: weights are packed as the fp16 pieces of S_w w, S_w a power of two chosen PER CONV from the tensor's largest
+// magnitude (it goes to [2^12, 2^13)): weights of any magnitude work (r04 packed 64 w: |w| >= 2^9 overflowed to inf), and an
+// element within 2^16 of the tensor's largest weight keeps 22 significand bits.  A pack is two launches: partial maxima
+// (W_NPART workgroups per conv, written into the image's tail), then the pack proper, whose threads reduce the partials and
+// whose first thread leaves 1 / S_w in the tail for the consuming kernels.
+constexpr int W_NPART = 16;               // partial maxima per conv
+// tail of an NP = 2 image (floats): [conv][W_NPART] partial maxima, then [conv] 1 / S_w
+__host__ __device__ constexpr int wtail_floats(int nconv) { return nconv * W_NPART + nconv; }
 
 template <int NP> __host__ __device__ constexpr int xrs() { return NP * 32 + 16; }   // bytes per LDS column of one chunk
 
@@ -60,6 +67,17 @@ __device__ __forceinline__ void block_scale(float m, float& S, float& invS) {
     const bool ok = eb >= 16u && eb <= 250u;
     S = ok ? __builtin_bit_cast(float, (268u - eb) << 23) : 1.f;
     invS = ok ? __builtin_bit_cast(float, (eb - 14u) << 23) : 1.f;
+}
+
+// weight scale of a conv from its W_NPART partial maxima: S_w = 2^k with max S_w in [2^12, 2^13); 1 for an all-zero tensor
+__device__ __forceinline__ void weight_scale(const float* __restrict__ pm, float& S, float& invS) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < W_NPART; ++i) m = fmaxf(m, pm[i]);
+    const unsigned eb = (__builtin_bit_cast(unsigned, m) >> 23) & 0xFFu;
+    const bool ok = eb >= 16u && eb <= 250u;
+    S = ok ? __builtin_bit_cast(float, (266u - eb) << 23) : 1.f;
+    invS = ok ? __builtin_bit_cast(float, (eb - 12u) << 23) : 1.f;
 }
 
 __device__ __forceinline__ float wave_max(float v) {

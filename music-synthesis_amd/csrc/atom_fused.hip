@@ -25,7 +25,7 @@
 //           THREE products on v_mfma_f32_32x32x16_f16 instead of six, 4 instead of 6 bytes per operand
 //           element in LDS and in the weight stream.  Power-of-two scalings are exact; the result differs from the fp32
 //           FMA chain by what two fp32 summation orders differ by (measured against float64: tests/test_gpu_atom.py).
-//           Weights are pre-scaled by 2^6 (|w| < 2^9 assumed: anything larger overflows fp16 loudly to inf).
+//           Weights are packed under a per-conv power-of-two scale taken from their largest magnitude (atom_common.h): any magnitude.
 //           Ceiling 2500 / 3 TFLOP/s.
 //
 // LDS: [chunk][column][NP pieces x 16 channels x 2 B | 16 pad] = 112 / 80 B per (column, chunk): an odd multiple of 16 B, so
@@ -43,13 +43,35 @@ struct AtomPackJob {
     int C;
     int first_block;     // prefix sum of blocks over the jobs
     int backward;        // 1: the images of the backward-data pass (rows = input channels, taps flipped, conv1 first)
-    int np;              // pieces per element (3: bf16 x 3, 2: fp16 x 2 of 64 w)
+    int np;              // pieces per element (3: bf16 x 3, 2: fp16 x 2 of S_w w)
 };
 constexpr int ATOM_PACK_MAX = 16;
 struct AtomPackTable {
     int count;
     AtomPackJob job[ATOM_PACK_MAX];
 };
+
+// tail of a job's NP = 2 image: partial maxima and 1 / S_w of its two convs (the allocation is sized for three pieces)
+__device__ __forceinline__ float* atom_image_tail(const AtomPackJob& jb) {
+    return reinterpret_cast<float*>(jb.image + 2 * atom_conv_image_u4(jb.C, 2));
+}
+
+// partial maxima of |w|: workgroup = (job, image conv slot, part)
+__global__ __launch_bounds__(256) void k_atom_wmax(AtomPackTable t) {
+    __shared__ float red[4];
+    const int j = blockIdx.x / (2 * W_NPART), r = blockIdx.x - j * 2 * W_NPART;
+    const int conv = r / W_NPART, part = r - conv * W_NPART;
+    const AtomPackJob jb = t.job[j];
+    const float* w = (conv != jb.backward) ? jb.w1 : jb.w0;          // (the tensor image slot `conv` is packed from: k_atom_pack)
+    const int n = jb.C * jb.C * 3, per = (n + W_NPART - 1) / W_NPART;
+    const int lo = part * per, hi = lo + per < n ? lo + per : n;
+    float m = 0.f;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) m = fmaxf(m, fabsf(w[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atom_image_tail(jb)[conv * W_NPART + part] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
 
 // one thread = one lane's 16-byte fragment of all pieces of one (conv, ms, chunk, tap)
 __global__ __launch_bounds__(256) void k_atom_pack(AtomPackTable t) {
@@ -72,6 +94,12 @@ __global__ __launch_bounds__(256) void k_atom_pack(AtomPackTable t) {
     // backward data: GEMM 0 = conv1 transposed, GEMM 1 = the dilated conv transposed: A[row = ci][k = co][tap] = W[co][ci][2 - tap]
     const float* w = (conv != jb.backward) ? jb.w1 : jb.w0;
     const int row = ms * 32 + (lane & 31), k0 = chunk * 16 + 8 * (lane >> 5);
+    float WS = 1.f, iWS = 1.f;
+    if (jb.np == 2) {
+        float* tail = atom_image_tail(jb);
+        weight_scale(tail + conv * W_NPART, WS, iWS);
+        if (ms == 0 && chunk == 0 && tap == 0 && lane == 0) tail[2 * W_NPART + conv] = iWS;
+    }
     unsigned pc[3][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -89,7 +117,7 @@ __global__ __launch_bounds__(256) void k_atom_pack(AtomPackTable t) {
             pc[0][q] = o[0]; pc[1][q] = o[1]; pc[2][q] = o[2];
         } else {
             unsigned o[2];
-            split_pair<2>(a * WSCALE, b * WSCALE, o);
+            split_pair<2>(a * WS, b * WS, o);
             pc[0][q] = o[0]; pc[1][q] = o[1]; pc[2][q] = 0u;
         }
     }
@@ -309,6 +337,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
     //  per-fragment pointers would be hoisted out of the tile loop and eat ~100 registers)
     u32x4 fa[2][TM][3][NP];
     const auto rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(IMG), 0, 0x80000000u, 0x00020000);
+    // NP = 2: 1 / S_w of the two GEMMs' weight images (the pack left them in the image's tail)
+    float winv0 = 1.f, winv1 = 1.f;
+    if (SC) {
+        const float* tail = reinterpret_cast<const float*>(IMG + 2 * atom_conv_image_u4(C, 2)) + 2 * W_NPART;
+        winv0 = tail[0]; winv1 = tail[1];
+    }
     const int a_voff = lane * 16 + wm * TM * NC * 3 * NP * 1024;
     // q: chunk counter inside a tile, 0 .. 2 NC - 1 (GEMM 0's chunks, then GEMM 1's); buffer q & 1
     auto load_a = [&](int q) {
@@ -469,7 +503,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- t epilogue, first half: accumulators -> the second GEMM's operand values, in place (fp32); stores of t
-        const float k1 = SC ? iS1 * (1.f / WSCALE) : 1.f;           // undoes the window's and the weights' scales
+        const float k1 = SC ? iS1 * winv0 : 1.f;                    // undoes the window's and the weights' scales
         float tmax = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -594,7 +628,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_atom_fwd(AtomP p, const float* _
         __syncthreads();                                             // t tile complete
         gemm(I1{}, h2, nxt < ntiles);                                // output column n reads t tile columns n, n + h2, n + 2 h2
 
-        const float k2 = SC ? iS2 * (1.f / WSCALE) : 1.f;
+        const float k2 = SC ? iS2 * winv1 : 1.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -774,6 +808,10 @@ int ms_residual_atom_pack_multi(const ms_atom_pack_desc* d, ms_stream_t stream) 
         t.job[i].np = atom_np();
         const int total = 2 * (C / 32) * (C / 16) * 3 * 64;
         blocks += (total + 255) / 256;
+    }
+    if (atom_np() == 2) {
+        hipLaunchKernelGGL(k_atom_wmax, dim3((unsigned)(d->count * 2 * W_NPART)), dim3(256), 0, (hipStream_t)stream, t);
+        MS_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_atom_pack, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
     MS_CHECK_LAUNCH();

@@ -44,7 +44,40 @@ constexpr int K5 = 5;
 constexpr int PX_MAX = 350;              // LDS columns per buffer (39.2 / 28 KB; two buffers)
 constexpr int R_MAX = 64;                // batch rows per tile (scale slots)
 constexpr unsigned OOB = 0xF0000000u;
-constexpr float WSCALE = 64.f;           // NP = 2: weights are packed as fp16 pieces of 64 w (|w| < 2^9)
+// NP = 2: weights are packed as the fp16 pieces of S_w w, S_w a power of two taken from the tensor's largest magnitude (it goes
+// to [2^12, 2^13): weights of any magnitude; r04 packed 64 w and overflowed to inf from |w| >= 2^9).  A pack is two launches:
+// W_NPART partial maxima into the image's tail (the allocation is sized for three pieces), then the pack proper, whose
+// threads reduce the partials and whose first thread leaves 1 / S_w in the tail for the consuming kernels.
+constexpr int W_NPART = 256;          // partial maxima of a weight tensor (one workgroup each)
+// (called by ALL 256 threads of a pack workgroup, before any of them returns: the first wave reduces the partials, LDS broadcasts)
+__device__ __forceinline__ void weight_scale(const float* __restrict__ pm, float& S, float& invS) {
+    __shared__ float wmax_s;
+    if (threadIdx.x < 64) {
+        float m = fmaxf(fmaxf(pm[threadIdx.x], pm[threadIdx.x + 64]), fmaxf(pm[threadIdx.x + 128], pm[threadIdx.x + 192]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (threadIdx.x == 0) wmax_s = m;
+    }
+    __syncthreads();
+    const float m = wmax_s;
+    const unsigned eb = (__builtin_bit_cast(unsigned, m) >> 23) & 0xFFu;
+    const bool ok = eb >= 16u && eb <= 250u;
+    S = ok ? __builtin_bit_cast(float, (266u - eb) << 23) : 1.f;
+    invS = ok ? __builtin_bit_cast(float, (eb - 12u) << 23) : 1.f;
+}
+__host__ __device__ inline size_t c5_tail_u4(int M, int CK) { return (size_t)(M / 32) * (CK / 16) * 5 * 2 * 64; }   // end of the NP = 2 data
+
+__global__ __launch_bounds__(256) void k_conv5_wmax(const float* __restrict__ W, size_t n, float* __restrict__ pm) {
+    __shared__ float red[4];
+    const size_t per = (n + W_NPART - 1) / W_NPART, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    float m = 0.f;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) m = fmaxf(m, fabsf(W[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) pm[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
 
 // (a, b) -> NP packed 16-bit pairs: NP = 3 exact bf16 pieces; NP = 2 fp16 pieces a = o[0] + o[1] (22 bits; the caller has
 // scaled a so that its block's largest magnitude sits in [2^8, 2^15): atom_fused.hip)
@@ -94,6 +127,12 @@ __global__ __launch_bounds__(256) void k_conv5_pack(const float* __restrict__ W,
     const int NC = CK / 16;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over ms x chunk x tap x lane
     const size_t total = (size_t)(M / 32) * NC * K5 * 64;
+    float WS = 1.f, iWS = 1.f;
+    if (np == 2) {
+        float* tail = reinterpret_cast<float*>(img + c5_tail_u4(M, CK));
+        weight_scale(tail, WS, iWS);
+        if (idx == 0) tail[W_NPART] = iWS;
+    }
     if (idx >= total) return;
     const int lane = (int)(idx & 63);
     size_t r = idx >> 6;
@@ -118,7 +157,7 @@ __global__ __launch_bounds__(256) void k_conv5_pack(const float* __restrict__ W,
             pc[0][q] = o[0]; pc[1][q] = o[1]; pc[2][q] = o[2];
         } else {
             unsigned o[2];
-            split_pair<2>(a * WSCALE, b * WSCALE, o);
+            split_pair<2>(a * WS, b * WS, o);
             pc[0][q] = o[0]; pc[1][q] = o[1]; pc[2][q] = 0u;
         }
     }
@@ -318,7 +357,7 @@ __device__ __forceinline__ void conv5_body(const C5P& p, const float* __restrict
     load_x(cbeg + 16, nchunks > 1);
     __syncthreads();
 
-    f32x16 acc[2];                                   // the running sums (NP = 2: fp32, unscaled except for WSCALE)
+    f32x16 acc[2];                                   // the running sums (NP = 2: fp32, unscaled except for the weight scale S_w)
     f32x16 cm[SC ? 2 : 1];                           // NP = 2: partial sums under the rows' current scales
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -402,6 +441,7 @@ __device__ __forceinline__ void conv5_body(const C5P& p, const float* __restrict
     if (SC) fold();
 
     // ---- epilogue: dword stores straight from the accumulators (32 lanes = 32 consecutive samples of one or two rows)
+    const float winv = SC ? reinterpret_cast<const float*>(IMG + c5_tail_u4(p.M, p.CK))[W_NPART] : 1.f;     // 1 / S_w (k_conv5_pack)
     int L4;
     asm volatile("s_mov_b32 %0, %1" : "=s"(L4) : "s"(4 * L));
     const bool fused = p.nsplit == 1;
@@ -419,7 +459,7 @@ __device__ __forceinline__ void conv5_body(const C5P& p, const float* __restrict
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v = acc[j][4 * g + q];
-                if (SC) v *= 1.f / WSCALE;
+                if (SC) v *= winv;
                 if (fused) {
                     if (MODE == 0) {
                         v += bv[q];
@@ -833,6 +873,11 @@ int ms_conv1d_img_pack(const ms_conv1d_desc* d, const float* w, int backward, vo
     if (!to_convp(d, &c) || !w || !image || (((uintptr_t)image) & 15)) return MS_ERR_INVALID_ARG;
     if (!c5_geometry(c, backward != 0, &p)) return MS_ERR_UNSUPPORTED;
     const size_t total = (size_t)(p.M / 32) * (p.CK / 16) * K5 * 64;
+    if (c5_np() == 2) {
+        hipLaunchKernelGGL(k_conv5_wmax, dim3(W_NPART), dim3(256), 0, (hipStream_t)stream, w, (size_t)p.M * p.CK * K5,
+                           reinterpret_cast<float*>((u32x4*)image + c5_tail_u4(p.M, p.CK)));
+        MS_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(k_conv5_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (u32x4*)image, p.M,
                        p.CK, backward ? 1 : 0, c5_np());
     MS_CHECK_LAUNCH();

@@ -14,7 +14,7 @@
 // Arithmetic (r04): block-scaled two-piece fp16 operands, three products per multiply into one fp32 accumulator
 // (atom_fused.hip): the tile's input window is scaled by the power of two that puts its largest magnitude at 2^14 (the
 // maximum of the NEXT window is published under the current tile, as in the atom kernel), the weights are packed as
-// pieces of 64 w.  The short-row K-loop kernel (convt_fwd_short.hip) shares the pack kernel and keeps the exact
+// pieces of S_w w (S_w: a power of two from the largest weight).  The short-row K-loop kernel (convt_fwd_short.hip) shares the pack kernel and keeps the exact
 // three-piece bf16 split (np = 3 images): agreement between the schemes ~3e-7.
 #include "ms_common.h"
 #include <stdlib.h>
@@ -33,7 +33,40 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int XRS = 80;                  // bytes per LDS column of a 16-channel chunk: 2 fp16 pieces x 32 + 16
 constexpr unsigned OOB = 0xF0000000u;
-constexpr float WSCALE = 64.f;           // fp16 pieces of the weights are taken from 64 w
+// NP = 2: the weights are packed as the fp16 pieces of S_w w, S_w a power of two from the tensor's largest magnitude (it goes to
+// [2^12, 2^13): weights of any magnitude; see conv5_img.hip): partial maxima -> image tail -> the pack reduces them and leaves
+// 1 / S_w there for the kernel.
+constexpr int W_NPART = 256;          // partial maxima of a weight tensor (one workgroup each)
+// (called by ALL 256 threads of a pack workgroup, before any of them returns: the first wave reduces the partials, LDS broadcasts)
+__device__ __forceinline__ void weight_scale(const float* __restrict__ pm, float& S, float& invS) {
+    __shared__ float wmax_s;
+    if (threadIdx.x < 64) {
+        float m = fmaxf(fmaxf(pm[threadIdx.x], pm[threadIdx.x + 64]), fmaxf(pm[threadIdx.x + 128], pm[threadIdx.x + 192]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (threadIdx.x == 0) wmax_s = m;
+    }
+    __syncthreads();
+    const float m = wmax_s;
+    const unsigned eb = (__builtin_bit_cast(unsigned, m) >> 23) & 0xFFu;
+    const bool ok = eb >= 16u && eb <= 250u;
+    S = ok ? __builtin_bit_cast(float, (266u - eb) << 23) : 1.f;
+    invS = ok ? __builtin_bit_cast(float, (eb - 12u) << 23) : 1.f;
+}
+// end of the NP = 2 data of an image (the allocation is sized for three pieces), in 16-byte units
+__host__ __device__ inline size_t ct_tail_u4(int Cin, int Cout, int S) { return (size_t)(Cout * S / 32) * (Cin / 16) * 2 * 2 * 64; }
+
+__global__ __launch_bounds__(256) void k_convt_wmax(const float* __restrict__ W, size_t n, float* __restrict__ pm) {
+    __shared__ float red[4];
+    const size_t per = (n + W_NPART - 1) / W_NPART, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    float m = 0.f;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) m = fmaxf(m, fabsf(W[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) pm[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
 
 // (a, b), scaled into fp16's range by the caller -> a = h.lo + l.lo to 22 significand bits (atom_fused.hip)
 __device__ __forceinline__ void split_pair2(float a, float b, unsigned& h, unsigned& l) {
@@ -81,6 +114,12 @@ __global__ __launch_bounds__(256) void k_convt_pack(const float* __restrict__ W,
     const int NC = Cin / 16, NCG = Cout * S / 64;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over cg x half x chunk x jj x lane
     const size_t total = (size_t)NCG * 2 * NC * 2 * 64;
+    float WS = 1.f, iWS = 1.f;
+    if (np == 2) {
+        float* tail = reinterpret_cast<float*>(img + ct_tail_u4(Cin, Cout, S));
+        weight_scale(tail, WS, iWS);
+        if (idx == 0) tail[W_NPART] = iWS;
+    }
     if (idx >= total) return;
     const int lane = (int)(idx & 63);
     size_t r = idx >> 6;
@@ -100,7 +139,7 @@ __global__ __launch_bounds__(256) void k_convt_pack(const float* __restrict__ W,
         const float a = W[((size_t)(ci0 + 2 * q) * Cout + co) * K + k];
         const float b = W[((size_t)(ci0 + 2 * q + 1) * Cout + co) * K + k];
         if (np == 3) split_pair(a, b, pc[0][q], pc[1][q], pc[2][q]);
-        else { split_pair2(a * WSCALE, b * WSCALE, pc[0][q], pc[1][q]); pc[2][q] = 0u; }
+        else { split_pair2(a * WS, b * WS, pc[0][q], pc[1][q]); pc[2][q] = 0u; }
     }
     u32x4* dst = img + ((size_t)((((cg * 2 + half) * NC + chunk) * 2 + jj) * np)) * 64 + lane;
     for (int pp = 0; pp < np; ++pp) dst[pp * 64] = u32x4{pc[pp][0], pc[pp][1], pc[pp][2], pc[pp][3]};
@@ -133,6 +172,7 @@ __global__ __launch_bounds__(256, 1) void k_convt_img(CtP p, const float* __rest
     const int ntiles = p.B * p.tiles_per_row * p.mtiles;
     const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, 0x80000000u, 0x00020000);
     const auto rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(IMG), 0, 0x80000000u, 0x00020000);
+    const float winv = reinterpret_cast<const float*>(IMG + ct_tail_u4(p.Cin, p.Cout, S))[W_NPART];      // 1 / S_w (k_convt_pack)
     const auto rsY = __builtin_amdgcn_make_buffer_rsrc(Y, 0, 0x80000000u, 0x00020000);
 
     // ---- staging units (tile-invariant): 4 channels x one aligned 4-sample vector; window column c <-> position q0 - 1 + c,
@@ -271,7 +311,7 @@ __global__ __launch_bounds__(256, 1) void k_convt_img(CtP p, const float* __rest
         int LS4;                                       // 4 * L * S (bytes per output channel row), opaque: see atom_fused.hip
         asm volatile("s_mov_b32 %0, %1" : "=s"(LS4) : "s"(4 * L * S));
         const int obase = b * p.Cout * LS4;
-        const float kscale = iS * (1.f / WSCALE);     // undoes the window's and the weights' scales
+        const float kscale = iS * winv;               // undoes the window's and the weights' scales
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = (wn * TN + j) * 32 + l31, q = q0 + n;
@@ -387,7 +427,12 @@ int ms_convt1d_img_pack(const ms_convt1d_desc* d, const float* w, void* image, m
     if (!d || !w || !image || (((uintptr_t)image) & 15)) return MS_ERR_INVALID_ARG;
     if (!ct_ok(d) && !msct_short_ok(d)) return MS_ERR_UNSUPPORTED;
     const size_t total = (size_t)(d->Cout * d->stride / 64) * 2 * (d->Cin / 16) * 2 * 64;
-    // the short-row K-loop kernel reads three bf16 pieces, the LDS-resident-window kernel two fp16 pieces of 64 w
+    // the short-row K-loop kernel reads three bf16 pieces, the LDS-resident-window kernel two fp16 pieces of S_w w
+    if (!msct_short_ok(d)) {
+        hipLaunchKernelGGL(k_convt_wmax, dim3(W_NPART), dim3(256), 0, (hipStream_t)stream, w, (size_t)d->Cin * d->Cout * d->K,
+                           reinterpret_cast<float*>((u32x4*)image + ct_tail_u4(d->Cin, d->Cout, d->stride)));
+        MS_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(k_convt_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (u32x4*)image,
                        d->Cin, d->Cout, d->stride, msct_short_ok(d) ? 3 : 2);
     MS_CHECK_LAUNCH();

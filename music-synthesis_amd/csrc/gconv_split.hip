@@ -36,7 +36,8 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int GK = 41, GS = 4, GCG = 4;
-constexpr float WSCALE = 64.f;            // fp16 pieces of the weights are taken from 64 w (|w| < 2^9)
+// The weights of a wave's group are split in registers under the wave's own power-of-two scale S_w (their largest magnitude goes to
+// [2^12, 2^13): weights of any magnitude; r04 took the pieces of 64 w and overflowed to inf from |w| >= 2^9).
 
 // Block-scaled two-piece fp16 split (r04, atom_fused.hip): (a, b) scaled into fp16's range by the caller ->
 // a = h.lo + l.lo to 22 significand bits (block maximum in [2^8, 2^15)); products h h' + h l' + l h' into one fp32
@@ -69,6 +70,14 @@ __device__ __forceinline__ float wave_max_dpp(float m) {
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 constexpr int NG = 6;                         // tap groups of 8
+
+// S = 2^k with m S in [2^12, 2^13), and 1 / S; 1 for a zero / denormal-range / non-finite maximum
+__device__ __forceinline__ void weight_scale(float m, float& S, float& invS) {
+    const unsigned eb = (__builtin_bit_cast(unsigned, m) >> 23) & 0xFFu;
+    const bool ok = eb >= 16u && eb <= 250u;
+    S = ok ? __builtin_bit_cast(float, (266u - eb) << 23) : 1.f;
+    invS = ok ? __builtin_bit_cast(float, (eb - 12u) << 23) : 1.f;
+}
 
 // (a, b) -> three packed bf16 pairs with a = h.lo + m.lo + l.lo exactly (same for b in the high halves)
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
@@ -214,21 +223,29 @@ __device__ __forceinline__ void gconv_fwd_body(const ConvP& p, int spr, int nseg
     f32x4 xp[C::NIT];
     gload(xp, ld); advance(ld);
 
-    // ---- weight fragments: lane (co = n, ci = kg) holds 64 w[g*Og + co][ci][8G .. 8G+7] in two fp16 pieces
+    // ---- weight fragments: lane (co = n, ci = kg) holds S_w w[g*Og + co][ci][8G .. 8G+7] in two fp16 pieces
     f16x8 A[NG][2];
+    float WS = 1.f, iWS = 1.f;
     {
         const bool ok = n < p.Og;
         const float* wr = w + ((size_t)(g * p.Og + (ok ? n : 0)) * GCG + kg) * GK;
         float wv[NG * 8];
+        float wm = 0.f;
 #pragma unroll
-        for (int j = 0; j < NG * 8; ++j) wv[j] = j < GK ? wr[j] : 0.f;
+        for (int j = 0; j < NG * 8; ++j) {
+            wv[j] = (j < GK && ok) ? wr[j] : 0.f;
+            wm = fmaxf(wm, fabsf(wv[j]));
+        }
+        weight_scale(wave_max_dpp(wm), WS, iWS);
+#pragma unroll
+        for (int j = 0; j < NG * 8; ++j) wv[j] *= WS;
 #pragma unroll
         for (int G = 0; G < NG; ++G) {
             u32x4 h, l;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 unsigned hh, ll;
-                split_pair2(ok ? wv[8 * G + 2 * q] * WSCALE : 0.f, ok ? wv[8 * G + 2 * q + 1] * WSCALE : 0.f, hh, ll);
+                split_pair2(wv[8 * G + 2 * q], wv[8 * G + 2 * q + 1], hh, ll);
                 h[q] = hh; l[q] = ll;
             }
             A[G][0] = __builtin_bit_cast(f16x8, h);
@@ -352,7 +369,7 @@ __device__ __forceinline__ void gconv_fwd_body(const ConvP& p, int spr, int nseg
         __builtin_amdgcn_wave_barrier();
         if (unit + wstride < nunits) gload(xp, ld);     // next unit's inputs: in flight across the MFMA loop
         advance(ld);
-        unit_mfma_store(invS * (1.f / WSCALE));
+        unit_mfma_store(invS * iWS);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -827,26 +844,34 @@ __device__ __forceinline__ void gconv_bwd_data_body(const ConvP& p, int tiles, i
     int b = unit / tiles, ti = unit - b * tiles;
     if (unit < nunits) gload(b, ti);
 
-    // ---- weight fragments: lane (m = (ci, r), kg = (octet, tap parity)) holds 64 w[g*16 + 8 oct + e][ci][r + 4 (2J + tp)]
+    // ---- weight fragments: lane (m = (ci, r), kg = (octet, tap parity)) holds S_w w[g*16 + 8 oct + e][ci][r + 4 (2J + tp)]
     // in two fp16 pieces
     f16x8 A[BJ][2];
+    float iWS = 1.f;
     {
         const int ci = n >> 2, r = n & 3;
+        float wall[BJ][8];
+        float wm = 0.f;
 #pragma unroll
         for (int J = 0; J < BJ; ++J) {
             const int tap = r + 4 * (2 * J + tp);
             const bool ok = tap < GK;
-            float wv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float v = w[((size_t)(g * 16 + 8 * oct + e) * GCG + ci) * GK + (ok ? tap : 0)];
-                wv[e] = ok ? v * WSCALE : 0.f;
+                wall[J][e] = ok ? v : 0.f;
+                wm = fmaxf(wm, fabsf(wall[J][e]));
             }
+        }
+        float WS;
+        weight_scale(wave_max_dpp(wm), WS, iWS);              // the group's weights under the wave's own scale
+#pragma unroll
+        for (int J = 0; J < BJ; ++J) {
             u32x4 h, l;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 unsigned hh, ll;
-                split_pair2(wv[2 * q], wv[2 * q + 1], hh, ll);
+                split_pair2(wall[J][2 * q] * WS, wall[J][2 * q + 1] * WS, hh, ll);
                 h[q] = hh; l[q] = ll;
             }
             A[J][0] = __builtin_bit_cast(f16x8, h);
@@ -927,7 +952,7 @@ __device__ __forceinline__ void gconv_bwd_data_body(const ConvP& p, int tiles, i
 #undef MS_B3_MMA
 #undef MS_B3_WAIT
 #undef MS_B3_READ
-        const float kscale = invS * (1.f / WSCALE);
+        const float kscale = invS * iWS;
 #pragma unroll
         for (int tq = 0; tq < 3; ++tq)
 #pragma unroll

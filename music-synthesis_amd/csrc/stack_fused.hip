@@ -237,12 +237,16 @@ __global__ __launch_bounds__(64 * NW, C >= 128 ? 1 : 2) void k_stack_fwd(StackP 
             const bool last = st + 1 == p.nst;
             const auto rs_cur = image_of(st), rs_next = image_of(last ? 0 : st + 1);
             const float* bias = sbias + st * 2 * C;
+            // 1 / S_w of the stage's two weight images (atom_common.h: the pack leaves them in the image's tail)
+            const float* wtail = reinterpret_cast<const float*>((st == 0 ? p.img[0] : (st == 1 ? p.img[1] : p.img[2])) +
+                                                                2 * atom_conv_image_u4(C, 2)) + 2 * W_NPART;
+            const float winv0 = wtail[0], winv1 = wtail[1];
             gemm(I0{}, d, true, rs_cur, rs_cur);
             if (last && nxt < ntiles) load_x(nxt);                   // travels under the t epilogue and the last GEMM
             __builtin_amdgcn_sched_barrier(0);
 
             // ---- t epilogue: accumulators -> lrelu(conv_d + b0), zero outside the row, in place; block maximum
-            const float k1 = iS1 * (1.f / WSCALE);
+            const float k1 = iS1 * winv0;
             float tmax = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(64 * NW, C >= 128 ? 1 : 2) void k_stack_fwd(StackP 
             gemm(I1{}, 1, !last || nxt < ntiles, rs_cur, rs_next);
 
             // ---- y = residual + lrelu(conv1 + b1)
-            const float k2 = iS2 * (1.f / WSCALE);
+            const float k2 = iS2 * winv1;
             float ymax = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i)

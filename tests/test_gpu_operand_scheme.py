@@ -122,7 +122,7 @@ def test_convt8_in_tile_dynamic_range(p2):
     from featuresynth._ops import lib as L
     from featuresynth._ops import prims as P
     rng = np.random.default_rng(200 + p2)
-    B, Cin, Cout, Lin = 2, 256, 128, 256
+    B, Cin, Cout, Lin = 8, 256, 128, 256            # (B * Lin >= 1024: the geometry the image kernel takes)
     x = rng.standard_normal((B, Cin, Lin)).astype(np.float32)
     x[0, 7, 100] = 2.0 ** p2
     w = (rng.standard_normal((Cin, Cout, 16)) / np.sqrt(2 * Cin)).astype(np.float32)
@@ -136,3 +136,88 @@ def test_convt8_in_tile_dynamic_range(p2):
                                          stride=8, padding=4), 0.2)
     wsum = float(np.abs(w).sum(axis=(0, 2)).max())
     _check(y, yr, 2.0 ** p2, wsum, "convT8 fwd", (slice(1, None),), K=2 * Cin)
+
+
+@pytest.mark.parametrize("wexp", [-18, 12])
+def test_weights_of_any_magnitude(wexp):
+    """The weight images carry their own power-of-two scale (taken from the tensor's largest magnitude by the pack launches; per
+    wave group in the grouped kernels): weights 2^12 times larger than the usual O(0.05) -- r04's fixed 64 w overflowed fp16 to
+    inf from |w| >= 2^9 -- and 2^18 times smaller keep the fp32-level accuracy.  Inputs are scaled the other way so that the
+    outputs stay O(1).  Families: fused atom (forward, backward data), k5 layer (parts launch), grouped conv (forward, backward
+    data), stride-8 transposed conv."""
+    import torch.nn.functional as F
+    from featuresynth._ops import graph as G
+    from featuresynth._ops import lib as L
+    from featuresynth._ops import prims as P
+    ws = 2.0 ** wexp
+    rng = np.random.default_rng(100 + wexp)
+
+    def rel(a, b):
+        a, b = a.double().cpu().flatten(), b.double().flatten()
+        return float((a - b).norm() / b.norm())
+
+    # ---- atom
+    C, Lg = 64, 512
+    x = (rng.standard_normal((2, C, Lg)) / ws).astype(np.float32)
+    w0 = (rng.standard_normal((C, C, 3)) / np.sqrt(3 * C) * ws).astype(np.float32)
+    # the second conv scaled the OTHER way: y - x = u and gx - g stay comparable to x and g (no cancellation in the test itself)
+    w1 = (rng.standard_normal((C, C, 3)) / np.sqrt(3 * C) / ws).astype(np.float32)
+    b0 = (rng.standard_normal(C) * 0.1).astype(np.float32)
+    b1 = (rng.standard_normal(C) * 0.1 / ws).astype(np.float32)
+    xt, w0t, w1t, b0t, b1t = (dev(a) for a in (x, w0, w1, b0, b1))
+    img, imgb = P.atom_image(C, xt.device), P.atom_image(C, xt.device)
+    P.atom_pack([(w0t, w1t, img)]); P.atom_pack([(w0t, w1t, imgb)], backward=True)
+    y, rec = G.atom_forward(xt, w0t, b0t, w1t, b1t, 3, True, image=img)
+    xd = torch.from_numpy(x).double()
+    t = F.leaky_relu(F.conv1d(xd, torch.from_numpy(w0).double(), torch.from_numpy(b0).double(), padding=3, dilation=3), 0.2)
+    u = F.leaky_relu(F.conv1d(t, torch.from_numpy(w1).double(), torch.from_numpy(b1).double(), padding=1), 0.2)
+    assert torch.isfinite(y).all()
+    assert rel(rec[3], t) < 2e-6 and rel(y - xt, u) < 4e-6, (rel(rec[3], t), rel(y - xt, u))
+    g = dev(rng.standard_normal((2, C, Lg)).astype(np.float32))
+    gt, gx, _ = P.atom_bwd_data(g, rec[4], rec[3], imgb, 3)
+    gd = g.double().cpu() * torch.where(rec[4].cpu() > 0, 1.0, 0.2).double()
+    gt_r = F.conv_transpose1d(gd, torch.from_numpy(w1).double(), padding=1)
+    gx_r = F.conv_transpose1d(gt_r * torch.where(rec[3].cpu() > 0, 1.0, 0.2).double(), torch.from_numpy(w0).double(), padding=3, dilation=3)
+    assert rel(gt, gt_r) < 2e-6 and rel(gx - g, gx_r) < 4e-6, (rel(gt, gt_r), rel(gx - g, gx_r))
+
+    # ---- k5 layer over the three scales
+    Ck, B = 1024, 32
+    xs = [(rng.standard_normal((B, Ck, l)) / ws).astype(np.float32) for l in (32, 17, 9)]
+    w = (rng.standard_normal((Ck, Ck, 5)) / np.sqrt(5 * Ck) * ws).astype(np.float32)
+    b = (rng.standard_normal(Ck) * 0.1).astype(np.float32)
+    xst, wt, bt = [dev(a) for a in xs], dev(w), dev(b)
+    d, _ = P.conv_desc(xst[0].shape, wt.shape, pad=2, act=L.ACT_LRELU)
+    ys = P.conv1d_parts_fwd(xst, wt, bt, d, image=P.conv_img_pack(d, wt))
+    for a, yk in zip(xs, ys):
+        yr = F.leaky_relu(F.conv1d(torch.from_numpy(a).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=2), 0.2)
+        assert torch.isfinite(yk).all() and rel(yk, yr) < 2e-6, rel(yk, yr)
+
+    # ---- grouped conv, forward and backward data
+    Bg, Cin, Cout, groups, Lin = 2, 64, 256, 16, 2048
+    xg = (rng.standard_normal((Bg, Cin, Lin)) / ws).astype(np.float32)
+    wg = (rng.standard_normal((Cout, Cin // groups, 41)) / np.sqrt(164) * ws).astype(np.float32)
+    bg = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
+    xgt, wgt, bgt = dev(xg), dev(wg), dev(bg)
+    dg, lo = P.conv_desc(xgt.shape, wgt.shape, stride=4, pad=20, groups=groups, act=L.ACT_LRELU)
+    yg, _ = P.conv1d_fwd(xgt, wgt, bgt, dg, lo)
+    pre = F.conv1d(torch.from_numpy(xg).double(), torch.from_numpy(wg).double(), torch.from_numpy(bg).double(), stride=4, padding=20,
+                   groups=groups)
+    assert torch.isfinite(yg).all() and rel(yg, F.leaky_relu(pre, 0.2)) < 2e-6
+    gy = dev((rng.standard_normal(tuple(yg.shape)) / ws).astype(np.float32))
+    gxg = P.conv1d_bwd_data(gy, yg, wgt, dg)
+    pg = gy.double().cpu() * torch.where(yg.cpu() > 0, 1.0, 0.2).double()
+    gxr = F.conv_transpose1d(pg, torch.from_numpy(wg).double(), stride=4, padding=20, groups=groups, output_padding=Lin - ((lo - 1) * 4 - 40 + 41))
+    assert torch.isfinite(gxg).all() and rel(gxg, gxr) < 2e-6, rel(gxg, gxr)
+
+    # ---- stride-8 transposed conv on its weight image
+    Bt, Ci, Co, Li = 16, 256, 128, 256
+    xc = (rng.standard_normal((Bt, Ci, Li)) / ws).astype(np.float32)
+    wc = (rng.standard_normal((Ci, Co, 16)) / np.sqrt(2 * Ci) * ws).astype(np.float32)
+    bc = (rng.standard_normal(Co) * 0.1).astype(np.float32)
+    xct, wct, bct = dev(xc), dev(wc), dev(bc)
+    dc, loc = P.convt_desc(xct.shape, wct.shape, 8, 4, act=L.ACT_LRELU)
+    assert P.convt_img_bytes(dc) > 0
+    yc = P.convt1d_fwd(xct, wct, bct, dc, loc)
+    ycr = F.leaky_relu(F.conv_transpose1d(torch.from_numpy(xc).double(), torch.from_numpy(wc).double(), torch.from_numpy(bc).double(),
+                                          stride=8, padding=4), 0.2)
+    assert torch.isfinite(yc).all() and rel(yc, ycr) < 2e-6, rel(yc, ycr)
