@@ -218,6 +218,14 @@ int ms_conv1d_out_len(const ms_conv1d_desc* d) {
     return make_conv(d, &p) ? p.Lout : MS_ERR_INVALID_ARG;
 }
 
+// a single tensor as a table of one part (the 4 x 4 group kernels of gconv4.hip take 1 .. 3 parts)
+static ms_conv1d_parts one_part(const ConvP& p) {
+    ms_conv1d_parts q{};
+    q.count = 1;
+    q.B[0] = p.B; q.Lin[0] = p.Lin;
+    return q;
+}
+
 int ms_conv1d_fwd(const ms_conv1d_desc* d, const float* x, const float* w, const float* bias,
                   const float* residual, float* y, float* y_act, void* workspace,
                   size_t workspace_bytes, ms_stream_t stream) {
@@ -245,6 +253,11 @@ int ms_conv1d_fwd(const ms_conv1d_desc* d, const float* x, const float* w, const
     }
     if (msm_fwd_applicable(p))
         return msm_conv1d_fwd(p, x, xa, xk, w, bias, residual, y, y_act, workspace, workspace_bytes, s);
+    if (!residual && !y_act && !p.in_act) {
+        ms_conv1d_parts q = one_part(p);
+        q.x[0] = x; q.y[0] = y;
+        if (msg4_parts_applicable(p, &q)) return msg4_parts_fwd(p, &q, w, bias, s);
+    }
     if (msg3_fwd_applicable(p) && !residual && !y_act && !p.in_act) return msg3_conv1d_fwd(p, x, w, bias, y, s);
     if (msg_fwd_applicable(p) && !residual && !y_act && !p.in_act) return msg_conv1d_fwd(p, x, w, bias, y, s);
     if (mst_fwd_applicable(p) && !y_act) return mst_conv1d_fwd(p, x, w, bias, residual, y, s);
@@ -285,7 +298,10 @@ int ms_conv1d_bwd_data(const ms_conv1d_desc* d, const float* gy, const float* y_
     if (padded) {
     } else if (msm_bwd_data_applicable(p))
         rc = msm_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, workspace, workspace_bytes, s);
-    else if (msg3_bwd_data_applicable(p))
+    else if (ms_conv1d_parts q4 = one_part(p); msg4_parts_applicable(p, &q4)) {
+        q4.gy[0] = gy; q4.y_act[0] = y_act; q4.gx_add[0] = gx_add; q4.gx[0] = gx;
+        rc = msg4_parts_bwd_data(p, &q4, w, s);
+    } else if (msg3_bwd_data_applicable(p))
         rc = msg3_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, s);
     else if (msg_bwd_data_applicable(p))
         rc = msg_conv1d_bwd_data(p, gy, y_act, w, gx_add, gx, s);
@@ -321,6 +337,11 @@ int ms_conv1d_bwd_weight(const ms_conv1d_desc* d, const float* x, const float* g
     if (msm_bwd_weight_applicable(p))
         return msm_conv1d_bwd_weight(p, x, xa, xk, gy, y_act, p.act, gw, gb, beta, workspace,
                                      workspace_bytes, s);
+    if (!p.in_act) {
+        ms_conv1d_parts q = one_part(p);
+        q.x[0] = x; q.gy[0] = gy; q.y_act[0] = y_act;
+        if (msg4_parts_applicable(p, &q)) return msg4_parts_bwd_weight(p, &q, gw, gb, beta, s);
+    }
     if (msg3_bwd_weight_applicable(p) && !p.in_act)
         return msg3_conv1d_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
     if (msg_bwd_weight_applicable(p) && !p.in_act)
@@ -353,7 +374,7 @@ ms_conv1d_desc part_desc(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, 
 // 1: a parts kernel takes the call; 0: part by part
 int parts_kernel(const ConvP& c, const ms_conv1d_parts* parts, int which, bool with_image) {
     if (parts->count < 2 || c.in_act) return 0;
-    if (msd_parts_applicable(c, parts, which)) return 1;
+    if (msd_parts_applicable(c, parts, which) || msg4_parts_applicable(c, parts)) return 1;
     if (which == 0) return (with_image && ms5_parts_applicable(c, parts, false)) || msg3_parts_fwd_applicable(c, parts);
     if (which == 1) return (with_image && ms5_parts_applicable(c, parts, true)) || msg3_parts_bwd_data_applicable(c, parts);
     return msw5_parts_applicable(c, parts) || msg3_parts_bwd_weight_applicable(c, parts);
@@ -371,6 +392,7 @@ size_t ms_conv1d_parts_workspace_bytes(const ms_conv1d_desc* d, const ms_conv1d_
     ConvP c;
     if (!parts_ok(d, parts, &c) || which < 0 || which > 2) return 0;
     if (parts_kernel(c, parts, which, with_image != 0)) {
+        if (msg4_parts_applicable(c, parts)) return 0;
         if (which != 2) {
             if (msd_parts_applicable(c, parts, which)) return 0;
             return (with_image && ms5_parts_applicable(c, parts, which == 1)) ? ms5_parts_ws(c, parts, which == 1) : 0;
@@ -398,6 +420,7 @@ int ms_conv1d_parts_fwd(const ms_conv1d_desc* d, const ms_conv1d_parts* parts, c
             const int rc = msd_parts_fwd(c, parts, w, bias, s);
             if (rc != MS_ERR_UNSUPPORTED) return rc;
         }
+        if (w && msg4_parts_applicable(c, parts)) return msg4_parts_fwd(c, parts, w, bias, s);
         if (image && ms5_parts_applicable(c, parts, false))
             return ms5_parts_fwd(c, parts, image, bias, workspace, workspace_bytes, s);
         if (w && msg3_parts_fwd_applicable(c, parts)) return msg3_parts_fwd(c, parts, w, bias, s);
@@ -426,6 +449,7 @@ int ms_conv1d_parts_bwd_data(const ms_conv1d_desc* d, const ms_conv1d_parts* par
             const int rc = msd_parts_bwd_data(c, parts, w, s);
             if (rc != MS_ERR_UNSUPPORTED) return rc;
         }
+        if (w && msg4_parts_applicable(c, parts)) return msg4_parts_bwd_data(c, parts, w, s);
         if (image_bwd && ms5_parts_applicable(c, parts, true))
             return ms5_parts_bwd_data(c, parts, image_bwd, workspace, workspace_bytes, s);
         if (w && msg3_parts_bwd_data_applicable(c, parts)) return msg3_parts_bwd_data(c, parts, w, s);
@@ -454,6 +478,8 @@ int ms_conv1d_parts_bwd_weight(const ms_conv1d_desc* d, const ms_conv1d_parts* p
         const int rc = msd_parts_bwd_weight(c, parts, gw, gb, beta, workspace, workspace_bytes, (hipStream_t)stream);
         if (rc != MS_ERR_UNSUPPORTED) return rc;
     }
+    if (parts->count >= 2 && !c.in_act && msg4_parts_applicable(c, parts))
+        return msg4_parts_bwd_weight(c, parts, gw, gb, beta, (hipStream_t)stream);
     if (parts->count >= 2 && !c.in_act && msw5_parts_applicable(c, parts))
         return msw5_parts_bwd_weight(c, parts, gw, gb, beta, workspace, workspace_bytes, (hipStream_t)stream);
     if (parts->count >= 2 && !c.in_act && msg3_parts_bwd_weight_applicable(c, parts))
@@ -584,6 +610,10 @@ const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which) {
     // (rows padded to a multiple of 4, see pad4_applicable: the kernel of the padded problem)
     if (which == 0 && msm_fwd_applicable(p) && pad4_applicable(p)) return msm_fwd_name(pad4_conv(p));
     if (which == 1 && msm_bwd_data_applicable(p) && pad4_applicable(p)) return msm_bwd_data_name(pad4_conv(p));
+    if (!p.in_act && !msm_fwd_applicable(p)) {
+        const ms_conv1d_parts q = one_part(p);
+        if (msg4_parts_applicable(p, &q)) return which == 0 ? "k_g4_fwd" : (which == 1 ? "k_g4_bwd_data" : "k_g4_wgrad");
+    }
     if (which == 0)
         return msm_fwd_applicable(p) ? msm_fwd_name(p)
                : (msg3_fwd_applicable(p) ? msg3_fwd_name(p)

@@ -63,3 +63,8 @@ int msd_parts_fwd(const ConvP& c, const ms_conv1d_parts* parts, const float* w, 
 int msd_parts_bwd_data(const ConvP& c, const ms_conv1d_parts* parts, const float* w, hipStream_t s);
 int msd_parts_bwd_weight(const ConvP& c, const ms_conv1d_parts* parts, float* gw, float* gb, float beta, void* ws,
                          size_t ws_bytes, hipStream_t s);
+// the 256-group layer (4 x 4 channels per group) on the vector pipe, fp32 FMA (gconv4.hip); count = 1 .. 3 parts
+bool msg4_parts_applicable(const ConvP& c, const ms_conv1d_parts* parts);
+int msg4_parts_fwd(const ConvP& c, const ms_conv1d_parts* parts, const float* w, const float* bias, hipStream_t s);
+int msg4_parts_bwd_data(const ConvP& c, const ms_conv1d_parts* parts, const float* w, hipStream_t s);
+int msg4_parts_bwd_weight(const ConvP& c, const ms_conv1d_parts* parts, float* gw, float* gb, float beta, hipStream_t s);

@@ -471,10 +471,15 @@ def test_grouped_kernel_generations_agree(shape, monkeypatch):
     gb0 = dev(rng.standard_normal((Cout,)).astype(np.float32))
     lib = P.L.load()
     out = {}
-    for gen in ("0", "1"):
-        monkeypatch.setenv("MSYNTH_GCONV3", gen)
+    og4 = Cout // groups == 4          # the 4 x 4 layer has a vector-pipe fp32 generation of its own (csrc/gconv4.hip)
+    for gen in ("0", "1") + (("4",) if og4 else ()):
+        monkeypatch.setenv("MSYNTH_GCONV3", "1" if gen == "4" else gen)
+        monkeypatch.setenv("MSYNTH_G4", "1" if gen == "4" else "0")
         names = [lib.ms_conv1d_kernel_name(d, k).decode() for k in range(3)]
-        assert all(("split" in nm) == (gen == "1") or (k == 1 and Cout // groups != 16) for k, nm in enumerate(names)), names
+        if gen == "4":
+            assert names == ["k_g4_fwd", "k_g4_bwd_data", "k_g4_wgrad"], names
+        else:
+            assert all(("split" in nm) == (gen == "1") or (k == 1 and Cout // groups != 16) for k, nm in enumerate(names)), names
         y, _ = P.conv1d_fwd(x, w, b, d, lo)
         ya = y if gen == "0" else out["0"][0]                 # one activation mask for both generations
         gx = P.conv1d_bwd_data(gy, ya, w, d, gx_add=res)
@@ -482,6 +487,9 @@ def test_grouped_kernel_generations_agree(shape, monkeypatch):
         out[gen] = (y, gx, gw, gb)
     for a, c in zip(out["1"], out["0"]):
         assert rel_l2(host(a), host(c)) < 2e-6     # (r04: block-scaled fp16 x 2 / three products against fp32 MFMA: fp32 summation-order level)
+    if og4:
+        for a, c in zip(out["4"], out["0"]):
+            assert rel_l2(host(a), host(c)) < 2e-6
 
 
 @pytest.mark.parametrize("case", [

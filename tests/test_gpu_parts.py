@@ -116,6 +116,47 @@ def test_grouped_layer_over_three_scales(layer, B, L0):
     assert rel(gw2, 2 * gw) < 1e-6 and rel(gb2, 2 * gb) < 1e-6
 
 
+@pytest.mark.parametrize("lens,B", [((29, 256, 100), 5), ((128,), 70), ((33, 65), 1)], ids=["edges", "single", "pair"])
+def test_group4_layer_on_the_vector_pipe(lens, B, monkeypatch):
+    """The 256-group layer (4 x 4 channels per group) runs in fp32 FMA on the vector pipe (csrc/gconv4.hip) for rows of
+    29 .. 256 samples: shortest and longest rows, row counts that leave the last workgroup partly empty, one / two / three
+    parts; float64 torch at 1e-6 (plain fp32 accumulation of 164 terms), the recorded kernel names, and the matrix-pipe
+    kernels it replaces (MSYNTH_G4=0) at 2e-6."""
+    import torch.nn.functional as F
+    from featuresynth._ops import lib as L
+    from featuresynth._ops import prims as P
+    geo = GROUPED[3]
+    xs, w, b = _inputs(geo, B, lens, 300 + len(lens))
+    d, _ = _desc(geo, xs[0], w)
+    L.profile_begin()
+    ys = P.conv1d_parts_fwd(xs, w, b, d)
+    gys = [dev(np.random.default_rng(27 + i).standard_normal(tuple(y.shape))) for i, y in enumerate(ys)]
+    gxs = P.conv1d_parts_bwd_data(gys, ys, w, d, [x.shape for x in xs])
+    gw, gb = P.conv1d_parts_bwd_weight(xs, gys, ys, d, w.shape)
+    names = [cost.get("kernel", "") for _, cost, _ in L.profile_end()]
+    assert names == ["k_g4_fwd", "k_g4_bwd_data", "k_g4_wgrad"], names
+    Cin, Cout, K, stride, pad, groups = geo
+    wd, bd = w.double().cpu().requires_grad_(True), b.double().cpu().requires_grad_(True)
+    tot = 0
+    for i, x in enumerate(xs):
+        xd = x.double().cpu().requires_grad_(True)
+        pre = F.conv1d(xd, wd, bd, stride=stride, padding=pad, groups=groups)
+        assert rel(ys[i].cpu(), F.leaky_relu(pre, 0.2).detach()) < 1e-6, ("forward", i)
+        pre_grad = gys[i].double().cpu() * torch.where(ys[i].cpu() > 0, 1.0, 0.2).double()
+        (gxr,) = torch.autograd.grad(pre, xd, pre_grad, retain_graph=True)
+        assert rel(gxs[i].cpu(), gxr) < 1e-6, ("backward data", i, rel(gxs[i].cpu(), gxr))
+        tot = tot + (pre * pre_grad).sum()
+    gwr, gbr = torch.autograd.grad(tot, (wd, bd))
+    assert rel(gw.cpu(), gwr) < 1e-6 and rel(gb.cpu(), gbr) < 1e-6, (rel(gw.cpu(), gwr), rel(gb.cpu(), gbr))
+    monkeypatch.setenv("MSYNTH_G4", "0")
+    ys0 = P.conv1d_parts_fwd(xs, w, b, d)
+    gxs0 = P.conv1d_parts_bwd_data(gys, ys, w, d, [x.shape for x in xs])
+    gw0, gb0 = P.conv1d_parts_bwd_weight(xs, gys, ys, d, w.shape)
+    for i in range(len(xs)):
+        assert rel(ys[i], ys0[i]) < 2e-6 and rel(gxs[i], gxs0[i]) < 2e-6
+    assert rel(gw, gw0) < 2e-6 and rel(gb, gb0) < 2e-6
+
+
 @pytest.mark.parametrize("B,rows", [(64, 64), (64, 32), (6, 6)], ids=["b64", "b64_grad32", "small"])
 def test_k5_layer_over_three_scales(B, rows):
     """The 1024 -> 1024 k5 layer on its weight image over rows of 32 / 17 / 9 samples: one launch without split-K slabs at

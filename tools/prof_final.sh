@@ -8,8 +8,8 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 cd /tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/replay -- python3 $R/bench.py --prime 0 --steps 20 --warmup 6 --no-cpu-baseline --no-roofline --no-gforward > $O/replay_bench.json 2> $O/replay_bench.log; echo "replay rc=$?"
-MSYNTH_STREAMS=0 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -- python3 $R/bench.py --prime 0 --steps 20 --warmup 6 --no-cpu-baseline --no-roofline --no-gforward > $O/serial_bench.json 2> $O/serial_bench.log; echo "serial rc=$?"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/replay -- python3 $R/bench.py --prime 0 --steps 20 --warmup 6 --no-cpu-baseline --no-roofline --no-gforward --no-exact --no-dp-overhead > $O/replay_bench.json 2> $O/replay_bench.log; echo "replay rc=$?"
+MSYNTH_STREAMS=0 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -- python3 $R/bench.py --prime 0 --steps 20 --warmup 6 --no-cpu-baseline --no-roofline --no-gforward --no-exact --no-dp-overhead > $O/serial_bench.json 2> $O/serial_bench.log; echo "serial rc=$?"
 cd $R
 timeout -k 10 600 python3 bench.py --steps 20 --warmup 6 > $O/bench.json 2> $O/bench.log; echo "bench rc=$?"
 python3 - <<'PY'

@@ -32,4 +32,10 @@ for rep in range(3):
 for rep in (1, 2):
     bad = [k for k in res[0] if not np.array_equal(np.asarray(res[0][k]), np.asarray(res[rep][k]))]
     print("run %d vs run 0: %d of %d differ:" % (rep, len(bad), len(res[0])), bad[:12])
+    for k in bad[:3]:
+        a, b = np.asarray(res[0][k]), np.asarray(res[rep][k])
+        if a.ndim == 3:
+            idx = np.argwhere(a != b)
+            print("   ", k, a.shape, "differing elements", len(idx), "max |d|", float(np.abs(a - b).max()), "rel", float(np.abs(a - b).max() / np.abs(a).max()))
+            print("    co:", sorted(set(idx[:, 0].tolist()))[:24], "ci:", sorted(set(idx[:, 1].tolist())), "k:", sorted(set(idx[:, 2].tolist())))
 print("d_loss", [r["d_loss"] for r in res], "g_loss", [r["g_loss"] for r in res])
