@@ -272,56 +272,78 @@ constexpr int WBUF = XS + 4 * ITEMS + ITEMS;     // floats per buffer
 //  (taps 4i + 1, even output channels) differed from run to run whenever the kernel shared the chip with the backward-data
 //  chain on another stream; alone, or built with -fno-slp-vectorize, or with the packed FMA written without operand selection,
 //  it was bit-stable.  tests/test_gpu_dp.py caught it.)
+// PMC on the first form: 13.8 k vector instructions per wave beside 3 k MFMAs -- address arithmetic, row-end masks and
+// register shuffling of the staging pass, on one wave per SIMD.  What does not change from chunk to chunk of a part now lives
+// in a per-thread PLAN (rebuilt three times per launch); a chunk costs one add per load.
+constexpr unsigned XINV = 0x80000000u;           // "no load": beyond every tensor (< 2 GB), and + a row step it does not wrap
+
+struct G4Plan {
+    unsigned xoff[NQX];                          // byte offset of the thread's quads for a chunk that starts at row 0, or XINV
+    int keep[NQX];                               // samples of the quad inside the row (row ends of lengths not a multiple of 4)
+    int row, j;                                  // the thread's item of the part's next chunk
+    int r_lo, rem;                               // first row of that chunk, and its first item's position in it (uniform)
+    int dq, dr;                                  // ITEMS / n, ITEMS % n (uniform)
+};
+
 struct G4Stage {                                 // a chunk on its way to LDS, in registers: RAW loads -- nothing here may
     f32x4 xq[NQX];                               // depend on the loaded values before g4_stage_store, or the loads' latency
-    int keep[NQX];                               // is paid in front of the arithmetic instead of behind it
-    f32x4 gy, ya;
+    f32x4 gy, ya;                                // is paid in front of the arithmetic instead of behind it
     int woff;
 };
 
-__device__ __forceinline__ void g4_stage_load(const G4Part& p, int C, int g, int act, G4Stage& st) {
+__device__ __forceinline__ void g4_plan(const G4Part& p, int C, int g, G4Plan& pl) {
     const int tid = threadIdx.x;
-    const int n = p.n, L = p.L, total = p.B * n, e0 = p.wg * ITEMS;
-    const int WL = 4 * n + 44, QW = n + 11;
-    int r_lo, nrows;
-    item_rows(e0, total, n, r_lo, nrows);
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, 4u * (unsigned)(p.B * C * L), 0x00020000);
+    const int n = p.n, L = p.L, QW = n + 11;
+    const int rows_max = ITEMS / n + 2 < p.B ? ITEMS / n + 2 : p.B;
     const unsigned magic = ((1u << 20) + QW - 1) / QW;               // i / QW for i < 2^20 / QW
-    const int nquads = nrows * CG * QW;
 #pragma unroll
     for (int u = 0; u < NQX; ++u) {
         const int i = tid + 256 * u;
         const int line = (int)(((unsigned)i * magic) >> 20), qi = i - line * QW;
-        const unsigned row_elems = (unsigned)(((r_lo + (line >> 2)) * C + CG * g + (line & 3)) * L);
         const int t = 4 * qi - PAD4;                                 // a multiple of 4: in front of the row, or starting inside it
-        const bool any = i < nquads && t >= 0 && t < L;
-        st.keep[u] = any ? (L - t < 4 ? L - t : 4) : 0;              // samples of the quad inside the row
-        st.xq[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, any ? (row_elems + (unsigned)t) * 4u : OOB, 0, 0));
+        const bool ok = line < rows_max * CG && t >= 0 && t < L;
+        pl.xoff[u] = ok ? 4u * (unsigned)(((line >> 2) * C + CG * g + (line & 3)) * L + t) : XINV;
+        pl.keep[u] = ok ? (L - t < 4 ? L - t : 4) : 0;
     }
-    const int e = e0 + tid;
-    st.woff = 0;
-    const bool valid = e < total;
-    const int ec = valid ? e : total - 1;
-    const int row = ec / n, j = ec - row * n;
-    if (valid) st.woff = (row - r_lo) * CG * WL + 4 * j;
-    const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, 4u * (unsigned)(p.B * C * n), 0x00020000);
-    const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(act != MS_ACT_NONE ? p.c : p.b), 0, 4u * (unsigned)(p.B * C * n), 0x00020000);
-#pragma unroll
-    for (int co = 0; co < CG; ++co) {
-        const unsigned off = valid ? 4u * (unsigned)((row * C + CG * g + co) * n + j) : OOB;      // (an invalid item reads 0.0)
-        st.gy[co] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, off, 0, 0));
-        st.ya[co] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0));
-    }
+    pl.row = tid / n; pl.j = tid - pl.row * n;
+    pl.r_lo = 0; pl.rem = 0;
+    pl.dq = ITEMS / n; pl.dr = ITEMS - pl.dq * n;
 }
 
-__device__ __forceinline__ void g4_stage_store(const G4Stage& st, int act, float slope, float* buf) {
+// issues the loads of the part's next chunk and moves the plan on by one chunk
+__device__ __forceinline__ void g4_stage_load(const G4Part& p, int C, int g, int act, G4Plan& pl, G4Stage& st) {
+    const int n = p.n, L = p.L, WL = 4 * n + 44;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, 4u * (unsigned)(p.B * C * L), 0x00020000);
+    const unsigned rstep = 4u * (unsigned)(pl.r_lo * C * L);         // (rows beyond the chunk's own but inside the tensor are read too)
+#pragma unroll
+    for (int u = 0; u < NQX; ++u)
+        st.xq[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, pl.xoff[u] + rstep, 0, 0));
+    const bool valid = pl.row < p.B;
+    st.woff = valid ? (pl.row - pl.r_lo) * CG * WL + 4 * pl.j : 0;
+    const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, 4u * (unsigned)(p.B * C * n), 0x00020000);
+    const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(act != MS_ACT_NONE ? p.c : p.b), 0, 4u * (unsigned)(p.B * C * n), 0x00020000);
+    const unsigned off0 = valid ? 4u * (unsigned)((pl.row * C + CG * g) * n + pl.j) : XINV;       // (an invalid item reads 0.0)
+#pragma unroll
+    for (int co = 0; co < CG; ++co) {
+        st.gy[co] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, off0 + 4u * (unsigned)(co * n), 0, 0));
+        st.ya[co] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, off0 + 4u * (unsigned)(co * n), 0, 0));
+    }
+    pl.row += pl.dq; pl.j += pl.dr;
+    if (pl.j >= n) { pl.j -= n; ++pl.row; }
+    pl.r_lo += pl.dq; pl.rem += pl.dr;
+    if (pl.rem >= n) { pl.rem -= n; ++pl.r_lo; }
+}
+
+__device__ __forceinline__ void g4_stage_store(const G4Stage& st, const G4Plan& pl, bool ragged, int act, float slope, float* buf) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int u = 0; u < NQX; ++u) {
         const int i = tid + 256 * u;                                 // quad qi of line l sits at l WL + 4 qi = 4 i
         f32x4 v = st.xq[u];
+        if (ragged) {                                                // (uniform: rows whose length is not a multiple of 4)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = e < st.keep[u] ? v[e] : 0.f;
+            for (int e = 0; e < 4; ++e) v[e] = e < pl.keep[u] ? v[e] : 0.f;
+        }
         if (i < XS / 4) *reinterpret_cast<f32x4*>(buf + 4 * i) = v;
     }
     f32x4 gp = st.gy;
@@ -330,7 +352,7 @@ __device__ __forceinline__ void g4_stage_store(const G4Stage& st, int act, float
         for (int co = 0; co < CG; ++co) gp[co] = ms_act_grad(st.gy[co], st.ya[co], act, slope);
     }
     *reinterpret_cast<f32x4*>(buf + XS + 4 * tid) = gp;
-    reinterpret_cast<int*>(buf + XS + 4 * ITEMS)[tid] = st.woff;
+    reinterpret_cast<int*>(buf + XS + 4 * ITEMS)[tid] = 4 * st.woff;     // (in bytes)
 }
 
 __global__ __launch_bounds__(256) void k_g4_wgrad(G4Parts q, int C, int act, float slope, float beta, float* __restrict__ gw,
@@ -350,16 +372,26 @@ __global__ __launch_bounds__(256) void k_g4_wgrad(G4Parts q, int C, int act, flo
 #pragma unroll
     for (int u = 0; u < 3; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float gsum = 0.f;                               // lane 4t + r: sum of gp[co = r] over the items this lane held in its A register
+    // Chunks travel global -> registers -> LDS one chunk ahead of the arithmetic (two chunks ahead measured the same: the
+    // kernel was bound by its vector instructions, not by the loads).
+    G4Plan pl;
     G4Stage st;
-    G4Part p = pick_part(q, 0);
-    g4_stage_load(p, C, g, act, st);
-    g4_stage_store(st, act, slope, g4_smem);
+    {
+        const G4Part p0 = pick_part(q, 0);
+        g4_plan(p0, C, g, pl);
+        g4_stage_load(p0, C, g, act, pl, st);
+        g4_stage_store(st, pl, (p0.L & 3) != 0, act, slope, g4_smem);
+    }
     __syncthreads();
+#pragma unroll 1
     for (int c = 0; c < nch; ++c) {
         const float* buf = g4_smem + (c & 1) * WBUF;
         const G4Part pn = pick_part(q, c + 1 < nch ? c + 1 : c);
-        if (c + 1 < nch) g4_stage_load(pn, C, g, act, st);
-        const int WL = 4 * p.n + 44;
+        if (c + 1 < nch) {
+            if (pn.wg == 0) g4_plan(pn, C, g, pl);                  // the next chunk opens a part
+            g4_stage_load(pn, C, g, act, pl, st);
+        }
+        const int WL = 4 * pick_part(q, c).n + 44;
         unsigned off[3];                            // LDS byte address of this lane's window sample for an item at float 0
 #pragma unroll
         for (int u = 0; u < 3; ++u) off[u] = (unsigned)(uintptr_t)buf + 4u * (unsigned)(bci[u] * WL + 4 * bqq[u] + jj);
@@ -372,7 +404,7 @@ __global__ __launch_bounds__(256) void k_g4_wgrad(G4Parts q, int C, int act, flo
             const int W = reinterpret_cast<const int*>(buf + XS + 4 * ITEMS)[it0 + (lane & 15)];
             static_for<0, 16>([&](auto T) {
                 constexpr int t = decltype(T)::value;
-                const unsigned base = 4u * (unsigned)__builtin_amdgcn_readlane(W, t);
+                const unsigned base = (unsigned)__builtin_amdgcn_readlane(W, t);
 #pragma unroll
                 for (int u = 0; u < 3; ++u)
                     xd[t][u] = *reinterpret_cast<const float __attribute__((address_space(3)))*>(off[u] + base);
@@ -391,8 +423,7 @@ __global__ __launch_bounds__(256) void k_g4_wgrad(G4Parts q, int C, int act, flo
             });
             __builtin_amdgcn_sched_barrier(0);
         });
-        if (c + 1 < nch) g4_stage_store(st, act, slope, g4_smem + ((c + 1) & 1) * WBUF);
-        p = pn;
+        if (c + 1 < nch) g4_stage_store(st, pl, (pn.L & 3) != 0, act, slope, g4_smem + ((c + 1) & 1) * WBUF);
         __syncthreads();
     }
     // the four waves' sums, added in a fixed order

@@ -5,6 +5,16 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "music-synthesis
 import torch
 from featuresynth._ops import prims as P
 op = sys.argv[1]
+if op == "g4":        # the 256-group layer over three scales (gconv4.hip): g4 B
+    B = int(sys.argv[2])
+    from featuresynth._ops import lib as L
+    xs = [torch.randn(B, 1024, l, device="cuda") for l in (128, 65, 33)]
+    w = torch.randn(1024, 4, 41, device="cuda") * 0.08; b = torch.randn(1024, device="cuda") * 0.1
+    d, _ = P.conv_desc(xs[0].shape, w.shape, stride=4, pad=20, groups=256, act=L.ACT_LRELU)
+    ys = P.conv1d_parts_fwd(xs, w, b, d); gys = [torch.randn_like(y) for y in ys]
+    for _ in range(5):
+        P.conv1d_parts_fwd(xs, w, b, d); P.conv1d_parts_bwd_data(gys, ys, w, d, [x.shape for x in xs]); P.conv1d_parts_bwd_weight(xs, gys, ys, d, w.shape)
+    torch.cuda.synchronize(); sys.exit(0)
 if op == "dwgrad":      # dense weight gradient: dwgrad B Cin L Cout K dil
     B, Cin, Lg, Cout, K, dil = map(int, sys.argv[2:8])
     x = torch.randn(B, Cin, Lg, device="cuda"); gy = torch.randn(B, Cout, Lg, device="cuda"); ya = torch.randn(B, Cout, Lg, device="cuda")

@@ -20,7 +20,7 @@ for f in glob.glob("gpurun_out/pmc_$tag/p*/**/*counter_collection.csv", recursiv
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"][:110]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in agg.items():
-    if not any(t in k for t in ("gconv", "reduce", "wgrad", "rows", "atom", "conv5", "convt")): continue
+    if not any(t in k for t in ("gconv", "reduce", "wgrad", "rows", "atom", "conv5", "convt", "k_g4")): continue
     print(k)
     for c, v in sorted(cs.items()):
         print("   %-34s n=%d  mean %.4g" % (c, len(v), sum(v) / len(v)))
