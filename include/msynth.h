@@ -263,6 +263,9 @@ int ms_residual_stack_fwd(const ms_stack_desc* d, const float* x, const void* co
 size_t ms_conv1d_img_bytes(const ms_conv1d_desc* d);
 size_t ms_conv1d_img_workspace_bytes(const ms_conv1d_desc* d, int which);
 int ms_conv1d_img_pack(const ms_conv1d_desc* d, const float* w, int backward, void* image, ms_stream_t stream);
+/* Both images of a layer (forward, backward data) from ONE pass over the weights for their common scale: what a train step
+ * needs, one launch fewer than two ms_conv1d_img_pack calls. */
+int ms_conv1d_img_pack2(const ms_conv1d_desc* d, const float* w, void* image_fwd, void* image_bwd, ms_stream_t stream);
 int ms_conv1d_img_fwd(const ms_conv1d_desc* d, const float* x, const void* image, const float* bias, float* y,
                       void* workspace, size_t workspace_bytes, ms_stream_t stream);
 int ms_conv1d_img_bwd_data(const ms_conv1d_desc* d, const float* gy, const float* y_act, const void* image_bwd,

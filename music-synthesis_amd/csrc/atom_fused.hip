@@ -66,7 +66,13 @@ __global__ __launch_bounds__(256) void k_atom_wmax(AtomPackTable t) {
     const int n = jb.C * jb.C * 3, per = (n + W_NPART - 1) / W_NPART;
     const int lo = part * per, hi = lo + per < n ? lo + per : n;
     float m = 0.f;
-    for (int i = lo + threadIdx.x; i < hi; i += 256) m = fmaxf(m, fabsf(w[i]));
+    typedef float f32x4w __attribute__((ext_vector_type(4), aligned(4)));      // (16 bytes per lane at any 4-byte aligned address)
+    int i = lo + 4 * (int)threadIdx.x;
+    for (; i + 3 < hi; i += 1024) {
+        const f32x4w v = *reinterpret_cast<const f32x4w*>(w + i);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    for (; i < hi; ++i) m = fmaxf(m, fabsf(w[i]));
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();

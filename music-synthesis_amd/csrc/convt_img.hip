@@ -60,7 +60,14 @@ __global__ __launch_bounds__(256) void k_convt_wmax(const float* __restrict__ W,
     __shared__ float red[4];
     const size_t per = (n + W_NPART - 1) / W_NPART, lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
     float m = 0.f;
-    for (size_t i = lo + threadIdx.x; i < hi; i += 256) m = fmaxf(m, fabsf(W[i]));
+    // 16 bytes per lane at any 4-byte aligned address (a view into a flat parameter bucket): a 21 MB tensor in ~7 us, not 21
+    typedef float f32x4w __attribute__((ext_vector_type(4), aligned(4)));
+    size_t i = lo + 4 * (size_t)threadIdx.x;
+    for (; i + 3 < hi; i += 1024) {
+        const f32x4w v = *reinterpret_cast<const f32x4w*>(W + i);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    for (; i < hi; ++i) m = fmaxf(m, fabsf(W[i]));                     // (the one thread whose quad crosses the part's end)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;

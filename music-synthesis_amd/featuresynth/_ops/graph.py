@@ -427,6 +427,18 @@ def pack_k5_image(x_shape, params, backward=False):
     return P.conv_img_pack(d, w, backward=backward)
 
 
+def pack_k5_image_pair(x_shape, params):
+    """(forward, backward-data) image of the k5 layer from one pass over its weights (P.conv_img_pack2); (None, None) when the
+    image kernel does not take the layer."""
+    w = params[10]
+    if tuple(w.shape[1:]) != (w.shape[0], 5) or params[11].data_ptr() % 16:
+        return None, None
+    d = L.ConvDesc(x_shape[0], w.shape[1], 32, w.shape[0], 5, 1, 2, 1, 1, L.PAD_ZERO, L.ACT_LRELU, P.SLOPE, L.ACT_NONE)
+    if not P.conv_img_bytes(d):
+        return None, None
+    return P.conv_img_pack2(d, w)
+
+
 def fork_aux(device):
     """Fork point of the aux stream, placed BEFORE the caller issues its own chain: what is put on the aux stream later
     (pack_k5_images_aside(forked=True), the G-step's real pass) then depends on nothing the caller issued in between.
@@ -443,13 +455,12 @@ def pack_k5_images_aside(x_shape, params, device, forked_at=None):
     (None, None, None) when the image kernel does not take the layer / streams are serialised.  forked_at = the result
     of an earlier fork_aux(): the aux stream already branched off there and is not made to wait for the caller again."""
     if not (_may_fork(device) if forked_at is None else forked_at):
-        return pack_k5_image(x_shape, params), pack_k5_image(x_shape, params, backward=True), None
+        return pack_k5_image_pair(x_shape, params) + (None,)
     main, aux = torch.cuda.current_stream(device), aux_stream(device)
     if forked_at is None:
         aux.wait_stream(main)
     with forked(aux):
-        f = pack_k5_image(x_shape, params)
-        b = pack_k5_image(x_shape, params, backward=True)
+        f, b = pack_k5_image_pair(x_shape, params)
         ev = torch.cuda.Event()
         ev.record(aux)
     for t in (f, b):

@@ -155,6 +155,7 @@ SIGNATURES = {
     "ms_conv1d_img_bytes": (_sz, [ctypes.POINTER(ConvDesc)]),
     "ms_conv1d_img_workspace_bytes": (_sz, [ctypes.POINTER(ConvDesc), _c_int]),
     "ms_conv1d_img_pack": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _c_int, _vp, _vp]),
+    "ms_conv1d_img_pack2": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "ms_conv1d_img_fwd": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ms_conv1d_img_bwd_data": (_c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ms_conv1d_workspace_bytes": (_sz, [ctypes.POINTER(ConvDesc), _c_int]),

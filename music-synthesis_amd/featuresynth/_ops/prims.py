@@ -290,6 +290,15 @@ def conv_img_pack(d, w, backward=False):
     return img
 
 
+def conv_img_pack2(d, w):
+    """-> (forward image, backward-data image) of w: one pass over the weights for their common scale, then the two packs."""
+    L.require(w, "conv1d weight")
+    img = torch.empty(conv_img_bytes(d), dtype=torch.uint8, device=w.device)
+    imgb = torch.empty(conv_img_bytes(d), dtype=torch.uint8, device=w.device)
+    L.call("ms_conv1d_img_pack2", _scost(w.numel(), 1, 2.5), d, w.data_ptr(), img.data_ptr(), imgb.data_ptr(), L.stream())
+    return img, imgb
+
+
 def conv1d_img_fwd(x, image, b, d, lout, out=None):
     L.require(x, "conv1d input")
     y = _out(out, (d.B, d.Cout, lout), x.device, "conv1d output")

@@ -108,3 +108,22 @@ def test_conv5_image_used_by_the_discriminator_and_switchable(monkeypatch):
     for a, b_ in zip(out["1"][0], out["0"][0]):
         assert rel_l2(a, b_) < 1e-5           # (the judgements are small sums of cancelling terms: measured 1.1e-6)
     assert rel_l2(out["1"][1], out["0"][1]) < 1e-5
+
+
+def test_image_pair_from_one_maxima_pass():
+    """ms_conv1d_img_pack2: the forward and the backward-data image of a layer packed from ONE pass over the weights for their
+    common scale -- the kernels give bitwise what they give on the two separately packed images."""
+    from featuresynth._ops import lib as L
+    from featuresynth._ops import prims as P
+    rng = np.random.default_rng(5)
+    C, B, Lg = 1024, 32, 32
+    x = dev(rng.standard_normal((B, C, Lg)).astype(np.float32))
+    w = dev((rng.standard_normal((C, C, 5)) * 0.02).astype(np.float32))
+    b = dev(rng.standard_normal(C).astype(np.float32) * 0.1)
+    d, lo = P.conv_desc(x.shape, w.shape, pad=2, act=L.ACT_LRELU)
+    f1, b1 = P.conv_img_pack(d, w), P.conv_img_pack(d, w, backward=True)
+    f2, b2 = P.conv_img_pack2(d, w)
+    y1, y2 = P.conv1d_img_fwd(x, f1, b, d, lo), P.conv1d_img_fwd(x, f2, b, d, lo)
+    gy = dev(rng.standard_normal(tuple(y1.shape)).astype(np.float32))
+    g1, g2 = P.conv1d_img_bwd_data(gy, y1, b1, d), P.conv1d_img_bwd_data(gy, y1, b2, d)
+    assert torch.equal(y1, y2) and torch.equal(g1, g2)
