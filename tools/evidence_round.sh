@@ -5,9 +5,9 @@
 #   2. serial + replay kernel stats and the bench line (tools/prof_final.sh)
 #   3. MFMA / VALU / LDS counters of the dominant kernels (tools/pmc_kernels.sh)
 #   4. the two-stage and RealMelGan bench lines
-# usage (GPU box): bash tools/evidence_round.sh r04
+# usage (GPU box): bash tools/evidence_round.sh r05
 set -o pipefail
-tag=${1:-r04}
+tag=${1:-r05}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 bash tools/pmc_traffic.sh > gpurun_out/ev_pmc_traffic.log 2>&1; tail -3 gpurun_out/ev_pmc_traffic.log
