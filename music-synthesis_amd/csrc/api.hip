@@ -324,6 +324,10 @@ int ms_conv1d_bwd_weight(const ms_conv1d_desc* d, const float* x, const float* g
     const int xk = p.in_act ? MS_MOD_LRELU_FWD : 0;
     if (mst_bwd_weight_applicable(p))   // one-channel side: HBM-bound stream kernels
         return mst_conv1d_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
+    if (msws_applicable(p) && workspace && workspace_bytes >= msws_ws(p)) {     // reflection-padded conv on short rows
+        const int rc = msws_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
+        if (rc != MS_ERR_UNSUPPORTED) return rc;
+    }
     if (msw32_applicable(p)) {          // 32 -> 32 k3 atoms: HBM-bound, per-wave units
         const int rc = msw32_bwd_weight(p, x, gy, y_act, gw, gb, beta, workspace, workspace_bytes, s);
         if (rc != MS_ERR_UNSUPPORTED) return rc;
@@ -585,6 +589,11 @@ size_t ms_conv1d_workspace_bytes(const ms_conv1d_desc* d, int which) {
     }
     if (which == 2) {
         if (mst_bwd_weight_applicable(p)) return mst_bwd_weight_ws(p);
+        if (msws_applicable(p)) {
+            const size_t a = msws_ws(p);
+            const size_t rest = msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p);
+            return a > rest ? a : rest;
+        }
         if (msw32_applicable(p)) {
             const size_t a32 = msw32_ws(p);
             const size_t rest = msm_bwd_weight_applicable(p) ? msm_bwd_weight_ws(p) : msk_conv1d_bwd_weight_ws(p);
@@ -631,6 +640,7 @@ const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which) {
                   : (mst_bwd_data_applicable(p) && p.pad_mode == MS_PAD_ZERO ? mst_bwd_data_name(p)
                                                                               : msk_conv1d_bwd_data_direct_name(p)));
     if (which == 2 && mst_bwd_weight_applicable(p)) return mst_bwd_weight_name(p);
+    if (which == 2 && msws_applicable(p)) return "k_wgrad_short";
     if (which == 2 && msw32_applicable(p)) return p.act == MS_ACT_LRELU ? "k_wgrad32<1>" : "k_wgrad32<0>";
     if (which == 2 && msw5_applicable(p)) return msw5_name(p);
     if (which == 2 && msw_bwd_weight_applicable(p)) return msw_bwd_weight_name(p);

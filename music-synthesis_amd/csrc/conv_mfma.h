@@ -96,3 +96,9 @@ bool msw32_applicable(const ConvP& p);
 size_t msw32_ws(const ConvP& p);
 int msw32_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act, float* gw,
                      float* gb, float beta, void* ws, size_t ws_bytes, hipStream_t s);
+
+// reflection-padded dense conv on short rows (the generator's first layer): weight gradient on fp32 MFMA (wgrad_short.hip)
+bool msws_applicable(const ConvP& c);
+size_t msws_ws(const ConvP& c);
+int msws_bwd_weight(const ConvP& c, const float* x, const float* gy, const float* y_act, float* gw, float* gb, float beta,
+                    void* ws, size_t ws_bytes, hipStream_t s);

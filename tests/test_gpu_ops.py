@@ -279,11 +279,12 @@ HOT_CONVS = [
     ("mfma_m96_k5", 2, 36, 41, 96, 5, 1, 2, 1, 1, 0, False),
     ("mfma_tile128", 4, 128, 12288, 128, 3, 1, 9, 9, 1, 1, False),
     ("mfma_m160_k7_reflect", 2, 24, 50, 160, 7, 1, 3, 1, 1, 2, True),
-    # reflection-padded weight gradient through the zero-padded row-tile kernel (api.hip refl_wgrad_conv): the generator's first
-    # conv at the bench batch, a ragged length with tanh, a k3 with the pad next to the row length
+    # reflection-padded weight gradients: the generator's first conv at the bench batch (wgrad_short.hip: fp32 MFMA, one wave per
+    # tile), a ragged length with tanh and a k3 with the pad next to the row length (im2col kernel)
     ("g_first_k7_b32", 32, 80, 32, 512, 7, 1, 3, 1, 1, 1, True),
     ("w_reflect_k7_l37_tanh", 3, 48, 37, 96, 7, 1, 3, 1, 1, 2, True),
     ("w_reflect_k3_l5", 4, 64, 5, 64, 3, 1, 1, 1, 1, 0, True),
+    ("w_short_k5_l64_tanh", 8, 36, 64, 96, 5, 1, 2, 1, 1, 2, True),      # wgrad_short.hip: two 32-sample blocks per row, K = 5
     # row-tile weight gradient: short rows packed R per chunk (16-byte and scalar loaders), batch
     # tail, 1x1, K = 7, M / channel tails
     ("w32_d1", 3, 32, 2052, 32, 3, 1, 1, 1, 1, 1, False),
