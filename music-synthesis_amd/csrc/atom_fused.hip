@@ -765,6 +765,10 @@ int dispatch_atom(int mode, const ms_atom_desc* d, const float* x, const void* i
             return launch_atom<64, 128, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
         case 128:
             if (cols < 60 * 128 && (mode & 3) != 2) return launch_atom<128, 32, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
+            // forward at full batch: 96-column tiles (92 outputs per pass over the 393 KB weight image instead of 60, three
+            // accumulator tiles per wave, the rounds of the persistent grid fuller): 6 % faster than 64 columns in an interleaved
+            // A/B at B = 32 (tools/scratch/probe_atom_cfg2.py); the backward pass, whose halo is the dilation, is 5-10 % slower on them
+            if (cols >= 512 * 92 && (mode & 3) != 2) return launch_atom<128, 96, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
             return launch_atom<128, 64, 4>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);
         case 256:
             if (cols < 60 * 64 && (mode & 3) != 2) return launch_atom<256, 32, 8>(mode, p, x, image, b0, b1, y, t, u, tm, am, s);

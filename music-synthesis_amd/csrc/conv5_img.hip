@@ -293,7 +293,8 @@ __device__ __forceinline__ void conv5_body(const C5P& p, const float* __restrict
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(rx[k][cc][e]));
+                    for (int e = 0; e < 4; ++e)
+                        if (u_l[k] + e < L) m = fmaxf(m, fabsf(rx[k][cc][e]));      // (samples behind the row belong to a neighbour: not staged, not in the scale)
                 // 16 lanes by DPP (quad swaps, half-row mirror, row mirror), wider spans by lane shuffles
                 m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, true)));
                 m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, true)));

@@ -560,6 +560,9 @@ __device__ __forceinline__ void gconv_wgrad_body(const ConvP& p, const float* __
 #pragma unroll
         for (int j = 0; j < NKT; ++j) acc[c][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float Sg = 0.f, Sx = 0.f;                          // current scales (0: none yet)
+    float Sg_lo = 0.f, Sx_lo = 0.f;                    // smallest scales so far (the largest magnitudes seen): a scale never rises more
+                                                       // than 2^30 above them, so the sums are re-expressed by at most 2^60 in total and
+                                                       // stay finite; operands that much smaller than earlier ones are below the sums' resolution
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
     // fragment addresses of this lane
@@ -591,6 +594,10 @@ __device__ __forceinline__ void gconv_wgrad_body(const ConvP& p, const float* __
             if (mx > 0.f && !(mx * Sx >= 256.f && mx * Sx < 32768.f)) block_scale(mx * 4.f, nSx, inv);
             if (nSg == 0.f) nSg = 1.f;
             if (nSx == 0.f) nSx = 1.f;
+            if (Sg_lo != 0.f) nSg = fminf(nSg, Sg_lo * 0x1p30f);
+            if (Sx_lo != 0.f) nSx = fminf(nSx, Sx_lo * 0x1p30f);
+            if (mg > 0.f) Sg_lo = Sg_lo == 0.f ? nSg : fminf(Sg_lo, nSg);      // (an all-zero unit sets no reference)
+            if (mx > 0.f) Sx_lo = Sx_lo == 0.f ? nSx : fminf(Sx_lo, nSx);
             if ((nSg != Sg || nSx != Sx) && Sg != 0.f) {               // (wave-uniform) a scale moved: re-express the sums
                 const float ratio = (nSg / Sg) * (nSx / Sx);
 #pragma unroll

@@ -97,7 +97,7 @@ def _rel(a, b):
     return float((a - b).norm() / b.norm())
 
 
-@pytest.mark.parametrize("C,Lg,dil", [(32, 8192, 9), (64, 4096, 3), (128, 2048, 1), (256, 256, 9)])
+@pytest.mark.parametrize("C,Lg,dil", [(32, 8192, 9), (64, 4096, 3), (128, 2048, 1), (128, 2048, 9), (256, 256, 9)])
 def test_fused_atom_at_bench_shapes(C, Lg, dil):
     """BASELINE config 3's shapes (B = 32).  Against float64 the fused kernel (fp16 x 2, three products) is as close as
     the two row-tile launches (bf16 x 3, six exact products) -- both are bounded by fp32 accumulation, ~2-5e-7 -- and the
@@ -264,7 +264,9 @@ def _decode_signs(words):
 
 
 SIGN_CASES = [("s32", 2, 32, 1032, 3), ("s32_long", 3, 32, 8192, 9), ("s64", 2, 64, 4096, 1), ("s64_ragged", 1, 64, 252, 9),
-              ("s128", 2, 128, 2048, 3), ("s128_short", 1, 128, 188, 9), ("s256", 3, 256, 256, 1), ("s256_narrow", 1, 256, 100, 9)]
+              ("s128", 2, 128, 2048, 3), ("s128_short", 1, 128, 188, 9), ("s256", 3, 256, 256, 1), ("s256_narrow", 1, 256, 100, 9),
+              # (B L >= 512 x 92 columns at 128 channels: the forward runs on 96-column tiles, the last tile of a row is partial)
+              ("s128_wide_ragged", 24, 128, 2052, 9)]
 
 
 @pytest.mark.parametrize("case", SIGN_CASES, ids=[c[0] for c in SIGN_CASES])

@@ -115,6 +115,36 @@ def test_grouped_layer_in_unit_dynamic_range(p2):
     _check(y, yr, 2.0 ** p2, float(np.abs(w).sum(axis=(1, 2)).max()), "grouped fwd", (slice(1, None),), K=164)
 
 
+def test_grouped_wgrad_scale_swing():
+    """Weight gradient of the grouped k41 layer: a wave keeps its sums under STICKY power-of-two operand scales and re-expresses
+    them when a scale moves.  Batch rows whose operands are 2^90 times smaller than the rows before them (a product swing of
+    2^180, beyond fp32's range) must neither overflow the sums nor disturb them: a scale never rises more than 2^30 above the
+    smallest one used so far (gconv_split.hip), operands that much smaller are below the sums' resolution anyway."""
+    import torch.nn.functional as F
+    from featuresynth._ops import lib as L
+    from featuresynth._ops import prims as P
+    rng = np.random.default_rng(77)
+    B, Cin, Cout, groups, Lin = 32, 16, 64, 4, 8192
+    x = rng.standard_normal((B, Cin, Lin)).astype(np.float32)
+    Lout = (Lin + 2 * 20 - 41) // 4 + 1
+    gy = rng.standard_normal((B, Cout, Lout)).astype(np.float32)
+    scale = np.where(np.arange(B) < B // 2, 2.0 ** 45, 2.0 ** -45).astype(np.float32)[:, None, None]
+    x *= scale; gy *= scale
+    xt, gt = dev(x), dev(gy)
+    d, lo = P.conv_desc(xt.shape, (Cout, Cin // groups, 41), stride=4, pad=20, groups=groups)
+    assert lo == Lout
+    assert L.load().ms_conv1d_kernel_name(d, 2).decode().startswith("k_gconv_split")
+    gw, gb = P.conv1d_bwd_weight(xt, gt, None, d, (Cout, Cin // groups, 41))
+    xd, gd = torch.from_numpy(x).double(), torch.from_numpy(gy).double()
+    wd = torch.zeros(Cout, Cin // groups, 41, dtype=torch.float64, requires_grad=True)
+    (F.conv1d(xd, wd, None, stride=4, padding=20, groups=groups) * gd).sum().backward()
+    assert bool(torch.isfinite(gw).all()) and bool(torch.isfinite(gb).all())
+    e = float((gw.double().cpu() - wd.grad).norm() / wd.grad.norm())
+    eb = float((gb.double().cpu() - gd.sum(dim=(0, 2))).norm() / gd.sum(dim=(0, 2)).norm())
+    print("grouped wgrad under a 2^180 product swing: rel-L2 %.2e (bias %.2e)" % (e, eb))
+    assert e < 2e-6 and eb < 2e-6
+
+
 @pytest.mark.parametrize("p2", [20, 30])
 def test_convt8_in_tile_dynamic_range(p2):
     """Stride-8 transposed conv on its weight image (generator/full.py:27-32), forward: block = the tile's input window."""
