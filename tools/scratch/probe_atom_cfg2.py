@@ -22,9 +22,12 @@ def timeit(fn, n=60):
 
 torch.manual_seed(0)
 B = 32
-cases = [(128, 2048, "infer", ("0", "3")), (128, 2048, "train", ("0", "3")), (128, 2048, "bwd", ("0", "3")),
-         (64, 4096, "train", ("0", "4")), (64, 4096, "infer", ("0", "4")), (64, 4096, "bwd", ("0", "4")),
-         (32, 8192, "bwd", ("0", "3")), (32, 8192, "train", ("0", "3")), (32, 8192, "infer", ("0", "3"))]
+if os.environ.get("PROBE_WIDE8"):      # 8-wave workgroups on double-width tiles (cfg 5: <128, 128, 8>, <64, 256, 8>) vs what runs
+    cases = [(C, Lg, m, ("0", "5")) for (C, Lg) in ((128, 2048), (64, 4096)) for m in ("infer", "train", "bwd")]
+else:
+  cases = [(128, 2048, "infer", ("0", "3")), (128, 2048, "train", ("0", "3")), (128, 2048, "bwd", ("0", "3")),
+           (64, 4096, "train", ("0", "4")), (64, 4096, "infer", ("0", "4")), (64, 4096, "bwd", ("0", "4")),
+           (32, 8192, "bwd", ("0", "3")), (32, 8192, "train", ("0", "3")), (32, 8192, "infer", ("0", "3"))]
 for C, Lg, mode, cfgs in cases:
     for dil in (1, 3, 9):
         x = torch.randn(B, C, Lg, device="cuda")
