@@ -6,10 +6,11 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 bash tools/pmc_one.sh atom64 atom 32 64 4096 3 > gpurun_out/pmc_atom64.txt 2>&1
 bash tools/pmc_one.sh atom128 atom 32 128 2048 1 > gpurun_out/pmc_atom128.txt 2>&1
-bash tools/pmc_one.sh k5 k5img 64 1024 32 > gpurun_out/pmc_k5.txt 2>&1
+bash tools/pmc_one.sh k5 k5parts 64 > gpurun_out/pmc_k5.txt 2>&1
 bash tools/pmc_one.sh ctbwd ctbwd 32 256 256 128 8 > gpurun_out/pmc_ctbwd.txt 2>&1
 bash tools/pmc_one.sh gfwd fwd 64 64 2048 256 16 > gpurun_out/pmc_gfwd.txt 2>&1
 bash tools/pmc_one.sh gwgrad wgrad 64 64 2048 256 16 > gpurun_out/pmc_gwgrad.txt 2>&1
 bash tools/pmc_one.sh g4 g4 64 > gpurun_out/pmc_g4.txt 2>&1
-python3 tools/pmc_ratios.py gpurun_out/pmc_atom64.txt gpurun_out/pmc_atom128.txt gpurun_out/pmc_k5.txt gpurun_out/pmc_ctbwd.txt gpurun_out/pmc_gfwd.txt gpurun_out/pmc_gwgrad.txt gpurun_out/pmc_g4.txt > gpurun_out/r05_pmc_kernels_summary.txt
+bash tools/pmc_one.sh gen gen 32 > gpurun_out/pmc_gen.txt 2>&1      # every generator kernel of a training pass (atoms at all four widths, batched weight gradients)
+python3 tools/pmc_ratios.py gpurun_out/pmc_atom64.txt gpurun_out/pmc_atom128.txt gpurun_out/pmc_k5.txt gpurun_out/pmc_ctbwd.txt gpurun_out/pmc_gfwd.txt gpurun_out/pmc_gwgrad.txt gpurun_out/pmc_g4.txt gpurun_out/pmc_gen.txt > gpurun_out/r05_pmc_kernels_summary.txt
 cat gpurun_out/r05_pmc_kernels_summary.txt

@@ -42,6 +42,30 @@ if op == "k5img":     # the k5 layer on weight images (conv5_img.hip), forward +
     for _ in range(5):
         P.conv1d_img_fwd(x, img, b, d, lo); P.conv1d_img_bwd_data(gy, y, imgb, d)
     torch.cuda.synchronize(); sys.exit(0)
+if op == "gen":       # the generator's training forward + backward at B (all atoms, their batched weight gradients, transposed convs): gen B
+    from featuresynth._ops import graph as G
+    from featuresynth._synthetic import synthetic_state_dict, module_param_shapes
+    import featuresynth as fs
+    B = int(sys.argv[2])
+    g = fs.MelGanGenerator(32, 80)
+    sd = synthetic_state_dict(module_param_shapes(g), seed=7, bias_scale=0.02)
+    params = [torch.from_numpy(v).cuda() for v in sd.values()]
+    x = torch.randn(B, 80, 32, device="cuda")
+    for _ in range(3):
+        y, tape = G.gen_forward(x, params, save=True)
+        G.gen_backward(tape, params, torch.randn_like(y) * 1e-3)
+    torch.cuda.synchronize(); sys.exit(0)
+if op == "k5parts":   # the k5 layer as the train step runs it: ONE parts launch over the three scales on pre-split operands: k5parts B
+    B = int(sys.argv[2]); C = 1024
+    xs = [torch.randn(B, C, Lg, device="cuda") for Lg in (32, 17, 9)]
+    w = torch.randn(C, C, 5, device="cuda") * 0.02; b = torch.randn(C, device="cuda")
+    d, lo = P.conv_desc(xs[0].shape, w.shape, pad=2, act=1)
+    img, imgb = P.conv_img_pack2(d, w)
+    ys = P.conv1d_parts_fwd(xs, w, b, d, image=img); gys = [torch.randn_like(y) for y in ys]
+    for _ in range(5):
+        P.conv1d_parts_fwd(xs, w, b, d, image=img)
+        P.conv1d_parts_bwd_data(gys, ys, w, d, [x.shape for x in xs], image_bwd=imgb)
+    torch.cuda.synchronize(); sys.exit(0)
 if op == "ctbwd":     # transposed-conv backward data on weight images (convt_bwd_img.hip): ctbwd B Cin Lin Cout S
     B, Cin, Lin, Cout, S = map(int, sys.argv[2:7])
     w = torch.randn(Cin, Cout, 2 * S, device="cuda") * 0.05; gy = torch.randn(B, Cout, Lin * S, device="cuda"); y = torch.randn_like(gy)
