@@ -78,6 +78,47 @@ def test_host_side_queries(lib):
     assert L.ms_adam_step(None, None, None, None, 4, 1e-4, 0.5, 0.9, 1e-8, 1.0, None, None) == -1
 
 
+def test_discriminator_layers_are_one_launch_per_pass(lib):
+    """r05: the reference applies ONE FullDiscriminator to x, pool(x), pool(pool(x))
+    (discriminator/melgan.py:13-27) and the trainers run it on [fake; real]: a layer's three scales are one piece of work.
+    ms_conv1d_parts_launches (host arithmetic; the placeholder addresses are never dereferenced) must plan ONE launch per
+    layer and pass -- forward, backward data, weight gradient -- at the bench geometry: the 8192-sample window at B = 64
+    ([fake; real] of the D-step / G-step forward) and B = 32 (the G-step's backward over the fake half)."""
+    L = lib.load()
+
+    def out_len(Lin, K, s, p):
+        return (Lin + 2 * p - K) // s + 1
+
+    # (Cin, Cout, K, stride, pad, groups) of FullDiscriminator.main and the judge conv (discriminator/full.py:13-22)
+    layers = [(1, 16, 15, 1, 7, 1), (16, 64, 41, 4, 20, 4), (64, 256, 41, 4, 20, 16), (256, 1024, 41, 4, 20, 64),
+              (1024, 1024, 41, 4, 20, 256), (1024, 1024, 5, 1, 2, 1), (1024, 1, 3, 1, 1, 1)]
+    for B in (64, 32):
+        Ls = [8192, 4097, 2049]                      # AvgPool1d(4, 2, padding=2) twice
+        for li, (ci, co, K, s, p, g) in enumerate(layers):
+            d = lib.ConvDesc(B, ci, Ls[0], co, K, s, p, 1, g, 0, 1 if li < 6 else 0, 0.2, 0)
+            parts = lib.ConvParts()
+            parts.count = 3
+            for i in range(3):
+                parts.B[i], parts.Lin[i] = B, Ls[i]
+                for f, base in (("x", 0x10000000), ("y", 0x20000000), ("gy", 0x30000000), ("y_act", 0x40000000), ("gx", 0x50000000)):
+                    getattr(parts, f)[i] = base + 0x1000000 * i
+            for which in (0, 1, 2):
+                n = L.ms_conv1d_parts_launches(d, parts, which, 1 if li == 5 else 0)
+                assert n == 1, "layer %d, pass %d at B = %d: %d launches" % (li, which, B, n)
+            Ls = [out_len(v, K, s, p) for v in Ls]
+        assert Ls == [32, 17, 9]
+    # a single tensor is not a parts call, and rows the parts kernels do not take fall back part by part (never an error)
+    d = lib.ConvDesc(2, 16, 8000, 64, 41, 4, 20, 1, 4, 0, 1, 0.2, 0)
+    parts = lib.ConvParts()
+    parts.count = 3
+    for i, v in enumerate((8000, 4001, 2001)):
+        parts.B[i], parts.Lin[i] = 2, v
+        parts.x[i] = parts.y[i] = 0x10000000 + 0x1000000 * i
+    assert L.ms_conv1d_parts_launches(d, parts, 0, 0) in (1, 3)
+    parts.count = 0
+    assert L.ms_conv1d_parts_launches(d, parts, 0, 0) < 0
+
+
 def test_struct_layout(lib):
     assert ctypes.sizeof(lib.ConvDesc) == 13 * 4
     assert ctypes.sizeof(lib.ConvTDesc) == 10 * 4
