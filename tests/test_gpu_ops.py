@@ -651,3 +651,29 @@ def test_side_stream_tracking_under_capture():
     torch.cuda.synchronize()
     assert float(z.min()) == 3.0 and float(z.max()) == 3.0 and float(w.max()) == 3.0
     G.begin_step()
+
+
+@pytest.mark.parametrize("n", [1, 255, 4096 + 3, 1 << 20])
+def test_elementwise_entries_without_a_network_test(n):
+    """ms_add (out of place and in place) and ms_l1_mean_bwd (overwrite and accumulate): C-ABI entries of the generic autograd
+    path (functional.py) that no network-level test dispatches (tools/trace_dispatch.sh) -- bit-exact against numpy: one fp32
+    add, and d/df mean|r - f| = sign(f - r) / n times the upstream gradient and the scale (reference loss/loss.py:44-49:
+    F.l1_loss on feature maps)."""
+    from featuresynth._ops import prims as P
+    rng = np.random.default_rng(n)
+    a, b = (rng.standard_normal(n).astype(np.float32) for _ in range(2))
+    at, bt = dev(a), dev(b)
+    assert np.array_equal(host(P.add(at, bt)), a + b)
+    ct = at.clone()
+    P.add_(ct, bt)
+    assert np.array_equal(host(ct), a + b)
+    b[::7] = a[::7]                                   # ties: the gradient of |r - f| at 0 is 0 (torch's sign convention)
+    bt = dev(b)
+    gout = dev(np.array(0.37, np.float32))
+    want = (np.sign(b.astype(np.float64) - a) * (0.37 * 2.5 / n)).astype(np.float32)
+    got = host(P.l1_mean_bwd(at, bt, gout, scale=2.5))
+    assert np.allclose(got, want, rtol=1e-6, atol=0), float(np.abs(got - want).max())
+    assert np.array_equal(got[::7], np.zeros_like(got[::7]))
+    acc = dev(np.ones(n, np.float32))
+    P.l1_mean_bwd(at, bt, gout, scale=2.5, gf=acc)
+    assert np.allclose(host(acc), 1.0 + want, rtol=1e-6, atol=0)
