@@ -496,8 +496,12 @@ constexpr size_t w3_lds_bytes(int BM) {
 // GM: the activation whose derivative multiplies the gradient arrives as sign words -- one 16-bit word per (batch row,
 // 32-channel block, lane half, column), bit 15 - r = "positive" of channel 32 blk + (r & 3) + 8 (r >> 2) + 4 h
 // (atom_fused.hip, MASK): a thread's four columns are ONE 8-byte load where the fp32 tensor cost 16 bytes per column quad x 4.
-template <int TM, int NP, bool GM = false>
-__global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restrict__ X_,
+// SOLO (r05, the NP = 2 launches): ONE group of four waves per workgroup (256 threads) that walks both halves of every chunk
+// itself -- stage, barrier, multiply, barrier -- into one set of accumulators (no merge): up to three such workgroups share a
+// CU and drift apart, where the two groups of the eight-wave form (kept for NP = 3, whose accumulators need its registers)
+// alternate in lockstep behind two barriers per slot.
+template <int TM, int NP, bool GM = false, bool SOLO = false>
+__global__ __launch_bounds__(SOLO ? 256 : 512) void k_wgrad_rows3(WrP p, const float* __restrict__ X_,
                                                     const float* __restrict__ G_,
                                                     const float* __restrict__ Gact_,
                                                     float* __restrict__ partial, size_t pstride, WrMulti mp) {
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
     constexpr bool SC = NP == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5;
-    const int g = __builtin_amdgcn_readfirstlane(wid >> 2), gt = tid & 255, gw = wid & 3;
+    const int g = SOLO ? 0 : __builtin_amdgcn_readfirstlane(wid >> 2), gt = tid & 255, gw = wid & 3;
     const int wm = gw >> 1, wn = gw & 1;
     unsigned char* const Gs = smem3 + g * (BM * W3_GRS + 64 * W3_XRS);
     unsigned char* const Xs = Gs + BM * W3_GRS;
@@ -554,6 +558,10 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
     float Sx = 1.f, Sg = 1.f, kfin = 1.f;
     if (SC) {
         float mx = fmaxf(xmax[tid], xmax[tid + 512]), mg = fmaxf(gmax[tid], gmax[tid + 512]);
+        if (SOLO) {
+            mx = fmaxf(mx, fmaxf(xmax[tid + 256], xmax[tid + 768]));
+            mg = fmaxf(mg, fmaxf(gmax[tid + 256], gmax[tid + 768]));
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -564,7 +572,7 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
         __syncthreads();
         mx = red[0]; mg = red[8];
 #pragma unroll
-        for (int w = 1; w < 8; ++w) { mx = fmaxf(mx, red[w]); mg = fmaxf(mg, red[8 + w]); }
+        for (int w = 1; w < (SOLO ? 4 : 8); ++w) { mx = fmaxf(mx, red[w]); mg = fmaxf(mg, red[8 + w]); }
         float ix, ig;
         w3_block_scale(mx, Sx, ix);
         w3_block_scale(mg, Sg, ig);
@@ -584,9 +592,9 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
 #pragma unroll
     for (int q = 0; q < NGU; ++q) bs[q] = 0.f;
 
-    auto load_chunk = [&](int ch, int c_end) {
+    auto load_chunk = [&](int ch, int c_end, int half = 0) {
         const int b = ch / p.tiles_per_row;
-        const int t0 = (ch - b * p.tiles_per_row) * p.Lt + 32 * g;
+        const int t0 = (ch - b * p.tiles_per_row) * p.Lt + 32 * (SOLO ? half : g);
         const bool live = ch < c_end && b < p.B;
         const int tg = t0 + g_t, tx = t0 - PADA + x_u;        // multiples of 4: a vector is all in or all out
         const unsigned go = (live && tg < p.L) ? 4u * (unsigned)((b * p.M + m0 + g_row) * p.L + tg) : OOB;
@@ -728,6 +736,16 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
     // land (one slot did not cover the HBM latency under load).  One straight-line loop per group (the group is
     // wave-uniform): the compiler then waits for a fetch where it is first used, not at a merged back edge.
     const int n = c_end - c_begin;
+    if constexpr (SOLO) {
+        load_chunk(c_begin, c_end, 0);
+        for (int u = 0; u < 2 * n; ++u) {
+            stage();                                 // (waits for unit u's registers)
+            load_chunk(c_begin + ((u + 1) >> 1), c_end, (u + 1) & 1);
+            __syncthreads();                         // tiles staged
+            compute_dil();
+            __syncthreads();                         // tiles free
+        }
+    } else {
     load_chunk(c_begin, c_end);
     if (g == 0) {
         stage();
@@ -750,17 +768,18 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
             __syncthreads();
         }
     }
+    }
 
     // ---- merge the two groups and write the slab (layout of k_wgrad_rows)
     float* const mrg = reinterpret_cast<float*>(smem3);                 // [wave][tile][reg][lane]
-    float* const bsum = mrg + 4 * TM * K * 16 * 64;                      // [group][row]
+    float* const bsum = SOLO ? mrg : mrg + 4 * TM * K * 16 * 64;        // [group][row] (SOLO: no merge area, one group)
 #pragma unroll
     for (int q = 0; q < NGU; ++q) {     // row sums of the gradient tile: the 8 lanes that share a row
         float v = bs[q];
         v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
         bs[q] = v;
     }
-    if (g == 1) {
+    if (!SOLO && g == 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -782,13 +801,14 @@ __global__ __launch_bounds__(512) void k_wgrad_rows3(WrP p, const float* __restr
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
-                for (int j = 0; j < K; ++j)
-                    part[(size_t)m * NG + (size_t)c * K + j] =
-                        SC ? (acc[i][j][r] + mrg[((gw * TM * K + i * K + j) * 16 + r) * 64 + lane]) * kfin
-                           : acc[i][j][r] + mrg[((gw * TM * K + i * K + j) * 16 + r) * 64 + lane];
+                for (int j = 0; j < K; ++j) {
+                    const float other = SOLO ? 0.f : mrg[((gw * TM * K + i * K + j) * 16 + r) * 64 + lane];
+                    part[(size_t)m * NG + (size_t)c * K + j] = SC ? (acc[i][j][r] + other) * kfin : acc[i][j][r] + other;
+                }
             }
-    } else if (bx == 0 && gt < BM) {
-        part[(size_t)p.M * NG + m0 + gt] = bsum[gt] + bsum[BM + gt];
+    }
+    if (SOLO ? (bx == 0 && gt < BM) : (g == 1 && bx == 0 && gt < BM)) {
+        part[(size_t)p.M * NG + m0 + gt] = SOLO ? bsum[gt] : bsum[gt] + bsum[BM + gt];
     }
 }
 
@@ -906,12 +926,12 @@ bool wrows3_ok(const WrPlan& q, int K, int TM, bool vec, bool has_yact) {
 // of a 512-thread workgroup may hold (96 accumulators + fragments + the chunk in flight) and spills.  The plan's grid /
 // batching descriptor are re-derived for 64-row tiles; the slab layout does not depend on it.
 // NP = 2 (every problem of a batched launch carries bounds of both operands): block-scaled fp16 x 2, three products.
-template <int TM, int NP, bool GM = false>
+template <int TM, int NP, bool GM = false, bool SOLO = false>
 void launch_wrows3_np(const WrPlan& q, const float* x, const float* gy, const float* y_act, float* partial, hipStream_t s) {
-    const size_t lds = w3_lds_bytes<NP>(64 * TM);
+    const size_t lds = SOLO ? (size_t)(64 * TM) * w3_grs<NP>() + 64 * w3_xrs<NP>() + 2 * 64 * TM * sizeof(float) : w3_lds_bytes<NP>(64 * TM);
     static unsigned long long attr_set = 0;
     if (ms_first_on_device(attr_set)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_rows3<TM, NP, GM>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_rows3<TM, NP, GM, SOLO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         ms_done_on_device(attr_set);
     }
@@ -919,8 +939,8 @@ void launch_wrows3_np(const WrPlan& q, const float* x, const float* gy, const fl
     const int tiles_m = q.p.M / (64 * TM);
     if (mp.n > 0) mp.tiles_m = tiles_m;
     const dim3 grid(q.grid.x, (unsigned)((mp.n > 0 ? mp.n : 1) * tiles_m), q.grid.z);
-    ms_note_kernel(NP == 2 ? 3 : 6, "k_wgrad_rows3<%d, %d, %s>", TM, NP, GM ? "true" : "false");
-    hipLaunchKernelGGL((k_wgrad_rows3<TM, NP, GM>), grid, dim3(512), lds, s, q.p, x, gy, y_act, partial, q.stride_floats, mp);
+    ms_note_kernel(NP == 2 ? 3 : 6, "k_wgrad_rows3<%d, %d, %s, %s>", TM, NP, GM ? "true" : "false", SOLO ? "true" : "false");
+    hipLaunchKernelGGL((k_wgrad_rows3<TM, NP, GM, SOLO>), grid, dim3(SOLO ? 256 : 512), lds, s, q.p, x, gy, y_act, partial, q.stride_floats, mp);
 }
 
 bool wrows3_scaled(const WrPlan& q) {
@@ -932,11 +952,14 @@ bool wrows3_scaled(const WrPlan& q) {
 }
 
 void launch_wrows3(const WrPlan& q, const float* x, const float* gy, const float* y_act, float* partial, hipStream_t s) {
+    // NP = 2 runs the four-wave (SOLO) form: 168 registers and 27 KB of LDS per workgroup instead of 252 / 53 KB -- alone it
+    // takes the same time as the eight-wave form (C = 256: -8 %, 128 / 64: +3 %), but it shares the chip better with the
+    // backward-data chain it runs beside: train step -1.3 % per call over four interleaved A/B pairs (r05)
     if (q.mp.n > 0 && q.mp.signs) {                  // (sign words only travel with the two-piece scheme: checked by the caller)
-        launch_wrows3_np<1, 2, true>(q, x, gy, y_act, partial, s);
+        launch_wrows3_np<1, 2, true, true>(q, x, gy, y_act, partial, s);
         return;
     }
-    if (wrows3_scaled(q)) launch_wrows3_np<1, 2>(q, x, gy, y_act, partial, s);
+    if (wrows3_scaled(q)) launch_wrows3_np<1, 2, false, true>(q, x, gy, y_act, partial, s);
     else launch_wrows3_np<1, 3>(q, x, gy, y_act, partial, s);
 }
 
