@@ -501,7 +501,7 @@ constexpr size_t w3_lds_bytes(int BM) {
 // CU and drift apart, where the two groups of the eight-wave form (kept for NP = 3, whose accumulators need its registers)
 // alternate in lockstep behind two barriers per slot.
 template <int TM, int NP, bool GM = false, bool SOLO = false>
-__global__ __launch_bounds__(SOLO ? 256 : 512) void k_wgrad_rows3(WrP p, const float* __restrict__ X_,
+__global__ __launch_bounds__(SOLO ? 256 : 512, SOLO ? 3 : 2) void k_wgrad_rows3(WrP p, const float* __restrict__ X_,
                                                     const float* __restrict__ G_,
                                                     const float* __restrict__ Gact_,
                                                     float* __restrict__ partial, size_t pstride, WrMulti mp) {
@@ -723,52 +723,54 @@ __global__ __launch_bounds__(SOLO ? 256 : 512) void k_wgrad_rows3(WrP p, const f
             }
         }
     };
-    auto compute_dil = [&]() __attribute__((always_inline)) {
-        if (p.dil == 1) compute(std::integral_constant<int, 1>());
-        else if (p.dil == 3) compute(std::integral_constant<int, 3>());
-        else compute(std::integral_constant<int, 9>());
-    };
-
     const int c_begin = (int)bz * p.cps;
     const int c_end = min(c_begin + p.cps, p.nchunks);
     // Slot 2i: group 0 multiplies its half of chunk i while group 1 stages its half and at once fetches the next;
     // slot 2i + 1: the roles swap.  A fetch so has the rest of its staging slot plus the whole multiply slot to
     // land (one slot did not cover the HBM latency under load).  One straight-line loop per group (the group is
     // wave-uniform): the compiler then waits for a fetch where it is first used, not at a merged back edge.
+    // The dilation is dispatched ONCE, around the whole loop: with the three compute bodies inside one loop the register
+    // allocator gave each its own accumulator registers and moved all 48 of them through the accumulation file on every
+    // iteration (48 v_accvgpr_read + 48 v_accvgpr_write per 18 MFMAs: a third of the kernel's vector instructions, r05).
     const int n = c_end - c_begin;
-    if constexpr (SOLO) {
-        load_chunk(c_begin, c_end, 0);
-        for (int u = 0; u < 2 * n; ++u) {
-            stage();                                 // (waits for unit u's registers)
-            load_chunk(c_begin + ((u + 1) >> 1), c_end, (u + 1) & 1);
-            __syncthreads();                         // tiles staged
-            compute_dil();
-            __syncthreads();                         // tiles free
+    auto main_loop = [&](auto dilc) __attribute__((always_inline)) {
+        if constexpr (SOLO) {
+            load_chunk(c_begin, c_end, 0);
+            for (int u = 0; u < 2 * n; ++u) {
+                stage();                                 // (waits for unit u's registers)
+                load_chunk(c_begin + ((u + 1) >> 1), c_end, (u + 1) & 1);
+                __syncthreads();                         // tiles staged
+                compute(dilc);
+                __syncthreads();                         // tiles free
+            }
+        } else {
+            load_chunk(c_begin, c_end);
+            if (g == 0) {
+                stage();
+                load_chunk(c_begin + 1, c_end);
+                __syncthreads();
+                for (int i = 0; i < n; ++i) {
+                    compute(dilc);
+                    __syncthreads();
+                    stage();
+                    load_chunk(c_begin + i + 2, c_end);
+                    __syncthreads();
+                }
+            } else {
+                __syncthreads();
+                for (int i = 0; i < n; ++i) {
+                    stage();
+                    load_chunk(c_begin + i + 1, c_end);
+                    __syncthreads();
+                    compute(dilc);
+                    __syncthreads();
+                }
+            }
         }
-    } else {
-    load_chunk(c_begin, c_end);
-    if (g == 0) {
-        stage();
-        load_chunk(c_begin + 1, c_end);
-        __syncthreads();
-        for (int i = 0; i < n; ++i) {
-            compute_dil();
-            __syncthreads();
-            stage();
-            load_chunk(c_begin + i + 2, c_end);
-            __syncthreads();
-        }
-    } else {
-        __syncthreads();
-        for (int i = 0; i < n; ++i) {
-            stage();
-            load_chunk(c_begin + i + 1, c_end);
-            __syncthreads();
-            compute_dil();
-            __syncthreads();
-        }
-    }
-    }
+    };
+    if (p.dil == 1) main_loop(std::integral_constant<int, 1>());
+    else if (p.dil == 3) main_loop(std::integral_constant<int, 3>());
+    else main_loop(std::integral_constant<int, 9>());
 
     // ---- merge the two groups and write the slab (layout of k_wgrad_rows)
     float* const mrg = reinterpret_cast<float*>(smem3);                 // [wave][tile][reg][lane]
