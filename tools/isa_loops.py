@@ -11,20 +11,34 @@ for m in re.finditer(r"^(_Z\S+):\s*; @\S+\n(.*?)\n\s*s_endpgm", src, re.S | re.M
     if flt and not all(f in name for f in flt):
         continue
     lines = body.split("\n")
-    heads = [i for i, l in enumerate(lines) if "Inner Loop Header" in l]
-    if not heads:
+    # LLVM annotates basic blocks: ".LBBn_m:  ; =>This Inner Loop Header: Depth=d" and ".LBBn_k:  ;   in Loop: Header=BBn_m Depth=d"
+    blocks, cur = {}, None
+    owner = {}
+    for l in lines:
+        m2 = re.match(r"^(\.LBB\d+_\d+):(.*)$", l)
+        if m2:
+            cur = m2.group(1)
+            blocks[cur] = []
+            c = m2.group(2)
+            if "Inner Loop Header" in c:
+                owner[cur] = cur
+            else:
+                h = re.search(r"in Loop: Header=(BB\d+_\d+)", c)
+                if h:
+                    owner[cur] = ".L" + h.group(1)
+            continue
+        if cur is not None:
+            blocks[cur].append(l)
+    loops = collections.OrderedDict()
+    for blk, hdr in owner.items():
+        loops.setdefault(hdr, []).extend(blocks[blk])
+    inner = [h for h in loops if h in owner and owner[h] == h]
+    if not inner:
         continue
     print(name[:150])
-    for h in heads:
-        label = lines[h].split(":")[0].strip()
-        end = None
-        for j in range(h + 1, len(lines)):
-            if re.search(r"s_cbranch\S*\s+%s\b" % re.escape(label), lines[j]) or re.search(r"s_branch\s+%s\b" % re.escape(label), lines[j]):
-                end = j
-        if end is None:
-            continue
+    for hdr in inner:
         c = collections.Counter()
-        for l in lines[h:end + 1]:
+        for l in loops[hdr]:
             l = l.strip()
             if not l or l.startswith((";", ".")) or l.endswith(":"):
                 continue
@@ -40,4 +54,4 @@ for m in re.finditer(r"^(_Z\S+):\s*; @\S+\n(.*?)\n\s*s_endpgm", src, re.S | re.M
             elif op.startswith("s_barrier"): c["barrier"] += 1
             elif op.startswith("s_"): c["salu"] += 1
         if c["mfma"] or c["valu"] > 40:
-            print("   loop %-10s %4d lines: " % (label, end - h) + "  ".join("%s %d" % (k, c[k]) for k in ("mfma", "valu", "v_mov", "accvgpr", "scratch", "lds", "vmem", "salu", "waitcnt", "barrier") if c[k]))
+            print("   loop %-10s " % hdr + "  ".join("%s %d" % (k, c[k]) for k in ("mfma", "valu", "v_mov", "accvgpr", "scratch", "lds", "vmem", "salu", "waitcnt", "barrier") if c[k]))
