@@ -69,16 +69,16 @@ def _may_fork(device):
 
 
 class _WgradFork:
-    """Weight gradients of the generator on a side stream (MSYNTH_WGSTREAM=0 disables): each layer's
+    """Weight gradients on a side stream (idx: which of the two; MSYNTH_WGSTREAM=0 disables): each layer's
     weight-grad only needs the incoming gradient, so it can run beside the backward-data chain.
     Tensors it reads are kept alive until the join (the caching allocator is per stream)."""
 
-    def __init__(self, device):
-        self.on = os.environ.get("MSYNTH_WGSTREAM", "1") == "1" and _may_fork(device)
+    def __init__(self, device, idx=0):
+        self.on = os.environ.get("MSYNTH_WGSTREAM", "2") != "0" and _may_fork(device)
         self.keep = []
         if self.on:
             self.main = torch.cuda.current_stream(device)
-            self.side = _side_streams(device, 2)[0]
+            self.side = _side_streams(device, 2)[idx]
 
     def run(self, fn, *tensors):
         if not self.on:
@@ -354,6 +354,9 @@ def gen_backward(tape, params, gy, sink=None, need_gx=False, cut=None):
     g = gy
     gx = None
     fork = _WgradFork(gy.device)
+    # (r05: TWO side streams -- the stacks' batched weight gradients on one, the transposed convs' and the first / last conv's on
+    #  the other: -0.85 % per trainer call over six interleaved A/B pairs.  MSYNTH_WGSTREAM=1: one side stream, 0: none)
+    fork_b = _WgradFork(gy.device, 1) if (fork.on and os.environ.get("MSYNTH_WGSTREAM", "2") == "2") else fork
     batch = [] if os.environ.get("MSYNTH_WMULTI", "1") == "1" else None
     deferred = []
     conv0 = tape[0]
@@ -373,7 +376,7 @@ def gen_backward(tape, params, gy, sink=None, need_gx=False, cut=None):
             _, d, h, y = rec
             i -= 2
             gw, gb, acc = sink.pair(i)
-            fork.run(lambda: sink.put(i, *P.conv1d_bwd_weight(h, g, y, d, params[i].shape, gw, gb, acc)), h, g, y)
+            fork_b.run(lambda: sink.put(i, *P.conv1d_bwd_weight(h, g, y, d, params[i].shape, gw, gb, acc)), h, g, y)
             g = P.conv1d_bwd_data(g, y, params[i], d)
         elif kind == "atom":
             i -= 4
@@ -385,6 +388,8 @@ def gen_backward(tape, params, gy, sink=None, need_gx=False, cut=None):
             gw, gb, acc = sink.pair(i)
             if i == 2 and cut is not None:
                 fork.join()                          # slots G_TAIL_PARAM.. are complete on the main stream
+                if fork_b is not fork:
+                    fork_b.join()
                 cut()
             if i == 2 and fork.on:
                 # the FIRST transposed conv is processed last: by then the side stream still holds the last
@@ -394,13 +399,13 @@ def gen_backward(tape, params, gy, sink=None, need_gx=False, cut=None):
                     sink.put(i, *P.convt1d_bwd_weight(hin, g, h, dt, params[i].shape, gw, gb, acc))
                 deferred.append(late)
             else:
-                fork.run(lambda: sink.put(i, *P.convt1d_bwd_weight(hin, g, h, dt, params[i].shape, gw, gb, acc)), hin, g, h)
+                fork_b.run(lambda: sink.put(i, *P.convt1d_bwd_weight(hin, g, h, dt, params[i].shape, gw, gb, acc)), hin, g, h)
             g = P.convt1d_bwd_data(g, h, params[i], dt, img=images_bwd.get(i))
         else:  # conv0 (reflection-padded): the gradient reaches the mel features only on request
             _, d, x, h = rec
             i -= 2
             gw, gb, acc = sink.pair(i)
-            fork.run(lambda: sink.put(i, *P.conv1d_bwd_weight(x, g, h, d, params[i].shape, gw, gb, acc)), x, g, h)
+            fork_b.run(lambda: sink.put(i, *P.conv1d_bwd_weight(x, g, h, d, params[i].shape, gw, gb, acc)), x, g, h)
             if need_gx:
                 gx = P.conv1d_bwd_data(g, h, params[i], d)
     if batch:
@@ -408,6 +413,8 @@ def gen_backward(tape, params, gy, sink=None, need_gx=False, cut=None):
     for fn in deferred:
         fn()
     fork.join()
+    if fork_b is not fork:
+        fork_b.join()
     assert i == 0
     return sink, gx
 
@@ -576,9 +583,14 @@ def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, nee
     def own(s, li):
         return g_feats[s][li] if (g_feats is not None and g_feats[s] is not None and li >= 0) else None
 
-    # the weight gradients only need the chain's gradients, never the other way round: they run on a side stream beside the
+    # the weight gradients only need the chain's gradients, never the other way round: they run on side streams beside the
     # backward-data chain (MSYNTH_DWGSTREAM=0: on the caller's stream)
-    fork = _WgradFork(xs[0].device) if (need_wgrad and os.environ.get("MSYNTH_DWGSTREAM", "1") != "0") else None
+    # (r05: on TWO side streams -- the head's (k5 layer, judge conv: final first, the data-parallel cut waits for them) on one,
+    #  the grouped layers' and the first conv's on the other: -1 % per trainer call over ten interleaved A/B pairs, the D-step's
+    #  weight-gradient chain (0.46 ms) is longer than the backward-data chain it runs beside (0.27).  MSYNTH_DWGSTREAM=1: one)
+    mode = os.environ.get("MSYNTH_DWGSTREAM", "2")
+    fork = _WgradFork(xs[0].device) if (need_wgrad and mode != "0") else None
+    fork2 = _WgradFork(xs[0].device, 1) if (fork is not None and mode == "2") else None
 
     def wgrad(slot, live, xs_, gys, yas, d, w_shape):
         gw, gb, acc = sink.pair(slot)
@@ -587,7 +599,7 @@ def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, nee
         def go():
             sink.put(slot, *P.conv1d_parts_bwd_weight(a, b_, c, d, w_shape, gw, gb, acc))
         if fork is not None:
-            fork.run(go, *(a + b_ + (c or [])))
+            (fork2 if (fork2 is not None and slot < D_HEAD_PARAM) else fork).run(go, *(a + b_ + (c or [])))
         else:
             go()
 
@@ -633,6 +645,8 @@ def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, nee
             cut()
     if fork is not None:
         fork.join()
+    if fork2 is not None:
+        fork2.join()
     gx_next = None
     for s in range(n - 1, -1, -1):
         gx = g[s]
