@@ -355,8 +355,10 @@ def gen_backward(tape, params, gy, sink=None, need_gx=False, cut=None):
     gx = None
     fork = _WgradFork(gy.device)
     # (r05: TWO side streams -- the stacks' batched weight gradients on one, the transposed convs' and the first / last conv's on
-    #  the other: -0.85 % per trainer call over six interleaved A/B pairs.  MSYNTH_WGSTREAM=1: one side stream, 0: none)
-    fork_b = _WgradFork(gy.device, 1) if (fork.on and os.environ.get("MSYNTH_WGSTREAM", "2") == "2") else fork
+    #  the other: -0.85 % per trainer call over six interleaved A/B pairs.  MSYNTH_WGSTREAM=1: one side stream, 0: none.
+    #  Not under the data-parallel schedule (cut given): there the pass is cut into graph segments at a join of all weight
+    #  gradients so far, and the second stream measured +2 % on that path.)
+    fork_b = _WgradFork(gy.device, 1) if (fork.on and cut is None and os.environ.get("MSYNTH_WGSTREAM", "2") == "2") else fork
     batch = [] if os.environ.get("MSYNTH_WMULTI", "1") == "1" else None
     deferred = []
     conv0 = tape[0]
@@ -590,7 +592,7 @@ def melgan_backward(ctx, params, g_feats, g_judges, sink=None, need_gx=True, nee
     #  weight-gradient chain (0.46 ms) is longer than the backward-data chain it runs beside (0.27).  MSYNTH_DWGSTREAM=1: one)
     mode = os.environ.get("MSYNTH_DWGSTREAM", "2")
     fork = _WgradFork(xs[0].device) if (need_wgrad and mode != "0") else None
-    fork2 = _WgradFork(xs[0].device, 1) if (fork is not None and mode == "2") else None
+    fork2 = _WgradFork(xs[0].device, 1) if (fork is not None and mode == "2" and cut is None) else None   # (single-graph step only)
 
     def wgrad(slot, live, xs_, gys, yas, d, w_shape):
         gw, gb, acc = sink.pair(slot)
