@@ -237,6 +237,8 @@ int ms_conv1d_fwd(const ms_conv1d_desc* d, const float* x, const float* w, const
     const int xk = p.in_act ? MS_MOD_LRELU_FWD : 0;
     if (mst_fwd_short_applicable(p) && !y_act && !residual)   // judge conv: a 12-MFLOP reduction, not a GEMM
         return mst_conv1d_fwd(p, x, w, bias, residual, y, s);
+    if (!y_act && !residual && mss_conv_applicable(p))        // a few dozen columns in the whole batch: a weight stream
+        return mss_conv_fwd(p, x, w, bias, y, s);
     if (msm_fwd_applicable(p) && pad4_applicable(p) && !residual && !y_act) {
         const ConvP q = pad4_conv(p);
         const size_t xb = pad4_bytes(q, p.Cin), yb = pad4_bytes(q, p.Cout);
@@ -616,6 +618,7 @@ const char* ms_conv1d_kernel_name(const ms_conv1d_desc* d, int which) {
     ConvP p;
     if (!make_conv(d, &p)) return "";
     if (which == 0 && mst_fwd_short_applicable(p)) return mst_fwd_name(p);
+    if (which == 0 && mss_conv_applicable(p)) return mss_conv_name(p);
     // (rows padded to a multiple of 4, see pad4_applicable: the kernel of the padded problem)
     if (which == 0 && msm_fwd_applicable(p) && pad4_applicable(p)) return msm_fwd_name(pad4_conv(p));
     if (which == 1 && msm_bwd_data_applicable(p) && pad4_applicable(p)) return msm_bwd_data_name(pad4_conv(p));
@@ -655,6 +658,7 @@ const char* ms_convt1d_kernel_name(const ms_convt1d_desc* d, int which) {
     ConvP p;
     if (!make_convt(d, &p)) return "";
     if (which == 0 && mst_convt1_applicable(p)) return mst_convt1_fwd_name();
+    if (which == 0 && mss_convt_applicable(d)) return mss_convt_name(d);
     if (which == 2 && mst_convt1_applicable(p)) return mst_convt1_wgrad_name();
     if (which == 0) return msm_convt_fwd_applicable(p) ? msm_convt_fwd_name(p) : msk_conv1d_bwd_data_direct_name(p);
     if (which == 1) {
@@ -684,6 +688,10 @@ int ms_convt1d_fwd(const ms_convt1d_desc* d, const float* x, const float* w, con
     if (!make_convt(d, &p) || !x || !w || !y) return MS_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (mst_convt1_applicable(p)) return mst_convt1_fwd(p, x, w, bias, y, s);      // one output channel: a stream
+    if (mss_convt_applicable(d)) {                                                 // inference batch: a weight stream
+        const int rc = mss_convt_fwd(d, x, w, bias, y, s);
+        if (rc != MS_ERR_UNSUPPORTED) return rc;
+    }
     if (msm_convt_fwd_applicable(p))
         return msm_convt1d_fwd(p, x, w, bias, y, workspace, workspace_bytes, s);
     ConvP q = p;     // direct path: the loader modifier kind rides in q.act, the epilogue gets p.act

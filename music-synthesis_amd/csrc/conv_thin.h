@@ -27,3 +27,12 @@ int mst_convt1_fwd(const ConvP& p, const float* x, const float* w, const float* 
 size_t mst_convt1_wgrad_ws(const ConvP& p);
 int mst_convt1_bwd_weight(const ConvP& p, const float* x, const float* gy, const float* y_act, float* gw, float beta,
                           void* ws, size_t ws_bytes, hipStream_t s);
+
+// small_rows.hip: the generator's first conv and first transposed conv at inference batch sizes (a few dozen columns in the
+// whole batch): weight streams spread over the chip, fp32 FMA, no weight image
+bool mss_conv_applicable(const ConvP& p);
+const char* mss_conv_name(const ConvP& p);
+int mss_conv_fwd(const ConvP& p, const float* x, const float* w, const float* bias, float* y, hipStream_t s);
+bool mss_convt_applicable(const ms_convt1d_desc* d);
+const char* mss_convt_name(const ms_convt1d_desc* d);
+int mss_convt_fwd(const ms_convt1d_desc* d, const float* x, const float* w, const float* bias, float* y, hipStream_t s);

@@ -388,6 +388,62 @@ def test_convt_paired_split_kernel(shape, in_act):
     assert float((y.double() - ref).norm() / ref.norm()) < 1e-6
 
 
+@pytest.mark.parametrize("shape", [(1, 256, 256, 128, 8), (1, 128, 2048, 64, 2), (1, 64, 4096, 32, 2), (2, 256, 100, 128, 8),
+                                   (1, 48, 70, 16, 2), (3, 20, 65, 6, 8), (1, 512, 64, 256, 8)],
+                         ids=["cfg2_convt2", "cfg2_convt3", "cfg2_convt4", "tile_tail_B2", "s2_partial_round", "s8_one_partial_round",
+                              "one_tile_16_rounds"])
+@pytest.mark.parametrize("in_act", [0, 1])
+def test_convt_small_batch_weight_stream(shape, in_act):
+    """ConvTranspose1d (kernel 2 S / stride S / padding S / 2) + LeakyReLU at INFERENCE batch sizes -- BASELINE config 2's
+    upsampling layers on long rows at B = 1 (generator/full.py:31-40) -- on the fp32 vector-FMA kernel of csrc/small_rows.hip
+    (64 positions x 32 / 2 S output channels per workgroup) against the same op in float64: the three config-2 shapes, a tile
+    tail, input-channel counts that leave a partial LDS round, with and without the activation in front; every output element
+    written; launch-to-launch determinism.  fp32 products and sums: 1e-6."""
+    import torch.nn.functional as TF
+    from featuresynth._ops import prims as P
+    B, Cin, Lin, Cout, S = shape
+    g = torch.Generator(device="cuda").manual_seed(stable_seed("convtsmall%s%d" % (shape, in_act)) % (1 << 31))
+    x = torch.randn(B, Cin, Lin, device="cuda", generator=g)
+    w = torch.randn(Cin, Cout, 2 * S, device="cuda", generator=g) * 0.05
+    b = torch.randn(Cout, device="cuda", generator=g)
+    d, lo = P.convt_desc(x.shape, w.shape, S, S // 2, act=1, in_act=in_act)
+    assert "k_convt_long" in P.L.load().ms_convt1d_kernel_name(d, 0).decode()
+    y = torch.full((B, Cout, lo), float("nan"), device="cuda")            # every output element must be written
+    P.convt1d_fwd(x, w, b, d, lo, out=y)
+    xin = TF.leaky_relu(x.double(), 0.2) if in_act else x.double()
+    ref = TF.leaky_relu(TF.conv_transpose1d(xin, w.double(), b.double(), stride=S, padding=S // 2), 0.2)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert float((y.double() - ref).norm() / ref.norm()) < 1e-6
+    y2 = torch.empty_like(y)
+    P.convt1d_fwd(x, w, b, d, lo, out=y2)
+    assert torch.equal(y, y2), "launch-to-launch determinism"
+
+
+@pytest.mark.parametrize("shape", [(1, 80, 32, 512, 3, 1), (1, 80, 4, 512, 3, 1), (2, 80, 50, 512, 3, 1), (1, 128, 100, 128, 3, 0),
+                                   (4, 16, 7, 132, 0, 0)],
+                         ids=["cfg2_first_conv", "smoke_T4", "tile_tail_B2", "zero_pad_4_tiles", "valid_conv_one_column"])
+def test_conv_small_batch_weight_stream(shape):
+    """Conv1d k7 behind ReflectionPad1d(3) (or zero padding) + LeakyReLU at inference batch sizes -- the generator's first layer
+    in BASELINE config 2 (generator/full.py:23-25) -- on the fp32 weight-stream kernel (csrc/small_rows.hip) against float64:
+    reflection at rows shorter than a tile (4 positions: every tap of the edge windows is mirrored), a tile tail, zero padding,
+    no padding."""
+    import torch.nn.functional as TF
+    from featuresynth._ops import prims as P
+    B, Cin, Lin, Cout, pad, reflect = shape
+    g = torch.Generator(device="cuda").manual_seed(stable_seed("convsmall%s" % (shape,)) % (1 << 31))
+    x = torch.randn(B, Cin, Lin, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, 7, device="cuda", generator=g) * 0.05
+    b = torch.randn(Cout, device="cuda", generator=g)
+    d, lo = P.conv_desc(x.shape, w.shape, pad=pad, pad_mode=P.L.PAD_REFLECT if reflect else P.L.PAD_ZERO, act=P.L.ACT_LRELU)
+    assert "k_conv_small" in P.L.load().ms_conv1d_kernel_name(d, 0).decode()
+    y = torch.full((B, Cout, lo), float("nan"), device="cuda")
+    P.conv1d_fwd(x, w, b, d, lo, out=y)
+    xin = TF.pad(x.double(), (pad, pad), mode="reflect") if reflect else x.double()
+    ref = TF.leaky_relu(TF.conv1d(xin, w.double(), b.double(), padding=0 if reflect else pad), 0.2)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert float((y.double() - ref).norm() / ref.norm()) < 1e-6
+
+
 def test_bad_arguments_raise():
     from featuresynth._ops import functional as F_
     x = torch.zeros(1, 4, 16, device="cuda")
