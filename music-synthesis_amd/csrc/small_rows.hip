@@ -1,21 +1,24 @@
 // The generator at INFERENCE batch sizes (BASELINE config 2: B = 1, 32 frames; generator/full.py:23-40): the first conv
-// (nn.Conv1d(80, 512, 7) behind ReflectionPad1d(3)) and the upsampling layers on long rows (nn.ConvTranspose1d 256 -> 128 /
-// k16 s8 on 256 positions, 128 -> 64 and 64 -> 32 / k4 s2 on 2048 and 4096), each + LeakyReLU.  With one batch row these are
-// 18 / 134 / 67 / 34 MFLOP: nothing for the vector pipe, but 10 + 15 + 13 + 11 us on the row-tile matrix kernels, whose
-// tiles (64+ rows x 128+ columns per workgroup, operands split for the 16-bit matrix pipe) give such a layer a few dozen
-// workgroups and a launch-latency-sized critical path.  Here: plain fp32 FMA (exact fp32 products), ~256 small workgroups,
-// no weight image, no pack launch, one launch per layer.  Measured at B = 1 (tools/gfwd_b1.py --list, us): 10.1 -> 4.4,
-// 15.0 -> 11.5, 13.1 -> 5.6, 11.2 -> 1.7; the 30-layer forward 237 -> 219 us.  Dispatched only while the whole layer is at
-// most two workgroups per CU (conv: four tiles of 32 positions): the train step (B = 32) never comes here.
+// (nn.Conv1d(80, 512, 7) behind ReflectionPad1d(3)) and the four upsampling layers (nn.ConvTranspose1d 512 -> 256 and 256 -> 128
+// / k16 s8 on 32 and 256 positions, 128 -> 64 and 64 -> 32 / k4 s2 on 2048 and 4096), each + LeakyReLU.  With one batch row these
+// are 18 / 67 / 134 / 67 / 34 MFLOP: nothing for the vector pipe, but 10 + 20 + 15 + 13 + 11 us on the row-tile matrix kernels,
+// whose tiles (64+ rows x 128+ columns per workgroup, operands split for the 16-bit matrix pipe) give such a layer a few dozen
+// workgroups and a launch-latency-sized critical path.  Here: plain fp32 FMA (exact fp32 products), up to 256 small
+// workgroups, no weight image, no pack launch, one launch per layer.  Measured at B = 1 (tools/gfwd_b1.py --list, us):
+// 10.1 -> 5.0, 20.4 -> 20.5, 15.0 -> 10.4, 13.1 -> 4.5, 11.2 -> 1.4; the 30-layer forward 237.5 -> 214.0 us.  Dispatched only while
+// the whole layer is at most two workgroups per CU (conv: four tiles of 32 positions): the train step (B = 32) never comes here.
 //
-// k_convt_long<S, R> ConvTranspose1d, kernel 2 S / stride S / padding S / 2, rows of >= 64 positions:
-//     y[b, co, j S + k - S/2] = sum_ci x[b, ci, j] w[ci, co, k].  A workgroup owns 64 input positions j x R output channels
-//     (R 2 S = 32 weights per input channel, CONTIGUOUS in w[ci, co, k]) and writes the S outputs j S .. j S + S - 1 of each:
-//     output j S + r takes taps (j, r + S/2) and (j - 1, r + S/2 + S) for r < S/2, (j + 1, r - S/2) and (j, r + S/2)
-//     otherwise -- three window values per channel and lane for 32 FMAs.  Input channels in rounds of 64 through LDS (window
-//     rows of 66, the 64 x 32 weights; wave-uniform 16-byte weight reads are broadcasts); inside a round wave v walks channels
-//     [16 v, 16 v + 16).  The four waves' partial sums meet in LDS; wave v finishes a quarter of the 16 accumulators, adding in
-//     wave order (deterministic), + bias + activation.  1024 waves at B = 1 for each of the three layers.
+// k_convt_lanes<S>   ConvTranspose1d, kernel 2 S / stride S / padding S / 2:  y[b, co, j S + k - S/2] = sum_ci x[b, ci, j] w[ci, co, k].
+//     A workgroup owns 16 input positions x 64 / S output channels; a wave's LANES are the (output channel, output phase r)
+//     pairs and every lane keeps the 16 outputs j S + r of its pair: output j S + r takes taps (j, r + S/2) and
+//     (j - 1, r + S/2 + S) for r < S/2, (j + 1, r - S/2) and (j, r + S/2) otherwise -- per input channel a lane reads its OWN two
+//     weights and the 17 window values as wave broadcasts (two addresses per read: the two phase halves look one position apart)
+//     for 32 FMAs.  (A first form with lanes = positions read all 32 weights of a channel as 16-byte broadcasts: 64 LDS cycles
+//     per wave and channel, x 4 waves per CU = twice the FMA time.)  Input channels in rounds of 64 through LDS (64 x 128
+//     weights, CONTIGUOUS 512-byte runs of w[ci, co, k]; window rows of 18); inside a round wave v walks channels
+//     [16 v, 16 v + 16).  The four waves' partial sums meet in LDS; wave v finishes four of the 16 positions, adding in wave order
+//     (deterministic), + bias + activation; lanes of one channel store 4 S contiguous bytes.  Partial channel groups, partial
+//     rounds and tile tails are masked.
 // k_conv_small<K>    Conv1d, stride 1, dilation 1, one group, zero or reflection padding, tiles of 32 output positions:
 //     thread = (half of the input channels, output channel of 4, position of 32); window and weights from LDS; 128 workgroups
 //     x 9 KB of weights for the 80 -> 512 layer.
@@ -37,28 +40,29 @@ struct CtsP {
 // in flight per thread and the round takes (elements per thread) x (memory latency) -- measured on the first form of
 // k_conv_small: 9.8 us, 4.5 us since.  The NEXT round's loads are issued before the current round's arithmetic.
 constexpr int CL_CR = 64;         // input channels per LDS round
-constexpr int CL_XS = 66;         // 64 positions + one either side
+constexpr int CL_JT = 16;         // input positions per workgroup
+constexpr int CL_XS = 18;         // window columns per channel: positions jt 16 - 1 .. jt 16 + 16
 
-template <int S, int R>
-__global__ __launch_bounds__(256) void k_convt_long(const CtsP p, const float* __restrict__ x, const float* __restrict__ w,
-                                                    const float* __restrict__ bias, float* __restrict__ y) {
-    constexpr int K = 2 * S, NA = R * S;
-    static_assert(R * K == 32 && NA == 16, "32 weights per input channel, 16 accumulators");
-    constexpr int NX = CL_CR * CL_XS;                  // 4224 window values per round
-    constexpr int XPT = (NX + 255) / 256;              // 17
-    constexpr int WPT = CL_CR * 8 / 256;               // 16-byte pieces of a round's weights per thread
-    __shared__ float xl[NX];
-    __shared__ __attribute__((aligned(16))) float wl[CL_CR * 32];
-    __shared__ float red[4 * NA * 64];
-    const int jt = blockIdx.x, co0 = blockIdx.y * R, b = blockIdx.z;
+template <int S>
+__global__ __launch_bounds__(256) void k_convt_lanes(const CtsP p, const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ y) {
+    constexpr int K = 2 * S, CG = 64 / S;              // a wave's lanes = CG output channels x S output phases
+    constexpr int WROW = CG * K;                       // 128 weights per input channel, contiguous in w[ci, co, k]
+    constexpr int NX = CL_CR * CL_XS;                  // 1152 window values per round
+    constexpr int XPT = (NX + 255) / 256;              // 5
+    constexpr int WPT = CL_CR * WROW / 4 / 256;        // 8 pieces of 16 bytes per thread and round
+    __shared__ float xl[NX + 2];
+    __shared__ __attribute__((aligned(16))) float wl[CL_CR * WROW];
+    __shared__ float red[4 * CL_JT * 64];
+    const int jt = blockIdx.x, co0 = blockIdx.y * CG, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int j = jt * 64 + lane;
-    const bool in = j < p.Lin;
-    float acc[R][S];
+    const int col = lane / S, r = lane % S;
+    const int hi = r >= S / 2 ? 1 : 0;
+    // output j S + r of position j: taps (j, r + S/2) and (j - 1, r + S/2 + S) for r < S/2, (j + 1, r - S/2) and (j, r + S/2) otherwise
+    const int ka = hi ? r - S / 2 : r + S / 2, kb = hi ? r + S / 2 : r + S / 2 + S;
+    float acc[CL_JT];
 #pragma unroll
-    for (int q = 0; q < R; ++q)
-#pragma unroll
-        for (int r = 0; r < S; ++r) acc[q][r] = 0.f;
+    for (int i = 0; i < CL_JT; ++i) acc[i] = 0.f;
     const float* xb = x + (size_t)b * p.Cin * p.Lin;
     float xv[XPT];
     f32x4 wq[WPT];
@@ -67,14 +71,16 @@ __global__ __launch_bounds__(256) void k_convt_long(const CtsP p, const float* _
         for (int u = 0; u < XPT; ++u) {
             const int e = tid + 256 * u;
             const int c = e / CL_XS, m = e - c * CL_XS;
-            const int jj = jt * 64 - 1 + m;            // column m of a row holds x[jt 64 - 1 + m]; zero outside the row
+            const int jj = jt * CL_JT - 1 + m;         // column m of a row holds x[jt 16 - 1 + m]; zero outside the row
             xv[u] = (e < NX && c0 + c < p.Cin && jj >= 0 && jj < p.Lin) ? xb[(size_t)(c0 + c) * p.Lin + jj] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < WPT; ++u) {                 // channel x 8 pieces of 16 bytes: the R output channels' 2 S taps
-            const int c = (tid + 256 * u) >> 3, part = tid & 7;
-            wq[u] = (c0 + c < p.Cin) ? *reinterpret_cast<const f32x4*>(w + ((size_t)(c0 + c) * p.Cout + co0) * K + part * 4)
-                                     : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < WPT; ++u) {
+            const int e = tid + 256 * u;
+            const int c = e / (WROW / 4), part = e % (WROW / 4);
+            const bool ok = c0 + c < p.Cin && co0 + part / (K / 4) < p.Cout;
+            wq[u] = ok ? *reinterpret_cast<const f32x4*>(w + ((size_t)(c0 + c) * p.Cout + co0) * K + part * 4)
+                       : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
     fetch(0);
@@ -96,38 +102,31 @@ __global__ __launch_bounds__(256) void k_convt_long(const CtsP p, const float* _
         const int cb = wv * (CL_CR / 4);
 #pragma unroll 2
         for (int c = cb; c < cb + CL_CR / 4; ++c) {
-            const float xm = xl[c * CL_XS + lane], x0 = xl[c * CL_XS + lane + 1], x1 = xl[c * CL_XS + lane + 2];
-            float wr[32];
+            const float wa = wl[c * WROW + col * K + ka], wb = wl[c * WROW + col * K + kb];
+            const float* xr = xl + c * CL_XS + hi;      // two addresses per wave: a broadcast each
+            float prev = xr[0];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(wl + c * 32 + i * 4);      // wave-uniform address: a broadcast
-                wr[4 * i] = t.x; wr[4 * i + 1] = t.y; wr[4 * i + 2] = t.z; wr[4 * i + 3] = t.w;
-            }
-#pragma unroll
-            for (int q = 0; q < R; ++q) {
-#pragma unroll
-                for (int r = 0; r < S; ++r) {
-                    if (r < S / 2) acc[q][r] = fmaf(wr[q * K + r + S / 2], x0, fmaf(wr[q * K + r + S / 2 + S], xm, acc[q][r]));
-                    else acc[q][r] = fmaf(wr[q * K + r - S / 2], x1, fmaf(wr[q * K + r + S / 2], x0, acc[q][r]));
-                }
+            for (int i = 0; i < CL_JT; ++i) {
+                const float cur = xr[i + 1];
+                acc[i] = fmaf(wa, cur, fmaf(wb, prev, acc[i]));
+                prev = cur;
             }
         }
     }
 #pragma unroll
-    for (int q = 0; q < R; ++q)
-#pragma unroll
-        for (int r = 0; r < S; ++r) red[(wv * NA + q * S + r) * 64 + lane] = acc[q][r];
+    for (int i = 0; i < CL_JT; ++i) red[(wv * CL_JT + i) * 64 + lane] = acc[i];
     __syncthreads();
+    const int co = co0 + col;
+    const float bv = (bias && co < p.Cout) ? bias[co] : 0.f;
 #pragma unroll
-    for (int i = 0; i < NA / 4; ++i) {
-        const int a = wv * (NA / 4) + i;
-        float v = red[a * 64 + lane];
-        v += red[(NA + a) * 64 + lane];
-        v += red[(2 * NA + a) * 64 + lane];
-        v += red[(3 * NA + a) * 64 + lane];
-        const int q = a / S, r = a % S;
-        if (in)
-            y[((size_t)b * p.Cout + co0 + q) * p.Lout + (size_t)j * S + r] = ms_apply_act(v + (bias ? bias[co0 + q] : 0.f), p.act, p.slope);
+    for (int i = 0; i < CL_JT / 4; ++i) {
+        const int jl = wv * (CL_JT / 4) + i;
+        float v = red[jl * 64 + lane];
+        v += red[(CL_JT + jl) * 64 + lane];
+        v += red[(2 * CL_JT + jl) * 64 + lane];
+        v += red[(3 * CL_JT + jl) * 64 + lane];
+        const int j = jt * CL_JT + jl;
+        if (j < p.Lin && co < p.Cout) y[((size_t)b * p.Cout + co) * p.Lout + (size_t)j * S + r] = ms_apply_act(v + bv, p.act, p.slope);
     }
 }
 
@@ -209,7 +208,7 @@ bool small_rows_on() {
     return on != 0;
 }
 
-// 64 positions x (32 / 2 S) output channels per workgroup, while that is at most two workgroups per CU
+// 16 positions x (64 / S) output channels per workgroup, while that is at most two workgroups per CU
 bool ctl_plan(const ms_convt1d_desc* d, CtsP* q) {
     if (!d || !small_rows_on()) return false;
     const int S = d->stride;
@@ -217,14 +216,10 @@ bool ctl_plan(const ms_convt1d_desc* d, CtsP* q) {
     if (d->K != 2 * S || d->pad != S / 2) return false;
     if (d->in_act != MS_ACT_NONE && d->in_act != MS_ACT_LRELU) return false;
     if (d->act < MS_ACT_NONE || d->act > MS_ACT_TANH) return false;
-    if (d->B <= 0 || d->B > 65535 || d->Cin < 16 || d->Cout <= 0) return false;
-    // rows shorter than a tile leave lanes idle and the layer is then all weights (512 -> 256 on 32 positions: 8.4 MB; 22.9 us
-    // here against 20.4 us on the row-tile kernel; a one-workgroup-per-output-channel form took 39 us -- DESIGN section 8)
-    if (d->Lin < 64) return false;
-    const int R = 16 / S;
-    if (d->Cout % R) return false;
-    const long long groups = (long long)ms_ceil_div(d->Lin, 64) * (d->Cout / R) * d->B;
-    if (groups > 512 || d->Cout / R > 65535) return false;                            // beyond that the matrix kernels
+    if (d->B <= 0 || d->B > 65535 || d->Cin < 16 || d->Cout <= 0 || d->Lin <= 0) return false;
+    const int CG = 64 / S;
+    const long long groups = (long long)ms_ceil_div(d->Lin, CL_JT) * ms_ceil_div(d->Cout, CG) * d->B;
+    if (groups > 512 || ms_ceil_div(d->Cout, CG) > 65535) return false;               // beyond that the matrix kernels
     if ((long long)d->B * d->Cout * d->Lin * S >= (1ll << 31)) return false;
     q->B = d->B; q->Cin = d->Cin; q->Cout = d->Cout; q->Lin = d->Lin; q->Lout = d->Lin * S;
     q->act = d->act; q->in_act = d->in_act; q->slope = d->slope;
@@ -238,16 +233,16 @@ bool mss_convt_applicable(const ms_convt1d_desc* d) {
     return ctl_plan(d, &q);
 }
 
-const char* mss_convt_name(const ms_convt1d_desc* d) { return d->stride == 8 ? "k_convt_long<8, 2>" : "k_convt_long<2, 8>"; }
+const char* mss_convt_name(const ms_convt1d_desc* d) { return d->stride == 8 ? "k_convt_lanes<8>" : "k_convt_lanes<2>"; }
 
 int mss_convt_fwd(const ms_convt1d_desc* d, const float* x, const float* w, const float* bias, float* y, hipStream_t s) {
     CtsP q;
     if (!ctl_plan(d, &q)) return MS_ERR_UNSUPPORTED;
     if (((uintptr_t)w) & 15) return MS_ERR_UNSUPPORTED;          // (16-byte weight loads: the caller falls through to the row-tile kernels)
     ms_note_kernel(0, "%s", mss_convt_name(d));
-    const dim3 grid(ms_ceil_div(q.Lin, 64), q.Cout / (16 / d->stride), q.B);
-    if (d->stride == 8) hipLaunchKernelGGL((k_convt_long<8, 2>), grid, dim3(256), 0, s, q, x, w, bias, y);
-    else hipLaunchKernelGGL((k_convt_long<2, 8>), grid, dim3(256), 0, s, q, x, w, bias, y);
+    const dim3 grid(ms_ceil_div(q.Lin, CL_JT), ms_ceil_div(q.Cout, 64 / d->stride), q.B);
+    if (d->stride == 8) hipLaunchKernelGGL(k_convt_lanes<8>, grid, dim3(256), 0, s, q, x, w, bias, y);
+    else hipLaunchKernelGGL(k_convt_lanes<2>, grid, dim3(256), 0, s, q, x, w, bias, y);
     MS_CHECK_LAUNCH();
     return MS_OK;
 }

@@ -389,16 +389,17 @@ def test_convt_paired_split_kernel(shape, in_act):
 
 
 @pytest.mark.parametrize("shape", [(1, 256, 256, 128, 8), (1, 128, 2048, 64, 2), (1, 64, 4096, 32, 2), (2, 256, 100, 128, 8),
-                                   (1, 48, 70, 16, 2), (3, 20, 65, 6, 8), (1, 512, 64, 256, 8)],
-                         ids=["cfg2_convt2", "cfg2_convt3", "cfg2_convt4", "tile_tail_B2", "s2_partial_round", "s8_one_partial_round",
-                              "one_tile_16_rounds"])
+                                   (1, 48, 70, 16, 2), (3, 20, 65, 6, 8), (1, 512, 32, 256, 8), (2, 512, 4, 256, 8), (1, 64, 1, 32, 2)],
+                         ids=["cfg2_convt2", "cfg2_convt3", "cfg2_convt4", "tile_tail_B2", "s2_partial_round_and_channel_group",
+                              "s8_partial_round_and_channel_group", "cfg2_convt1", "smoke_T4", "one_position"])
 @pytest.mark.parametrize("in_act", [0, 1])
 def test_convt_small_batch_weight_stream(shape, in_act):
     """ConvTranspose1d (kernel 2 S / stride S / padding S / 2) + LeakyReLU at INFERENCE batch sizes -- BASELINE config 2's
-    upsampling layers on long rows at B = 1 (generator/full.py:31-40) -- on the fp32 vector-FMA kernel of csrc/small_rows.hip
-    (64 positions x 32 / 2 S output channels per workgroup) against the same op in float64: the three config-2 shapes, a tile
-    tail, input-channel counts that leave a partial LDS round, with and without the activation in front; every output element
-    written; launch-to-launch determinism.  fp32 products and sums: 1e-6."""
+    four upsampling layers at B = 1 (generator/full.py:27-40) -- on the fp32 vector-FMA kernel of csrc/small_rows.hip (16
+    positions x 64 / S output channels per workgroup, lanes own (output channel, phase) pairs) against the same op in float64: the
+    four config-2 shapes, a tile tail, input-channel counts that leave a partial LDS round, output-channel counts that leave a
+    partial channel group, rows shorter than a tile, with and without the activation in front; every output element written;
+    launch-to-launch determinism.  fp32 products and sums: 1e-6."""
     import torch.nn.functional as TF
     from featuresynth._ops import prims as P
     B, Cin, Lin, Cout, S = shape
@@ -407,7 +408,7 @@ def test_convt_small_batch_weight_stream(shape, in_act):
     w = torch.randn(Cin, Cout, 2 * S, device="cuda", generator=g) * 0.05
     b = torch.randn(Cout, device="cuda", generator=g)
     d, lo = P.convt_desc(x.shape, w.shape, S, S // 2, act=1, in_act=in_act)
-    assert "k_convt_long" in P.L.load().ms_convt1d_kernel_name(d, 0).decode()
+    assert "k_convt_lanes" in P.L.load().ms_convt1d_kernel_name(d, 0).decode()
     y = torch.full((B, Cout, lo), float("nan"), device="cuda")            # every output element must be written
     P.convt1d_fwd(x, w, b, d, lo, out=y)
     xin = TF.leaky_relu(x.double(), 0.2) if in_act else x.double()
