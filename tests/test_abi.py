@@ -35,6 +35,28 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert set(lib.SIGNATURES) == set(syms)
 
 
+def test_integration_md_lists_every_entry_point():
+    """INTEGRATION.md's table (entry point -> the reference interface it replaces) covers every symbol the header declares,
+    spelled out, through the table's `ms_stem_a / _b` and `(+ _suffix)` shorthands, or through a `ms_*_suffix` row."""
+    lines = open(os.path.join(ROOT, "INTEGRATION.md")).read().splitlines()
+
+    def covered(sym):
+        parts = sym.split("_")
+        for ln in lines:
+            if sym in ln:
+                return True
+            for i in range(2, len(parts)):
+                stem, rest = "_".join(parts[:i]), "_" + "_".join(parts[i:])
+                if ("ms_*" + rest) in ln:
+                    return True
+                if re.search("`" + re.escape(stem) + r"[a-z0-9_]*\b", ln) and (rest in ln or (stem + "_*") in ln):
+                    return True
+        return False
+
+    missing = [s for s in declared_symbols() if not covered(s)]
+    assert not missing, "INTEGRATION.md does not mention %s" % missing
+
+
 def test_host_side_queries(lib):
     L = lib.load()
     assert L.ms_version() == 200
