@@ -18,6 +18,11 @@ PATCHES = {
     # only the first round is fetched; later rounds store the same registers again
     "nofetch": [("        if (c0 + CL_CR < p.Cin) fetch(c0 + CL_CR);\n        const int cb = wv * (CL_CR / 4);",
                  "        const int cb = wv * (CL_CR / 4);")],
+    # NOT an ablation -- a candidate (same FMAs in the same order: results bitwise those of base): a round's 2 x 16 weights per lane
+    # read into registers ahead of the channel loop, the loop fully unrolled, so that no FMA waits for the LAST LDS read issued
+    "wregs": [("#pragma unroll 2\n        for (int c = cb; c < cb + CL_CR / 4; ++c) {\n            const float wa = wl[c * WROW + col * K + ka], wb = wl[c * WROW + col * K + kb];",
+               "        float wav[CL_CR / 4], wbv[CL_CR / 4];\n#pragma unroll\n        for (int q = 0; q < CL_CR / 4; ++q) { wav[q] = wl[(cb + q) * WROW + col * K + ka]; wbv[q] = wl[(cb + q) * WROW + col * K + kb]; }\n"
+               "#pragma unroll\n        for (int c = cb; c < cb + CL_CR / 4; ++c) {\n            const float wa = wav[c - cb], wb = wbv[c - cb];")],
     # one of a wave's sixteen channels per round: a sixteenth of the FMAs and LDS reads, the whole fetch / store / barrier chain
     "fewfma": [("        for (int c = cb; c < cb + CL_CR / 4; ++c) {\n            const float wa = wl[c * WROW + col * K + ka]",
                 "        for (int c = cb; c < cb + 1; ++c) {\n            const float wa = wl[c * WROW + col * K + ka]")],
