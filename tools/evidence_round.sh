@@ -5,7 +5,8 @@
 #   2. serial + replay kernel stats and the bench line (tools/prof_final.sh)
 #   3. MFMA / VALU / LDS counters of the dominant kernels (tools/pmc_kernels.sh)
 #   4. the two-stage and RealMelGan bench lines
-# usage (GPU box): bash tools/evidence_round.sh r05 [a|b|ab]
+#   5. (part c) config 2: per-call listing + replay latency of the B = 1 generator forward and its kernels' counters
+# usage (GPU box): bash tools/evidence_round.sh r05 [a|b|c|ab|abc]
 set -o pipefail
 tag=${1:-r05}
 part=${2:-ab}          # a: traffic + traces + bench line; b: kernel counters + the two other bench lines (a call is at most 20 minutes)
@@ -22,4 +23,9 @@ bash tools/pmc_kernels.sh > gpurun_out/ev_pmc_kernels.log 2>&1; tail -3 gpurun_o
 timeout -k 10 300 python3 bench.py --model twostage --steps 20 --warmup 6 > gpurun_out/ev_bench_twostage.json 2> gpurun_out/ev_bench_twostage.log; echo "twostage rc=$?"
 timeout -k 10 300 python3 bench.py --model realmelgan --steps 20 --warmup 6 > gpurun_out/ev_bench_realmelgan.json 2> gpurun_out/ev_bench_realmelgan.log; echo "realmelgan rc=$?"
 cut -c1-200 gpurun_out/ev_bench_twostage.json; cut -c1-200 gpurun_out/ev_bench_realmelgan.json
+fi
+if [[ $part == *c* ]]; then
+timeout -k 10 200 python3 tools/gfwd_b1.py --list > gpurun_out/${tag}_gfwd_b1_list.txt 2> gpurun_out/ev_gfwd_b1.log; echo "gfwd_b1 rc=$?"
+bash tools/pmc_gfwd_b1.sh $tag > gpurun_out/ev_pmc_gfwd_b1.log 2>&1; tail -3 gpurun_out/ev_pmc_gfwd_b1.log
+cp gpurun_out/${tag}_gfwd_b1_list.txt gpurun_out/${tag}_pmc_gfwd_b1.txt profiles/ 2>/dev/null
 fi

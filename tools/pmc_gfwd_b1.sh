@@ -2,7 +2,8 @@
 # Counters of the kernels of the B = 1 generator forward (BASELINE config 2; tools/gfwd_b1.py: three eager forwards + 200 graph
 # replays): wave / wait cycles, instruction mix, LDS conflicts, and the bytes each launch fetches from beyond its L2
 # (TCC FETCH_SIZE, x2 on gfx950 as in tools/pmc_summarize.py).  Separate --pmc passes, kernel-trace only.
-# Output: gpurun_out/r05_pmc_gfwd_b1.txt
+# usage (GPU box): bash tools/pmc_gfwd_b1.sh [tag]     Output: gpurun_out/<tag>_pmc_gfwd_b1.txt
+tag=${1:-r05}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
@@ -17,7 +18,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   echo "pass $i done"
 done
 cd $R
-python3 - <<'PY' > gpurun_out/r05_pmc_gfwd_b1.txt
+python3 - <<'PY' > gpurun_out/${tag}_pmc_gfwd_b1.txt
 import csv, glob, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_gfwd_b1/p*/**/*counter_collection.csv", recursive=True):
@@ -41,4 +42,4 @@ for k, cs in sorted(agg.items()):
         line += "  lds_conflict %4.0f%%" % (100 * m.get("SQ_LDS_BANK_CONFLICT", 0) / m["SQ_LDS_IDX_ACTIVE"])
     print(line)
 PY
-cat gpurun_out/r05_pmc_gfwd_b1.txt
+cat gpurun_out/${tag}_pmc_gfwd_b1.txt
