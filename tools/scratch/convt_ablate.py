@@ -5,7 +5,8 @@ Patches a COPY of csrc/small_rows.hip, links it with the normal build's other ob
     python3 tools/scratch/convt_ablate.py build      (here: cross-compiles)
     python3 tools/scratch/convt_ablate.py run        (GPU box: tools/gfwd_b1.py --list per build, the k_convt_lanes lines)
 Reading: `sameweights` ~ base  -> not the walk (every round's 32 KB come from the vector L1 / L2 after the first);
-         `nofetch` ~ base      -> not the fetch at all;   `fewfma` ~ base -> not the arithmetic / LDS delivery either (barriers, launch)."""
+         `nofetch` ~ base      -> not the fetch at all;   `fewfma` ~ base -> not the arithmetic / LDS delivery either (barriers, launch).
+`split4` / `wregs` are candidates, not ablations (see their comments)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "music-synthesis_amd", "csrc")
@@ -18,6 +19,15 @@ PATCHES = {
     # only the first round is fetched; later rounds store the same registers again
     "nofetch": [("        if (c0 + CL_CR < p.Cin) fetch(c0 + CL_CR);\n        const int cb = wv * (CL_CR / 4);",
                  "        const int cb = wv * (CL_CR / 4);")],
+    # timing of a candidate's main pass: layers of >= 256 input channels split the contraction over FOUR workgroups (grid z = 4 B;
+    # all four write the same outputs here -- the real thing writes partial sums and adds an ordered second pass of ~ 1-2 us)
+    "split4": [("    const int jt = blockIdx.x, co0 = blockIdx.y * CG, b = blockIdx.z;",
+                "    const int NS = p.Cin >= 256 ? 4 : 1;\n    const int jt = blockIdx.x, co0 = blockIdx.y * CG, b = blockIdx.z / NS;\n"
+                "    const int cfirst = (blockIdx.z % NS) * (p.Cin / NS), cend = cfirst + p.Cin / NS;"),
+               ("    fetch(0);\n    for (int c0 = 0; c0 < p.Cin; c0 += CL_CR) {", "    fetch(cfirst);\n    for (int c0 = cfirst; c0 < cend; c0 += CL_CR) {"),
+               ("        if (c0 + CL_CR < p.Cin) fetch(c0 + CL_CR);\n        const int cb", "        if (c0 + CL_CR < cend) fetch(c0 + CL_CR);\n        const int cb"),
+               ("    const dim3 grid(ms_ceil_div(q.Lin, CL_JT), ms_ceil_div(q.Cout, 64 / d->stride), q.B);",
+                "    const dim3 grid(ms_ceil_div(q.Lin, CL_JT), ms_ceil_div(q.Cout, 64 / d->stride), q.B * (q.Cin >= 256 ? 4 : 1));")],
     # NOT an ablation -- a candidate (same FMAs in the same order: results bitwise those of base): a round's 2 x 16 weights per lane
     # read into registers ahead of the channel loop, the loop fully unrolled, so that no FMA waits for the LAST LDS read issued
     "wregs": [("#pragma unroll 2\n        for (int c = cb; c < cb + CL_CR / 4; ++c) {\n            const float wa = wl[c * WROW + col * K + ka], wb = wl[c * WROW + col * K + kb];",
